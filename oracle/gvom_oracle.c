@@ -1,0 +1,517 @@
+/*
+ * gvom_oracle.c -- CPU restatement of G-VOM's process_pointcloud -> combine_maps path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the parity referee for the HIP path and the
+ * timed host-CPU baseline ("port") of bench.py.  Nothing under g-vom_amd/ may import,
+ * link or call it.  It is pinned against golden vectors captured from the reference
+ * itself (imported unmodified under Numba's CUDA simulator, tests/golden/make_golden.py;
+ * fixtures in tests/golden/ *.npz; checked by tests/test_oracle_golden.py).
+ *
+ * Every function restates one kernel of /root/reference/scripts/gvom.py ("gvom.py:NNN"
+ * below) with the SAME memory layout (voxel index = x + y*xy + z*xy*xy, 2-D maps [x][y]
+ * C-order), the same dtypes and the same floating-point operation order as the
+ * reference executes under the simulator.  Build with
+ * -ffp-contract=off and without fast-math: one fused multiply-add changes a floor().
+ *
+ * The GPU kernels' atomics are order-independent for every quantity restated here
+ * (int32 sums, f32 min), so a sequential loop is one valid serialisation.  Compact row
+ * numbering (atomic counter order in the reference, gvom.py:964,993,1158) is assigned
+ * in voxel order here; it is value-neutral and tests compare dense equivalents only.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------
+ * helpers
+ * ---------------------------------------------------------------------------------- */
+
+/* Python's max(a, b): returns a unless b > a (matters only for NaN, where no DDA step
+ * is taken anyway).  gvom.py:1116 */
+static inline float py_maxf(float a, float b) { return (b > a) ? b : a; }
+static inline double py_maxd(double a, double b) { return (b > a) ? b : a; }
+static inline double py_mind(double a, double b) { return (b < a) ? b : a; }
+
+/* floor() then range test done in double so that huge coordinates never hit an
+ * undefined double->int conversion.  Returns 1 if 0 <= floor(v) < size. */
+static inline int floor_in_range(double v, int64_t size, int64_t *out)
+{
+    double f = floor(v);
+    if (!(f >= 0.0) || !(f < (double)size)) return 0;
+    *out = (int64_t)f;
+    return 1;
+}
+
+/* ------------------------------------------------------------------------------------
+ * Per-point kernels, generated for float32 and float64 clouds.  `stride` is the row
+ * stride in ELEMENTS (>= 3): the reference indexes points[i, 0..2] of an (N, >=3) array.
+ * ---------------------------------------------------------------------------------- */
+
+#define GEN_POINT_KERNELS(T, SUF)                                                               \
+                                                                                                \
+/* gvom.py:1040-1056  __transform_pointcloud: f64 accumulate, left to right, rows 0..2 of     \
+ * the 4x4 (row-major double[16]); written back in the cloud's dtype. */                       \
+ORC_API void orc_transform_pointcloud_##SUF(T *pts, int64_t n, int64_t stride, const double *tf)\
+{                                                                                               \
+    for (int64_t i = 0; i < n; ++i) {                                                           \
+        T *p = pts + i * stride;                                                                \
+        double x = (double)p[0], y = (double)p[1], z = (double)p[2];                            \
+        double o0 = ((x * tf[0] + y * tf[1]) + z * tf[2]) + tf[3];                              \
+        double o1 = ((x * tf[4] + y * tf[5]) + z * tf[6]) + tf[7];                              \
+        double o2 = ((x * tf[8] + y * tf[9]) + z * tf[10]) + tf[11];                            \
+        p[0] = (T)o0; p[1] = (T)o1; p[2] = (T)o2;                                               \
+    }                                                                                           \
+}                                                                                               \
+                                                                                                \
+/* gvom.py:1060-1150  __point_2_map: min-distance reject (from the WORLD origin),             \
+ * endpoint hit, dominant-axis DDA from ego marking `total`.  Returns the number of            \
+ * accumulator updates performed (sum of all +1s), used for roofline accounting. */            \
+ORC_API int64_t orc_point_2_map_##SUF(double xy_res, double z_res, int64_t xy, int64_t zs,      \
+        double min_distance, const T *pts, int64_t n, int64_t stride,                           \
+        int32_t *hit, int32_t *total, const double *ego, const double *origin)                  \
+{                                                                                               \
+    int64_t updates = 0;                                                                        \
+    const double md2 = min_distance * min_distance;                                             \
+    for (int64_t i = 0; i < n; ++i) {                                                           \
+        const T *p = pts + i * stride;                                                          \
+        /* :1064 d2 in the cloud's dtype, (x*x + y*y) + z*z */                                  \
+        T d2 = (T)((T)((T)(p[0] * p[0]) + (T)(p[1] * p[1])) + (T)(p[2] * p[2]));                \
+        if ((double)d2 < md2) continue;                               /* :1067 */               \
+        int64_t xi = 0, yi = 0, zi = 0;                                                         \
+        int inx = floor_in_range((double)p[0] / xy_res - origin[0], xy, &xi);   /* :1072 */    \
+        int iny = floor_in_range((double)p[1] / xy_res - origin[1], xy, &yi);   /* :1076 */    \
+        int inz = floor_in_range((double)p[2] / z_res - origin[2], zs, &zi);    /* :1080 */    \
+        if (inx && iny && inz) {                                                                \
+            int64_t idx = xi + yi * xy + zi * xy * xy;                /* :1086 */               \
+            hit[idx] += 1; total[idx] += 1; updates += 2;             /* :1089-1090 */          \
+        }                                                                                       \
+        float pt[3], end[3], slope[3];                                /* :1093-1095 f32 */      \
+        pt[0] = (float)(ego[0] / xy_res);                             /* :1097-1099 */          \
+        pt[1] = (float)(ego[1] / xy_res);                                                       \
+        pt[2] = (float)(ego[2] / z_res);                                                        \
+        end[0] = (float)((double)p[0] / xy_res);                      /* :1101-1103 */          \
+        end[1] = (float)((double)p[1] / xy_res);                                                \
+        end[2] = (float)((double)p[2] / z_res);                                                 \
+        slope[0] = end[0] - pt[0];                                    /* :1105-1107 f32 */      \
+        slope[1] = end[1] - pt[1];                                                              \
+        slope[2] = end[2] - pt[2];                                                              \
+        /* :1109 f32 products and sums, then math.sqrt -> Python float (f64) */                 \
+        float ss = (float)((float)((float)(slope[0] * slope[0]) + (float)(slope[1] * slope[1])) \
+                           + (float)(slope[2] * slope[2]));                                     \
+        double ray_length = sqrt((double)ss);                                                   \
+        slope[0] = (float)((double)slope[0] / ray_length);            /* :1112-1114 */          \
+        slope[1] = (float)((double)slope[1] / ray_length);                                      \
+        slope[2] = (float)((double)slope[2] / ray_length);                                      \
+        float a0 = fabsf(slope[0]), a1 = fabsf(slope[1]), a2 = fabsf(slope[2]);                 \
+        float slope_max = py_maxf(a0, py_maxf(a1, a2));               /* :1116 */               \
+        int si = 0;                                                                             \
+        if (slope_max == a1) si = 1;                                  /* :1120 */               \
+        if (slope_max == a2) si = 2;                                  /* :1122 */               \
+        double length = 0.0;                                          /* :1125 */               \
+        float adom = fabsf(slope[si]);                                                          \
+        float direction = slope[si] / adom;                           /* :1126 f32 */           \
+        int o1 = (si + 1) % 3, o2 = (si + 2) % 3;                                               \
+        float inc1 = slope[o1] / adom;                                /* :1129-1132 f32 */      \
+        float inc2 = slope[o2] / adom;                                                          \
+        double step_len = fabs(1.0 / (double)slope[si]);              /* :1150 f64 */           \
+        while (length < ray_length - 1.0) {                           /* :1127 */               \
+            pt[si] = pt[si] + direction;                                                        \
+            pt[o1] = pt[o1] + inc1;                                                             \
+            pt[o2] = pt[o2] + inc2;                                                             \
+            if (!floor_in_range((double)pt[0] - origin[0], xy, &xi)) break;   /* :1134-1136 */  \
+            if (!floor_in_range((double)pt[1] - origin[1], xy, &yi)) break;   /* :1138-1140 */  \
+            if (!floor_in_range((double)pt[2] - origin[2], zs, &zi)) break;   /* :1142-1144 */  \
+            total[xi + yi * xy + zi * xy * xy] += 1;                  /* :1146-1148 */          \
+            updates += 1;                                                                       \
+            length += step_len;                                       /* :1150 */               \
+        }                                                                                       \
+    }                                                                                           \
+    return updates;                                                                             \
+}                                                                                               \
+                                                                                                \
+/* gvom.py:1303-1329  __calculate_min_height: per in-grid point, f32 atomic-min of the        \
+ * fractional z inside its voxel, keyed by compact row.  Returns #points that updated. */      \
+ORC_API int64_t orc_calculate_min_height_##SUF(double xy_res, double z_res, int64_t xy,         \
+        int64_t zs, double min_distance, const int32_t *index_map, const T *pts, int64_t n,     \
+        int64_t stride, float *min_height, const double *origin)                                \
+{                                                                                               \
+    int64_t n_in = 0;                                                                           \
+    const double md2 = min_distance * min_distance;                                             \
+    for (int64_t i = 0; i < n; ++i) {                                                           \
+        const T *p = pts + i * stride;                                                          \
+        T d2 = (T)((T)((T)(p[0] * p[0]) + (T)(p[1] * p[1])) + (T)(p[2] * p[2]));                \
+        if ((double)d2 < md2) continue;                               /* :1308 */               \
+        int64_t xi = 0, yi = 0, zi = 0;                                                         \
+        if (!floor_in_range((double)p[0] / xy_res - origin[0], xy, &xi)) continue;              \
+        if (!floor_in_range((double)p[1] / xy_res - origin[1], xy, &yi)) continue;              \
+        if (!floor_in_range((double)p[2] / z_res - origin[2], zs, &zi)) continue;               \
+        double lz = ((double)p[2] / z_res - origin[2]) - (double)zi;  /* :1326 */               \
+        int32_t row = index_map[xi + yi * xy + zi * xy * xy];         /* :1328 */               \
+        float v = (float)lz;                                          /* :1329 f64 -> f32 */    \
+        if (row >= 0) { if (v < min_height[row]) min_height[row] = v; ++n_in; }                 \
+    }                                                                                           \
+    return n_in;                                                                                \
+}
+
+GEN_POINT_KERNELS(float, f32)
+GEN_POINT_KERNELS(double, f64)
+
+/* ------------------------------------------------------------------------------------
+ * Sparse encoding of one scan
+ * ---------------------------------------------------------------------------------- */
+
+/* gvom.py:1154-1160 __assign_indices.  >=0 compact row (occupied), -1 never observed,
+ * -m-1 free with m ray passes.  Returns cell_count. */
+ORC_API int32_t orc_assign_indices(const int32_t *hit, const int32_t *total, int32_t *index_map,
+                                   int64_t voxel_count)
+{
+    int32_t cell_count = 0;
+    for (int64_t i = 0; i < voxel_count; ++i) {
+        if (hit[i] > 0) index_map[i] = cell_count++;
+        else index_map[i] = -total[i] - 1;
+    }
+    return cell_count;
+}
+
+/* gvom.py:1164-1168 __move_data */
+ORC_API void orc_move_data(const int32_t *old, int32_t *neu, const int32_t *index_map,
+                           int64_t voxel_count)
+{
+    for (int64_t i = 0; i < voxel_count; ++i)
+        if (index_map[i] >= 0) neu[index_map[i]] = old[i];
+}
+
+/* ------------------------------------------------------------------------------------
+ * Temporal fusion
+ * ---------------------------------------------------------------------------------- */
+
+/* shared window test of gvom.py:950-956 / 979-985 / 829-834: d = combined - old origin
+ * (f64, integer valued); returns 0 if the shifted voxel falls outside the old window. */
+static inline int shifted_index(int64_t x, int64_t y, int64_t z, const double *d, int64_t xy,
+                                int64_t zs, int64_t *index_old)
+{
+    double xs = (double)x + d[0], ys = (double)y + d[1], zz = (double)z + d[2];
+    if (xs >= (double)xy || ys >= (double)xy || zz >= (double)zs || xs < 0 || ys < 0 || zz < 0)
+        return 0;
+    *index_old = (int64_t)(xs + ys * (double)xy + zz * (double)xy * (double)xy);
+    return 1;
+}
+
+/* gvom.py:943-968 __combine_indices (one ring slot folded into the fused lookup table) */
+ORC_API void orc_combine_indices(int64_t *combined_cell_count, int32_t *combined_index_map,
+        const double *combined_origin, const int32_t *old_index_map, const double *old_origin,
+        int64_t xy, int64_t zs)
+{
+    double d[3] = { combined_origin[0] - old_origin[0], combined_origin[1] - old_origin[1],
+                    combined_origin[2] - old_origin[2] };
+    for (int64_t z = 0; z < zs; ++z)
+        for (int64_t y = 0; y < xy; ++y)
+            for (int64_t x = 0; x < xy; ++x) {
+                int64_t io;
+                if (!shifted_index(x, y, z, d, xy, zs, &io)) continue;
+                int64_t idx = x + y * xy + z * xy * xy;
+                if (old_index_map[io] >= 0 && combined_index_map[idx] <= -1)          /* :963 */
+                    combined_index_map[idx] = (int32_t)((*combined_cell_count)++);
+                else if (old_index_map[io] < -1 && combined_index_map[idx] <= -1)     /* :967 */
+                    combined_index_map[idx] += old_index_map[io] + 1;
+            }
+}
+
+/* gvom.py:972-997 __combine_old_indices (previous fused map; decay window [-11,-1]) */
+ORC_API void orc_combine_old_indices(int64_t *combined_cell_count, int32_t *combined_index_map,
+        const double *combined_origin, const int32_t *old_index_map, const double *old_origin,
+        int64_t xy, int64_t zs)
+{
+    double d[3] = { combined_origin[0] - old_origin[0], combined_origin[1] - old_origin[1],
+                    combined_origin[2] - old_origin[2] };
+    for (int64_t z = 0; z < zs; ++z)
+        for (int64_t y = 0; y < xy; ++y)
+            for (int64_t x = 0; x < xy; ++x) {
+                int64_t io;
+                if (!shifted_index(x, y, z, d, xy, zs, &io)) continue;
+                int64_t idx = x + y * xy + z * xy * xy;
+                int32_t c = combined_index_map[idx];
+                if (old_index_map[io] >= 0 && c <= -1 && c >= -11)                    /* :992 */
+                    combined_index_map[idx] = (int32_t)((*combined_cell_count)++);
+                else if (old_index_map[io] < -1 && c <= -1)                           /* :996 */
+                    combined_index_map[idx] += old_index_map[io] + 1;
+            }
+}
+
+/* gvom.py:821-912 __combine_metrics, lines 910-912 only (hit/total sum, min-height min).
+ * The pooled mean/covariance merge (:858-909) feeds no returned map. */
+ORC_API void orc_combine_metrics(int32_t *combined_hit, int32_t *combined_total,
+        float *combined_min_height, const int32_t *combined_index_map,
+        const double *combined_origin, const int32_t *old_hit, const int32_t *old_total,
+        const float *old_min_height, const int32_t *old_index_map, const double *old_origin,
+        int64_t xy, int64_t zs)
+{
+    double d[3] = { combined_origin[0] - old_origin[0], combined_origin[1] - old_origin[1],
+                    combined_origin[2] - old_origin[2] };
+    for (int64_t z = 0; z < zs; ++z)
+        for (int64_t y = 0; y < xy; ++y)
+            for (int64_t x = 0; x < xy; ++x) {
+                int64_t io;
+                if (!shifted_index(x, y, z, d, xy, zs, &io)) continue;
+                int32_t index = combined_index_map[x + y * xy + z * xy * xy];
+                int32_t index_old = old_index_map[io];
+                if (index < 0 || index_old < 0) continue;                             /* :841 */
+                combined_hit[index] = combined_hit[index] + old_hit[index_old];       /* :910 */
+                combined_total[index] = combined_total[index] + old_total[index_old]; /* :911 */
+                float a = combined_min_height[index], b = old_min_height[index_old];
+                combined_min_height[index] = (b < a) ? b : a;                         /* :912 */
+            }
+}
+
+/* ------------------------------------------------------------------------------------
+ * Column reductions and 2-D maps.  Maps are [x][y] C-order: m[x * xy + y].
+ * ---------------------------------------------------------------------------------- */
+
+/* gvom.py:525-540 __make_height_map */
+ORC_API void orc_make_height_map(const double *combined_origin, const int32_t *combined_index_map,
+        const float *min_height, int64_t xy, int64_t zs, double xy_res, double z_res,
+        const double *ego, double radius, double ground_to_lidar_height, double *height_map)
+{
+    for (int64_t x = 0; x < xy; ++x)
+        for (int64_t y = 0; y < xy; ++y) {
+            double xp = ((combined_origin[0] + (double)x) * xy_res) - ego[0];         /* :531 */
+            double yp = ((combined_origin[1] + (double)y) * xy_res) - ego[1];         /* :532 */
+            if (xp * xp + yp * yp <= radius * radius)                                 /* :533 */
+                height_map[x * xy + y] = ego[2] - ground_to_lidar_height;
+            for (int64_t z = 0; z < zs; ++z) {
+                int32_t index = combined_index_map[x + y * xy + z * xy * xy];
+                if (index >= 0) {                                                     /* :538 */
+                    height_map[x * xy + y] =
+                        (((double)min_height[index] + (double)z) + combined_origin[2]) * z_res;
+                    break;
+                }
+            }
+        }
+}
+
+/* gvom.py:544-554 __make_inferred_height_map */
+ORC_API void orc_make_inferred_height_map(const double *combined_origin,
+        const int32_t *combined_index_map, int64_t xy, int64_t zs, double z_res,
+        double *inferred_height_map)
+{
+    for (int64_t x = 0; x < xy; ++x)
+        for (int64_t y = 0; y < xy; ++y)
+            for (int64_t z = 0; z < zs; ++z) {
+                int32_t index = combined_index_map[x + y * xy + z * xy * xy];
+                if (index < -1) {                                                     /* :551 */
+                    inferred_height_map[x * xy + y] = ((double)z + combined_origin[2]) * z_res;
+                    break;
+                }
+            }
+}
+
+/* gvom.py:665-734 __calculate_slope: 3x3 least-squares plane, f64, source order. */
+ORC_API void orc_calculate_slope(const double *height_map, int64_t xy, double xy_res,
+        double *slope_x, double *slope_y, double *roughness)
+{
+    const int64_t radius = 1;
+    for (int64_t x0 = 0; x0 < xy; ++x0)
+        for (int64_t y0 = 0; y0 < xy; ++y0) {
+            int64_t xlo = x0 - radius < 0 ? 0 : x0 - radius, xhi = x0 + radius + 1 > xy ? xy : x0 + radius + 1;
+            int64_t ylo = y0 - radius < 0 ? 0 : y0 - radius, yhi = y0 + radius + 1 > xy ? xy : y0 + radius + 1;
+            int n_good = 0;
+            for (int64_t x = xlo; x < xhi; ++x)
+                for (int64_t y = ylo; y < yhi; ++y)
+                    if (height_map[x * xy + y] > -1000) ++n_good;                     /* :674 */
+            if (n_good < 3) continue;                                                 /* :676 */
+            double p0[9], p1[9], p2[9];
+            int i = 0;
+            double mean_x = 0.0, mean_y = 0.0, mean_z = 0.0;
+            for (int64_t x = xlo; x < xhi; ++x)
+                for (int64_t y = ylo; y < yhi; ++y)
+                    if (height_map[x * xy + y] > -1000) {
+                        p0[i] = (double)x * xy_res;                                   /* :687 */
+                        p1[i] = (double)y * xy_res;
+                        p2[i] = height_map[x * xy + y];
+                        mean_x += p0[i]; mean_y += p1[i]; mean_z += p2[i];
+                        ++i;
+                    }
+            mean_x /= (double)i; mean_y /= (double)i; mean_z /= (double)i;            /* :695 */
+            double xx = 0.0, xyv = 0.0, xz = 0.0, yy = 0.0, yz = 0.0;
+            for (int k = 0; k < n_good; ++k) {                                        /* :704 */
+                xx += (p0[k] - mean_x) * (p0[k] - mean_x);
+                xyv += (p0[k] - mean_x) * (p1[k] - mean_y);
+                xz += (p0[k] - mean_x) * (p2[k] - mean_z);
+                yy += (p1[k] - mean_y) * (p1[k] - mean_y);
+                yz += (p1[k] - mean_y) * (p2[k] - mean_z);
+            }
+            double det = xx * yy - xyv * xyv;                                         /* :711 */
+            if (det == 0.0) continue;
+            double a0 = (yy * xz - xyv * yz) / det;                                   /* :715 */
+            double a1 = (xx * yz - xyv * xz) / det;
+            double m = sqrt((a0 * a0 + a1 * a1) + 1.0);                               /* :717 */
+            a0 /= m; a1 /= m;
+            double error = 0.0;
+            for (int k = 0; k < n_good; ++k) {                                        /* :722 */
+                double e = (p2[k] - mean_z) - (a0 * (p0[k] - mean_x) + a1 * (p1[k] - mean_y));
+                error += e * e;
+            }
+            error /= (double)n_good;
+            if (error > 0) error = log(error);                                        /* :727 */
+            roughness[x0 * xy + y0] = error;
+            slope_x[x0 * xy + y0] = atan2(a0, 1.0 / m);                               /* :731 */
+            slope_y[x0 * xy + y0] = atan2(a1, 1.0 / m);
+        }
+}
+
+/* gvom.py:558-661 __guess_height, including the loop-guard typo (:581: x_n_done twice)
+ * and the y_nh guard typo (:655 tests x_nh). */
+ORC_API void orc_guess_height(const double *height_map, const double *inferred_height_map,
+        int64_t xy, double *guessed_height_delta)
+{
+    for (int64_t x0 = 0; x0 < xy; ++x0)
+        for (int64_t y0 = 0; y0 < xy; ++y0) {
+            if (height_map[x0 * xy + y0] > -1000 || inferred_height_map[x0 * xy + y0] == -1000.0)
+                continue;                                                             /* :563 */
+            int x_p_done = 0, x_n_done = 0, y_p_done = 0, y_n_done = 0;
+            int64_t x_p = x0, x_n = x0, y_p = y0, y_n = y0;
+            double x_ph = -1000, x_nh = -1000, y_ph = -1000, y_nh = -1000;
+            int64_t i = 0;
+            while (i < 15 && !(x_n_done && x_n_done && y_p_done && y_n_done)) {       /* :581 */
+                x_p += 1; x_n -= 1; y_p += 1; y_n -= 1; i += 1;
+                if (!x_p_done) {
+                    if (x_p < xy) {
+                        for (int64_t dy = -i; dy < i; ++dy) {                         /* :590 */
+                            if (y0 + dy >= xy || y0 + dy < 0) continue;
+                            if (height_map[x_p * xy + y0 + dy] > -1000) {
+                                x_ph = height_map[x_p * xy + y0 + dy]; x_p_done = 1; break;
+                            }
+                        }
+                    } else x_p_done = 1;
+                }
+                if (!x_n_done) {
+                    if (x_n >= 0) {
+                        for (int64_t dy = -i + 1; dy < i + 1; ++dy) {                 /* :603 */
+                            if (y0 + dy >= xy || y0 + dy < 0) continue;
+                            if (height_map[x_n * xy + y0 + dy] > -1000) {
+                                x_nh = height_map[x_n * xy + y0 + dy]; x_n_done = 1; break;
+                            }
+                        }
+                    } else x_n_done = 1;
+                }
+                if (!y_p_done) {
+                    if (y_p < xy) {
+                        for (int64_t dx = -i + 1; dx < i + 1; ++dx) {                 /* :616 */
+                            if (x0 + dx >= xy || x0 + dx < 0) continue;
+                            if (height_map[(x0 + dx) * xy + y_p] > -1000) {
+                                y_ph = height_map[(x0 + dx) * xy + y_p]; y_p_done = 1; break;
+                            }
+                        }
+                    } else y_p_done = 1;
+                }
+                if (!y_n_done) {
+                    if (y_n >= 0) {
+                        for (int64_t dx = -i; dx < i; ++dx) {                         /* :629 */
+                            if (x0 + dx >= xy || x0 + dx < 0) continue;
+                            if (height_map[(x0 + dx) * xy + y_n] > -1000) {
+                                y_nh = height_map[(x0 + dx) * xy + y_n]; y_n_done = 1; break;
+                            }
+                        }
+                    } else y_n_done = 1;
+                }
+            }
+            double min_h = 1000.0;                                                    /* :640 */
+            double max_h = inferred_height_map[x0 * xy + y0];
+            if (x_ph > -1000) { min_h = py_mind(x_ph, min_h); max_h = py_maxd(x_ph, max_h); }
+            if (x_nh > -1000) { min_h = py_mind(x_nh, min_h); max_h = py_maxd(x_nh, max_h); }
+            if (y_ph > -1000) { min_h = py_mind(y_ph, min_h); max_h = py_maxd(y_ph, max_h); }
+            if (x_nh > -1000) { min_h = py_mind(y_nh, min_h); max_h = py_maxd(y_nh, max_h); } /* :655 */
+            double dh = max_h - min_h;
+            if (dh > 0) guessed_height_delta[x0 * xy + y0] = dh;                      /* :660 */
+        }
+}
+
+/* gvom.py:489-521 __make_positive_obstacle_map */
+ORC_API void orc_make_positive_obstacle_map(const int32_t *combined_index_map,
+        const double *height_map, int64_t xy, int64_t zs, double z_res,
+        double positive_obstacle_threshold, const int32_t *hit_count, const int32_t *total_count,
+        double robot_height, const double *origin, const double *x_slope, const double *y_slope,
+        double slope_threshold, int32_t *obstacle_map)
+{
+    for (int64_t x = 0; x < xy; ++x)
+        for (int64_t y = 0; y < xy; ++y) {
+            double sx = x_slope[x * xy + y], sy = y_slope[x * xy + y];
+            if (sqrt(sx * sx + sy * sy) >= slope_threshold) {                         /* :498 */
+                obstacle_map[x * xy + y] = 100;
+                continue;
+            }
+            double min_obs_height = height_map[x * xy + y] + positive_obstacle_threshold;
+            double fmin = floor((min_obs_height / z_res) - origin[2]) + 1.0;          /* :503 */
+            double max_obs_height = height_map[x * xy + y] + robot_height;
+            double fmax = floor((max_obs_height / z_res) - origin[2]);                /* :505 */
+            if (!(fmin >= 0 && fmin < (double)zs)) continue;                          /* :506 */
+            if (!(fmax >= 0 && fmax < (double)zs)) continue;                          /* :508 */
+            int64_t zmin = (int64_t)fmin, zmax = (int64_t)fmax;
+            double density = 0.0, n = 0.0;
+            for (int64_t z = zmin; z < zmax + 1; ++z) {                               /* :513 */
+                int32_t index = combined_index_map[x + y * xy + z * xy * xy];
+                if (index >= 0 && hit_count[index] > 10) {                            /* :515 */
+                    n += (double)total_count[index];
+                    density += (double)hit_count[index];
+                }
+            }
+            if (n > 0.0) density /= n;
+            obstacle_map[x * xy + y] = (int32_t)(density * 100);                      /* :521 */
+        }
+}
+
+/* gvom.py:479-485 __make_negative_obstacle_map */
+ORC_API void orc_make_negative_obstacle_map(const double *guessed_height_delta,
+        int32_t *negative_obstacle_map, double negative_obstacle_threshold, int64_t xy)
+{
+    for (int64_t i = 0; i < xy * xy; ++i)
+        if (guessed_height_delta[i] > negative_obstacle_threshold) negative_obstacle_map[i] = 100;
+}
+
+/* gvom.py:414-422 __make_visibility_map */
+ORC_API void orc_make_visibility_map(int32_t *visibility, const double *height_map, int64_t xy)
+{
+    for (int64_t i = 0; i < xy * xy; ++i) visibility[i] = height_map[i] > -1000 ? 1 : 0;
+}
+
+/* ------------------------------------------------------------------------------------
+ * "Next" rows: debug/accessor gathers.
+ * ---------------------------------------------------------------------------------- */
+
+/* gvom.py:426-438 __make_height_map_pointcloud -> f32[xy*xy, 7] */
+ORC_API void orc_make_height_map_pointcloud(const double *height_map, const double *roughness,
+        const double *x_slope, const double *y_slope, const double *origin, float *out,
+        int64_t xy, double xy_res, double z_res)
+{
+    for (int64_t x = 0; x < xy; ++x)
+        for (int64_t y = 0; y < xy; ++y) {
+            int64_t index = x + y * xy;
+            double sx = x_slope[x * xy + y], sy = y_slope[x * xy + y];
+            out[index * 7 + 0] = (float)(((double)x + origin[0]) * xy_res);
+            out[index * 7 + 1] = (float)(((double)y + origin[1]) * xy_res);
+            out[index * 7 + 2] = (float)(height_map[x * xy + y] - z_res);
+            out[index * 7 + 3] = (float)roughness[x * xy + y];
+            out[index * 7 + 4] = (float)sx;
+            out[index * 7 + 5] = (float)sy;
+            out[index * 7 + 6] = (float)sqrt(sx * sx + sy * sy);
+        }
+}
+
+/* gvom.py:442-450 __make_infered_height_map_pointcloud -> f32[xy*xy, 3] (fed with
+ * guessed_height_delta by gvom.py:407) */
+ORC_API void orc_make_inferred_height_map_pointcloud(const double *map, const double *origin,
+        float *out, int64_t xy, double xy_res, double z_res)
+{
+    for (int64_t x = 0; x < xy; ++x)
+        for (int64_t y = 0; y < xy; ++y) {
+            int64_t index = x + y * xy;
+            out[index * 3 + 0] = (float)(((double)x + origin[0]) * xy_res);
+            out[index * 3 + 1] = (float)(((double)y + origin[1]) * xy_res);
+            out[index * 3 + 2] = (float)(map[x * xy + y] - z_res);
+        }
+}
+
+ORC_API int orc_abi_version(void) { return 1; }

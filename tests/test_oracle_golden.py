@@ -1,0 +1,50 @@
+"""Pins the CPU oracle against end-to-end golden vectors recorded from the reference
+(tests/golden/f*.npz).  Every recorded per-slot dense accumulator,
+fused map, internal 2-D map and returned map must be reproduced: ints bit-exact, floats
+exactly except log/atan2-derived maps (1e-9: same glibc on both sides)."""
+import os
+
+import numpy as np
+import pytest
+
+import scenarios
+from parity import compare_records
+from oracle import oracle
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+NAMES = ["f1", "f2", "f3", "f4", "f5", "f6", "f7"]
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_reproduces_reference(name, capsys):
+    path = os.path.join(G, name + ".npz")
+    if not os.path.exists(path):
+        pytest.skip("fixture %s not generated yet" % name)
+    want = np.load(path)
+    sc = scenarios.scenario_from_record(want)
+    got = scenarios.run_and_record(oracle.OracleGvom, sc, record_debug=(name != "f7"))
+    n = compare_records(got, want, float_tol=1e-9)
+    assert n > 5
+
+
+def test_warning_strings_and_return_types(capsys):
+    g = oracle.OracleGvom(0.4, 0.4, 16, 8, 2, 1.0, 0.5, 0.5, 0.3, 2.0, 4.0, 1.0, 1, 1)
+    assert g.combine_maps() is None
+    assert "[WARNING] The map buffer is empty, nothing will happen!" in capsys.readouterr().out
+    assert g.process_pointcloud(np.zeros((0, 3)), (0, 0, 0)) is None
+    assert "[WARNING] Processing an empty pointcloud, nothing will happen!" in capsys.readouterr().out
+    g.process_pointcloud(np.full((4, 3), 500.0), (0, 0, 0))
+    assert "[WARNING] The pointcloud points don't overlap with any voxels, nothing will happen!" \
+        in capsys.readouterr().out
+    assert g.buffer_index == 0
+    rng = np.random.default_rng(0)
+    pc = np.stack([rng.uniform(-3, 3, 300), rng.uniform(-3, 3, 300), rng.uniform(-1.5, .5, 300)], 1)
+    g.process_pointcloud(pc, (0, 0, 0), np.eye(4))
+    out = g.combine_maps()
+    assert [o.dtype for o in out] == [np.float64, np.int32, np.int32, np.float64, np.int32]
+    assert [o.shape for o in out] == [(3,), (16, 16), (16, 16), (16, 16), (16, 16)]
+    # SURVEY Appendix C end-to-end smoke values
+    assert np.allclose(out[0], [-3.2, -3.2, -1.6])
+    assert np.count_nonzero(out[1]) == 207 and np.count_nonzero(out[2]) == 0
+    assert out[4].sum() == 250
+    assert out[3].min() == pytest.approx(-7.333893209065674, abs=1e-9)
