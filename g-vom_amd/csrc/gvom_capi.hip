@@ -1,0 +1,830 @@
+// gvom_capi.hip -- host side of libgvom_hip.so: the C ABI declared in include/gvom_hip.h.
+//
+// Replaces the host bodies of the reference's Gvom.__init__ / process_pointcloud /
+// combine_maps (/root/reference/scripts/gvom.py:29-354, "gvom.py:NNN").  Differences in
+// mechanism, not in results:
+//   * all device memory is a grow-only arena owned by the handle (the reference allocates
+//     ~17 arrays per call);
+//   * 3 launches per scan and 2 per combine on one private HIP stream (reference: ~20 and
+//     ~35+3B), one 16-byte D2H per scan, one D2H of the four maps per combine;
+//   * ring slots are swapped with a spare staging slot on commit, so a rejected scan
+//     (gvom.py:148-150) leaves the ring untouched.
+#include "gvom_internal.h"
+#include "../../include/gvom_hip.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#define VIS __attribute__((visibility("default")))
+
+namespace {
+
+struct Buf {                                   // grow-only device buffer
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+struct Slot {                                  // one scan in sparse form
+    int32_t *state = nullptr;                  // [V] storage order
+    Buf chit, ctotal, cminh;                   // compact rows
+    int64_t origin[3] = {0, 0, 0};
+    int64_t count = 0;
+    bool filled = false;
+    bool stats_valid = false;
+    gvom_scan_stats stats = {0, 0, 0, 0};
+};
+
+struct Fused {
+    int32_t *state = nullptr;
+    Buf hit, total, minh;
+    int64_t origin[3] = {0, 0, 0};
+    int64_t count = 0;                         // rows on THIS rank
+    bool valid = false;
+};
+
+}  // namespace
+
+struct gvom_handle {
+    gvom_params prm;
+    int device = 0;
+    int rank = 0, world = 1;
+    int sy_lo = 0, sy_hi = 0;
+    size_t V = 0, slabV = 0, cells2d = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    std::string err;
+
+    uint32_t *hit = nullptr, *total = nullptr;          // dense accumulators, zero between scans
+    std::vector<Slot> slots;                            // buffer_size + 1 (one is staging)
+    std::vector<int> ring;                              // ring position -> slots index
+    int staging = 0;
+    int buffer_index = 0, last_buffer_index = 0;
+    Buf in_pts, world_pts;
+    uint32_t *counters = nullptr;                       // device: [0] scan rows, [2..3] fuse rows (u64)
+    uint32_t *counters_host = nullptr;                  // pinned mirror
+
+    // pending (uncommitted) scan
+    bool pending = false;
+    int64_t pending_origin[3] = {0, 0, 0};
+    int64_t pending_n = 0;
+
+    Fused fused[2];
+    int cur = 0;                                        // fused[cur] is the latest if valid
+    bool has_combined = false;
+    int64_t combined_cell_count = 0;                    // global count if set by the sharded layer
+    MapDesc *descs_dev = nullptr, *descs_host = nullptr;
+
+    double *height = nullptr, *inferred = nullptr, *slope_x = nullptr, *slope_y = nullptr,
+           *rough = nullptr, *guessed = nullptr;        // [sy][sx] storage order
+    int32_t *out_pos = nullptr, *out_neg = nullptr, *out_vis = nullptr;
+    double *out_rough = nullptr;
+    void *out_host = nullptr;                           // pinned staging for the 4 outputs
+    bool maps_valid = false;
+
+    double ego[3] = {0, 0, 0};
+
+    bool profiling = false;
+    hipEvent_t ev[8] = {nullptr};
+    float stage_ms[GVOM_N_STAGES] = {0, 0, 0, 0, 0};
+};
+
+namespace {
+
+#define HIPCHK(h, call)                                                                         \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            char b_[512];                                                                       \
+            snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),      \
+                     __FILE__, __LINE__);                                                       \
+            (h)->err = b_;                                                                      \
+            return GVOM_ERR_HIP;                                                                \
+        }                                                                                       \
+    } while (0)
+
+int ensure(gvom_handle *h, Buf &b, size_t bytes)
+{
+    if (b.bytes >= bytes) return GVOM_OK;
+    size_t want = bytes + bytes / 2 + 256;
+    if (b.p) HIPCHK(h, hipFree(b.p));
+    b.p = nullptr; b.bytes = 0;
+    HIPCHK(h, hipMalloc(&b.p, want));
+    b.bytes = want;
+    return GVOM_OK;
+}
+
+inline int64_t floor_mod(int64_t a, int64_t n) { int64_t r = a % n; return r < 0 ? r + n : r; }
+
+inline int clamp_delta(int64_t d, int size)
+{   // any |d| >= size puts the whole source window outside; keep ints small
+    if (d > size) return size;
+    if (d < -size) return -size;
+    return (int)d;
+}
+
+void fill_scan_params(const gvom_handle *h, const int64_t origin[3], const double *tf, ScanParams &P)
+{
+    const gvom_params &p = h->prm;
+    P.xy_res = p.xy_resolution; P.z_res = p.z_resolution;
+    P.min_d2 = p.min_distance * p.min_distance;
+    for (int k = 0; k < 3; ++k) P.origin[k] = (double)origin[k];
+    P.has_tf = tf ? 1 : 0;
+    for (int k = 0; k < 12; ++k) P.tf[k] = tf ? tf[k] : 0.0;
+    P.pt0[0] = (float)(h->ego[0] / p.xy_resolution);
+    P.pt0[1] = (float)(h->ego[1] / p.xy_resolution);
+    P.pt0[2] = (float)(h->ego[2] / p.z_resolution);
+    P.xy = p.xy_size; P.zs = p.z_size;
+    P.om[0] = (int)floor_mod(origin[0], p.xy_size);
+    P.om[1] = (int)floor_mod(origin[1], p.xy_size);
+    P.om[2] = (int)floor_mod(origin[2], p.z_size);
+    P.sy_lo = h->sy_lo; P.sy_hi = h->sy_hi;
+}
+
+int create_impl(const gvom_params *params, int device_id, int rank, int world, gvom_t **out)
+{
+    if (!params || !out) return GVOM_ERR_INVALID;
+    *out = nullptr;
+    if (params->xy_size <= 0 || params->z_size <= 0 || params->buffer_size <= 0 ||
+        !(params->xy_resolution > 0) || !(params->z_resolution > 0) || world <= 0 || rank < 0 ||
+        rank >= world)
+        return GVOM_ERR_INVALID;
+    if (params->buffer_size >= GVOM_MAX_SLOTS || params->z_size > 1024) return GVOM_ERR_CAPACITY;
+    const double Vd = (double)params->xy_size * params->xy_size * params->z_size;
+    if (Vd >= 2147483648.0) return GVOM_ERR_CAPACITY;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev)
+        return GVOM_ERR_NO_DEVICE;
+    gvom_handle *h = new gvom_handle();
+    h->prm = *params;
+    h->device = device_id;
+    h->rank = rank; h->world = world;
+    const int xy = params->xy_size, zs = params->z_size;
+    h->sy_lo = (int)((int64_t)xy * rank / world);
+    h->sy_hi = (int)((int64_t)xy * (rank + 1) / world);
+    h->V = (size_t)xy * xy * zs;
+    h->slabV = (size_t)(h->sy_hi - h->sy_lo) * xy * zs;
+    h->cells2d = (size_t)xy * xy;
+#define CK(call)                                                                                \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            fprintf(stderr, "gvom_create: %s failed: %s\n", #call, hipGetErrorString(e_));      \
+            gvom_destroy(h);                                                                    \
+            return GVOM_ERR_HIP;                                                                \
+        }                                                                                       \
+    } while (0)
+    CK(hipSetDevice(device_id));
+    CK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    CK(hipMalloc((void **)&h->hit, h->V * 4));
+    CK(hipMalloc((void **)&h->total, h->V * 4));
+    CK(hipMemsetAsync(h->hit, 0, h->V * 4, h->stream));
+    CK(hipMemsetAsync(h->total, 0, h->V * 4, h->stream));
+    h->slots.resize(params->buffer_size + 1);
+    for (auto &s : h->slots) CK(hipMalloc((void **)&s.state, h->V * 4));
+    h->ring.resize(params->buffer_size);
+    for (int i = 0; i < params->buffer_size; ++i) h->ring[i] = i;
+    h->staging = params->buffer_size;
+    for (int k = 0; k < 2; ++k) CK(hipMalloc((void **)&h->fused[k].state, h->V * 4));
+    CK(hipMalloc((void **)&h->counters, 64));
+    CK(hipHostMalloc((void **)&h->counters_host, 64));
+    CK(hipMalloc((void **)&h->descs_dev, sizeof(MapDesc) * (GVOM_MAX_SLOTS + 1)));
+    CK(hipHostMalloc((void **)&h->descs_host, sizeof(MapDesc) * (GVOM_MAX_SLOTS + 1)));
+    double **maps[6] = {&h->height, &h->inferred, &h->slope_x, &h->slope_y, &h->rough, &h->guessed};
+    for (auto m : maps) CK(hipMalloc((void **)m, h->cells2d * 8));
+    CK(hipMalloc((void **)&h->out_pos, h->cells2d * 4));
+    CK(hipMalloc((void **)&h->out_neg, h->cells2d * 4));
+    CK(hipMalloc((void **)&h->out_vis, h->cells2d * 4));
+    CK(hipMalloc((void **)&h->out_rough, h->cells2d * 8));
+    CK(hipHostMalloc(&h->out_host, h->cells2d * 20));
+    for (auto &e : h->ev) CK(hipEventCreate(&e));
+    CK(hipStreamSynchronize(h->stream));
+#undef CK
+    *out = h;
+    return GVOM_OK;
+}
+
+// Scan kernels up to (not including) the commit.  `dev_pts` is device memory.
+int scan_launch(gvom_handle *h, const void *dev_pts, int64_t n, int64_t stride_elems, int dtype,
+                const double *tf)
+{
+    const gvom_params &p = h->prm;
+    int64_t origin[3];
+    origin[0] = (int64_t)floor((h->ego[0] / p.xy_resolution) - p.xy_size / 2.0);     // gvom.py:124
+    origin[1] = (int64_t)floor((h->ego[1] / p.xy_resolution) - p.xy_size / 2.0);
+    origin[2] = (int64_t)floor((h->ego[2] / p.z_resolution) - p.z_size / 2.0);
+    ScanParams P;
+    fill_scan_params(h, origin, tf, P);
+    Slot &st = h->slots[h->staging];
+    const size_t esz = dtype == GVOM_DTYPE_F32 ? 4 : 8;
+    int rc;
+    if ((rc = ensure(h, h->world_pts, (size_t)n * 3 * esz))) return rc;
+    const size_t cap = (size_t)n < h->slabV ? (size_t)n : h->slabV;      // C <= min(N, slab voxels)
+    if ((rc = ensure(h, st.chit, cap * 4))) return rc;
+    if ((rc = ensure(h, st.ctotal, cap * 4))) return rc;
+    if ((rc = ensure(h, st.cminh, cap * 4))) return rc;
+    HIPCHK(h, hipMemsetAsync(h->counters, 0, 4, h->stream));
+    if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+    HIPCHK(h, gvom_launch_trace(h->stream, P, dtype, dev_pts, stride_elems, n, h->world_pts.p, h->hit,
+                                h->total, st.state, h->counters));
+    if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+    HIPCHK(h, gvom_launch_encode(h->stream, p.xy_size, p.z_size, h->sy_lo, h->sy_hi, h->hit, h->total,
+                                 st.state, (uint32_t *)st.chit.p, (uint32_t *)st.ctotal.p,
+                                 (uint32_t *)st.cminh.p, nullptr));
+    if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
+    HIPCHK(h, gvom_launch_minh(h->stream, P, dtype, h->world_pts.p, n, st.state, (uint32_t *)st.cminh.p));
+    if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->counters_host, h->counters, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->profiling) {
+        hipEventElapsedTime(&h->stage_ms[0], h->ev[0], h->ev[1]);
+        hipEventElapsedTime(&h->stage_ms[1], h->ev[1], h->ev[2]);
+        hipEventElapsedTime(&h->stage_ms[2], h->ev[2], h->ev[3]);
+    }
+    st.count = h->counters_host[0];
+    st.origin[0] = origin[0]; st.origin[1] = origin[1]; st.origin[2] = origin[2];
+    st.stats_valid = false;
+    st.stats.points = n;
+    h->pending = true;
+    h->pending_n = n;
+    return GVOM_OK;
+}
+
+void scan_commit(gvom_handle *h, bool accept)
+{
+    if (!h->pending) return;
+    h->pending = false;
+    if (!accept) return;                                   // gvom.py:148-150: ring untouched
+    const int b = h->buffer_index;                         // gvom.py:163-175
+    const int old = h->ring[b];
+    h->ring[b] = h->staging;
+    h->staging = old;
+    h->slots[h->ring[b]].filled = true;
+    h->slots[old].filled = false;
+    h->last_buffer_index = b;
+    h->buffer_index = (b + 1 >= h->prm.buffer_size) ? 0 : b + 1;
+}
+
+int process_impl(gvom_handle *h, const void *xyz, bool on_device, int64_t n, int64_t row_stride_bytes,
+                 int dtype, const double ego[3], const double *tf, bool defer)
+{
+    if (!h || !ego || n < 0 || (dtype != GVOM_DTYPE_F32 && dtype != GVOM_DTYPE_F64))
+        return GVOM_ERR_INVALID;
+    const size_t esz = dtype == GVOM_DTYPE_F32 ? 4 : 8;
+    if (n > 0 && (!xyz || row_stride_bytes < (int64_t)(3 * esz) || row_stride_bytes % esz != 0))
+        return GVOM_ERR_INVALID;
+    if (n >= 2147483647LL) return GVOM_ERR_CAPACITY;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    h->ego[0] = ego[0]; h->ego[1] = ego[1]; h->ego[2] = ego[2];       // gvom.py:102-104
+    h->pending = false;
+    if (n == 0) return GVOM_EMPTY_CLOUD;                               // gvom.py:107-109
+    const void *dev = xyz;
+    if (!on_device) {
+        int rc = ensure(h, h->in_pts, (size_t)n * row_stride_bytes);
+        if (rc) return rc;
+        HIPCHK(h, hipMemcpyAsync(h->in_pts.p, xyz, (size_t)(n - 1) * row_stride_bytes + 3 * esz,
+                                 hipMemcpyHostToDevice, h->stream));
+        dev = h->in_pts.p;
+    }
+    int rc = scan_launch(h, dev, n, row_stride_bytes / (int64_t)esz, dtype, tf);
+    if (rc) return rc;
+    if (defer) return GVOM_OK;
+    const bool accept = h->slots[h->staging].count > 0;
+    scan_commit(h, accept);
+    return accept ? GVOM_OK : GVOM_NO_OVERLAP;
+}
+
+int choose_nz(int zs, int *zc)
+{
+    int nz = (zs + 15) / 16;
+    if (nz < 1) nz = 1;
+    if (nz > 16) nz = 16;
+    *zc = (zs + nz - 1) / nz;
+    return nz;
+}
+
+// fusion + column reductions (k_fuse) into fused[1 - cur]
+int fuse_impl(gvom_handle *h)
+{
+    const gvom_params &p = h->prm;
+    const Slot &last = h->slots[h->ring[h->last_buffer_index]];
+    if (!last.filled) return GVOM_EMPTY_BUFFER;                        // gvom.py:179-181
+    const int nxt = h->has_combined ? 1 - h->cur : 0;
+    Fused &F = h->fused[nxt];
+    const Fused *prev = (h->has_combined && h->fused[h->cur].valid) ? &h->fused[h->cur] : nullptr;
+    F.origin[0] = last.origin[0]; F.origin[1] = last.origin[1]; F.origin[2] = last.origin[2];
+    FuseParams P;
+    memset(&P, 0, sizeof P);
+    P.xy = p.xy_size; P.zs = p.z_size;
+    P.om[0] = (int)floor_mod(F.origin[0], p.xy_size);
+    P.om[1] = (int)floor_mod(F.origin[1], p.xy_size);
+    P.om[2] = (int)floor_mod(F.origin[2], p.z_size);
+    int ns = 0;
+    int64_t bound = 0;
+    for (int i = 0; i < p.buffer_size; ++i) {                          // slot order, gvom.py:198
+        const Slot &s = h->slots[h->ring[i]];
+        if (!s.filled) continue;
+        MapDesc &d = h->descs_host[ns++];
+        d.state = s.state; d.hit = (const uint32_t *)s.chit.p; d.total = (const uint32_t *)s.ctotal.p;
+        d.minh = (const uint32_t *)s.cminh.p;
+        d.d[0] = clamp_delta(F.origin[0] - s.origin[0], p.xy_size);
+        d.d[1] = clamp_delta(F.origin[1] - s.origin[1], p.xy_size);
+        d.d[2] = clamp_delta(F.origin[2] - s.origin[2], p.z_size);
+        d.pad = 0;
+        bound += s.count;
+    }
+    P.nslots = ns;
+    P.has_prev = prev ? 1 : 0;
+    if (prev) {
+        MapDesc &d = h->descs_host[ns];
+        d.state = prev->state; d.hit = (const uint32_t *)prev->hit.p;
+        d.total = (const uint32_t *)prev->total.p; d.minh = (const uint32_t *)prev->minh.p;
+        d.d[0] = clamp_delta(F.origin[0] - prev->origin[0], p.xy_size);
+        d.d[1] = clamp_delta(F.origin[1] - prev->origin[1], p.xy_size);
+        d.d[2] = clamp_delta(F.origin[2] - prev->origin[2], p.z_size);
+        d.pad = 0;
+        bound += prev->count;
+    }
+    if ((size_t)bound > h->slabV) bound = (int64_t)h->slabV;
+    int rc;
+    if ((rc = ensure(h, F.hit, (size_t)bound * 4))) return rc;
+    if ((rc = ensure(h, F.total, (size_t)bound * 4))) return rc;
+    if ((rc = ensure(h, F.minh, (size_t)bound * 4))) return rc;
+    P.sy_lo = h->sy_lo; P.sy_hi = h->sy_hi;
+    P.nz = choose_nz(p.z_size, &P.zc);
+    for (int k = 0; k < 3; ++k) { P.origin[k] = (double)F.origin[k]; P.ego[k] = h->ego[k]; }
+    P.xy_res = p.xy_resolution; P.z_res = p.z_resolution;
+    P.radius2 = p.robot_radius * p.robot_radius;
+    P.ground_to_lidar_height = p.ground_to_lidar_height;
+    HIPCHK(h, hipMemcpyAsync(h->descs_dev, h->descs_host, sizeof(MapDesc) * (ns + (prev ? 1 : 0)),
+                             hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->counters + 2, 0, 8, h->stream));
+    if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[4], h->stream));
+    HIPCHK(h, gvom_launch_fuse(h->stream, P, h->descs_dev, F.state, (uint32_t *)F.hit.p,
+                               (uint32_t *)F.total.p, (uint32_t *)F.minh.p,
+                               (unsigned long long *)(h->counters + 2), h->height, h->inferred));
+    if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[5], h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->counters_host + 2, h->counters + 2, 8, hipMemcpyDeviceToHost, h->stream));
+    F.valid = true;
+    h->cur = nxt;
+    h->has_combined = true;
+    h->maps_valid = false;
+    return GVOM_OK;
+}
+
+// 2-D maps (k_map2d) from height/inferred of the whole window (all rows must be present)
+int map2d_impl(gvom_handle *h, bool storage_order_out)
+{
+    const gvom_params &p = h->prm;
+    const Fused &F = h->fused[h->cur];
+    Map2dParams P;
+    memset(&P, 0, sizeof P);
+    P.xy = p.xy_size; P.zs = p.z_size;
+    P.om[0] = (int)floor_mod(F.origin[0], p.xy_size);
+    P.om[1] = (int)floor_mod(F.origin[1], p.xy_size);
+    P.om[2] = (int)floor_mod(F.origin[2], p.z_size);
+    P.y_lo = h->sy_lo; P.y_hi = h->sy_hi;
+    P.origin_z = (double)F.origin[2];
+    P.xy_res = p.xy_resolution; P.z_res = p.z_resolution;
+    P.pos_thr = p.positive_obstacle_threshold; P.neg_thr = p.negative_obstacle_threshold;
+    P.slope_thr = p.slope_obstacle_threshold; P.robot_height = p.robot_height;
+    P.out_storage_order = storage_order_out ? 1 : 0;
+    if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[6], h->stream));
+    HIPCHK(h, gvom_launch_map2d(h->stream, P, F.state, (const uint32_t *)F.hit.p,
+                                (const uint32_t *)F.total.p, h->height, h->inferred, h->slope_x,
+                                h->slope_y, h->rough, h->guessed, h->out_pos, h->out_neg, h->out_rough,
+                                h->out_vis));
+    if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[7], h->stream));
+    h->maps_valid = true;
+    return GVOM_OK;
+}
+
+int finish_combine(gvom_handle *h)
+{
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    Fused &F = h->fused[h->cur];
+    unsigned long long c;
+    memcpy(&c, h->counters_host + 2, 8);
+    F.count = (int64_t)c;
+    h->combined_cell_count = F.count;
+    if (h->profiling) {
+        hipEventElapsedTime(&h->stage_ms[3], h->ev[4], h->ev[5]);
+        hipEventElapsedTime(&h->stage_ms[4], h->ev[6], h->ev[7]);
+    }
+    return GVOM_OK;
+}
+
+}  // namespace
+
+// =========================================================================================
+// C ABI
+// =========================================================================================
+extern "C" {
+
+VIS int gvom_create(const gvom_params *params, int device_id, gvom_t **out)
+{
+    return create_impl(params, device_id, 0, 1, out);
+}
+
+VIS int gvom_create_sharded(const gvom_params *params, int device_id, int rank, int world, gvom_t **out)
+{
+    return create_impl(params, device_id, rank, world, out);
+}
+
+VIS void gvom_destroy(gvom_t *h)
+{
+    if (!h) return;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    auto fb = [](Buf &b) { if (b.p) hipFree(b.p); b.p = nullptr; b.bytes = 0; };
+    hipFree(h->hit); hipFree(h->total);
+    for (auto &s : h->slots) { hipFree(s.state); fb(s.chit); fb(s.ctotal); fb(s.cminh); }
+    for (auto &f : h->fused) { hipFree(f.state); fb(f.hit); fb(f.total); fb(f.minh); }
+    fb(h->in_pts); fb(h->world_pts);
+    hipFree(h->counters); if (h->counters_host) hipHostFree(h->counters_host);
+    hipFree(h->descs_dev); if (h->descs_host) hipHostFree(h->descs_host);
+    hipFree(h->height); hipFree(h->inferred); hipFree(h->slope_x); hipFree(h->slope_y);
+    hipFree(h->rough); hipFree(h->guessed);
+    hipFree(h->out_pos); hipFree(h->out_neg); hipFree(h->out_vis); hipFree(h->out_rough);
+    if (h->out_host) hipHostFree(h->out_host);
+    for (auto &e : h->ev) if (e) hipEventDestroy(e);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+VIS int gvom_process_pointcloud(gvom_t *h, const void *xyz, int64_t n, int64_t row_stride_bytes,
+                                int dtype, const double ego[3], const double *transform_4x4)
+{
+    return process_impl(h, xyz, false, n, row_stride_bytes, dtype, ego, transform_4x4, false);
+}
+
+VIS int gvom_process_pointcloud_device(gvom_t *h, const void *xyz_dev, int64_t n,
+                                       int64_t row_stride_bytes, int dtype, const double ego[3],
+                                       const double *transform_4x4)
+{
+    return process_impl(h, xyz_dev, true, n, row_stride_bytes, dtype, ego, transform_4x4, false);
+}
+
+// Sharded runs: run the scan kernels but leave the ring untouched until every rank's cell
+// count is known (the reference's "no overlap" test is on the global count, gvom.py:147-150).
+VIS int gvom_scan_begin(gvom_t *h, const void *xyz, int on_device, int64_t n, int64_t row_stride_bytes,
+                        int dtype, const double ego[3], const double *transform_4x4,
+                        int64_t *local_cells)
+{
+    int rc = process_impl(h, xyz, on_device != 0, n, row_stride_bytes, dtype, ego, transform_4x4, true);
+    if (local_cells) *local_cells = (rc == GVOM_OK) ? h->slots[h->staging].count : 0;
+    return rc;
+}
+
+VIS int gvom_scan_commit(gvom_t *h, int accept)
+{
+    if (!h) return GVOM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    scan_commit(h, accept != 0);
+    return GVOM_OK;
+}
+
+VIS int gvom_combine_maps(gvom_t *h, double origin_world[3], int32_t *positive, int32_t *negative,
+                          double *roughness, int32_t *visibility)
+{
+    if (!h) return GVOM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = fuse_impl(h);
+    if (rc) return rc;
+    if ((rc = map2d_impl(h, false))) return rc;
+    const size_t n2 = h->cells2d;
+    char *stage = (char *)h->out_host;
+    if (positive) HIPCHK(h, hipMemcpyAsync(stage, h->out_pos, n2 * 4, hipMemcpyDeviceToHost, h->stream));
+    if (negative) HIPCHK(h, hipMemcpyAsync(stage + n2 * 4, h->out_neg, n2 * 4, hipMemcpyDeviceToHost, h->stream));
+    if (visibility) HIPCHK(h, hipMemcpyAsync(stage + n2 * 8, h->out_vis, n2 * 4, hipMemcpyDeviceToHost, h->stream));
+    if (roughness) HIPCHK(h, hipMemcpyAsync(stage + n2 * 12, h->out_rough, n2 * 8, hipMemcpyDeviceToHost, h->stream));
+    if ((rc = finish_combine(h))) return rc;
+    if (positive) memcpy(positive, stage, n2 * 4);
+    if (negative) memcpy(negative, stage + n2 * 4, n2 * 4);
+    if (visibility) memcpy(visibility, stage + n2 * 8, n2 * 4);
+    if (roughness) memcpy(roughness, stage + n2 * 12, n2 * 8);
+    if (origin_world) {                                                // gvom.py:185-188
+        const Fused &F = h->fused[h->cur];
+        origin_world[0] = (double)F.origin[0] * h->prm.xy_resolution;
+        origin_world[1] = (double)F.origin[1] * h->prm.xy_resolution;
+        origin_world[2] = (double)F.origin[2] * h->prm.z_resolution;
+    }
+    return GVOM_OK;
+}
+
+// ---- split combine for the sharded layer (g-vom_amd/gvom_sharded.py) ---------------------
+// 1. gvom_combine_fuse: local slab fusion; height/inferred rows of this rank are valid.
+// 2. gvom_rows_export / gvom_rows_import: device<->device copies of 2-D map rows in storage
+//    order ([sy][sx], row range of a rank is contiguous) to/from caller-owned device buffers
+//    (the collectives run on those, e.g. torch.distributed all_gather over RCCL).
+// 3. gvom_combine_map2d: local rows of the four outputs, in storage order.
+// 4. gvom_finalize_outputs: storage order -> the reference's [x][y] window order (rank 0).
+VIS int gvom_combine_fuse(gvom_t *h, int64_t *local_cells)
+{
+    if (!h) return GVOM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = fuse_impl(h);
+    if (rc) return rc;
+    if ((rc = finish_combine(h))) return rc;
+    if (local_cells) *local_cells = h->fused[h->cur].count;
+    return GVOM_OK;
+}
+
+VIS int gvom_set_combined_cell_count(gvom_t *h, int64_t global_cells)
+{
+    if (!h) return GVOM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->combined_cell_count = global_cells;
+    return GVOM_OK;
+}
+
+static void *map_ptr(gvom_handle *h, int which, size_t *esz)
+{
+    *esz = 8;
+    switch (which) {
+    case GVOM_MAP_HEIGHT: return h->height;
+    case GVOM_MAP_INFERRED_HEIGHT: return h->inferred;
+    case GVOM_MAP_SLOPE_X: return h->slope_x;
+    case GVOM_MAP_SLOPE_Y: return h->slope_y;
+    case GVOM_MAP_ROUGHNESS: return h->rough;
+    case GVOM_MAP_GUESSED_DELTA: return h->guessed;
+    case 100: *esz = 4; return h->out_pos;
+    case 101: *esz = 4; return h->out_neg;
+    case 102: return h->out_rough;
+    case 103: *esz = 4; return h->out_vis;
+    default: return nullptr;
+    }
+}
+
+// copies storage rows [row_lo, row_hi) of map `which` (100..103 = the four outputs) between
+// the library's buffer and dev_buf (which holds exactly those rows, densely).
+VIS int gvom_rows_export(gvom_t *h, int which, int row_lo, int row_hi, void *dev_buf)
+{
+    if (!h || !dev_buf) return GVOM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    size_t esz; char *m = (char *)map_ptr(h, which, &esz);
+    if (!m || row_lo < 0 || row_hi > h->prm.xy_size || row_lo > row_hi) return GVOM_ERR_INVALID;
+    const size_t rb = (size_t)h->prm.xy_size * esz;
+    HIPCHK(h, hipMemcpyAsync(dev_buf, m + row_lo * rb, (row_hi - row_lo) * rb, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return GVOM_OK;
+}
+
+VIS int gvom_rows_import(gvom_t *h, int which, int row_lo, int row_hi, const void *dev_buf)
+{
+    if (!h || !dev_buf) return GVOM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    size_t esz; char *m = (char *)map_ptr(h, which, &esz);
+    if (!m || row_lo < 0 || row_hi > h->prm.xy_size || row_lo > row_hi) return GVOM_ERR_INVALID;
+    const size_t rb = (size_t)h->prm.xy_size * esz;
+    HIPCHK(h, hipMemcpyAsync(m + row_lo * rb, dev_buf, (row_hi - row_lo) * rb, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return GVOM_OK;
+}
+
+VIS int gvom_combine_map2d(gvom_t *h)
+{
+    if (!h) return GVOM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!h->has_combined) return GVOM_NO_DATA;
+    int rc = map2d_impl(h, true);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->profiling) hipEventElapsedTime(&h->stage_ms[4], h->ev[6], h->ev[7]);
+    return GVOM_OK;
+}
+
+VIS int gvom_finalize_outputs(gvom_t *h, double origin_world[3], int32_t *positive, int32_t *negative,
+                              double *roughness, int32_t *visibility);
+
+VIS int gvom_get_state(gvom_t *h, gvom_state *out)
+{
+    if (!h || !out) return GVOM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    memset(out, 0, sizeof *out);
+    out->buffer_index = h->buffer_index;
+    out->last_buffer_index = h->last_buffer_index;
+    out->has_combined = h->has_combined ? 1 : 0;
+    out->combined_cell_count = h->combined_cell_count;
+    if (h->has_combined)
+        for (int k = 0; k < 3; ++k) out->combined_origin[k] = (double)h->fused[h->cur].origin[k];
+    for (int k = 0; k < 3; ++k) out->ego_position[k] = h->ego[k];
+    return GVOM_OK;
+}
+
+VIS int gvom_slot_filled(gvom_t *h, int slot)
+{
+    if (!h || slot < 0 || slot >= h->prm.buffer_size) return GVOM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    return h->slots[h->ring[slot]].filled ? 1 : 0;
+}
+
+VIS int gvom_read_dense(gvom_t *h, int which, int32_t *state, int32_t *hit, int32_t *total,
+                        float *min_h, double origin[3], int64_t *cell_count)
+{
+    if (!h) return GVOM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    const int32_t *st; const uint32_t *ch, *ct, *cm; const int64_t *org; int64_t cnt;
+    if (which == GVOM_WHICH_FUSED) {
+        if (!h->has_combined) return GVOM_NO_DATA;
+        const Fused &F = h->fused[h->cur];
+        st = F.state; ch = (const uint32_t *)F.hit.p; ct = (const uint32_t *)F.total.p;
+        cm = (const uint32_t *)F.minh.p; org = F.origin; cnt = F.count;
+    } else {
+        if (which < 0 || which >= h->prm.buffer_size) return GVOM_ERR_INVALID;
+        const Slot &s = h->slots[h->ring[which]];
+        if (!s.filled) return GVOM_NO_DATA;
+        st = s.state; ch = (const uint32_t *)s.chit.p; ct = (const uint32_t *)s.ctotal.p;
+        cm = (const uint32_t *)s.cminh.p; org = s.origin; cnt = s.count;
+    }
+    const size_t V = h->V;
+    int32_t *tmp = nullptr;
+    HIPCHK(h, hipMalloc((void **)&tmp, V * 16));
+    int om[3] = {(int)floor_mod(org[0], h->prm.xy_size), (int)floor_mod(org[1], h->prm.xy_size),
+                 (int)floor_mod(org[2], h->prm.z_size)};
+    hipError_t e = gvom_launch_read_dense(h->stream, h->prm.xy_size, h->prm.z_size, om, st, ch, ct, cm,
+                                          tmp, tmp + V, tmp + 2 * V, (float *)(tmp + 3 * V));
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess && state) e = hipMemcpy(state, tmp, V * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && hit) e = hipMemcpy(hit, tmp + V, V * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && total) e = hipMemcpy(total, tmp + 2 * V, V * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && min_h) e = hipMemcpy(min_h, tmp + 3 * V, V * 4, hipMemcpyDeviceToHost);
+    hipFree(tmp);
+    HIPCHK(h, e);
+    if (origin) for (int k = 0; k < 3; ++k) origin[k] = (double)org[k];
+    if (cell_count) *cell_count = cnt;
+    return GVOM_OK;
+}
+
+VIS int gvom_read_map2d(gvom_t *h, int which2d, double *out)
+{
+    if (!h || !out) return GVOM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!h->has_combined || !h->maps_valid) return GVOM_NO_DATA;
+    HIPCHK(h, hipSetDevice(h->device));
+    size_t esz; const double *src = (const double *)map_ptr(h, which2d, &esz);
+    if (!src || esz != 8 || which2d >= 100) return GVOM_ERR_INVALID;
+    const Fused &F = h->fused[h->cur];
+    double *tmp = nullptr;
+    HIPCHK(h, hipMalloc((void **)&tmp, h->cells2d * 8));
+    hipError_t e = gvom_launch_unwrap_f64(h->stream, h->prm.xy_size, (int)floor_mod(F.origin[0], h->prm.xy_size),
+                                          (int)floor_mod(F.origin[1], h->prm.xy_size), src, tmp);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, tmp, h->cells2d * 8, hipMemcpyDeviceToHost);
+    hipFree(tmp);
+    HIPCHK(h, e);
+    return GVOM_OK;
+}
+
+VIS int gvom_finalize_outputs(gvom_t *h, double origin_world[3], int32_t *positive, int32_t *negative,
+                              double *roughness, int32_t *visibility)
+{
+    if (!h) return GVOM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!h->has_combined) return GVOM_NO_DATA;
+    HIPCHK(h, hipSetDevice(h->device));
+    const Fused &F = h->fused[h->cur];
+    const int om0 = (int)floor_mod(F.origin[0], h->prm.xy_size), om1 = (int)floor_mod(F.origin[1], h->prm.xy_size);
+    const size_t n2 = h->cells2d;
+    void *tmp = nullptr;
+    HIPCHK(h, hipMalloc(&tmp, n2 * 8));
+    hipError_t e = hipSuccess;
+    struct { void *src; void *dst; int esz; } jobs[4] = {
+        {h->out_pos, positive, 4}, {h->out_neg, negative, 4}, {h->out_rough, roughness, 8}, {h->out_vis, visibility, 4}};
+    for (auto &j : jobs) {
+        if (!j.dst || e != hipSuccess) continue;
+        if (j.esz == 8) e = gvom_launch_unwrap_f64(h->stream, h->prm.xy_size, om0, om1, (const double *)j.src, (double *)tmp);
+        else e = gvom_launch_unwrap_i32(h->stream, h->prm.xy_size, om0, om1, (const int32_t *)j.src, (int32_t *)tmp);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e == hipSuccess) e = hipMemcpy(j.dst, tmp, n2 * j.esz, hipMemcpyDeviceToHost);
+    }
+    hipFree(tmp);
+    HIPCHK(h, e);
+    if (origin_world) {
+        origin_world[0] = (double)F.origin[0] * h->prm.xy_resolution;
+        origin_world[1] = (double)F.origin[1] * h->prm.xy_resolution;
+        origin_world[2] = (double)F.origin[2] * h->prm.z_resolution;
+    }
+    return GVOM_OK;
+}
+
+VIS int gvom_get_occupancy(gvom_t *h, uint8_t *out_xyz)
+{
+    if (!h || !out_xyz) return GVOM_ERR_INVALID;
+    std::vector<int32_t> st;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        if (!h->has_combined) return GVOM_NO_DATA;
+        st.resize(h->V);
+    }
+    int rc = gvom_read_dense(h, GVOM_WHICH_FUSED, st.data(), nullptr, nullptr, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    const int xy = h->prm.xy_size, zs = h->prm.z_size;
+    // reference: lookup.reshape((xy, xy, z), order='F') >= 0  -> out[x][y][z]
+    for (int x = 0; x < xy; ++x)
+        for (int y = 0; y < xy; ++y)
+            for (int z = 0; z < zs; ++z)
+                out_xyz[((size_t)x * xy + y) * zs + z] = st[(size_t)x + (size_t)y * xy + (size_t)z * xy * xy] >= 0;
+    return GVOM_OK;
+}
+
+static int debug_maps(gvom_t *h, float *out7, float *out3)
+{
+    if (!h) return GVOM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!h->has_combined || !h->maps_valid) return GVOM_NO_DATA;      // gvom.py:381-383
+    HIPCHK(h, hipSetDevice(h->device));
+    const Fused &F = h->fused[h->cur];
+    const size_t n2 = h->cells2d;
+    float *tmp = nullptr;
+    HIPCHK(h, hipMalloc((void **)&tmp, n2 * 7 * 4));
+    double org[3] = {(double)F.origin[0], (double)F.origin[1], (double)F.origin[2]};
+    hipError_t e = gvom_launch_debug_height(h->stream, h->prm.xy_size, (int)floor_mod(F.origin[0], h->prm.xy_size),
+                                            (int)floor_mod(F.origin[1], h->prm.xy_size), org,
+                                            h->prm.xy_resolution, h->prm.z_resolution, h->height, h->rough,
+                                            h->slope_x, h->slope_y, out7 ? tmp : nullptr, h->guessed,
+                                            out3 ? tmp : nullptr);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) e = hipMemcpy(out7 ? out7 : out3, tmp, n2 * (out7 ? 7 : 3) * 4, hipMemcpyDeviceToHost);
+    hipFree(tmp);
+    HIPCHK(h, e);
+    return GVOM_OK;
+}
+
+VIS int gvom_debug_height_map(gvom_t *h, float *out) { return out ? debug_maps(h, out, nullptr) : GVOM_ERR_INVALID; }
+VIS int gvom_debug_inferred_height_map(gvom_t *h, float *out) { return out ? debug_maps(h, nullptr, out) : GVOM_ERR_INVALID; }
+
+VIS int gvom_get_scan_stats(gvom_t *h, gvom_scan_stats *out)
+{
+    if (!h || !out) return GVOM_ERR_INVALID;
+    int slot;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        slot = h->last_buffer_index;
+        if (!h->slots[h->ring[slot]].filled) return GVOM_NO_DATA;
+    }
+    const size_t V = h->V;
+    std::vector<int32_t> hit(V), total(V);
+    int64_t cells = 0;
+    int rc = gvom_read_dense(h, slot, nullptr, hit.data(), nullptr, nullptr, nullptr, &cells);
+    if (rc) return rc;
+    // total of free voxels lives in the state code; read it densely
+    std::vector<int32_t> state(V);
+    rc = gvom_read_dense(h, slot, state.data(), nullptr, total.data(), nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    int64_t sh = 0, st = 0;
+    for (size_t i = 0; i < V; ++i) {
+        sh += hit[i];
+        st += state[i] >= 0 ? (int64_t)total[i] : (int64_t)(-(int64_t)state[i] - 1);
+    }
+    std::lock_guard<std::mutex> lk(h->mu);
+    out->points = h->slots[h->ring[slot]].stats.points;
+    out->cells = cells; out->sum_hit = sh; out->sum_total = st;
+    return GVOM_OK;
+}
+
+VIS int gvom_last_stage_ms(gvom_t *h, float ms[GVOM_N_STAGES])
+{
+    if (!h || !ms) return GVOM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    for (int k = 0; k < GVOM_N_STAGES; ++k) ms[k] = h->stage_ms[k];
+    return GVOM_OK;
+}
+
+VIS int gvom_set_profiling(gvom_t *h, int on)
+{
+    if (!h) return GVOM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->profiling = on != 0;
+    return GVOM_OK;
+}
+
+VIS void *gvom_stream(gvom_t *h) { return h ? (void *)h->stream : nullptr; }
+
+VIS const char *gvom_last_error(gvom_t *h) { return h ? h->err.c_str() : "null handle"; }
+
+VIS int gvom_backend_info(char *buf, size_t len)
+{
+    if (!buf || len == 0) return GVOM_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        snprintf(buf, len, "libgvom_hip abi %d (gfx950 code object); no HIP device visible", GVOM_ABI_VERSION);
+        return GVOM_ERR_NO_DEVICE;
+    }
+    hipDeviceProp_t pr;
+    if (hipGetDeviceProperties(&pr, 0) != hipSuccess) return GVOM_ERR_HIP;
+    snprintf(buf, len, "libgvom_hip abi %d; device0=%s arch=%s CUs=%d; %d device(s)", GVOM_ABI_VERSION,
+             pr.name, pr.gcnArchName, pr.multiProcessorCount, ndev);
+    return GVOM_OK;
+}
+
+VIS int gvom_abi_version(void) { return GVOM_ABI_VERSION; }
+
+}  // extern "C"

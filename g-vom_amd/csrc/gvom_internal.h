@@ -1,0 +1,96 @@
+// gvom_internal.h -- shared between the kernels (gvom_kernels.hip) and the C-ABI host
+// layer (gvom_capi.hip).  Not part of the public interface (include/gvom_hip.h is).
+//
+// STORAGE LAYOUT (DESIGN.md "Data layout in HBM")
+//   Voxels are stored WORLD-ANCHORED (toroidal): the voxel with world index (xw, yw, zw)
+//   lives at storage coordinates (sx, sy, sz) = (xw mod xy, yw mod xy, zw mod zs) and linear
+//   index L = (sy * zs + sz) * xy + sx   -- x fastest (coalesced 64-lane rows), then z (a
+//   whole column of one y-row is a contiguous xy*zs*4-byte block), y slowest (multi-GPU
+//   slabs are contiguous).  Every per-voxel array of every scan and of the fused map uses
+//   the same L for the same world voxel, so temporal fusion is element-wise and rows
+//   never migrate between GPUs when the robot-centred window moves.
+//   A map with integer origin o (window voxel (0,0,0) == world voxel o) converts window
+//   coordinates with om = o mod size:  s = w + om (minus size if >= size).
+//   2-D maps are stored in the same anchoring: [sy][sx] (x fastest); a rank's rows are one
+//   contiguous block, so the height-map all-gather of a sharded run is a plain all_gather.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define GVOM_MAX_SLOTS 64
+
+struct ScanParams {
+    double xy_res, z_res;
+    double min_d2;        // min_distance * min_distance (f64 product, gvom.py:1067)
+    double origin[3];     // window origin in voxels, integer valued (gvom.py:123-126)
+    double tf[12];        // rows 0..2 of the 4x4 (gvom.py:1044-1052)
+    float  pt0[3];        // (float)(ego / res)  (gvom.py:1097-1099)
+    int    has_tf;
+    int    xy, zs;
+    int    om[3];         // origin mod size (storage offset)
+    int    sy_lo, sy_hi;  // storage rows owned by this rank: [sy_lo, sy_hi)
+};
+
+struct MapDesc {          // one source map of the fusion (ring slot or previous fused map)
+    const int32_t  *state;
+    const uint32_t *hit;
+    const uint32_t *total;
+    const uint32_t *minh;   // float bits
+    int d[3];               // fused origin - this map's origin (window shift), clamped
+    int pad;
+};
+
+struct FuseParams {
+    int xy, zs;
+    int om[3];              // fused origin mod size
+    int nslots;             // number of non-empty ring slots (descs[0..nslots))
+    int has_prev;           // descs[nslots] is the previous fused map
+    int sy_lo, sy_hi;
+    int nz;                 // z-chunks per workgroup (block = 64 * nz threads)
+    int zc;                 // window-z cells per chunk (<= 64)
+    double origin[3];       // fused origin (voxels)
+    double ego[3];          // latest ego (gvom.py:294-295)
+    double xy_res, z_res;
+    double radius2;         // robot_radius^2 (gvom.py:533)
+    double ground_to_lidar_height;
+};
+
+struct Map2dParams {
+    int xy, zs;
+    int om[3];
+    int y_lo, y_hi;         // STORAGE rows [sy] computed by this rank
+    int out_storage_order;  // 1: the four outputs stay [sy][sx] (sharded runs); 0: reference [x][y]
+    double origin_z;        // fused origin z (voxels)
+    double xy_res, z_res;
+    double pos_thr, neg_thr, slope_thr, robot_height;
+};
+
+// ---- launchers (gvom_kernels.hip) --------------------------------------------------------
+hipError_t gvom_launch_trace(hipStream_t s, const ScanParams &P, int dtype, const void *pts,
+                             int64_t stride_elems, int64_t n, void *world, uint32_t *hit,
+                             uint32_t *total, int32_t *state, uint32_t *counters);
+hipError_t gvom_launch_encode(hipStream_t s, int xy, int zs, int sy_lo, int sy_hi, uint32_t *hit,
+                              uint32_t *total, int32_t *state, uint32_t *chit, uint32_t *ctotal,
+                              uint32_t *cminh, unsigned long long *sums);
+hipError_t gvom_launch_minh(hipStream_t s, const ScanParams &P, int dtype, const void *world,
+                            int64_t n, const int32_t *state, uint32_t *cminh);
+hipError_t gvom_launch_fuse(hipStream_t s, const FuseParams &P, const MapDesc *descs_dev,
+                            int32_t *fstate, uint32_t *fhit, uint32_t *ftotal, uint32_t *fminh,
+                            unsigned long long *counter, double *height, double *inferred);
+hipError_t gvom_launch_map2d(hipStream_t s, const Map2dParams &P, const int32_t *fstate,
+                             const uint32_t *fhit, const uint32_t *ftotal, const double *height,
+                             const double *inferred, double *slope_x, double *slope_y,
+                             double *rough, double *guessed, int32_t *out_pos, int32_t *out_neg,
+                             double *out_rough, int32_t *out_vis);
+// test hooks / debug accessors
+hipError_t gvom_launch_read_dense(hipStream_t s, int xy, int zs, const int om[3],
+                                  const int32_t *state, const uint32_t *chit,
+                                  const uint32_t *ctotal, const uint32_t *cminh, int32_t *o_state,
+                                  int32_t *o_hit, int32_t *o_total, float *o_minh);
+// storage order [sy][sx] -> reference order [x][y] (window coordinates)
+hipError_t gvom_launch_unwrap_f64(hipStream_t s, int xy, int om0, int om1, const double *in, double *out_xy);
+hipError_t gvom_launch_unwrap_i32(hipStream_t s, int xy, int om0, int om1, const int32_t *in, int32_t *out_xy);
+hipError_t gvom_launch_debug_height(hipStream_t s, int xy, int om0, int om1, const double origin[3], double xy_res,
+                                    double z_res, const double *height, const double *rough,
+                                    const double *sx, const double *sy, float *out7,
+                                    const double *guessed, float *out3);

@@ -1,0 +1,735 @@
+// gvom_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the G-VOM hot path.
+//
+// Five kernels replace the reference's ~55 Numba-CUDA launches per scan+combine
+// (reference: /root/reference/scripts/gvom.py, cited as "gvom.py:NNN"):
+//
+//   k_trace   gvom.py:1040-1056 (transform) + :1060-1150 (hit + dominant-axis DDA)
+//             + the row-claim half of :1154-1160 (first hit of a voxel claims its compact row)
+//   k_encode  gvom.py:1154-1168 (state code + dense->compact move) + the three V-sized clears
+//             of :114-121 (accumulators are cleared as they are read; no separate fill)
+//   k_minh    gvom.py:1303-1329 (+ fill :1014-1015 folded into k_encode)
+//   k_fuse    gvom.py:943-968 x slots, :972-997, :821-912 (count/min lines 910-912) x (slots+1),
+//             :525-540 (height) and :544-554 (inferred height): ONE pass over the fused grid
+//   k_map2d   gvom.py:665-734 (slope/roughness), :558-661 (guess height), :489-521 (positive),
+//             :479-485 (negative), :414-422 (visibility)
+//
+// Numerics are the reference's as executed by the Numba simulator:
+// compile with -ffp-contract=off, IEEE division/sqrt, no fast-math.  Integer results are
+// bit-exact; only log()/atan2() may differ from glibc in the last ulp.
+//
+// No MFMA: there is no dense contraction on this path.  The work is scattered 4-byte
+// atomics (k_trace) and streaming passes over V = xy*xy*zs voxels (k_encode, k_fuse).
+#include "gvom_internal.h"
+#include <limits.h>
+
+#define WAVE 64
+
+__device__ __forceinline__ int wrap_add(int a, int b, int n) { int s = a + b; return s >= n ? s - n : s; }
+__device__ __forceinline__ int wrap_sub(int a, int b, int n) { int s = a - b; return s < 0 ? s + n : s; }
+// Python's max(a, b): a unless b > a  (gvom.py:1116; differs from fmaxf only for NaN)
+__device__ __forceinline__ float py_maxf(float a, float b) { return (b > a) ? b : a; }
+__device__ __forceinline__ double py_maxd(double a, double b) { return (b > a) ? b : a; }
+__device__ __forceinline__ double py_mind(double a, double b) { return (b < a) ? b : a; }
+__device__ __forceinline__ unsigned long long lanemask_lt() {
+    return (1ull << (threadIdx.x & 63)) - 1ull;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_trace: one lane per lidar return.
+//   1. optional rigid transform (f64, written back in the cloud's dtype)      gvom.py:1040-1056
+//   2. min-distance reject measured from the WORLD origin                       gvom.py:1064-1068
+//   3. endpoint voxel: hit += 1, total += 1; the lane that sees hit go 0 -> 1 claims the
+//      voxel's compact row with ONE wave-aggregated atomic (ballot + popcount)  gvom.py:1070-1090,1158
+//   4. dominant-axis DDA from the ego position, total += 1 per step             gvom.py:1093-1150
+// Only voxels whose storage row sy lies in [sy_lo, sy_hi) are committed (multi-GPU slabs).
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_trace(const ScanParams P, const T *__restrict__ in,
+                                               long stride, long n, T *__restrict__ world,
+                                               uint32_t *hit, uint32_t *total, int32_t *state,
+                                               uint32_t *counters)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < n;
+    T x = 0, y = 0, z = 0;
+    if (live) {
+        const T *p = in + i * stride;
+        x = p[0]; y = p[1]; z = p[2];
+        if (P.has_tf) {
+            const double dx = (double)x, dy = (double)y, dz = (double)z;
+            const double o0 = ((dx * P.tf[0] + dy * P.tf[1]) + dz * P.tf[2]) + P.tf[3];
+            const double o1 = ((dx * P.tf[4] + dy * P.tf[5]) + dz * P.tf[6]) + P.tf[7];
+            const double o2 = ((dx * P.tf[8] + dy * P.tf[9]) + dz * P.tf[10]) + P.tf[11];
+            x = (T)o0; y = (T)o1; z = (T)o2;
+        }
+        world[3 * i + 0] = x; world[3 * i + 1] = y; world[3 * i + 2] = z;
+    }
+    const T d2 = (x * x + y * y) + z * z;
+    const bool pass = live && !((double)d2 < P.min_d2);
+    const double dxy = (double)P.xy, dzs = (double)P.zs;
+
+    // ---- endpoint ------------------------------------------------------------------------
+    bool ingrid = false;
+    uint32_t L = 0;
+    if (pass) {
+        const double fx = floor((double)x / P.xy_res - P.origin[0]);
+        const double fy = floor((double)y / P.xy_res - P.origin[1]);
+        const double fz = floor((double)z / P.z_res - P.origin[2]);
+        if (fx >= 0.0 && fx < dxy && fy >= 0.0 && fy < dxy && fz >= 0.0 && fz < dzs) {
+            const int sx = wrap_add((int)fx, P.om[0], P.xy);
+            const int sy = wrap_add((int)fy, P.om[1], P.xy);
+            const int sz = wrap_add((int)fz, P.om[2], P.zs);
+            if (sy >= P.sy_lo && sy < P.sy_hi) {
+                ingrid = true;
+                L = ((uint32_t)sy * P.zs + sz) * P.xy + sx;
+            }
+        }
+    }
+    uint32_t old = 1;
+    if (ingrid) {
+        old = atomicAdd(&hit[L], 1u);
+        atomicAdd(&total[L], 1u);
+    }
+    const bool claim = ingrid && old == 0;
+    const unsigned long long cm = __ballot(claim);
+    if (cm != 0ull) {                                   // wave-uniform
+        const int leader = __ffsll((long long)cm) - 1;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&counters[0], (uint32_t)__popcll(cm));
+        base = __shfl(base, leader);
+        if (claim) state[L] = (int32_t)(base + (uint32_t)__popcll(cm & lanemask_lt()));
+    }
+    if (!pass) return;
+
+    // ---- ray ------------------------------------------------------------------------------
+    const float e0 = (float)((double)x / P.xy_res);
+    const float e1 = (float)((double)y / P.xy_res);
+    const float e2 = (float)((double)z / P.z_res);
+    float s0 = e0 - P.pt0[0], s1 = e1 - P.pt0[1], s2 = e2 - P.pt0[2];
+    const float ss = (s0 * s0 + s1 * s1) + s2 * s2;
+    const double ray_length = sqrt((double)ss);          // math.sqrt -> f64
+    s0 = (float)((double)s0 / ray_length);
+    s1 = (float)((double)s1 / ray_length);
+    s2 = (float)((double)s2 / ray_length);
+    const float a0 = fabsf(s0), a1 = fabsf(s1), a2 = fabsf(s2);
+    const float smax = py_maxf(a0, py_maxf(a1, a2));
+    int si = 0;
+    if (smax == a1) si = 1;
+    if (smax == a2) si = 2;                              // ties: z over y over x
+    // axis permutation kept in registers: (d, o1, o2) = (si, si+1, si+2) mod 3
+    const float sd  = si == 0 ? s0 : (si == 1 ? s1 : s2);
+    const float so1 = si == 0 ? s1 : (si == 1 ? s2 : s0);
+    const float so2 = si == 0 ? s2 : (si == 1 ? s0 : s1);
+    const float adom = fabsf(sd);
+    const float dir = sd / adom;
+    const float inc1 = so1 / adom;
+    const float inc2 = so2 / adom;
+    const double step_len = fabs(1.0 / (double)sd);
+    float pd = si == 0 ? P.pt0[0] : (si == 1 ? P.pt0[1] : P.pt0[2]);
+    float p1 = si == 0 ? P.pt0[1] : (si == 1 ? P.pt0[2] : P.pt0[0]);
+    float p2 = si == 0 ? P.pt0[2] : (si == 1 ? P.pt0[0] : P.pt0[1]);
+    double length = 0.0;
+    const double lim = ray_length - 1.0;
+    while (length < lim) {
+        pd = pd + dir; p1 = p1 + inc1; p2 = p2 + inc2;
+        const float px = si == 0 ? pd : (si == 1 ? p2 : p1);
+        const float py = si == 0 ? p1 : (si == 1 ? pd : p2);
+        const float pz = si == 0 ? p2 : (si == 1 ? p1 : pd);
+        const double fx = floor((double)px - P.origin[0]);
+        if (!(fx >= 0.0 && fx < dxy)) break;
+        const double fy = floor((double)py - P.origin[1]);
+        if (!(fy >= 0.0 && fy < dxy)) break;
+        const double fz = floor((double)pz - P.origin[2]);
+        if (!(fz >= 0.0 && fz < dzs)) break;
+        const int sy = wrap_add((int)fy, P.om[1], P.xy);
+        if (sy >= P.sy_lo && sy < P.sy_hi) {
+            const int sx = wrap_add((int)fx, P.om[0], P.xy);
+            const int sz = wrap_add((int)fz, P.om[2], P.zs);
+            atomicAdd(&total[((uint32_t)sy * P.zs + sz) * P.xy + sx], 1u);
+        }
+        length += step_len;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_encode: one streaming pass over the slab's accumulators.
+//   occupied (hit > 0): row was claimed in k_trace -> move hit/total to the compact arrays,
+//                       initialise min-height to 1.0f                  gvom.py:1164-1168,1014
+//   else              : state = -total - 1                             gvom.py:1160
+//   and the accumulators are zeroed for the next scan (replaces the fills of gvom.py:114-121).
+// 4 voxels per lane (16-byte loads/stores) when the slab is 16-byte tileable.
+// ------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void k_encode(size_t begin, size_t count, uint32_t *hit,
+                                                uint32_t *total, int32_t *state, uint32_t *chit,
+                                                uint32_t *ctotal, uint32_t *cminh)
+{
+    const size_t nvec = count / VEC;
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec;
+         v += (size_t)gridDim.x * blockDim.x) {
+        const size_t L0 = begin + v * VEC;
+        uint32_t h[VEC], t[VEC];
+        int32_t st[VEC];
+        if (VEC == 4) {
+            const uint4 hv = *reinterpret_cast<const uint4 *>(hit + L0);
+            const uint4 tv = *reinterpret_cast<const uint4 *>(total + L0);
+            h[0] = hv.x; h[1 % VEC] = hv.y; h[2 % VEC] = hv.z; h[3 % VEC] = hv.w;
+            t[0] = tv.x; t[1 % VEC] = tv.y; t[2 % VEC] = tv.z; t[3 % VEC] = tv.w;
+        } else {
+            h[0] = hit[L0]; t[0] = total[L0];
+        }
+        uint32_t any_h = 0, any_t = 0;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) { any_h |= h[k]; any_t |= t[k]; }
+        if (any_h) {                                   // rare: some voxel of the vector is occupied
+            int32_t rows[VEC];
+            if (VEC == 4) {
+                const int4 sv = *reinterpret_cast<const int4 *>(state + L0);
+                rows[0] = sv.x; rows[1 % VEC] = sv.y; rows[2 % VEC] = sv.z; rows[3 % VEC] = sv.w;
+            } else rows[0] = state[L0];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                if (h[k] > 0) {
+                    const int32_t row = rows[k];
+                    chit[row] = h[k]; ctotal[row] = t[k]; cminh[row] = 0x3f800000u;
+                    st[k] = row;
+                } else st[k] = -(int32_t)t[k] - 1;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) st[k] = -(int32_t)t[k] - 1;
+        }
+        if (VEC == 4) {
+            *reinterpret_cast<int4 *>(state + L0) = make_int4(st[0], st[1 % VEC], st[2 % VEC], st[3 % VEC]);
+            if (any_h) *reinterpret_cast<uint4 *>(hit + L0) = make_uint4(0, 0, 0, 0);
+            if (any_t) *reinterpret_cast<uint4 *>(total + L0) = make_uint4(0, 0, 0, 0);
+        } else {
+            state[L0] = st[0];
+            if (any_h) hit[L0] = 0;
+            if (any_t) total[L0] = 0;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_minh: per in-grid return, f32 atomic-min of the fractional z inside its voxel, keyed by
+// the voxel's compact row (gvom.py:1303-1329).  The value is a - floor(a) >= 0, so the float
+// order equals the order of its bit pattern and an unsigned atomicMin is exact.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_minh(const ScanParams P, const T *__restrict__ world,
+                                              long n, const int32_t *__restrict__ state,
+                                              uint32_t *cminh)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const T x = world[3 * i + 0], y = world[3 * i + 1], z = world[3 * i + 2];
+    const T d2 = (x * x + y * y) + z * z;
+    if ((double)d2 < P.min_d2) return;
+    const double fx = floor((double)x / P.xy_res - P.origin[0]);
+    if (!(fx >= 0.0 && fx < (double)P.xy)) return;
+    const double fy = floor((double)y / P.xy_res - P.origin[1]);
+    if (!(fy >= 0.0 && fy < (double)P.xy)) return;
+    const double az = (double)z / P.z_res - P.origin[2];
+    const double fz = floor(az);
+    if (!(fz >= 0.0 && fz < (double)P.zs)) return;
+    const int sy = wrap_add((int)fy, P.om[1], P.xy);
+    if (sy < P.sy_lo || sy >= P.sy_hi) return;
+    const int sx = wrap_add((int)fx, P.om[0], P.xy);
+    const int sz = wrap_add((int)fz, P.om[2], P.zs);
+    const int32_t row = state[((uint32_t)sy * P.zs + sz) * P.xy + sx];
+    const float v = (float)(az - fz);                   // local_point[2], f64 -> f32 (gvom.py:1326,1329)
+    if (row >= 0) atomicMin(&cminh[row], __float_as_uint(v));
+}
+
+// ------------------------------------------------------------------------------------------
+// k_fuse: temporal fusion + per-column height reductions in ONE pass over the fused grid.
+//
+// Workgroup = 64 storage columns (consecutive sx of one storage row sy) x all z, as nz waves
+// that each own a chunk of <= 64 consecutive WINDOW z levels.  Storage is world-anchored, so
+// every source map holds the voxel at the same linear index L and only a window test
+// (is this world voxel inside the source's window?) replaces the reference's shifted gather.
+//
+// Pass A  per voxel: fold the ring slots in slot order, then the previous fused map
+//         (gvom.py:963-968, 992-997) into "occupied" or a free/unknown code; non-occupied
+//         codes are stored right away; occupied voxels are remembered in a 64-bit mask.
+//         Wave popcounts -> LDS scan -> ONE global atomic per workgroup reserves its rows.
+// Pass B  per occupied voxel: ballot/prefix-sum row assignment, hit/total sums and min-height
+//         min over every source where the voxel is occupied (gvom.py:910-912).
+// Tail    lowest occupied z (+ its min-height) and lowest observed-free z per column are
+//         combined across the nz waves through LDS -> height_map / inferred_height_map.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_fuse(const FuseParams P, const MapDesc *__restrict__ descs,
+                                               int32_t *fstate, uint32_t *fhit, uint32_t *ftotal,
+                                               uint32_t *fminh, unsigned long long *counter,
+                                               double *height, double *inferred)
+{
+    __shared__ uint32_t s_wave_tot[16];
+    __shared__ uint32_t s_base;
+    __shared__ int s_zocc[16][WAVE];
+    __shared__ uint32_t s_hocc[16][WAVE];
+    __shared__ int s_zfree[16][WAVE];
+
+    const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x >> 6;
+    const int sx = blockIdx.x * WAVE + lane;
+    const int sy = P.sy_lo + blockIdx.y;
+    const bool col_ok = sx < P.xy;
+    const int x = wrap_sub(col_ok ? sx : 0, P.om[0], P.xy);
+    const int y = wrap_sub(sy, P.om[1], P.xy);
+    const int nsrc = P.nslots + P.has_prev;
+
+    unsigned long long okmask = 0ull;                    // sources whose window contains (x, y)
+    for (int s = 0; s < nsrc; ++s) {
+        const int xs = x + descs[s].d[0], ys = y + descs[s].d[1];
+        if (xs >= 0 && xs < P.xy && ys >= 0 && ys < P.xy) okmask |= 1ull << s;
+    }
+    if (!col_ok) okmask = 0ull;
+
+    const int z0 = w * P.zc;
+    const int z1 = min(z0 + P.zc, P.zs);
+    const uint32_t colbase = (uint32_t)sy * P.zs * P.xy + (col_ok ? sx : 0);
+    unsigned long long occmask = 0ull;
+    int zocc = INT_MAX, zfree = INT_MAX;
+
+    // ---- pass A ----------------------------------------------------------------------------
+    for (int z = z0; z < z1; ++z) {
+        const int sz = wrap_add(z, P.om[2], P.zs);
+        const uint32_t L = colbase + (uint32_t)sz * P.xy;
+        int c = -1;
+        bool occ = false;
+        for (int s = 0; s < P.nslots; ++s) {
+            const int zs_ = z + descs[s].d[2];
+            if (((okmask >> s) & 1ull) && zs_ >= 0 && zs_ < P.zs) {
+                const int st = descs[s].state[L];
+                if (st >= 0) occ = true;                                  // gvom.py:963
+                else if (st < -1 && !occ) c += st + 1;                    // gvom.py:967
+            }
+        }
+        if (P.has_prev) {
+            const int s = P.nslots;
+            const int zs_ = z + descs[s].d[2];
+            if (((okmask >> s) & 1ull) && zs_ >= 0 && zs_ < P.zs && !occ) {
+                const int p = descs[s].state[L];
+                if (p >= 0 && c >= -11) occ = true;                       // gvom.py:992
+                else if (p < -1) c += p + 1;                              // gvom.py:996
+            }
+        }
+        if (col_ok) {
+            if (occ) {
+                occmask |= 1ull << (z - z0);
+                if (zocc == INT_MAX) zocc = z;
+            } else {
+                fstate[L] = c;
+                if (c < -1 && zfree == INT_MAX) zfree = z;                // gvom.py:551
+            }
+        }
+    }
+
+    // ---- reserve rows: one atomic per workgroup ------------------------------------------
+    const uint32_t wt = wave_sum((uint32_t)__popcll(occmask));
+    if (lane == 0) s_wave_tot[w] = wt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int k = 0; k < P.nz; ++k) { const uint32_t t = s_wave_tot[k]; s_wave_tot[k] = tot; tot += t; }
+        s_base = tot ? (uint32_t)atomicAdd(counter, (unsigned long long)tot) : 0u;
+    }
+    __syncthreads();
+    uint32_t running = s_base + s_wave_tot[w];
+
+    // ---- pass B ----------------------------------------------------------------------------
+    uint32_t hocc = 0x3f800000u;
+    if (wt != 0) {                                       // wave-uniform
+        for (int z = z0; z < z1; ++z) {
+            const bool occ = (occmask >> (z - z0)) & 1ull;
+            const unsigned long long b = __ballot(occ);
+            if (b == 0ull) continue;
+            if (occ) {
+                const int sz = wrap_add(z, P.om[2], P.zs);
+                const uint32_t L = colbase + (uint32_t)sz * P.xy;
+                const uint32_t row = running + (uint32_t)__popcll(b & lanemask_lt());
+                uint32_t h = 0, t = 0, m = 0x3f800000u;  // gvom.py:222-228 (0, 0, 1.0f)
+                for (int s = 0; s < nsrc; ++s) {
+                    const int zs_ = z + descs[s].d[2];
+                    if (((okmask >> s) & 1ull) && zs_ >= 0 && zs_ < P.zs) {
+                        const int st = descs[s].state[L];
+                        if (st >= 0) {                                    // gvom.py:841,910-912
+                            h += descs[s].hit[st];
+                            t += descs[s].total[st];
+                            m = min(m, descs[s].minh[st]);
+                        }
+                    }
+                }
+                fstate[L] = (int32_t)row;
+                fhit[row] = h; ftotal[row] = t; fminh[row] = m;
+                if (z == zocc) hocc = m;
+            }
+            running += (uint32_t)__popcll(b);
+        }
+    }
+
+    // ---- column tail: height (gvom.py:525-540) and inferred height (gvom.py:544-554) ------
+    s_zocc[w][lane] = zocc; s_hocc[w][lane] = hocc; s_zfree[w][lane] = zfree;
+    __syncthreads();
+    if (w == 0 && col_ok) {
+        int zo = INT_MAX, zf = INT_MAX;
+        uint32_t hb = 0x3f800000u;
+        for (int k = 0; k < P.nz; ++k) {
+            if (zo == INT_MAX && s_zocc[k][lane] != INT_MAX) { zo = s_zocc[k][lane]; hb = s_hocc[k][lane]; }
+            if (zf == INT_MAX && s_zfree[k][lane] != INT_MAX) zf = s_zfree[k][lane];
+        }
+        double hval = -1000.0;
+        const double xp = ((P.origin[0] + (double)x) * P.xy_res) - P.ego[0];
+        const double yp = ((P.origin[1] + (double)y) * P.xy_res) - P.ego[1];
+        if (xp * xp + yp * yp <= P.radius2) hval = P.ego[2] - P.ground_to_lidar_height;
+        if (zo != INT_MAX)
+            hval = (((double)__uint_as_float(hb) + (double)zo) + P.origin[2]) * P.z_res;
+        height[(size_t)sy * P.xy + sx] = hval;
+        inferred[(size_t)sy * P.xy + sx] =
+            (zf != INT_MAX) ? ((double)zf + P.origin[2]) * P.z_res : -1000.0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_map2d: every 2-D output of combine_maps from height/inferred height, one lane per cell.
+// Lanes run along storage x; internal maps are [sy][sx]; the four returned maps are written
+// in the reference's [x][y] window order (or left in storage order for sharded runs).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_map2d(const Map2dParams P, const int32_t *__restrict__ fstate,
+                                               const uint32_t *__restrict__ fhit,
+                                               const uint32_t *__restrict__ ftotal,
+                                               const double *__restrict__ height,
+                                               const double *__restrict__ inferred,
+                                               double *slope_x, double *slope_y, double *rough,
+                                               double *guessed, int32_t *out_pos, int32_t *out_neg,
+                                               double *out_rough, int32_t *out_vis)
+{
+    const int xy = P.xy;
+    const int sx0 = blockIdx.x * 64 + threadIdx.x;
+    const int sy0 = P.y_lo + blockIdx.y * 4 + threadIdx.y;
+    if (sx0 >= xy || sy0 >= P.y_hi) return;
+    const int x0 = wrap_sub(sx0, P.om[0], xy);              // window coordinates of this cell
+    const int y0 = wrap_sub(sy0, P.om[1], xy);
+#define H(xx, yy) height[(size_t)wrap_add((yy), P.om[1], xy) * xy + wrap_add((xx), P.om[0], xy)]
+    const double h00 = height[(size_t)sy0 * xy + sx0];
+
+    // ---- slope / roughness: 3x3 least-squares plane (gvom.py:665-734) ---------------------
+    double sxv = 0.0, syv = 0.0, rv = -1.0;
+    {
+        const int xlo = max(0, x0 - 1), xhi = min(xy, x0 + 2);
+        const int ylo = max(0, y0 - 1), yhi = min(xy, y0 + 2);
+        int n_good = 0;
+        for (int xx = xlo; xx < xhi; ++xx)
+            for (int yy = ylo; yy < yhi; ++yy)
+                if (H(xx, yy) > -1000) ++n_good;
+        if (n_good >= 3) {
+            double mean_x = 0.0, mean_y = 0.0, mean_z = 0.0;
+            for (int xx = xlo; xx < xhi; ++xx)
+                for (int yy = ylo; yy < yhi; ++yy) {
+                    const double hz = H(xx, yy);
+                    if (hz > -1000) {
+                        mean_x += (double)xx * P.xy_res;
+                        mean_y += (double)yy * P.xy_res;
+                        mean_z += hz;
+                    }
+                }
+            const double fi = (double)n_good;
+            mean_x /= fi; mean_y /= fi; mean_z /= fi;
+            double cxx = 0.0, cxy = 0.0, cxz = 0.0, cyy = 0.0, cyz = 0.0;
+            for (int xx = xlo; xx < xhi; ++xx)
+                for (int yy = ylo; yy < yhi; ++yy) {
+                    const double hz = H(xx, yy);
+                    if (hz > -1000) {
+                        const double px = (double)xx * P.xy_res, py = (double)yy * P.xy_res;
+                        cxx += (px - mean_x) * (px - mean_x);
+                        cxy += (px - mean_x) * (py - mean_y);
+                        cxz += (px - mean_x) * (hz - mean_z);
+                        cyy += (py - mean_y) * (py - mean_y);
+                        cyz += (py - mean_y) * (hz - mean_z);
+                    }
+                }
+            const double det = cxx * cyy - cxy * cxy;
+            if (det != 0.0) {
+                double a0 = (cyy * cxz - cxy * cyz) / det;
+                double a1 = (cxx * cyz - cxy * cxz) / det;
+                const double m = sqrt((a0 * a0 + a1 * a1) + 1.0);
+                a0 /= m; a1 /= m;
+                double err = 0.0;
+                for (int xx = xlo; xx < xhi; ++xx)
+                    for (int yy = ylo; yy < yhi; ++yy) {
+                        const double hz = H(xx, yy);
+                        if (hz > -1000) {
+                            const double px = (double)xx * P.xy_res, py = (double)yy * P.xy_res;
+                            const double e = (hz - mean_z) - (a0 * (px - mean_x) + a1 * (py - mean_y));
+                            err += e * e;
+                        }
+                    }
+                err /= fi;
+                if (err > 0) err = log(err);
+                rv = err;
+                sxv = atan2(a0, 1.0 / m);
+                syv = atan2(a1, 1.0 / m);
+            }
+        }
+    }
+    const size_t c_yx = (size_t)sy0 * xy + sx0;
+    const size_t c_xy = P.out_storage_order ? c_yx : (size_t)x0 * xy + y0;
+    slope_x[c_yx] = sxv; slope_y[c_yx] = syv; rough[c_yx] = rv;
+    out_rough[c_xy] = rv;
+
+    // ---- guess height (gvom.py:558-661), typos at :581 and :655 reproduced ---------------
+    double dh_out = 0.0;
+    const double inf00 = inferred[c_yx];
+    if (!(h00 > -1000 || inf00 == -1000.0)) {
+        bool x_p_done = false, x_n_done = false, y_p_done = false, y_n_done = false;
+        int x_p = x0, x_n = x0, y_p = y0, y_n = y0;
+        double x_ph = -1000, x_nh = -1000, y_ph = -1000, y_nh = -1000;
+        int i = 0;
+        while (i < 15 && !(x_n_done && x_n_done && y_p_done && y_n_done)) {
+            x_p += 1; x_n -= 1; y_p += 1; y_n -= 1; i += 1;
+            if (!x_p_done) {
+                if (x_p < xy) {
+                    for (int dy = -i; dy < i; ++dy) {
+                        if (y0 + dy >= xy || y0 + dy < 0) continue;
+                        const double v = H(x_p, y0 + dy);
+                        if (v > -1000) { x_ph = v; x_p_done = true; break; }
+                    }
+                } else x_p_done = true;
+            }
+            if (!x_n_done) {
+                if (x_n >= 0) {
+                    for (int dy = -i + 1; dy < i + 1; ++dy) {
+                        if (y0 + dy >= xy || y0 + dy < 0) continue;
+                        const double v = H(x_n, y0 + dy);
+                        if (v > -1000) { x_nh = v; x_n_done = true; break; }
+                    }
+                } else x_n_done = true;
+            }
+            if (!y_p_done) {
+                if (y_p < xy) {
+                    for (int dx = -i + 1; dx < i + 1; ++dx) {
+                        if (x0 + dx >= xy || x0 + dx < 0) continue;
+                        const double v = H(x0 + dx, y_p);
+                        if (v > -1000) { y_ph = v; y_p_done = true; break; }
+                    }
+                } else y_p_done = true;
+            }
+            if (!y_n_done) {
+                if (y_n >= 0) {
+                    for (int dx = -i; dx < i; ++dx) {
+                        if (x0 + dx >= xy || x0 + dx < 0) continue;
+                        const double v = H(x0 + dx, y_n);
+                        if (v > -1000) { y_nh = v; y_n_done = true; break; }
+                    }
+                } else y_n_done = true;
+            }
+        }
+        double min_h = 1000.0, max_h = inf00;
+        if (x_ph > -1000) { min_h = py_mind(x_ph, min_h); max_h = py_maxd(x_ph, max_h); }
+        if (x_nh > -1000) { min_h = py_mind(x_nh, min_h); max_h = py_maxd(x_nh, max_h); }
+        if (y_ph > -1000) { min_h = py_mind(y_ph, min_h); max_h = py_maxd(y_ph, max_h); }
+        if (x_nh > -1000) { min_h = py_mind(y_nh, min_h); max_h = py_maxd(y_nh, max_h); }
+        const double dh = max_h - min_h;
+        if (dh > 0) dh_out = dh;
+    }
+    guessed[c_yx] = dh_out;
+    out_neg[c_xy] = dh_out > P.neg_thr ? 100 : 0;            // gvom.py:479-485
+    out_vis[c_xy] = h00 > -1000 ? 1 : 0;                     // gvom.py:414-422
+
+    // ---- positive obstacles (gvom.py:489-521) ------------------------------------------
+    int pos = 0;
+    if (sqrt(sxv * sxv + syv * syv) >= P.slope_thr) {
+        pos = 100;
+    } else {
+        const double fmin = floor(((h00 + P.pos_thr) / P.z_res) - P.origin_z) + 1.0;
+        const double fmax = floor(((h00 + P.robot_height) / P.z_res) - P.origin_z);
+        if (fmin >= 0 && fmin < (double)P.zs && fmax >= 0 && fmax < (double)P.zs) {
+            const int zmin = (int)fmin, zmax = (int)fmax;
+            const int sx = sx0, sy = sy0;
+            double density = 0.0, nn = 0.0;
+            for (int z = zmin; z <= zmax; ++z) {
+                const int sz = wrap_add(z, P.om[2], P.zs);
+                const int32_t row = fstate[((uint32_t)sy * P.zs + sz) * xy + sx];
+                if (row >= 0) {
+                    const uint32_t hc = fhit[row];
+                    if ((int32_t)hc > 10) { nn += (double)(int32_t)ftotal[row]; density += (double)(int32_t)hc; }
+                }
+            }
+            if (nn > 0.0) density /= nn;
+            pos = (int)(density * 100);
+        }
+    }
+    out_pos[c_xy] = pos;
+#undef H
+}
+
+// ------------------------------------------------------------------------------------------
+// Test hooks / debug accessors (not on the hot path)
+// ------------------------------------------------------------------------------------------
+// storage order + compact rows -> dense arrays in the reference's x + y*xy + z*xy*xy order
+__global__ void k_read_dense(int xy, int zs, int om0, int om1, int om2,
+                             const int32_t *__restrict__ state, const uint32_t *__restrict__ chit,
+                             const uint32_t *__restrict__ ctotal, const uint32_t *__restrict__ cminh,
+                             int32_t *o_state, int32_t *o_hit, int32_t *o_total, float *o_minh)
+{
+    const size_t V = (size_t)xy * xy * zs;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < V;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % xy), y = (int)((idx / xy) % xy), z = (int)(idx / ((size_t)xy * xy));
+        const int sx = wrap_add(x, om0, xy), sy = wrap_add(y, om1, xy), sz = wrap_add(z, om2, zs);
+        const int32_t st = state[((size_t)sy * zs + sz) * xy + sx];
+        if (st >= 0) {
+            o_state[idx] = 0; o_hit[idx] = (int32_t)chit[st]; o_total[idx] = (int32_t)ctotal[st];
+            o_minh[idx] = __uint_as_float(cminh[st]);
+        } else {
+            o_state[idx] = st; o_hit[idx] = 0; o_total[idx] = 0; o_minh[idx] = 1.0f;
+        }
+    }
+}
+
+template <typename E>
+__global__ void k_unwrap(int xy, int om0, int om1, const E *__restrict__ in, E *out_xy)
+{
+    const int sx = blockIdx.x * 64 + threadIdx.x, sy = blockIdx.y * 4 + threadIdx.y;
+    if (sx < xy && sy < xy)
+        out_xy[(size_t)wrap_sub(sx, om0, xy) * xy + wrap_sub(sy, om1, xy)] = in[(size_t)sy * xy + sx];
+}
+
+// gvom.py:426-438 (7 columns) and :442-450 (3 columns, fed with guessed_height_delta :407)
+__global__ void k_debug_height(int xy, int om0, int om1, double o0, double o1, double xy_res,
+                               double z_res, const double *height, const double *rough,
+                               const double *sx, const double *sy, float *out7,
+                               const double *guessed, float *out3)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= xy || y >= xy) return;
+    const size_t c = (size_t)y * xy + x;                 // == index = x + y*xy_size
+    const size_t g = (size_t)wrap_add(y, om1, xy) * xy + wrap_add(x, om0, xy);   // storage cell
+    const float wx = (float)(((double)x + o0) * xy_res), wy = (float)(((double)y + o1) * xy_res);
+    if (out7) {
+        const double a = sx[g], b = sy[g];
+        out7[c * 7 + 0] = wx; out7[c * 7 + 1] = wy;
+        out7[c * 7 + 2] = (float)(height[g] - z_res);
+        out7[c * 7 + 3] = (float)rough[g];
+        out7[c * 7 + 4] = (float)a; out7[c * 7 + 5] = (float)b;
+        out7[c * 7 + 6] = (float)sqrt(a * a + b * b);
+    }
+    if (out3) {
+        out3[c * 3 + 0] = wx; out3[c * 3 + 1] = wy;
+        out3[c * 3 + 2] = (float)(guessed[g] - z_res);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+hipError_t gvom_launch_trace(hipStream_t s, const ScanParams &P, int dtype, const void *pts,
+                             int64_t stride_elems, int64_t n, void *world, uint32_t *hit,
+                             uint32_t *total, int32_t *state, uint32_t *counters)
+{
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    if (dtype == 0)
+        hipLaunchKernelGGL(k_trace<float>, dim3(blocks), dim3(256), 0, s, P, (const float *)pts,
+                           (long)stride_elems, (long)n, (float *)world, hit, total, state, counters);
+    else
+        hipLaunchKernelGGL(k_trace<double>, dim3(blocks), dim3(256), 0, s, P, (const double *)pts,
+                           (long)stride_elems, (long)n, (double *)world, hit, total, state, counters);
+    return hipGetLastError();
+}
+
+hipError_t gvom_launch_encode(hipStream_t s, int xy, int zs, int sy_lo, int sy_hi, uint32_t *hit,
+                              uint32_t *total, int32_t *state, uint32_t *chit, uint32_t *ctotal,
+                              uint32_t *cminh, unsigned long long *)
+{
+    const size_t plane = (size_t)xy * zs;
+    const size_t begin = (size_t)sy_lo * plane, count = (size_t)(sy_hi - sy_lo) * plane;
+    if (count == 0) return hipSuccess;
+    if (plane % 4 == 0) {
+        const size_t nvec = count / 4;
+        const unsigned blocks = (unsigned)min((size_t)8192, (nvec + 255) / 256);
+        hipLaunchKernelGGL(k_encode<4>, dim3(blocks), dim3(256), 0, s, begin, count, hit, total,
+                           state, chit, ctotal, cminh);
+    } else {
+        const unsigned blocks = (unsigned)min((size_t)8192, (count + 255) / 256);
+        hipLaunchKernelGGL(k_encode<1>, dim3(blocks), dim3(256), 0, s, begin, count, hit, total,
+                           state, chit, ctotal, cminh);
+    }
+    return hipGetLastError();
+}
+
+hipError_t gvom_launch_minh(hipStream_t s, const ScanParams &P, int dtype, const void *world,
+                            int64_t n, const int32_t *state, uint32_t *cminh)
+{
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    if (dtype == 0)
+        hipLaunchKernelGGL(k_minh<float>, dim3(blocks), dim3(256), 0, s, P, (const float *)world,
+                           (long)n, state, cminh);
+    else
+        hipLaunchKernelGGL(k_minh<double>, dim3(blocks), dim3(256), 0, s, P, (const double *)world,
+                           (long)n, state, cminh);
+    return hipGetLastError();
+}
+
+hipError_t gvom_launch_fuse(hipStream_t s, const FuseParams &P, const MapDesc *descs_dev,
+                            int32_t *fstate, uint32_t *fhit, uint32_t *ftotal, uint32_t *fminh,
+                            unsigned long long *counter, double *height, double *inferred)
+{
+    const dim3 grid((P.xy + 63) / 64, P.sy_hi - P.sy_lo);
+    if (grid.y == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fuse, grid, dim3(64 * P.nz), 0, s, P, descs_dev, fstate, fhit, ftotal,
+                       fminh, counter, height, inferred);
+    return hipGetLastError();
+}
+
+hipError_t gvom_launch_map2d(hipStream_t s, const Map2dParams &P, const int32_t *fstate,
+                             const uint32_t *fhit, const uint32_t *ftotal, const double *height,
+                             const double *inferred, double *slope_x, double *slope_y,
+                             double *rough, double *guessed, int32_t *out_pos, int32_t *out_neg,
+                             double *out_rough, int32_t *out_vis)
+{
+    const dim3 grid((P.xy + 63) / 64, (P.y_hi - P.y_lo + 3) / 4);
+    if (grid.y == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_map2d, grid, dim3(64, 4), 0, s, P, fstate, fhit, ftotal, height, inferred,
+                       slope_x, slope_y, rough, guessed, out_pos, out_neg, out_rough, out_vis);
+    return hipGetLastError();
+}
+
+hipError_t gvom_launch_read_dense(hipStream_t s, int xy, int zs, const int om[3],
+                                  const int32_t *state, const uint32_t *chit,
+                                  const uint32_t *ctotal, const uint32_t *cminh, int32_t *o_state,
+                                  int32_t *o_hit, int32_t *o_total, float *o_minh)
+{
+    hipLaunchKernelGGL(k_read_dense, dim3(2048), dim3(256), 0, s, xy, zs, om[0], om[1], om[2], state,
+                       chit, ctotal, cminh, o_state, o_hit, o_total, o_minh);
+    return hipGetLastError();
+}
+
+hipError_t gvom_launch_unwrap_f64(hipStream_t s, int xy, int om0, int om1, const double *in, double *out_xy)
+{
+    hipLaunchKernelGGL(k_unwrap<double>, dim3((xy + 63) / 64, (xy + 3) / 4), dim3(64, 4), 0, s, xy,
+                       om0, om1, in, out_xy);
+    return hipGetLastError();
+}
+
+hipError_t gvom_launch_unwrap_i32(hipStream_t s, int xy, int om0, int om1, const int32_t *in, int32_t *out_xy)
+{
+    hipLaunchKernelGGL(k_unwrap<int32_t>, dim3((xy + 63) / 64, (xy + 3) / 4), dim3(64, 4), 0, s, xy,
+                       om0, om1, in, out_xy);
+    return hipGetLastError();
+}
+
+hipError_t gvom_launch_debug_height(hipStream_t s, int xy, int om0, int om1, const double origin[3],
+                                    double xy_res, double z_res, const double *height,
+                                    const double *rough, const double *sx, const double *sy,
+                                    float *out7, const double *guessed, float *out3)
+{
+    hipLaunchKernelGGL(k_debug_height, dim3((xy + 63) / 64, (xy + 3) / 4), dim3(64, 4), 0, s, xy, om0,
+                       om1, origin[0], origin[1], xy_res, z_res, height, rough, sx, sy, out7, guessed, out3);
+    return hipGetLastError();
+}

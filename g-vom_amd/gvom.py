@@ -1,0 +1,456 @@
+"""gvom -- drop-in replacement for the reference module `gvom` on AMD MI355X (gfx950).
+
+    import gvom
+    m = gvom.Gvom(xy_resolution, z_resolution, xy_size, z_size, buffer_size, min_distance,
+                  positive_obstacle_threshold, negative_obstacle_threshold,
+                  slope_obstacle_threshold, robot_height, robot_radius,
+                  ground_to_lidar_height, xy_eigen_dist, z_eigen_dist)
+    m.process_pointcloud(pc, ego_position, transform)       # gvom_ros.py:109
+    origin, positive, negative, roughness, visibility = m.combine_maps()   # gvom_ros.py:115
+
+Same constructor (14 positional args, reference gvom.py:29-31), same methods, return types,
+warning strings and ring-buffer attributes as the reference class
+(/root/reference/scripts/gvom.py:12-410), so the reference's ROS node (gvom_ros.py) runs
+against it unchanged.  All arithmetic happens in hand-written HIP kernels behind the C ABI
+of include/gvom_hip.h, bound here with ctypes.  No PyTorch, no Numba.
+
+There is NO CPU fallback: importing works anywhere, but constructing `Gvom` raises
+`GvomBackendError` if libgvom_hip.so is missing or no gfx950 device is visible.
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+__all__ = ["Gvom", "GvomBackendError", "load_library", "library_path"]
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+GVOM_OK, GVOM_EMPTY_CLOUD, GVOM_NO_OVERLAP, GVOM_EMPTY_BUFFER, GVOM_NO_DATA = 0, 1, 2, 3, 4
+GVOM_WHICH_FUSED = -1
+MAP_HEIGHT, MAP_INFERRED, MAP_SLOPE_X, MAP_SLOPE_Y, MAP_ROUGHNESS, MAP_GUESSED = range(6)
+OUT_POSITIVE, OUT_NEGATIVE, OUT_ROUGHNESS, OUT_VISIBILITY = 100, 101, 102, 103
+N_STAGES = 5
+STAGE_NAMES = ("trace", "encode", "min_height", "fuse", "map2d")
+
+
+class GvomBackendError(RuntimeError):
+    """The HIP backend is unavailable or a HIP call failed."""
+
+
+class GvomParams(ctypes.Structure):
+    _fields_ = [("xy_resolution", ctypes.c_double), ("z_resolution", ctypes.c_double),
+                ("xy_size", ctypes.c_int32), ("z_size", ctypes.c_int32),
+                ("buffer_size", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+                ("min_distance", ctypes.c_double),
+                ("positive_obstacle_threshold", ctypes.c_double),
+                ("negative_obstacle_threshold", ctypes.c_double),
+                ("slope_obstacle_threshold", ctypes.c_double),
+                ("robot_height", ctypes.c_double), ("robot_radius", ctypes.c_double),
+                ("ground_to_lidar_height", ctypes.c_double),
+                ("xy_eigen_dist", ctypes.c_int32), ("z_eigen_dist", ctypes.c_int32)]
+
+
+class GvomState(ctypes.Structure):
+    _fields_ = [("buffer_index", ctypes.c_int32), ("last_buffer_index", ctypes.c_int32),
+                ("has_combined", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+                ("combined_cell_count", ctypes.c_int64),
+                ("combined_origin", ctypes.c_double * 3), ("ego_position", ctypes.c_double * 3)]
+
+
+class GvomScanStats(ctypes.Structure):
+    _fields_ = [("points", ctypes.c_int64), ("cells", ctypes.c_int64),
+                ("sum_hit", ctypes.c_int64), ("sum_total", ctypes.c_int64)]
+
+
+def library_path():
+    return os.environ.get("GVOM_HIP_LIBRARY", os.path.join(_HERE, "lib", "libgvom_hip.so"))
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+# every symbol include/gvom_hip.h declares: (name, restype, argtypes)
+_P, _I, _I64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+_DP = ctypes.POINTER(ctypes.c_double)
+ABI = [
+    ("gvom_create", _I, [ctypes.POINTER(GvomParams), _I, ctypes.POINTER(_P)]),
+    ("gvom_create_sharded", _I, [ctypes.POINTER(GvomParams), _I, _I, _I, ctypes.POINTER(_P)]),
+    ("gvom_destroy", None, [_P]),
+    ("gvom_process_pointcloud", _I, [_P, _P, _I64, _I64, _I, _DP, _P]),
+    ("gvom_process_pointcloud_device", _I, [_P, _P, _I64, _I64, _I, _DP, _P]),
+    ("gvom_combine_maps", _I, [_P, _P, _P, _P, _P, _P]),
+    ("gvom_scan_begin", _I, [_P, _P, _I, _I64, _I64, _I, _DP, _P, ctypes.POINTER(_I64)]),
+    ("gvom_scan_commit", _I, [_P, _I]),
+    ("gvom_combine_fuse", _I, [_P, ctypes.POINTER(_I64)]),
+    ("gvom_set_combined_cell_count", _I, [_P, _I64]),
+    ("gvom_rows_export", _I, [_P, _I, _I, _I, _P]),
+    ("gvom_rows_import", _I, [_P, _I, _I, _I, _P]),
+    ("gvom_combine_map2d", _I, [_P]),
+    ("gvom_finalize_outputs", _I, [_P, _P, _P, _P, _P, _P]),
+    ("gvom_slot_filled", _I, [_P, _I]),
+    ("gvom_get_state", _I, [_P, ctypes.POINTER(GvomState)]),
+    ("gvom_get_scan_stats", _I, [_P, ctypes.POINTER(GvomScanStats)]),
+    ("gvom_get_occupancy", _I, [_P, _P]),
+    ("gvom_debug_height_map", _I, [_P, _P]),
+    ("gvom_debug_inferred_height_map", _I, [_P, _P]),
+    ("gvom_read_dense", _I, [_P, _I, _P, _P, _P, _P, _P, ctypes.POINTER(_I64)]),
+    ("gvom_read_map2d", _I, [_P, _I, _P]),
+    ("gvom_last_stage_ms", _I, [_P, ctypes.POINTER(ctypes.c_float * N_STAGES)]),
+    ("gvom_set_profiling", _I, [_P, _I]),
+    ("gvom_stream", _P, [_P]),
+    ("gvom_last_error", ctypes.c_char_p, [_P]),
+    ("gvom_backend_info", _I, [ctypes.c_char_p, ctypes.c_size_t]),
+    ("gvom_abi_version", _I, []),
+]
+
+
+def load_library(path=None):
+    """dlopen libgvom_hip.so and bind every C-ABI entry point.  Raises GvomBackendError."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None and path is None:
+            return _lib
+        p = path or library_path()
+        if not os.path.exists(p):
+            raise GvomBackendError(
+                "HIP backend not built: %s is missing. Run `make -C %s` (or "
+                "`python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback."
+                % (p, _HERE))
+        try:
+            L = ctypes.CDLL(p)
+        except OSError as e:
+            raise GvomBackendError("cannot load %s: %s" % (p, e))
+        for name, res, args in ABI:
+            try:
+                f = getattr(L, name)
+            except AttributeError:
+                raise GvomBackendError("%s does not export %s" % (p, name))
+            f.restype = res
+            f.argtypes = args
+        if path is None:
+            _lib = L
+        return L
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+class _DeviceArrayView(object):
+    """Stands in for the reference's numba device arrays: `.copy_to_host()` returns numpy."""
+
+    def __init__(self, fetch):
+        self._fetch = fetch
+
+    def copy_to_host(self):
+        return self._fetch()
+
+    def __array__(self, dtype=None):
+        a = self._fetch()
+        return a if dtype is None else a.astype(dtype)
+
+
+class Gvom(object):
+    """A class to convert lidar pointclouds into a cost map (reference gvom.py:12-27)."""
+
+    def __init__(self, xy_resolution, z_resolution, xy_size, z_size, buffer_size, min_distance,
+                 positive_obstacle_threshold, negative_obstacle_threshold, slope_obstacle_threshold,
+                 robot_height, robot_radius, ground_to_lidar_height, xy_eigen_dist, z_eigen_dist,
+                 device=0, _shard=None):
+        self.xy_resolution = xy_resolution
+        self.z_resolution = z_resolution
+        self.xy_size = xy_size
+        self.z_size = z_size
+        self.voxel_count = self.xy_size * self.xy_size * self.z_size
+        self.min_distance = min_distance
+        self.positive_obstacle_threshold = positive_obstacle_threshold
+        self.negative_obstacle_threshold = negative_obstacle_threshold
+        self.slope_obstacle_threshold = slope_obstacle_threshold
+        self.robot_height = robot_height
+        self.robot_radius = robot_radius
+        self.ground_to_lidar_height = ground_to_lidar_height
+        self.xy_eigen_dist = xy_eigen_dist
+        self.z_eigen_dist = z_eigen_dist
+        self.metrics_count = 10
+        self.buffer_size = buffer_size
+        self.threads_per_block = 256
+        self.threads_per_block_3D = (8, 8, 4)
+        self.threads_per_block_2D = (16, 16)
+        self.ego_position = [0, 0, 0]
+
+        self._lib = load_library()
+        self._h = ctypes.c_void_p()
+        prm = GvomParams(float(xy_resolution), float(z_resolution), int(xy_size), int(z_size),
+                         int(buffer_size), 0, float(min_distance),
+                         float(positive_obstacle_threshold), float(negative_obstacle_threshold),
+                         float(slope_obstacle_threshold), float(robot_height), float(robot_radius),
+                         float(ground_to_lidar_height), int(xy_eigen_dist), int(z_eigen_dist))
+        if _shard is None:
+            rc = self._lib.gvom_create(ctypes.byref(prm), int(device), ctypes.byref(self._h))
+        else:
+            rc = self._lib.gvom_create_sharded(ctypes.byref(prm), int(device), int(_shard[0]),
+                                               int(_shard[1]), ctypes.byref(self._h))
+        if rc != GVOM_OK:
+            info = ctypes.create_string_buffer(256)
+            self._lib.gvom_backend_info(info, 256)
+            self._h = ctypes.c_void_p()
+            raise GvomBackendError("gvom_create failed with code %d (%s). There is no CPU fallback."
+                                   % (rc, info.value.decode()))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                self._lib.gvom_destroy(h)
+            except Exception:
+                pass
+
+    # ------------------------------------------------------------------------------------
+    def _check(self, rc):
+        if rc < 0:
+            raise GvomBackendError("libgvom_hip call failed (%d): %s"
+                                   % (rc, self._lib.gvom_last_error(self._h).decode()))
+        return rc
+
+    @staticmethod
+    def _prepare_cloud(pointcloud):
+        """(array, n, row_stride_bytes, dtype_code).  float32/float64 rows of >= 3 columns are
+        passed without a copy when C-contiguous in the last axis; anything else is converted to
+        float64 (what ros_numpy delivers, gvom_ros.py:108)."""
+        pc = pointcloud if isinstance(pointcloud, np.ndarray) else np.asarray(pointcloud)
+        if pc.ndim != 2 or pc.shape[1] < 3:
+            raise ValueError("pointcloud must have shape (N, >=3), got %r" % (pc.shape,))
+        if pc.dtype not in (np.float32, np.float64):
+            pc = pc.astype(np.float64)
+        if pc.shape[0] > 0 and (pc.strides[1] != pc.itemsize or pc.strides[0] < 3 * pc.itemsize
+                                or pc.strides[0] % pc.itemsize):
+            pc = np.ascontiguousarray(pc)
+        stride = pc.strides[0] if pc.shape[0] > 0 else 3 * pc.itemsize
+        return pc, pc.shape[0], stride, (0 if pc.dtype == np.float32 else 1)
+
+    def process_pointcloud(self, pointcloud, ego_position, transform=None):
+        """Imports a pointcloud, processes it into a voxel map then adds the map to the buffer
+        (reference gvom.py:99-175).  Returns None."""
+        self.ego_position = ego_position
+        pc, n, stride, code = self._prepare_cloud(pointcloud)
+        ego = (ctypes.c_double * 3)(float(ego_position[0]), float(ego_position[1]),
+                                    float(ego_position[2]))
+        tf = None
+        if transform is not None:
+            tf = np.ascontiguousarray(np.asarray(transform, dtype=np.float64))
+            if tf.shape != (4, 4):
+                raise ValueError("transform must be 4x4")
+        rc = self._check(self._lib.gvom_process_pointcloud(self._h, _ptr(pc) if n else None, n,
+                                                           stride, code, ego, _ptr(tf)))
+        if rc == GVOM_EMPTY_CLOUD:
+            print("[WARNING] Processing an empty pointcloud, nothing will happen!")
+        elif rc == GVOM_NO_OVERLAP:
+            print("[WARNING] The pointcloud points don't overlap with any voxels, nothing will happen!")
+        return None
+
+    def process_pointcloud_device(self, dev_ptr, n, dtype, ego_position, transform=None,
+                                  row_stride_bytes=None):
+        """Same as process_pointcloud for a cloud already resident in HBM (raw device pointer)."""
+        self.ego_position = ego_position
+        code = 0 if np.dtype(dtype) == np.float32 else 1
+        stride = row_stride_bytes or 3 * np.dtype(dtype).itemsize
+        ego = (ctypes.c_double * 3)(float(ego_position[0]), float(ego_position[1]),
+                                    float(ego_position[2]))
+        tf = None
+        if transform is not None:
+            tf = np.ascontiguousarray(np.asarray(transform, dtype=np.float64))
+        return self._check(self._lib.gvom_process_pointcloud_device(
+            self._h, ctypes.c_void_p(int(dev_ptr)), int(n), int(stride), code, ego, _ptr(tf)))
+
+    def combine_maps(self):
+        """Combines all maps in the buffer and processes the resultant map into 2D maps
+        (reference gvom.py:177-354).  Returns None or (origin_world f64[3], positive i32[xy,xy],
+        negative i32[xy,xy], roughness f64[xy,xy], visibility i32[xy,xy])."""
+        xy = self.xy_size
+        origin = np.zeros(3, np.float64)
+        positive = np.empty((xy, xy), np.int32)
+        negative = np.empty((xy, xy), np.int32)
+        roughness = np.empty((xy, xy), np.float64)
+        visibility = np.empty((xy, xy), np.int32)
+        rc = self._check(self._lib.gvom_combine_maps(self._h, _ptr(origin), _ptr(positive),
+                                                     _ptr(negative), _ptr(roughness),
+                                                     _ptr(visibility)))
+        if rc == GVOM_EMPTY_BUFFER:
+            print("[WARNING] The map buffer is empty, nothing will happen!")
+            return None
+        return (origin, positive, negative, roughness, visibility)
+
+    # ---- accessors / debug API (reference gvom.py:356-410) ------------------------------
+    def get_map_as_occupancy_grid(self):
+        out = np.empty((self.xy_size, self.xy_size, self.z_size), np.uint8)
+        rc = self._check(self._lib.gvom_get_occupancy(self._h, _ptr(out)))
+        if rc == GVOM_NO_DATA:
+            raise AttributeError("'NoneType' object has no attribute 'copy_to_host'")  # as the reference
+        return out.astype(bool)
+
+    def make_debug_voxel_map(self):
+        # per-voxel eigenvalue statistics are a "next" row; the reference's
+        # caller tolerates None (gvom_ros.py:171-172)
+        if self.combined_cell_count_cpu is None:
+            print("No data")
+        return None
+
+    def make_debug_height_map(self):
+        out = np.empty((self.xy_size * self.xy_size, 7), np.float32)
+        rc = self._check(self._lib.gvom_debug_height_map(self._h, _ptr(out)))
+        if rc == GVOM_NO_DATA:
+            print("No data")
+            return None
+        return out
+
+    def make_debug_inferred_height_map(self):
+        out = np.empty((self.xy_size * self.xy_size, 3), np.float32)
+        rc = self._check(self._lib.gvom_debug_inferred_height_map(self._h, _ptr(out)))
+        if rc == GVOM_NO_DATA:
+            print("No data")
+            return None
+        return out
+
+    # ---- ring-buffer / fused-map attributes of the reference object ------------------
+    def _state(self):
+        st = GvomState()
+        self._check(self._lib.gvom_get_state(self._h, ctypes.byref(st)))
+        return st
+
+    @property
+    def buffer_index(self):
+        return int(self._state().buffer_index)
+
+    @property
+    def last_buffer_index(self):
+        return int(self._state().last_buffer_index)
+
+    @property
+    def combined_cell_count_cpu(self):
+        st = self._state()
+        return int(st.combined_cell_count) if st.has_combined else None
+
+    last_combined_cell_count_cpu = combined_cell_count_cpu
+
+    def read_dense(self, which):
+        """Test hook: (state, hit, total, min_h, origin, cell_count) dense arrays in the
+        reference's voxel order for ring slot `which` or GVOM_WHICH_FUSED; None if empty."""
+        V = self.voxel_count
+        state = np.empty(V, np.int32); hit = np.empty(V, np.int32); total = np.empty(V, np.int32)
+        minh = np.empty(V, np.float32); origin = np.zeros(3); cnt = ctypes.c_int64(0)
+        rc = self._check(self._lib.gvom_read_dense(self._h, int(which), _ptr(state), _ptr(hit),
+                                                   _ptr(total), _ptr(minh), _ptr(origin),
+                                                   ctypes.byref(cnt)))
+        if rc == GVOM_NO_DATA:
+            return None
+        return state, hit, total, minh, origin, int(cnt.value)
+
+    def _compact(self, which):
+        """Reference-shaped sparse form (index_map, hit[C], total[C], min_height) rebuilt from
+        the dense test hook; rows numbered in voxel order (row order is unspecified in the
+        reference, gvom.py:1158)."""
+        d = self.read_dense(which)
+        if d is None:
+            return None
+        state, hit, total, minh, origin, _ = d
+        occ = state >= 0
+        index_map = state.copy()
+        index_map[occ] = np.arange(int(occ.sum()), dtype=np.int32)
+        return index_map, hit[occ], total[occ], minh[occ], origin
+
+    def _slot_views(self, field):
+        out = []
+        for i in range(self.buffer_size):
+            if self._lib.gvom_slot_filled(self._h, i) != 1:
+                out.append(None)
+                continue
+
+            def fetch(i=i, field=field):
+                index_map, hit, total, minh, origin = self._compact(i)
+                if field == 4:                       # gvom.py:1014: min_height has 3*C entries
+                    return np.concatenate([minh, np.ones(2 * minh.shape[0], np.float32)])
+                return (index_map, hit, total, minh, origin)[field]
+            out.append(_DeviceArrayView(fetch))
+        return out
+
+    index_buffer = property(lambda self: self._slot_views(0))
+    hit_count_buffer = property(lambda self: self._slot_views(1))
+    total_count_buffer = property(lambda self: self._slot_views(2))
+    min_height_buffer = property(lambda self: self._slot_views(4))
+
+    @property
+    def origin_buffer(self):
+        out = []
+        for i in range(self.buffer_size):
+            if self._lib.gvom_slot_filled(self._h, i) != 1:
+                out.append(None)
+            else:
+                out.append(_DeviceArrayView(lambda i=i: self.read_dense(i)[4]))
+        return out
+
+    def _fused_view(self, field):
+        if not self._state().has_combined:
+            return None
+        return _DeviceArrayView(lambda: self._compact(GVOM_WHICH_FUSED)[field])
+
+    combined_index_map = property(lambda self: self._fused_view(0))
+    combined_hit_count = property(lambda self: self._fused_view(1))
+    combined_total_count = property(lambda self: self._fused_view(2))
+    combined_min_height = property(lambda self: self._fused_view(3))
+    last_combined_index_map = combined_index_map
+    last_combined_hit_count = combined_hit_count
+    last_combined_total_count = combined_total_count
+    last_combined_min_height = combined_min_height
+
+    @property
+    def combined_origin(self):
+        st = self._state()
+        if not st.has_combined:
+            return None
+        org = np.array(list(st.combined_origin), np.float64)
+        return _DeviceArrayView(lambda: org.copy())
+
+    last_combined_origin = combined_origin
+
+    def _map2d(self, which):
+        out = np.empty((self.xy_size, self.xy_size), np.float64)
+        rc = self._check(self._lib.gvom_read_map2d(self._h, which, _ptr(out)))
+        return None if rc == GVOM_NO_DATA else out
+
+    def _map_view(self, which):
+        if self._map2d(which) is None:
+            return None
+        return _DeviceArrayView(lambda: self._map2d(which))
+
+    height_map = property(lambda self: self._map_view(MAP_HEIGHT))
+    inferred_height_map = property(lambda self: self._map_view(MAP_INFERRED))
+    x_slope_map = property(lambda self: self._map_view(MAP_SLOPE_X))
+    y_slope_map = property(lambda self: self._map_view(MAP_SLOPE_Y))
+    roughness_map = property(lambda self: self._map_view(MAP_ROUGHNESS))
+    guessed_height_delta = property(lambda self: self._map_view(MAP_GUESSED))
+
+    # ---- measurement helpers ----------------------------------------------------------
+    def set_profiling(self, on):
+        self._check(self._lib.gvom_set_profiling(self._h, 1 if on else 0))
+
+    def last_stage_ms(self):
+        ms = (ctypes.c_float * N_STAGES)()
+        self._check(self._lib.gvom_last_stage_ms(self._h, ctypes.byref(ms)))
+        return dict(zip(STAGE_NAMES, [float(v) for v in ms]))
+
+    def scan_stats(self):
+        st = GvomScanStats()
+        rc = self._check(self._lib.gvom_get_scan_stats(self._h, ctypes.byref(st)))
+        if rc == GVOM_NO_DATA:
+            return None
+        return {"points": int(st.points), "cells": int(st.cells), "sum_hit": int(st.sum_hit),
+                "sum_total": int(st.sum_total)}
+
+    @staticmethod
+    def backend_info():
+        L = load_library()
+        buf = ctypes.create_string_buffer(256)
+        rc = L.gvom_backend_info(buf, 256)
+        return rc, buf.value.decode()

@@ -1,0 +1,196 @@
+/*
+ * gvom_hip.h -- C ABI of libgvom_hip.so: the MI355X (gfx950) implementation of G-VOM's
+ * process_pointcloud -> combine_maps hot path.
+ *
+ * This is the drop-in boundary.  The reference has no FFI of its own (it is a Python class
+ * that launches Numba-CUDA kernels); each entry point below replaces one *method* of the
+ * reference class `Gvom` (/root/reference/scripts/gvom.py, "gvom.py:NNN") and is bound
+ * from Python with ctypes by g-vom_amd/gvom.py (see INTEGRATION.md for the stub).
+ * Plain pointers and sizes only; no PyTorch / numpy types.  All functions are
+ * thread-safe per handle (an internal mutex replaces the reference's semaphores,
+ * gvom.py:65-67,96); ctypes drops the GIL around every call.
+ *
+ * Array conventions at this boundary are the REFERENCE's:
+ *   voxel arrays : index = x + y*xy_size + z*xy_size*xy_size        (gvom.py:1086,1146)
+ *   2-D maps     : [x][y] C-order, i.e. m[x*xy_size + y]            (gvom.py:288-349)
+ * (internally the library stores voxels world-anchored/toroidal as [y][z][x] and 2-D
+ * maps as [y][x]; see DESIGN.md.)
+ */
+#ifndef GVOM_HIP_H
+#define GVOM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GVOM_ABI_VERSION 1
+
+/* return codes (>= 0: the reference's documented outcomes; < 0: failures) */
+#define GVOM_OK                0
+#define GVOM_EMPTY_CLOUD       1   /* gvom.py:107-109 "[WARNING] Processing an empty pointcloud..." */
+#define GVOM_NO_OVERLAP        2   /* gvom.py:148-150 "[WARNING] The pointcloud points don't overlap..." */
+#define GVOM_EMPTY_BUFFER      3   /* gvom.py:179-181 "[WARNING] The map buffer is empty..." */
+#define GVOM_NO_DATA           4   /* gvom.py:364-366,381-383,397-399 "No data" */
+#define GVOM_ERR_INVALID      -1   /* bad argument */
+#define GVOM_ERR_HIP          -2   /* a HIP runtime call failed; see gvom_last_error() */
+#define GVOM_ERR_NO_DEVICE    -3   /* no usable gfx950 device / library built without GPU */
+#define GVOM_ERR_CAPACITY     -4   /* grid too large for 32-bit voxel indices, or > 64 ring slots */
+
+#define GVOM_DTYPE_F32 0
+#define GVOM_DTYPE_F64 1
+
+typedef struct gvom_handle gvom_t;
+
+/* The 14 positional constructor arguments of Gvom.__init__ (gvom.py:29-31), same order. */
+typedef struct gvom_params {
+    double  xy_resolution;
+    double  z_resolution;
+    int32_t xy_size;
+    int32_t z_size;
+    int32_t buffer_size;
+    int32_t reserved0;
+    double  min_distance;
+    double  positive_obstacle_threshold;
+    double  negative_obstacle_threshold;
+    double  slope_obstacle_threshold;
+    double  robot_height;
+    double  robot_radius;
+    double  ground_to_lidar_height;
+    int32_t xy_eigen_dist;
+    int32_t z_eigen_dist;
+} gvom_params;
+
+/* Ring-buffer bookkeeping visible on the reference object (gvom.py:56-58,172-175). */
+typedef struct gvom_state {
+    int32_t buffer_index;
+    int32_t last_buffer_index;
+    int32_t has_combined;          /* combine_maps has produced a fused map at least once */
+    int32_t reserved0;
+    int64_t combined_cell_count;   /* gvom.py:217 combined_cell_count_cpu (valid if has_combined) */
+    double  combined_origin[3];    /* gvom.py:184 (voxel units, integer valued) */
+    double  ego_position[3];       /* gvom.py:102-104 latest ego */
+} gvom_state;
+
+/* Exact integer accounting of the last accepted scan (used for roofline arithmetic). */
+typedef struct gvom_scan_stats {
+    int64_t points;                /* N */
+    int64_t cells;                 /* C: occupied voxels of the scan (gvom.py:147 cell_count_cpu) */
+    int64_t sum_hit;               /* sum of hit over the scan's voxels  */
+    int64_t sum_total;             /* sum of total over the scan's voxels (endpoint adds included) */
+} gvom_scan_stats;
+
+/* --- lifetime: replaces Gvom.__init__ (gvom.py:29-97) ------------------------------------ */
+int  gvom_create(const gvom_params *params, int device_id, gvom_t **out);
+/* Slab-sharded instance for multi-GPU runs: this rank owns storage rows
+ * [rank*xy/world, (rank+1)*xy/world) of the world-anchored y axis (DESIGN.md "Multi-GPU"). */
+int  gvom_create_sharded(const gvom_params *params, int device_id, int rank, int world,
+                         gvom_t **out);
+void gvom_destroy(gvom_t *h);
+
+/* --- Gvom.process_pointcloud (gvom.py:99-175) ---------------------------------------------
+ * xyz: N rows of >= 3 consecutive float32/float64 (row_stride_bytes apart), host memory for
+ * gvom_process_pointcloud, device (HBM) memory for the *_device variant.  The cloud is never
+ * modified.  transform: row-major 4x4 double or NULL (gvom.py:134-135).
+ * Returns GVOM_OK / GVOM_EMPTY_CLOUD / GVOM_NO_OVERLAP (ring untouched, ego still updated). */
+int gvom_process_pointcloud(gvom_t *h, const void *xyz, int64_t n, int64_t row_stride_bytes,
+                            int dtype, const double ego[3], const double *transform_4x4);
+int gvom_process_pointcloud_device(gvom_t *h, const void *xyz_dev, int64_t n,
+                                   int64_t row_stride_bytes, int dtype, const double ego[3],
+                                   const double *transform_4x4);
+
+/* --- Gvom.combine_maps (gvom.py:177-354) --------------------------------------------------
+ * Caller-allocated xy_size*xy_size outputs (any of them may be NULL to skip its copy).
+ * Returns GVOM_OK or GVOM_EMPTY_BUFFER. */
+int gvom_combine_maps(gvom_t *h, double origin_world[3], int32_t *positive, int32_t *negative,
+                      double *roughness, int32_t *visibility);
+
+/* --- split entry points for slab-sharded (multi-GPU) runs ---------------------------------
+ * Used by g-vom_amd/gvom_sharded.py; each rank holds a gvom_create_sharded() handle and
+ * drives these between its torch.distributed (RCCL) collectives.  Single-GPU callers never
+ * need them: gvom_process_pointcloud == scan_begin + scan_commit(local_cells > 0) and
+ * gvom_combine_maps == combine_fuse + combine_map2d + finalize_outputs.
+ *
+ * gvom_scan_begin   runs the scan kernels of process_pointcloud on this rank's slab but leaves
+ *                   the ring untouched; *local_cells = occupied voxels found in the slab.
+ * gvom_scan_commit  accept != 0 commits the pending scan to the ring (gvom.py:163-175); the
+ *                   reference's "no overlap" test (gvom.py:147-150) is on the GLOBAL count.
+ * gvom_combine_fuse fusion + column reductions of this rank's slab (gvom.py:183-304); the
+ *                   rank's rows of the height / inferred-height maps become valid.
+ * gvom_rows_export / gvom_rows_import
+ *                   device-to-device copy of storage rows [row_lo,row_hi) of a 2-D map (the
+ *                   GVOM_MAP_* ids, or GVOM_OUT_* for the four returned maps) to/from a
+ *                   caller-owned device buffer holding exactly those rows -- the collectives
+ *                   (all_gather over RCCL) run on the caller's buffers.
+ * gvom_combine_map2d  slope/roughness/guess/positive/negative/visibility for this rank's rows
+ *                   (needs all rows of height + inferred height), outputs in storage order.
+ * gvom_finalize_outputs  storage order -> the reference's [x][y] order, to host (rank 0). */
+int gvom_scan_begin(gvom_t *h, const void *xyz, int on_device, int64_t n, int64_t row_stride_bytes,
+                    int dtype, const double ego[3], const double *transform_4x4,
+                    int64_t *local_cells);
+int gvom_scan_commit(gvom_t *h, int accept);
+int gvom_combine_fuse(gvom_t *h, int64_t *local_cells);
+int gvom_set_combined_cell_count(gvom_t *h, int64_t global_cells);
+#define GVOM_OUT_POSITIVE   100
+#define GVOM_OUT_NEGATIVE   101
+#define GVOM_OUT_ROUGHNESS  102
+#define GVOM_OUT_VISIBILITY 103
+int gvom_rows_export(gvom_t *h, int which, int row_lo, int row_hi, void *dev_buf);
+int gvom_rows_import(gvom_t *h, int which, int row_lo, int row_hi, const void *dev_buf);
+int gvom_combine_map2d(gvom_t *h);
+int gvom_finalize_outputs(gvom_t *h, double origin_world[3], int32_t *positive, int32_t *negative,
+                          double *roughness, int32_t *visibility);
+
+/* --- accessors of the reference object ------------------------------------------------- */
+/* 1 if ring slot `slot` holds a scan (origin_buffer[slot] is not None, gvom.py:201). */
+int gvom_slot_filled(gvom_t *h, int slot);
+int gvom_get_state(gvom_t *h, gvom_state *out);
+int gvom_get_scan_stats(gvom_t *h, gvom_scan_stats *out);
+/* Gvom.get_map_as_occupancy_grid (gvom.py:356-361): uint8[xy][xy][z] C-order (== the
+ * reference's order='F' reshape of the lookup table), 1 where occupied. */
+int gvom_get_occupancy(gvom_t *h, uint8_t *out_xyz);
+/* Gvom.make_debug_height_map (gvom.py:380-394, kernel :426-438): float32[xy*xy][7]. */
+int gvom_debug_height_map(gvom_t *h, float *out);
+/* Gvom.make_debug_inferred_height_map (gvom.py:396-410, kernel :442-450): float32[xy*xy][3]. */
+int gvom_debug_inferred_height_map(gvom_t *h, float *out);
+
+/* --- test hooks: dense equivalents in the reference's voxel order ------------------------
+ * which: 0..buffer_size-1 = ring slot (index_buffer/hit_count_buffer/... gvom.py:59-64),
+ *        GVOM_WHICH_FUSED = current fused map (combined_* gvom.py:69-75).
+ * state: 0 where occupied, -1 never observed, -m-1 free with m ray passes (gvom.py:1154-1160);
+ * hit/total 0 and min_h 1.0f where not occupied.  origin: voxel units.  NULLs are skipped.
+ * Returns GVOM_NO_DATA if the slot / fused map is empty. */
+#define GVOM_WHICH_FUSED (-1)
+int gvom_read_dense(gvom_t *h, int which, int32_t *state, int32_t *hit, int32_t *total,
+                    float *min_h, double origin[3], int64_t *cell_count);
+/* which2d: internal float64 maps of the last combine, [x][y] C-order like the reference's
+ * attributes (gvom.py:85-88,310-313). */
+#define GVOM_MAP_HEIGHT          0
+#define GVOM_MAP_INFERRED_HEIGHT 1
+#define GVOM_MAP_SLOPE_X         2
+#define GVOM_MAP_SLOPE_Y         3
+#define GVOM_MAP_ROUGHNESS       4
+#define GVOM_MAP_GUESSED_DELTA   5
+int gvom_read_map2d(gvom_t *h, int which2d, double *out);
+
+/* --- measurement ------------------------------------------------------------------------
+ * Device time (HIP events on the library's own stream) of the kernels of the last
+ * process_pointcloud / combine_maps call, in milliseconds, by stage.  Stages:
+ * 0 trace (transform+hit+DDA), 1 encode, 2 min-height, 3 fuse (+column reductions), 4 maps2d. */
+#define GVOM_N_STAGES 5
+int gvom_last_stage_ms(gvom_t *h, float ms[GVOM_N_STAGES]);
+/* Enables/disables per-stage event timing (adds one host sync per call when on). */
+int gvom_set_profiling(gvom_t *h, int on);
+/* Raw HIP stream the library launches on (hipStream_t as void*), for external event timing. */
+void *gvom_stream(gvom_t *h);
+
+const char *gvom_last_error(gvom_t *h);      /* never NULL */
+int gvom_backend_info(char *buf, size_t len); /* "gfx950 ..." device + build string */
+int gvom_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GVOM_HIP_H */

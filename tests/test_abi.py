@@ -1,0 +1,88 @@
+"""CPU-side checks of the drop-in boundary: libgvom_hip.so loads and exports every symbol
+include/gvom_hip.h declares (no compute calls without a GPU); the Python class mirrors the
+reference's surface and fails loudly -- never silently falls back -- when the GPU is absent."""
+import inspect
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "gvom_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gvom_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    import ctypes
+    import gvom
+    path = gvom.library_path()
+    assert os.path.exists(path), "build first: python -c 'import __graft_entry__ as g; g.build()'"
+    L = ctypes.CDLL(path)
+    declared = _declared_symbols()
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(L, name), "libgvom_hip.so does not export %s" % name
+    bound = {n for n, _, _ in gvom.ABI}
+    assert set(declared) == bound, (set(declared) ^ bound)
+    assert gvom.load_library().gvom_abi_version() == 1
+
+
+def test_params_struct_layout_matches_header():
+    import ctypes
+    import gvom
+    assert ctypes.sizeof(gvom.GvomParams) == 8 * 2 + 4 * 4 + 8 * 7 + 4 * 2
+    assert gvom.GvomParams.min_distance.offset == 32
+    assert ctypes.sizeof(gvom.GvomState) == 16 + 8 + 24 + 24
+
+
+def test_constructor_signature_matches_reference():
+    import gvom
+    names = list(inspect.signature(gvom.Gvom.__init__).parameters)[1:15]
+    assert names == ["xy_resolution", "z_resolution", "xy_size", "z_size", "buffer_size",
+                     "min_distance", "positive_obstacle_threshold", "negative_obstacle_threshold",
+                     "slope_obstacle_threshold", "robot_height", "robot_radius",
+                     "ground_to_lidar_height", "xy_eigen_dist", "z_eigen_dist"]
+    for m in ("process_pointcloud", "combine_maps", "get_map_as_occupancy_grid",
+              "make_debug_voxel_map", "make_debug_height_map", "make_debug_inferred_height_map"):
+        assert callable(getattr(gvom.Gvom, m))
+    sig = inspect.signature(gvom.Gvom.process_pointcloud)
+    assert list(sig.parameters)[1:] == ["pointcloud", "ego_position", "transform"]
+    assert sig.parameters["transform"].default is None
+
+
+def test_no_silent_cpu_fallback():
+    """Without a GPU the product must refuse to run, not quietly compute on the CPU."""
+    import gvom
+    rc, info = gvom.Gvom.backend_info()
+    if rc == 0:
+        pytest.skip("a GPU is visible: %s" % info)
+    with pytest.raises(gvom.GvomBackendError):
+        gvom.Gvom(0.4, 0.4, 16, 8, 2, 1.0, 0.5, 0.5, 0.3, 2.0, 4.0, 1.0, 1, 1)
+    with pytest.raises(gvom.GvomBackendError):
+        gvom.load_library("/nonexistent/libgvom_hip.so")
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "g-vom_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.lower(), "%s mentions the oracle" % f
+
+
+def test_synthetic_inputs_are_seeded_and_shaped():
+    import synth
+    params, scans = synth.config_inputs("c2")
+    pc, ego, tf = scans[0]
+    assert pc.shape == (131072, 3) and pc.dtype == np.float32 and tf is None
+    params2, scans2 = synth.config_inputs("c2")
+    assert np.array_equal(pc, scans2[0][0])
+    assert np.isfinite(pc).all() and np.linalg.norm(pc, axis=1).max() <= 60.001
+    p1, s1 = synth.config_inputs("c1")
+    assert s1[0][0].shape == (50000, 3) and s1[0][0].dtype == np.float64
