@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py -- G-VOM hot path (process_pointcloud -> combine_maps) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config m256|c2|c3|m256b8]
+
+A "step" is one pass of the hot path over one synthetic lidar scan that is already resident
+in HBM: gvom_process_pointcloud_device (transform/hit/DDA trace, encode, min-height) followed
+by gvom_combine_maps (temporal fusion + column reductions + 2-D maps + D2H of the four
+returned maps).  Metric: M points/s (whole job), with end-to-end map Hz beside it.
+
+N = 1 runs the headline configuration of BASELINE.json's metric: the 256^3 voxel grid at
+0.2 m with the OS1-64-shaped 131,072-point scan (BASELINE.md row "M").  N > 1 runs the
+slab-sharded mapper (g-vom_amd/gvom_sharded.py): one rank per GPU, the grid partitioned into
+world-anchored y-slabs, N sensors' scans per step (weak scaling: per-GPU point count fixed).
+
+Rank 0 prints ONE JSON line with the `roofline` (dominant kernel, HIP-event timed inside the
+timed region on the library's own stream) and `cpu_baseline` (the CPU oracle, a "port" of the
+reference's algorithm, timed on this host's cores on a bounded sample) objects.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "g-vom_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np          # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+
+
+class Hip(object):
+    """Minimal HIP runtime binding for device buffers (plumbing only)."""
+
+    def __init__(self):
+        self.rt = ctypes.CDLL("libamdhip64.so")
+        self.rt.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+        self.rt.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        self.rt.hipFree.argtypes = [ctypes.c_void_p]
+        self.rt.hipSetDevice.argtypes = [ctypes.c_int]
+
+    def chk(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed with hipError %d" % (what, rc))
+
+    def set_device(self, d):
+        self.chk(self.rt.hipSetDevice(d), "hipSetDevice")
+
+    def to_device(self, arr):
+        p = ctypes.c_void_p()
+        self.chk(self.rt.hipMalloc(ctypes.byref(p), arr.nbytes), "hipMalloc")
+        self.chk(self.rt.hipMemcpy(p, arr.ctypes.data_as(ctypes.c_void_p), arr.nbytes, 1), "hipMemcpy")
+        self.chk(self.rt.hipDeviceSynchronize(), "hipDeviceSynchronize")
+        return p
+
+
+def cpu_baseline(params, scans, budget_s=20.0):
+    """Times the CPU oracle (single thread, C restatement of the reference's algorithm) on a
+    bounded sample of the same workload: whole steps (one scan + one combine) until the
+    budget is used, at least one."""
+    from oracle import oracle
+    g = oracle.OracleGvom(*params)
+    pts = 0
+    steps = 0
+    t0 = time.perf_counter()
+    while True:
+        pc, ego, tf = scans[steps % len(scans)]
+        g.process_pointcloud(pc, ego, tf)
+        g.combine_maps()
+        pts += pc.shape[0]
+        steps += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or steps >= 2 * len(scans) + 8:
+            break
+    return {"value": pts / el / 1e6, "unit": "M points/s", "cores": 1, "kind": "port",
+            "sample": "%d whole steps (scan+combine) of the same workload, %.1f s, "
+                      "oracle/gvom_oracle.c single thread" % (steps, el),
+            "ms_per_step": el / steps * 1e3}
+
+
+def run_single(args):
+    import gvom
+    import synth
+    hip = Hip()
+    hip.set_device(0)
+    name = args.config
+    params, scans = synth.config_inputs(name, n_scans=max(1, args.poses))
+    g = gvom.Gvom(*params, device=0)
+    dev = [(hip.to_device(pc), pc.shape[0], pc.dtype, ego, tf) for (pc, ego, tf) in scans]
+    n_pts = scans[0][0].shape[0]
+
+    def step(k):
+        d, n, dt, ego, tf = dev[k % len(dev)]
+        g.process_pointcloud_device(d.value, n, dt, ego, tf)
+        return g.combine_maps()
+
+    for k in range(args.warmup):
+        step(k)
+    # exact integer accounting for the roofline (algorithmic bytes)
+    stats = g.scan_stats()
+    g.set_profiling(True)
+    acc = dict.fromkeys(gvom.STAGE_NAMES, 0.0)
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k)
+        ms = g.last_stage_ms()
+        for s in acc:
+            acc[s] += ms[s]
+    elapsed = time.perf_counter() - t0
+    g.set_profiling(False)
+    stage_ms = {s: acc[s] / args.steps for s in acc}
+
+    V = params[2] * params[2] * params[3]
+    P = 12 if scans[0][0].dtype == np.float32 else 24
+    n_in = stats["sum_hit"]
+    alg = {                                                          # bytes per launch
+        "trace": n_pts * P + 4 * (stats["sum_hit"] + stats["sum_total"]),
+        "encode": 20 * V,
+        "min_height": n_pts * P + 4 * n_in,
+        "fuse": 4 * V * (min(args.poses, params[4]) + 1) + 4 * V + 4 * V,
+        "map2d": 68 * params[2] * params[2],
+    }
+    dom = max(stage_ms, key=lambda s: stage_ms[s])
+    achieved = alg[dom] / (stage_ms[dom] * 1e-3) / 1e9
+    out = {
+        "metric": "M points/sec (process_pointcloud + combine_maps, 256^3 voxel grid); map Hz beside it",
+        "value": n_pts * args.steps / elapsed / 1e6,
+        "unit": "M points/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "int32 atomics + f32 ray state + f64 compares/maps",
+        "data": "synthetic",
+        "config": {"workload": synth.CONFIGS[name][2], "name": name, "points_per_scan": n_pts,
+                   "grid": [params[2], params[2], params[3]], "buffer_size": params[4],
+                   "poses": len(scans), "input": "device-resident f32 xyz",
+                   "step": "1 scan + 1 combine incl. D2H of the 4 maps"},
+        "map_hz": args.steps / elapsed,
+        "stage_ms": stage_ms,
+        "sum_hit": stats["sum_hit"], "sum_total": stats["sum_total"], "cells": stats["cells"],
+        "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": stage_ms[dom],
+                     "all_stages_GBs": {s: alg[s] / (stage_ms[s] * 1e-3) / 1e9 if stage_ms[s] > 0 else None
+                                        for s in alg}},
+    }
+    if not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(params, scans, args.cpu_budget)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="m256", choices=["c2", "c3", "m256", "m256b8"])
+    ap.add_argument("--poses", type=int, default=1, help="distinct sensor poses cycled through")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        import bench_sharded
+        out = bench_sharded.run(args)
+        if out is None:
+            return
+    else:
+        out = run_single(args)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
