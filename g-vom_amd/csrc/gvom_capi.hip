@@ -14,6 +14,7 @@
 
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <mutex>
 #include <string>
@@ -65,7 +66,8 @@ struct gvom_handle {
     int buffer_index = 0, last_buffer_index = 0;
     Buf in_pts, world_pts;
     uint32_t *counters = nullptr;                       // device: [0] scan rows, [2..3] fuse rows (u64)
-    uint32_t *counters_host = nullptr;                  // pinned mirror
+    uint32_t *counters_host = nullptr;                  // pinned, device-mapped: kernels publish counts here
+    uint32_t *counters_host_dev = nullptr;              // device view of counters_host
 
     // pending (uncommitted) scan
     bool pending = false;
@@ -87,6 +89,7 @@ struct gvom_handle {
 
     double ego[3] = {0, 0, 0};
 
+    int trace_variant = 1;                              // GVOM_TRACE_VARIANT (k_trace strategy)
     bool profiling = false;
     hipEvent_t ev[8] = {nullptr};
     float stage_ms[GVOM_N_STAGES] = {0, 0, 0, 0, 0};
@@ -162,6 +165,7 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, g
     h->prm = *params;
     h->device = device_id;
     h->rank = rank; h->world = world;
+    if (const char *v = getenv("GVOM_TRACE_VARIANT")) h->trace_variant = atoi(v);
     const int xy = params->xy_size, zs = params->z_size;
     h->sy_lo = (int)((int64_t)xy * rank / world);
     h->sy_hi = (int)((int64_t)xy * (rank + 1) / world);
@@ -190,15 +194,18 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, g
     h->staging = params->buffer_size;
     for (int k = 0; k < 2; ++k) CK(hipMalloc((void **)&h->fused[k].state, h->V * 4));
     CK(hipMalloc((void **)&h->counters, 64));
-    CK(hipHostMalloc((void **)&h->counters_host, 64));
+    CK(hipHostMalloc((void **)&h->counters_host, 64, hipHostMallocMapped));
+    CK(hipHostGetDevicePointer((void **)&h->counters_host_dev, h->counters_host, 0));
+    memset(h->counters_host, 0, 64);
+    CK(hipMemsetAsync(h->counters, 0, 64, h->stream));
     CK(hipMalloc((void **)&h->descs_dev, sizeof(MapDesc) * (GVOM_MAX_SLOTS + 1)));
     CK(hipHostMalloc((void **)&h->descs_host, sizeof(MapDesc) * (GVOM_MAX_SLOTS + 1)));
     double **maps[6] = {&h->height, &h->inferred, &h->slope_x, &h->slope_y, &h->rough, &h->guessed};
     for (auto m : maps) CK(hipMalloc((void **)m, h->cells2d * 8));
-    CK(hipMalloc((void **)&h->out_pos, h->cells2d * 4));
-    CK(hipMalloc((void **)&h->out_neg, h->cells2d * 4));
-    CK(hipMalloc((void **)&h->out_vis, h->cells2d * 4));
-    CK(hipMalloc((void **)&h->out_rough, h->cells2d * 8));
+    CK(hipMalloc((void **)&h->out_pos, h->cells2d * 20));              // [pos | neg | vis | rough] packed:
+    h->out_neg = h->out_pos + h->cells2d;                              // one D2H copy per combine
+    h->out_vis = h->out_neg + h->cells2d;
+    h->out_rough = (double *)(h->out_vis + h->cells2d);
     CK(hipHostMalloc(&h->out_host, h->cells2d * 20));
     for (auto &e : h->ev) CK(hipEventCreate(&e));
     CK(hipStreamSynchronize(h->stream));
@@ -226,18 +233,17 @@ int scan_launch(gvom_handle *h, const void *dev_pts, int64_t n, int64_t stride_e
     if ((rc = ensure(h, st.chit, cap * 4))) return rc;
     if ((rc = ensure(h, st.ctotal, cap * 4))) return rc;
     if ((rc = ensure(h, st.cminh, cap * 4))) return rc;
-    HIPCHK(h, hipMemsetAsync(h->counters, 0, 4, h->stream));
     if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
     HIPCHK(h, gvom_launch_trace(h->stream, P, dtype, dev_pts, stride_elems, n, h->world_pts.p, h->hit,
-                                h->total, st.state, h->counters));
+                                h->total, st.state, h->counters, h->trace_variant));
     if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
     HIPCHK(h, gvom_launch_encode(h->stream, p.xy_size, p.z_size, h->sy_lo, h->sy_hi, h->hit, h->total,
                                  st.state, (uint32_t *)st.chit.p, (uint32_t *)st.ctotal.p,
                                  (uint32_t *)st.cminh.p, nullptr));
     if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
-    HIPCHK(h, gvom_launch_minh(h->stream, P, dtype, h->world_pts.p, n, st.state, (uint32_t *)st.cminh.p));
+    HIPCHK(h, gvom_launch_minh(h->stream, P, dtype, h->world_pts.p, n, st.state, (uint32_t *)st.cminh.p,
+                               h->counters, h->counters_host_dev));
     if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->counters_host, h->counters, 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->profiling) {
         hipEventElapsedTime(&h->stage_ms[0], h->ev[0], h->ev[1]);
@@ -308,7 +314,7 @@ int choose_nz(int zs, int *zc)
 }
 
 // fusion + column reductions (k_fuse) into fused[1 - cur]
-int fuse_impl(gvom_handle *h)
+int fuse_impl(gvom_handle *h, bool publish_now)
 {
     const gvom_params &p = h->prm;
     const Slot &last = h->slots[h->ring[h->last_buffer_index]];
@@ -360,15 +366,24 @@ int fuse_impl(gvom_handle *h)
     P.xy_res = p.xy_resolution; P.z_res = p.z_resolution;
     P.radius2 = p.robot_radius * p.robot_radius;
     P.ground_to_lidar_height = p.ground_to_lidar_height;
-    HIPCHK(h, hipMemcpyAsync(h->descs_dev, h->descs_host, sizeof(MapDesc) * (ns + (prev ? 1 : 0)),
-                             hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->counters + 2, 0, 8, h->stream));
+    const int nsrc = ns + (prev ? 1 : 0);
+    FuseDescs KD;
+    const MapDesc *descs_mem = nullptr;
+    if (nsrc <= GVOM_KARG_DESCS) {
+        memcpy(KD.d, h->descs_host, sizeof(MapDesc) * nsrc);
+    } else {
+        HIPCHK(h, hipMemcpyAsync(h->descs_dev, h->descs_host, sizeof(MapDesc) * nsrc,
+                                 hipMemcpyHostToDevice, h->stream));
+        descs_mem = h->descs_dev;
+    }
     if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[4], h->stream));
-    HIPCHK(h, gvom_launch_fuse(h->stream, P, h->descs_dev, F.state, (uint32_t *)F.hit.p,
+    HIPCHK(h, gvom_launch_fuse(h->stream, P, KD, descs_mem, F.state, (uint32_t *)F.hit.p,
                                (uint32_t *)F.total.p, (uint32_t *)F.minh.p,
                                (unsigned long long *)(h->counters + 2), h->height, h->inferred));
     if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[5], h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->counters_host + 2, h->counters + 2, 8, hipMemcpyDeviceToHost, h->stream));
+    if (publish_now)
+        HIPCHK(h, gvom_launch_publish_u64(h->stream, (unsigned long long *)(h->counters + 2),
+                                          (unsigned long long *)(h->counters_host_dev + 2)));
     F.valid = true;
     h->cur = nxt;
     h->has_combined = true;
@@ -377,7 +392,7 @@ int fuse_impl(gvom_handle *h)
 }
 
 // 2-D maps (k_map2d) from height/inferred of the whole window (all rows must be present)
-int map2d_impl(gvom_handle *h, bool storage_order_out)
+int map2d_impl(gvom_handle *h, bool storage_order_out, bool publish)
 {
     const gvom_params &p = h->prm;
     const Fused &F = h->fused[h->cur];
@@ -397,7 +412,8 @@ int map2d_impl(gvom_handle *h, bool storage_order_out)
     HIPCHK(h, gvom_launch_map2d(h->stream, P, F.state, (const uint32_t *)F.hit.p,
                                 (const uint32_t *)F.total.p, h->height, h->inferred, h->slope_x,
                                 h->slope_y, h->rough, h->guessed, h->out_pos, h->out_neg, h->out_rough,
-                                h->out_vis));
+                                h->out_vis, (unsigned long long *)(h->counters + 2),
+                                publish ? (unsigned long long *)(h->counters_host_dev + 2) : nullptr));
     if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[7], h->stream));
     h->maps_valid = true;
     return GVOM_OK;
@@ -449,7 +465,7 @@ VIS void gvom_destroy(gvom_t *h)
     hipFree(h->descs_dev); if (h->descs_host) hipHostFree(h->descs_host);
     hipFree(h->height); hipFree(h->inferred); hipFree(h->slope_x); hipFree(h->slope_y);
     hipFree(h->rough); hipFree(h->guessed);
-    hipFree(h->out_pos); hipFree(h->out_neg); hipFree(h->out_vis); hipFree(h->out_rough);
+    hipFree(h->out_pos);
     if (h->out_host) hipHostFree(h->out_host);
     for (auto &e : h->ev) if (e) hipEventDestroy(e);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -494,15 +510,13 @@ VIS int gvom_combine_maps(gvom_t *h, double origin_world[3], int32_t *positive, 
     if (!h) return GVOM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->device));
-    int rc = fuse_impl(h);
+    int rc = fuse_impl(h, false);
     if (rc) return rc;
-    if ((rc = map2d_impl(h, false))) return rc;
+    if ((rc = map2d_impl(h, false, true))) return rc;
     const size_t n2 = h->cells2d;
     char *stage = (char *)h->out_host;
-    if (positive) HIPCHK(h, hipMemcpyAsync(stage, h->out_pos, n2 * 4, hipMemcpyDeviceToHost, h->stream));
-    if (negative) HIPCHK(h, hipMemcpyAsync(stage + n2 * 4, h->out_neg, n2 * 4, hipMemcpyDeviceToHost, h->stream));
-    if (visibility) HIPCHK(h, hipMemcpyAsync(stage + n2 * 8, h->out_vis, n2 * 4, hipMemcpyDeviceToHost, h->stream));
-    if (roughness) HIPCHK(h, hipMemcpyAsync(stage + n2 * 12, h->out_rough, n2 * 8, hipMemcpyDeviceToHost, h->stream));
+    if (positive || negative || visibility || roughness)
+        HIPCHK(h, hipMemcpyAsync(stage, h->out_pos, n2 * 20, hipMemcpyDeviceToHost, h->stream));
     if ((rc = finish_combine(h))) return rc;
     if (positive) memcpy(positive, stage, n2 * 4);
     if (negative) memcpy(negative, stage + n2 * 4, n2 * 4);
@@ -529,7 +543,7 @@ VIS int gvom_combine_fuse(gvom_t *h, int64_t *local_cells)
     if (!h) return GVOM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->device));
-    int rc = fuse_impl(h);
+    int rc = fuse_impl(h, true);
     if (rc) return rc;
     if ((rc = finish_combine(h))) return rc;
     if (local_cells) *local_cells = h->fused[h->cur].count;
@@ -593,7 +607,7 @@ VIS int gvom_combine_map2d(gvom_t *h)
     if (!h) return GVOM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     if (!h->has_combined) return GVOM_NO_DATA;
-    int rc = map2d_impl(h, true);
+    int rc = map2d_impl(h, true, false);
     if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->profiling) hipEventElapsedTime(&h->stage_ms[4], h->ev[6], h->ev[7]);

@@ -40,6 +40,9 @@ struct MapDesc {          // one source map of the fusion (ring slot or previous
     int pad;
 };
 
+#define GVOM_KARG_DESCS 17   // ring slots + previous map passed by kernel argument when they fit
+struct FuseDescs { MapDesc d[GVOM_KARG_DESCS]; };
+
 struct FuseParams {
     int xy, zs;
     int om[3];              // fused origin mod size
@@ -68,20 +71,23 @@ struct Map2dParams {
 // ---- launchers (gvom_kernels.hip) --------------------------------------------------------
 hipError_t gvom_launch_trace(hipStream_t s, const ScanParams &P, int dtype, const void *pts,
                              int64_t stride_elems, int64_t n, void *world, uint32_t *hit,
-                             uint32_t *total, int32_t *state, uint32_t *counters);
+                             uint32_t *total, int32_t *state, uint32_t *counters, int variant);
 hipError_t gvom_launch_encode(hipStream_t s, int xy, int zs, int sy_lo, int sy_hi, uint32_t *hit,
                               uint32_t *total, int32_t *state, uint32_t *chit, uint32_t *ctotal,
                               uint32_t *cminh, unsigned long long *sums);
 hipError_t gvom_launch_minh(hipStream_t s, const ScanParams &P, int dtype, const void *world,
-                            int64_t n, const int32_t *state, uint32_t *cminh);
-hipError_t gvom_launch_fuse(hipStream_t s, const FuseParams &P, const MapDesc *descs_dev,
-                            int32_t *fstate, uint32_t *fhit, uint32_t *ftotal, uint32_t *fminh,
+                            int64_t n, const int32_t *state, uint32_t *cminh, uint32_t *counters,
+                            uint32_t *host_counters);
+hipError_t gvom_launch_publish_u64(hipStream_t s, unsigned long long *counter, unsigned long long *host_counter);
+hipError_t gvom_launch_fuse(hipStream_t s, const FuseParams &P, const FuseDescs &KD,
+                            const MapDesc *descs_dev, int32_t *fstate, uint32_t *fhit, uint32_t *ftotal, uint32_t *fminh,
                             unsigned long long *counter, double *height, double *inferred);
 hipError_t gvom_launch_map2d(hipStream_t s, const Map2dParams &P, const int32_t *fstate,
                              const uint32_t *fhit, const uint32_t *ftotal, const double *height,
                              const double *inferred, double *slope_x, double *slope_y,
                              double *rough, double *guessed, int32_t *out_pos, int32_t *out_neg,
-                             double *out_rough, int32_t *out_vis);
+                             double *out_rough, int32_t *out_vis, unsigned long long *counter,
+                             unsigned long long *host_counter);
 // test hooks / debug accessors
 hipError_t gvom_launch_read_dense(hipStream_t s, int xy, int zs, const int om[3],
                                   const int32_t *state, const uint32_t *chit,

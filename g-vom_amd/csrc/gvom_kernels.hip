@@ -48,7 +48,14 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 //   4. dominant-axis DDA from the ego position, total += 1 per step             gvom.py:1093-1150
 // Only voxels whose storage row sy lies in [sy_lo, sy_hi) are committed (multi-GPU slabs).
 // ------------------------------------------------------------------------------------------
-template <typename T>
+// VAR selects the accumulation strategy of the DDA loop (A/B-able at run time through the
+// GVOM_TRACE_VARIANT environment variable, read by gvom_create):
+//   0  one global atomic per lane and step (divergent per-lane loop)
+//   1  lock-step loop; lanes of a wave that step into the SAME voxel as their left neighbour
+//      are merged (ballot + run length) so one lane adds the whole run: near the sensor all 64
+//      rays of a wave share a voxel and 64 same-address atomics collapse into one
+//   9  diagnostic only: no DDA atomics at all (measures the arithmetic floor; results wrong)
+template <typename T, int VAR>
 __global__ __launch_bounds__(256) void k_trace(const ScanParams P, const T *__restrict__ in,
                                                long stride, long n, T *__restrict__ world,
                                                uint32_t *hit, uint32_t *total, int32_t *state,
@@ -105,7 +112,7 @@ __global__ __launch_bounds__(256) void k_trace(const ScanParams P, const T *__re
         base = __shfl(base, leader);
         if (claim) state[L] = (int32_t)(base + (uint32_t)__popcll(cm & lanemask_lt()));
     }
-    if (!pass) return;
+    if (VAR == 0 && !pass) return;
 
     // ---- ray ------------------------------------------------------------------------------
     const float e0 = (float)((double)x / P.xy_res);
@@ -136,24 +143,72 @@ __global__ __launch_bounds__(256) void k_trace(const ScanParams P, const T *__re
     float p2 = si == 0 ? P.pt0[2] : (si == 1 ? P.pt0[0] : P.pt0[1]);
     double length = 0.0;
     const double lim = ray_length - 1.0;
-    while (length < lim) {
-        pd = pd + dir; p1 = p1 + inc1; p2 = p2 + inc2;
-        const float px = si == 0 ? pd : (si == 1 ? p2 : p1);
-        const float py = si == 0 ? p1 : (si == 1 ? pd : p2);
-        const float pz = si == 0 ? p2 : (si == 1 ? p1 : pd);
-        const double fx = floor((double)px - P.origin[0]);
-        if (!(fx >= 0.0 && fx < dxy)) break;
-        const double fy = floor((double)py - P.origin[1]);
-        if (!(fy >= 0.0 && fy < dxy)) break;
-        const double fz = floor((double)pz - P.origin[2]);
-        if (!(fz >= 0.0 && fz < dzs)) break;
-        const int sy = wrap_add((int)fy, P.om[1], P.xy);
-        if (sy >= P.sy_lo && sy < P.sy_hi) {
-            const int sx = wrap_add((int)fx, P.om[0], P.xy);
-            const int sz = wrap_add((int)fz, P.om[2], P.zs);
-            atomicAdd(&total[((uint32_t)sy * P.zs + sz) * P.xy + sx], 1u);
+
+    if (VAR == 0 || VAR == 9) {
+        uint32_t sink = 0;
+        while (length < lim) {
+            pd = pd + dir; p1 = p1 + inc1; p2 = p2 + inc2;
+            const float px = si == 0 ? pd : (si == 1 ? p2 : p1);
+            const float py = si == 0 ? p1 : (si == 1 ? pd : p2);
+            const float pz = si == 0 ? p2 : (si == 1 ? p1 : pd);
+            const double fx = floor((double)px - P.origin[0]);
+            if (!(fx >= 0.0 && fx < dxy)) break;
+            const double fy = floor((double)py - P.origin[1]);
+            if (!(fy >= 0.0 && fy < dxy)) break;
+            const double fz = floor((double)pz - P.origin[2]);
+            if (!(fz >= 0.0 && fz < dzs)) break;
+            const int sy = wrap_add((int)fy, P.om[1], P.xy);
+            if (sy >= P.sy_lo && sy < P.sy_hi) {
+                const int sx = wrap_add((int)fx, P.om[0], P.xy);
+                const int sz = wrap_add((int)fz, P.om[2], P.zs);
+                const uint32_t Ls = ((uint32_t)sy * P.zs + sz) * P.xy + sx;
+                if (VAR == 0) atomicAdd(&total[Ls], 1u);
+                else sink += Ls;
+            }
+            length += step_len;
         }
-        length += step_len;
+        if (VAR == 9 && sink == 0xdeadbeefu) counters[1] = sink;   // keep the arithmetic alive
+        return;
+    }
+
+    // ---- VAR 1: lock-step, run-merged ----------------------------------------------------
+    bool active = pass && (length < lim);
+    while (__any(active)) {
+        bool commit = false;
+        uint32_t Ls = 0;
+        if (active) {
+            pd = pd + dir; p1 = p1 + inc1; p2 = p2 + inc2;
+            const float px = si == 0 ? pd : (si == 1 ? p2 : p1);
+            const float py = si == 0 ? p1 : (si == 1 ? pd : p2);
+            const float pz = si == 0 ? p2 : (si == 1 ? p1 : pd);
+            const double fx = floor((double)px - P.origin[0]);
+            const double fy = floor((double)py - P.origin[1]);
+            const double fz = floor((double)pz - P.origin[2]);
+            if (fx >= 0.0 && fx < dxy && fy >= 0.0 && fy < dxy && fz >= 0.0 && fz < dzs) {
+                const int sy = wrap_add((int)fy, P.om[1], P.xy);
+                if (sy >= P.sy_lo && sy < P.sy_hi) {
+                    const int sx = wrap_add((int)fx, P.om[0], P.xy);
+                    const int sz = wrap_add((int)fz, P.om[2], P.zs);
+                    Ls = ((uint32_t)sy * P.zs + sz) * P.xy + sx;
+                    commit = true;
+                }
+                length += step_len;
+                active = length < lim;
+            } else {
+                active = false;                           // ray left the grid (gvom.py:1135-1144)
+            }
+        }
+        // merge runs of equal voxel indices among neighbouring lanes
+        const uint32_t key = commit ? Ls : (0xFFFFFF00u | (uint32_t)lane);   // > any voxel index
+        const uint32_t left = (uint32_t)__shfl_up((int)key, 1);
+        const bool head = commit && (lane == 0 || left != key);
+        const unsigned long long cmask = __ballot(commit);
+        const unsigned long long nh = cmask & ~__ballot(head);               // followers
+        if (head) {
+            const unsigned long long after = (nh >> lane) >> 1;
+            const uint32_t run = (uint32_t)__ffsll((long long)~after);       // 1 + followers
+            atomicAdd(&total[Ls], run);
+        }
     }
 }
 
@@ -225,9 +280,14 @@ __global__ __launch_bounds__(256) void k_encode(size_t begin, size_t count, uint
 template <typename T>
 __global__ __launch_bounds__(256) void k_minh(const ScanParams P, const T *__restrict__ world,
                                               long n, const int32_t *__restrict__ state,
-                                              uint32_t *cminh)
+                                              uint32_t *cminh, uint32_t *counters,
+                                              volatile uint32_t *host_counters)
 {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) {          // k_trace is complete: publish the scan's row count (host-mapped) and re-arm
+        host_counters[0] = counters[0];
+        counters[0] = 0;
+    }
     if (i >= n) return;
     const T x = world[3 * i + 0], y = world[3 * i + 1], z = world[3 * i + 2];
     const T d2 = (x * x + y * y) + z * z;
@@ -265,7 +325,9 @@ __global__ __launch_bounds__(256) void k_minh(const ScanParams P, const T *__res
 // Tail    lowest occupied z (+ its min-height) and lowest observed-free z per column are
 //         combined across the nz waves through LDS -> height_map / inferred_height_map.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_fuse(const FuseParams P, const MapDesc *__restrict__ descs,
+template <bool ZC16>
+__global__ __launch_bounds__(1024) void k_fuse(const FuseParams P, const FuseDescs KD,
+                                               const MapDesc *__restrict__ descs_mem,
                                                int32_t *fstate, uint32_t *fhit, uint32_t *ftotal,
                                                uint32_t *fminh, unsigned long long *counter,
                                                double *height, double *inferred)
@@ -276,6 +338,8 @@ __global__ __launch_bounds__(1024) void k_fuse(const FuseParams P, const MapDesc
     __shared__ uint32_t s_hocc[16][WAVE];
     __shared__ int s_zfree[16][WAVE];
 
+    // source descriptors: by kernel argument when they fit (no H2D copy per combine)
+    const MapDesc *__restrict__ descs = descs_mem ? descs_mem : KD.d;
     const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x >> 6;
     const int sx = blockIdx.x * WAVE + lane;
     const int sy = P.sy_lo + blockIdx.y;
@@ -298,6 +362,58 @@ __global__ __launch_bounds__(1024) void k_fuse(const FuseParams P, const MapDesc
     int zocc = INT_MAX, zfree = INT_MAX;
 
     // ---- pass A ----------------------------------------------------------------------------
+    if (ZC16) {
+        // chunk of exactly <= 16 z levels: per source, 16 independent predicated loads are
+        // issued back to back (memory-level parallelism), then folded in source order.
+        int c[16];
+        uint32_t occbits = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) c[k] = -1;
+        for (int s = 0; s < nsrc; ++s) {
+            const int dz = descs[s].d[2];
+            const bool okxy = (okmask >> s) & 1ull;
+            const int32_t *__restrict__ sp = descs[s].state;
+            int st[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int z = z0 + k, zz = z + dz;
+                const bool ok = okxy && z < z1 && zz >= 0 && zz < P.zs;
+                const int sz = wrap_add(z < P.zs ? z : 0, P.om[2], P.zs);
+                st[k] = ok ? sp[colbase + (uint32_t)sz * P.xy] : -1;   // -1 == "never observed": no effect
+            }
+            if (s < P.nslots) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    if (st[k] >= 0) occbits |= 1u << k;                                   // gvom.py:963
+                    else if (st[k] < -1 && !((occbits >> k) & 1u)) c[k] += st[k] + 1;     // gvom.py:967
+                }
+            } else {                                     // previous fused map
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    if (!((occbits >> k) & 1u)) {
+                        if (st[k] >= 0 && c[k] >= -11) occbits |= 1u << k;                // gvom.py:992
+                        else if (st[k] < -1) c[k] += st[k] + 1;                           // gvom.py:996
+                    }
+                }
+            }
+        }
+        if (col_ok) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int z = z0 + k;
+                if (z < z1) {
+                    if ((occbits >> k) & 1u) {
+                        if (zocc == INT_MAX) zocc = z;
+                    } else {
+                        const int sz = wrap_add(z, P.om[2], P.zs);
+                        fstate[colbase + (uint32_t)sz * P.xy] = c[k];
+                        if (c[k] < -1 && zfree == INT_MAX) zfree = z;                     // gvom.py:551
+                    }
+                }
+            }
+            occmask = occbits;
+        }
+    } else
     for (int z = z0; z < z1; ++z) {
         const int sz = wrap_add(z, P.om[2], P.zs);
         const uint32_t L = colbase + (uint32_t)sz * P.xy;
@@ -398,9 +514,21 @@ __global__ __launch_bounds__(1024) void k_fuse(const FuseParams P, const MapDesc
 
 // ------------------------------------------------------------------------------------------
 // k_map2d: every 2-D output of combine_maps from height/inferred height, one lane per cell.
-// Lanes run along storage x; internal maps are [sy][sx]; the four returned maps are written
-// in the reference's [x][y] window order (or left in storage order for sharded runs).
+//
+// Workgroup = a 32 x 8 tile of WINDOW cells.  The height map of the tile plus a 15-cell halo
+// (the reach of __guess_height) is staged once in LDS together with two sets of validity
+// bitmasks (one 64-bit word per tile row over x, one per tile column over y).  The reference's
+// expanding-ring search (up to 15 rings x 4 directions x 30 cells of dependent global loads
+// per cell) becomes at most 60 LDS word reads + count-trailing-zeros per cell.
+// Internal maps are [sy][sx] storage order; the four returned maps are written in the
+// reference's [x][y] window order (or left in storage order for sharded runs).
 // ------------------------------------------------------------------------------------------
+#define M2_TX 32
+#define M2_TY 8
+#define M2_HALO 15
+#define M2_W (M2_TX + 2 * M2_HALO)   // 62
+#define M2_H (M2_TY + 2 * M2_HALO)   // 38
+
 __global__ __launch_bounds__(256) void k_map2d(const Map2dParams P, const int32_t *__restrict__ fstate,
                                                const uint32_t *__restrict__ fhit,
                                                const uint32_t *__restrict__ ftotal,
@@ -408,45 +536,82 @@ __global__ __launch_bounds__(256) void k_map2d(const Map2dParams P, const int32_
                                                const double *__restrict__ inferred,
                                                double *slope_x, double *slope_y, double *rough,
                                                double *guessed, int32_t *out_pos, int32_t *out_neg,
-                                               double *out_rough, int32_t *out_vis)
+                                               double *out_rough, int32_t *out_vis,
+                                               unsigned long long *counter,
+                                               volatile unsigned long long *host_counter)
 {
+    __shared__ double ht[M2_H][M2_W];
+    __shared__ unsigned long long rowm[M2_H];
+    __shared__ unsigned long long colm[M2_W];
+
     const int xy = P.xy;
-    const int sx0 = blockIdx.x * 64 + threadIdx.x;
-    const int sy0 = P.y_lo + blockIdx.y * 4 + threadIdx.y;
-    if (sx0 >= xy || sy0 >= P.y_hi) return;
-    const int x0 = wrap_sub(sx0, P.om[0], xy);              // window coordinates of this cell
-    const int y0 = wrap_sub(sy0, P.om[1], xy);
-#define H(xx, yy) height[(size_t)wrap_add((yy), P.om[1], xy) * xy + wrap_add((xx), P.om[0], xy)]
-    const double h00 = height[(size_t)sy0 * xy + sx0];
+    const int tid = threadIdx.y * M2_TX + threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int X0 = blockIdx.x * M2_TX, Y0 = blockIdx.y * M2_TY;
+    if (host_counter && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
+        *host_counter = *counter;      // k_fuse is complete: publish its row count (host-mapped)
+        *counter = 0ull;
+    }
+
+    // ---- stage the tile (+halo) and its row masks ------------------------------------------
+    for (int r = wv; r < M2_H; r += 4) {
+        const int gy = Y0 - M2_HALO + r, gx = X0 - M2_HALO + lane;
+        double v = -1000.0;
+        if (lane < M2_W && gy >= 0 && gy < xy && gx >= 0 && gx < xy)
+            v = height[(size_t)wrap_add(gy, P.om[1], xy) * xy + wrap_add(gx, P.om[0], xy)];
+        if (lane < M2_W) ht[r][lane] = v;
+        const unsigned long long m = __ballot(v > -1000);
+        if (lane == 0) rowm[r] = m;
+    }
+    __syncthreads();
+    if (tid < M2_W) {
+        unsigned long long m = 0ull;
+        for (int r = 0; r < M2_H; ++r) m |= ((rowm[r] >> tid) & 1ull) << r;
+        colm[tid] = m;
+    }
+    __syncthreads();
+
+    const int x0 = X0 + threadIdx.x, y0 = Y0 + threadIdx.y;          // window cell
+    if (x0 >= xy || y0 >= xy) return;
+    const int sx0 = wrap_add(x0, P.om[0], xy), sy0 = wrap_add(y0, P.om[1], xy);
+    if (sy0 < P.y_lo || sy0 >= P.y_hi) return;                        // another rank's row
+    const int lx = threadIdx.x + M2_HALO, ly = threadIdx.y + M2_HALO;
+    const double h00 = ht[ly][lx];
 
     // ---- slope / roughness: 3x3 least-squares plane (gvom.py:665-734) ---------------------
+    // cells outside the window hold -1000 in the tile, i.e. are skipped exactly like the
+    // reference's clipped ranges; iteration order is x outer / y inner as in the reference.
     double sxv = 0.0, syv = 0.0, rv = -1.0;
     {
-        const int xlo = max(0, x0 - 1), xhi = min(xy, x0 + 2);
-        const int ylo = max(0, y0 - 1), yhi = min(xy, y0 + 2);
         int n_good = 0;
-        for (int xx = xlo; xx < xhi; ++xx)
-            for (int yy = ylo; yy < yhi; ++yy)
-                if (H(xx, yy) > -1000) ++n_good;
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx)
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+                if (ht[ly + dy][lx + dx] > -1000) ++n_good;
         if (n_good >= 3) {
             double mean_x = 0.0, mean_y = 0.0, mean_z = 0.0;
-            for (int xx = xlo; xx < xhi; ++xx)
-                for (int yy = ylo; yy < yhi; ++yy) {
-                    const double hz = H(xx, yy);
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx)
+#pragma unroll
+                for (int dy = -1; dy <= 1; ++dy) {
+                    const double hz = ht[ly + dy][lx + dx];
                     if (hz > -1000) {
-                        mean_x += (double)xx * P.xy_res;
-                        mean_y += (double)yy * P.xy_res;
+                        mean_x += (double)(x0 + dx) * P.xy_res;
+                        mean_y += (double)(y0 + dy) * P.xy_res;
                         mean_z += hz;
                     }
                 }
             const double fi = (double)n_good;
             mean_x /= fi; mean_y /= fi; mean_z /= fi;
             double cxx = 0.0, cxy = 0.0, cxz = 0.0, cyy = 0.0, cyz = 0.0;
-            for (int xx = xlo; xx < xhi; ++xx)
-                for (int yy = ylo; yy < yhi; ++yy) {
-                    const double hz = H(xx, yy);
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx)
+#pragma unroll
+                for (int dy = -1; dy <= 1; ++dy) {
+                    const double hz = ht[ly + dy][lx + dx];
                     if (hz > -1000) {
-                        const double px = (double)xx * P.xy_res, py = (double)yy * P.xy_res;
+                        const double px = (double)(x0 + dx) * P.xy_res, py = (double)(y0 + dy) * P.xy_res;
                         cxx += (px - mean_x) * (px - mean_x);
                         cxy += (px - mean_x) * (py - mean_y);
                         cxz += (px - mean_x) * (hz - mean_z);
@@ -461,11 +626,13 @@ __global__ __launch_bounds__(256) void k_map2d(const Map2dParams P, const int32_
                 const double m = sqrt((a0 * a0 + a1 * a1) + 1.0);
                 a0 /= m; a1 /= m;
                 double err = 0.0;
-                for (int xx = xlo; xx < xhi; ++xx)
-                    for (int yy = ylo; yy < yhi; ++yy) {
-                        const double hz = H(xx, yy);
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx)
+#pragma unroll
+                    for (int dy = -1; dy <= 1; ++dy) {
+                        const double hz = ht[ly + dy][lx + dx];
                         if (hz > -1000) {
-                            const double px = (double)xx * P.xy_res, py = (double)yy * P.xy_res;
+                            const double px = (double)(x0 + dx) * P.xy_res, py = (double)(y0 + dy) * P.xy_res;
                             const double e = (hz - mean_z) - (a0 * (px - mean_x) + a1 * (py - mean_y));
                             err += e * e;
                         }
@@ -484,49 +651,40 @@ __global__ __launch_bounds__(256) void k_map2d(const Map2dParams P, const int32_
     out_rough[c_xy] = rv;
 
     // ---- guess height (gvom.py:558-661), typos at :581 and :655 reproduced ---------------
+    // ring i, direction +x: first valid cell of column x0+i for dy in [-i, i)   -> colm bit-scan
+    //                   -x: column x0-i, dy in [-i+1, i];  +y: row y0+i, dx in [-i+1, i];
+    //                   -y: row y0-i, dx in [-i, i)                               (gvom.py:588-638)
     double dh_out = 0.0;
     const double inf00 = inferred[c_yx];
     if (!(h00 > -1000 || inf00 == -1000.0)) {
         bool x_p_done = false, x_n_done = false, y_p_done = false, y_n_done = false;
-        int x_p = x0, x_n = x0, y_p = y0, y_n = y0;
         double x_ph = -1000, x_nh = -1000, y_ph = -1000, y_nh = -1000;
         int i = 0;
         while (i < 15 && !(x_n_done && x_n_done && y_p_done && y_n_done)) {
-            x_p += 1; x_n -= 1; y_p += 1; y_n -= 1; i += 1;
+            i += 1;
+            const unsigned long long span = (1ull << (2 * i)) - 1ull;
             if (!x_p_done) {
-                if (x_p < xy) {
-                    for (int dy = -i; dy < i; ++dy) {
-                        if (y0 + dy >= xy || y0 + dy < 0) continue;
-                        const double v = H(x_p, y0 + dy);
-                        if (v > -1000) { x_ph = v; x_p_done = true; break; }
-                    }
+                if (x0 + i < xy) {
+                    const unsigned long long m = (colm[lx + i] >> (ly - i)) & span;
+                    if (m) { x_ph = ht[ly - i + __ffsll((long long)m) - 1][lx + i]; x_p_done = true; }
                 } else x_p_done = true;
             }
             if (!x_n_done) {
-                if (x_n >= 0) {
-                    for (int dy = -i + 1; dy < i + 1; ++dy) {
-                        if (y0 + dy >= xy || y0 + dy < 0) continue;
-                        const double v = H(x_n, y0 + dy);
-                        if (v > -1000) { x_nh = v; x_n_done = true; break; }
-                    }
+                if (x0 - i >= 0) {
+                    const unsigned long long m = (colm[lx - i] >> (ly - i + 1)) & span;
+                    if (m) { x_nh = ht[ly - i + 1 + __ffsll((long long)m) - 1][lx - i]; x_n_done = true; }
                 } else x_n_done = true;
             }
             if (!y_p_done) {
-                if (y_p < xy) {
-                    for (int dx = -i + 1; dx < i + 1; ++dx) {
-                        if (x0 + dx >= xy || x0 + dx < 0) continue;
-                        const double v = H(x0 + dx, y_p);
-                        if (v > -1000) { y_ph = v; y_p_done = true; break; }
-                    }
+                if (y0 + i < xy) {
+                    const unsigned long long m = (rowm[ly + i] >> (lx - i + 1)) & span;
+                    if (m) { y_ph = ht[ly + i][lx - i + 1 + __ffsll((long long)m) - 1]; y_p_done = true; }
                 } else y_p_done = true;
             }
             if (!y_n_done) {
-                if (y_n >= 0) {
-                    for (int dx = -i; dx < i; ++dx) {
-                        if (x0 + dx >= xy || x0 + dx < 0) continue;
-                        const double v = H(x0 + dx, y_n);
-                        if (v > -1000) { y_nh = v; y_n_done = true; break; }
-                    }
+                if (y0 - i >= 0) {
+                    const unsigned long long m = (rowm[ly - i] >> (lx - i)) & span;
+                    if (m) { y_nh = ht[ly - i][lx - i + __ffsll((long long)m) - 1]; y_n_done = true; }
                 } else y_n_done = true;
             }
         }
@@ -551,11 +709,10 @@ __global__ __launch_bounds__(256) void k_map2d(const Map2dParams P, const int32_
         const double fmax = floor(((h00 + P.robot_height) / P.z_res) - P.origin_z);
         if (fmin >= 0 && fmin < (double)P.zs && fmax >= 0 && fmax < (double)P.zs) {
             const int zmin = (int)fmin, zmax = (int)fmax;
-            const int sx = sx0, sy = sy0;
             double density = 0.0, nn = 0.0;
             for (int z = zmin; z <= zmax; ++z) {
                 const int sz = wrap_add(z, P.om[2], P.zs);
-                const int32_t row = fstate[((uint32_t)sy * P.zs + sz) * xy + sx];
+                const int32_t row = fstate[((uint32_t)sy0 * P.zs + sz) * xy + sx0];
                 if (row >= 0) {
                     const uint32_t hc = fhit[row];
                     if ((int32_t)hc > 10) { nn += (double)(int32_t)ftotal[row]; density += (double)(int32_t)hc; }
@@ -566,7 +723,6 @@ __global__ __launch_bounds__(256) void k_map2d(const Map2dParams P, const int32_
         }
     }
     out_pos[c_xy] = pos;
-#undef H
 }
 
 // ------------------------------------------------------------------------------------------
@@ -626,20 +782,39 @@ __global__ void k_debug_height(int xy, int om0, int om1, double o0, double o1, d
     }
 }
 
+__global__ void k_publish_u64(unsigned long long *counter, volatile unsigned long long *host_counter)
+{
+    *host_counter = *counter;
+    *counter = 0ull;
+}
+
+hipError_t gvom_launch_publish_u64(hipStream_t s, unsigned long long *counter, unsigned long long *host_counter)
+{
+    hipLaunchKernelGGL(k_publish_u64, dim3(1), dim3(1), 0, s, counter, host_counter);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
 hipError_t gvom_launch_trace(hipStream_t s, const ScanParams &P, int dtype, const void *pts,
                              int64_t stride_elems, int64_t n, void *world, uint32_t *hit,
-                             uint32_t *total, int32_t *state, uint32_t *counters)
+                             uint32_t *total, int32_t *state, uint32_t *counters, int variant)
 {
     const unsigned blocks = (unsigned)((n + 255) / 256);
-    if (dtype == 0)
-        hipLaunchKernelGGL(k_trace<float>, dim3(blocks), dim3(256), 0, s, P, (const float *)pts,
-                           (long)stride_elems, (long)n, (float *)world, hit, total, state, counters);
-    else
-        hipLaunchKernelGGL(k_trace<double>, dim3(blocks), dim3(256), 0, s, P, (const double *)pts,
-                           (long)stride_elems, (long)n, (double *)world, hit, total, state, counters);
+#define TRACE_LAUNCH(TT, VV)                                                                     \
+    hipLaunchKernelGGL((k_trace<TT, VV>), dim3(blocks), dim3(256), 0, s, P, (const TT *)pts,      \
+                       (long)stride_elems, (long)n, (TT *)world, hit, total, state, counters)
+    if (dtype == 0) {
+        if (variant == 0) TRACE_LAUNCH(float, 0);
+        else if (variant == 9) TRACE_LAUNCH(float, 9);
+        else TRACE_LAUNCH(float, 1);
+    } else {
+        if (variant == 0) TRACE_LAUNCH(double, 0);
+        else if (variant == 9) TRACE_LAUNCH(double, 9);
+        else TRACE_LAUNCH(double, 1);
+    }
+#undef TRACE_LAUNCH
     return hipGetLastError();
 }
 
@@ -664,26 +839,31 @@ hipError_t gvom_launch_encode(hipStream_t s, int xy, int zs, int sy_lo, int sy_h
 }
 
 hipError_t gvom_launch_minh(hipStream_t s, const ScanParams &P, int dtype, const void *world,
-                            int64_t n, const int32_t *state, uint32_t *cminh)
+                            int64_t n, const int32_t *state, uint32_t *cminh, uint32_t *counters,
+                            uint32_t *host_counters)
 {
     const unsigned blocks = (unsigned)((n + 255) / 256);
     if (dtype == 0)
         hipLaunchKernelGGL(k_minh<float>, dim3(blocks), dim3(256), 0, s, P, (const float *)world,
-                           (long)n, state, cminh);
+                           (long)n, state, cminh, counters, host_counters);
     else
         hipLaunchKernelGGL(k_minh<double>, dim3(blocks), dim3(256), 0, s, P, (const double *)world,
-                           (long)n, state, cminh);
+                           (long)n, state, cminh, counters, host_counters);
     return hipGetLastError();
 }
 
-hipError_t gvom_launch_fuse(hipStream_t s, const FuseParams &P, const MapDesc *descs_dev,
-                            int32_t *fstate, uint32_t *fhit, uint32_t *ftotal, uint32_t *fminh,
+hipError_t gvom_launch_fuse(hipStream_t s, const FuseParams &P, const FuseDescs &KD,
+                            const MapDesc *descs_dev, int32_t *fstate, uint32_t *fhit, uint32_t *ftotal, uint32_t *fminh,
                             unsigned long long *counter, double *height, double *inferred)
 {
     const dim3 grid((P.xy + 63) / 64, P.sy_hi - P.sy_lo);
     if (grid.y == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_fuse, grid, dim3(64 * P.nz), 0, s, P, descs_dev, fstate, fhit, ftotal,
-                       fminh, counter, height, inferred);
+    if (P.zc <= 16)
+        hipLaunchKernelGGL(k_fuse<true>, grid, dim3(64 * P.nz), 0, s, P, KD, descs_dev, fstate, fhit,
+                           ftotal, fminh, counter, height, inferred);
+    else
+        hipLaunchKernelGGL(k_fuse<false>, grid, dim3(64 * P.nz), 0, s, P, KD, descs_dev, fstate, fhit,
+                           ftotal, fminh, counter, height, inferred);
     return hipGetLastError();
 }
 
@@ -691,12 +871,14 @@ hipError_t gvom_launch_map2d(hipStream_t s, const Map2dParams &P, const int32_t 
                              const uint32_t *fhit, const uint32_t *ftotal, const double *height,
                              const double *inferred, double *slope_x, double *slope_y,
                              double *rough, double *guessed, int32_t *out_pos, int32_t *out_neg,
-                             double *out_rough, int32_t *out_vis)
+                             double *out_rough, int32_t *out_vis, unsigned long long *counter,
+                             unsigned long long *host_counter)
 {
-    const dim3 grid((P.xy + 63) / 64, (P.y_hi - P.y_lo + 3) / 4);
-    if (grid.y == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_map2d, grid, dim3(64, 4), 0, s, P, fstate, fhit, ftotal, height, inferred,
-                       slope_x, slope_y, rough, guessed, out_pos, out_neg, out_rough, out_vis);
+    const dim3 grid((P.xy + M2_TX - 1) / M2_TX, (P.xy + M2_TY - 1) / M2_TY);
+    if (P.y_hi <= P.y_lo) return hipSuccess;
+    hipLaunchKernelGGL(k_map2d, grid, dim3(M2_TX, M2_TY), 0, s, P, fstate, fhit, ftotal, height, inferred,
+                       slope_x, slope_y, rough, guessed, out_pos, out_neg, out_rough, out_vis, counter,
+                       host_counter);
     return hipGetLastError();
 }
 
