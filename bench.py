@@ -165,7 +165,7 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or os.environ.get("GVOM_BENCH_FORCE_SHARDED"):
         import bench_sharded
         out = bench_sharded.run(args)
         if out is None:

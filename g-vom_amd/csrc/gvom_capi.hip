@@ -429,7 +429,8 @@ int finish_combine(gvom_handle *h)
     h->combined_cell_count = F.count;
     if (h->profiling) {
         hipEventElapsedTime(&h->stage_ms[3], h->ev[4], h->ev[5]);
-        hipEventElapsedTime(&h->stage_ms[4], h->ev[6], h->ev[7]);
+        if (h->maps_valid) hipEventElapsedTime(&h->stage_ms[4], h->ev[6], h->ev[7]);
+        (void)hipGetLastError();           // never leave a sticky error behind for the launchers
     }
     return GVOM_OK;
 }
@@ -607,6 +608,7 @@ VIS int gvom_combine_map2d(gvom_t *h)
     if (!h) return GVOM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     if (!h->has_combined) return GVOM_NO_DATA;
+    HIPCHK(h, hipSetDevice(h->device));
     int rc = map2d_impl(h, true, false);
     if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
