@@ -16,6 +16,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+#include <immintrin.h>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -84,11 +86,18 @@ struct gvom_handle {
            *rough = nullptr, *guessed = nullptr;        // [sy][sx] storage order
     int32_t *out_pos = nullptr, *out_neg = nullptr, *out_vis = nullptr;
     double *out_rough = nullptr;
-    void *out_host = nullptr;                           // pinned staging for the 4 outputs
+    void *out_host = nullptr;                           // pinned, device-mapped staging for the 4 outputs
+    char *out_host_dev = nullptr;                       // device view of out_host (zero-copy target)
+    bool zero_copy = true;                              // GVOM_ZERO_COPY=0: device buffer + D2H copy
+    uint32_t scan_seq = 0;                              // sequence number of the {seq,count} flag
+    bool ev_scan = false, ev_fuse = false, ev_map = false;   // which profiling events are recorded
     bool maps_valid = false;
 
     double ego[3] = {0, 0, 0};
 
+    double host_ns[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // host-side phase timing (GVOM_HOST_TIMING)
+    long host_calls = 0;
+    bool host_timing = false;
     int trace_variant = 1;                              // GVOM_TRACE_VARIANT (k_trace strategy)
     bool profiling = false;
     hipEvent_t ev[8] = {nullptr};
@@ -96,6 +105,9 @@ struct gvom_handle {
 };
 
 namespace {
+
+inline double now_ns() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e9 + t.tv_nsec; }
+#define HT(h, slot, t0) do { if ((h)->host_timing) { double n_ = now_ns(); (h)->host_ns[slot] += n_ - (t0); (t0) = n_; } } while (0)
 
 #define HIPCHK(h, call)                                                                         \
     do {                                                                                        \
@@ -166,6 +178,7 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, g
     h->device = device_id;
     h->rank = rank; h->world = world;
     if (const char *v = getenv("GVOM_TRACE_VARIANT")) h->trace_variant = atoi(v);
+    if (const char *v = getenv("GVOM_HOST_TIMING")) h->host_timing = atoi(v) != 0;
     const int xy = params->xy_size, zs = params->z_size;
     h->sy_lo = (int)((int64_t)xy * rank / world);
     h->sy_hi = (int)((int64_t)xy * (rank + 1) / world);
@@ -194,7 +207,7 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, g
     h->staging = params->buffer_size;
     for (int k = 0; k < 2; ++k) CK(hipMalloc((void **)&h->fused[k].state, h->V * 4));
     CK(hipMalloc((void **)&h->counters, 64));
-    CK(hipHostMalloc((void **)&h->counters_host, 64, hipHostMallocMapped));
+    CK(hipHostMalloc((void **)&h->counters_host, 64, hipHostMallocMapped | hipHostMallocCoherent));
     CK(hipHostGetDevicePointer((void **)&h->counters_host_dev, h->counters_host, 0));
     memset(h->counters_host, 0, 64);
     CK(hipMemsetAsync(h->counters, 0, 64, h->stream));
@@ -206,7 +219,9 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, g
     h->out_neg = h->out_pos + h->cells2d;                              // one D2H copy per combine
     h->out_vis = h->out_neg + h->cells2d;
     h->out_rough = (double *)(h->out_vis + h->cells2d);
-    CK(hipHostMalloc(&h->out_host, h->cells2d * 20));
+    CK(hipHostMalloc(&h->out_host, h->cells2d * 20, hipHostMallocMapped));
+    CK(hipHostGetDevicePointer((void **)&h->out_host_dev, h->out_host, 0));
+    if (const char *v = getenv("GVOM_ZERO_COPY")) h->zero_copy = atoi(v) != 0;
     for (auto &e : h->ev) CK(hipEventCreate(&e));
     CK(hipStreamSynchronize(h->stream));
 #undef CK
@@ -233,24 +248,38 @@ int scan_launch(gvom_handle *h, const void *dev_pts, int64_t n, int64_t stride_e
     if ((rc = ensure(h, st.chit, cap * 4))) return rc;
     if ((rc = ensure(h, st.ctotal, cap * 4))) return rc;
     if ((rc = ensure(h, st.cminh, cap * 4))) return rc;
+    double t0 = now_ns();
+    const uint32_t seq = ++h->scan_seq;
     if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
     HIPCHK(h, gvom_launch_trace(h->stream, P, dtype, dev_pts, stride_elems, n, h->world_pts.p, h->hit,
                                 h->total, st.state, h->counters, h->trace_variant));
     if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
     HIPCHK(h, gvom_launch_encode(h->stream, p.xy_size, p.z_size, h->sy_lo, h->sy_hi, h->hit, h->total,
                                  st.state, (uint32_t *)st.chit.p, (uint32_t *)st.ctotal.p,
-                                 (uint32_t *)st.cminh.p, nullptr));
+                                 (uint32_t *)st.cminh.p, h->counters,
+                                 (unsigned long long *)h->counters_host_dev, seq));
     if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
-    HIPCHK(h, gvom_launch_minh(h->stream, P, dtype, h->world_pts.p, n, st.state, (uint32_t *)st.cminh.p,
-                               h->counters, h->counters_host_dev));
-    if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (h->profiling) {
-        hipEventElapsedTime(&h->stage_ms[0], h->ev[0], h->ev[1]);
-        hipEventElapsedTime(&h->stage_ms[1], h->ev[1], h->ev[2]);
-        hipEventElapsedTime(&h->stage_ms[2], h->ev[2], h->ev[3]);
+    HIPCHK(h, gvom_launch_minh(h->stream, P, dtype, h->world_pts.p, n, st.state, (uint32_t *)st.cminh.p));
+    if (h->profiling) { HIPCHK(h, hipEventRecord(h->ev[3], h->stream)); h->ev_scan = true; }
+    HT(h, 0, t0);                                        // scan: launches
+    // Wait only for k_trace: k_encode's first thread publishes {seq, count} to host-mapped memory.
+    // The caller gets control back while k_encode / k_minh still run; everything it can do next
+    // with this handle is stream-ordered behind them.
+    {
+        volatile unsigned long long *flag = (volatile unsigned long long *)h->counters_host;
+        const double deadline = now_ns() + 2.0e9;
+        unsigned spins = 0;
+        while ((uint32_t)(*flag >> 32) != seq) {
+            _mm_pause();
+            if ((++spins & 0x3ff) == 0 && now_ns() > deadline) {      // device trouble: fall back
+                HIPCHK(h, hipStreamSynchronize(h->stream));
+                if ((uint32_t)(*flag >> 32) != seq) { h->err = "scan row count was never published"; return GVOM_ERR_HIP; }
+            }
+        }
     }
-    st.count = h->counters_host[0];
+    HT(h, 1, t0);                                        // scan: wait
+    if (h->host_timing) h->host_calls++;
+    st.count = (int64_t)(uint32_t)(*(volatile unsigned long long *)h->counters_host & 0xffffffffull);
     st.origin[0] = origin[0]; st.origin[1] = origin[1]; st.origin[2] = origin[2];
     st.stats_valid = false;
     st.stats.points = n;
@@ -380,7 +409,7 @@ int fuse_impl(gvom_handle *h, bool publish_now)
     HIPCHK(h, gvom_launch_fuse(h->stream, P, KD, descs_mem, F.state, (uint32_t *)F.hit.p,
                                (uint32_t *)F.total.p, (uint32_t *)F.minh.p,
                                (unsigned long long *)(h->counters + 2), h->height, h->inferred));
-    if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[5], h->stream));
+    if (h->profiling) { HIPCHK(h, hipEventRecord(h->ev[5], h->stream)); h->ev_fuse = true; }
     if (publish_now)
         HIPCHK(h, gvom_launch_publish_u64(h->stream, (unsigned long long *)(h->counters + 2),
                                           (unsigned long long *)(h->counters_host_dev + 2)));
@@ -392,7 +421,7 @@ int fuse_impl(gvom_handle *h, bool publish_now)
 }
 
 // 2-D maps (k_map2d) from height/inferred of the whole window (all rows must be present)
-int map2d_impl(gvom_handle *h, bool storage_order_out, bool publish)
+int map2d_impl(gvom_handle *h, bool storage_order_out, bool publish, bool zero_copy = false)
 {
     const gvom_params &p = h->prm;
     const Fused &F = h->fused[h->cur];
@@ -409,14 +438,35 @@ int map2d_impl(gvom_handle *h, bool storage_order_out, bool publish)
     P.slope_thr = p.slope_obstacle_threshold; P.robot_height = p.robot_height;
     P.out_storage_order = storage_order_out ? 1 : 0;
     if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[6], h->stream));
+    const size_t n2 = h->cells2d;
+    int32_t *o_pos = h->out_pos, *o_neg = h->out_neg, *o_vis = h->out_vis;
+    double *o_rgh = h->out_rough;
+    if (zero_copy) {                                     // k_map2d writes straight into pinned host memory
+        o_pos = (int32_t *)h->out_host_dev; o_neg = o_pos + n2; o_vis = o_neg + n2;
+        o_rgh = (double *)(o_vis + n2);
+    }
     HIPCHK(h, gvom_launch_map2d(h->stream, P, F.state, (const uint32_t *)F.hit.p,
                                 (const uint32_t *)F.total.p, h->height, h->inferred, h->slope_x,
-                                h->slope_y, h->rough, h->guessed, h->out_pos, h->out_neg, h->out_rough,
-                                h->out_vis, (unsigned long long *)(h->counters + 2),
+                                h->slope_y, h->rough, h->guessed, o_pos, o_neg, o_rgh, o_vis,
+                                (unsigned long long *)(h->counters + 2),
                                 publish ? (unsigned long long *)(h->counters_host_dev + 2) : nullptr));
-    if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[7], h->stream));
+    if (h->profiling) { HIPCHK(h, hipEventRecord(h->ev[7], h->stream)); h->ev_map = true; }
     h->maps_valid = true;
     return GVOM_OK;
+}
+
+// stage times of every profiling event pair recorded since the last collection (stream is idle)
+void collect_stage_ms(gvom_handle *h)
+{
+    if (h->ev_scan) {
+        hipEventElapsedTime(&h->stage_ms[0], h->ev[0], h->ev[1]);
+        hipEventElapsedTime(&h->stage_ms[1], h->ev[1], h->ev[2]);
+        hipEventElapsedTime(&h->stage_ms[2], h->ev[2], h->ev[3]);
+    }
+    if (h->ev_fuse) hipEventElapsedTime(&h->stage_ms[3], h->ev[4], h->ev[5]);
+    if (h->ev_map) hipEventElapsedTime(&h->stage_ms[4], h->ev[6], h->ev[7]);
+    h->ev_scan = h->ev_fuse = h->ev_map = false;
+    (void)hipGetLastError();               // never leave a sticky error behind for the launchers
 }
 
 int finish_combine(gvom_handle *h)
@@ -427,11 +477,7 @@ int finish_combine(gvom_handle *h)
     memcpy(&c, h->counters_host + 2, 8);
     F.count = (int64_t)c;
     h->combined_cell_count = F.count;
-    if (h->profiling) {
-        hipEventElapsedTime(&h->stage_ms[3], h->ev[4], h->ev[5]);
-        if (h->maps_valid) hipEventElapsedTime(&h->stage_ms[4], h->ev[6], h->ev[7]);
-        (void)hipGetLastError();           // never leave a sticky error behind for the launchers
-    }
+    collect_stage_ms(h);
     return GVOM_OK;
 }
 
@@ -511,19 +557,75 @@ VIS int gvom_combine_maps(gvom_t *h, double origin_world[3], int32_t *positive, 
     if (!h) return GVOM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->device));
+    double t0 = now_ns();
     int rc = fuse_impl(h, false);
     if (rc) return rc;
-    if ((rc = map2d_impl(h, false, true))) return rc;
+    if ((rc = map2d_impl(h, false, true, h->zero_copy))) return rc;
     const size_t n2 = h->cells2d;
     char *stage = (char *)h->out_host;
-    if (positive || negative || visibility || roughness)
+    if (!h->zero_copy && (positive || negative || visibility || roughness))
         HIPCHK(h, hipMemcpyAsync(stage, h->out_pos, n2 * 20, hipMemcpyDeviceToHost, h->stream));
+    HT(h, 2, t0);                                        // combine: launches
     if ((rc = finish_combine(h))) return rc;
+    HT(h, 3, t0);                                        // combine: wait
     if (positive) memcpy(positive, stage, n2 * 4);
     if (negative) memcpy(negative, stage + n2 * 4, n2 * 4);
     if (visibility) memcpy(visibility, stage + n2 * 8, n2 * 4);
     if (roughness) memcpy(roughness, stage + n2 * 12, n2 * 8);
+    HT(h, 4, t0);                                        // combine: pinned -> caller copies
     if (origin_world) {                                                // gvom.py:185-188
+        const Fused &F = h->fused[h->cur];
+        origin_world[0] = (double)F.origin[0] * h->prm.xy_resolution;
+        origin_world[1] = (double)F.origin[1] * h->prm.xy_resolution;
+        origin_world[2] = (double)F.origin[2] * h->prm.z_resolution;
+    }
+    return GVOM_OK;
+}
+
+// ---- zero-copy outputs ---------------------------------------------------------------------
+// gvom_output_buffer_alloc returns a pinned, device-mapped host buffer of 20*xy*xy bytes laid out
+// [positive i32 | negative i32 | visibility i32 | roughness f64] (each xy*xy, [x][y] order).
+// gvom_combine_maps_into makes k_map2d write the four maps straight into such a buffer: no D2H
+// copy command and no pinned->caller memcpy.  The caller owns the buffer until it frees it
+// (g-vom_amd/gvom.py recycles them through a pool when the returned numpy arrays are collected).
+VIS int gvom_output_buffer_alloc(gvom_t *h, void **host_ptr)
+{
+    if (!h || !host_ptr) return GVOM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipHostMalloc(host_ptr, h->cells2d * 20, hipHostMallocMapped));
+    return GVOM_OK;
+}
+
+VIS int gvom_output_buffer_free(gvom_t *h, void *host_ptr)
+{
+    if (!h || !host_ptr) return GVOM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipHostFree(host_ptr));
+    return GVOM_OK;
+}
+
+VIS int gvom_combine_maps_into(gvom_t *h, double origin_world[3], void *pinned_out)
+{
+    if (!h || !pinned_out) return GVOM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    double t0 = now_ns();
+    int rc = fuse_impl(h, false);
+    if (rc) return rc;
+    char *dev = nullptr;
+    HIPCHK(h, hipHostGetDevicePointer((void **)&dev, pinned_out, 0));
+    char *saved = h->out_host_dev;
+    h->out_host_dev = dev;
+    rc = map2d_impl(h, false, true, true);
+    h->out_host_dev = saved;
+    if (rc) return rc;
+    HT(h, 2, t0);
+    if ((rc = finish_combine(h))) return rc;
+    HT(h, 3, t0);
+    if (origin_world) {
         const Fused &F = h->fused[h->cur];
         origin_world[0] = (double)F.origin[0] * h->prm.xy_resolution;
         origin_world[1] = (double)F.origin[1] * h->prm.xy_resolution;
@@ -612,7 +714,7 @@ VIS int gvom_combine_map2d(gvom_t *h)
     int rc = map2d_impl(h, true, false);
     if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (h->profiling) hipEventElapsedTime(&h->stage_ms[4], h->ev[6], h->ev[7]);
+    collect_stage_ms(h);
     return GVOM_OK;
 }
 
@@ -810,7 +912,22 @@ VIS int gvom_last_stage_ms(gvom_t *h, float ms[GVOM_N_STAGES])
 {
     if (!h || !ms) return GVOM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
+    if (h->ev_scan || h->ev_fuse || h->ev_map) {
+        HIPCHK(h, hipSetDevice(h->device));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        collect_stage_ms(h);
+    }
     for (int k = 0; k < GVOM_N_STAGES; ++k) ms[k] = h->stage_ms[k];
+    return GVOM_OK;
+}
+
+// host-side phase times in microseconds per call, averaged since creation (GVOM_HOST_TIMING=1):
+// [0] scan launches [1] scan wait [2] combine launches [3] combine wait [4] output copies
+VIS int gvom_host_timing(gvom_t *h, double us[8])
+{
+    if (!h || !us) return GVOM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    for (int k = 0; k < 8; ++k) us[k] = h->host_calls ? h->host_ns[k] / h->host_calls / 1e3 : 0.0;
     return GVOM_OK;
 }
 

@@ -74,10 +74,10 @@ hipError_t gvom_launch_trace(hipStream_t s, const ScanParams &P, int dtype, cons
                              uint32_t *total, int32_t *state, uint32_t *counters, int variant);
 hipError_t gvom_launch_encode(hipStream_t s, int xy, int zs, int sy_lo, int sy_hi, uint32_t *hit,
                               uint32_t *total, int32_t *state, uint32_t *chit, uint32_t *ctotal,
-                              uint32_t *cminh, unsigned long long *sums);
+                              uint32_t *cminh, uint32_t *counters, unsigned long long *host_flag,
+                              uint32_t seq);
 hipError_t gvom_launch_minh(hipStream_t s, const ScanParams &P, int dtype, const void *world,
-                            int64_t n, const int32_t *state, uint32_t *cminh, uint32_t *counters,
-                            uint32_t *host_counters);
+                            int64_t n, const int32_t *state, uint32_t *cminh);
 hipError_t gvom_launch_publish_u64(hipStream_t s, unsigned long long *counter, unsigned long long *host_counter);
 hipError_t gvom_launch_fuse(hipStream_t s, const FuseParams &P, const FuseDescs &KD,
                             const MapDesc *descs_dev, int32_t *fstate, uint32_t *fhit, uint32_t *ftotal, uint32_t *fminh,

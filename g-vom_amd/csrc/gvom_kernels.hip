@@ -223,8 +223,18 @@ __global__ __launch_bounds__(256) void k_trace(const ScanParams P, const T *__re
 template <int VEC>
 __global__ __launch_bounds__(256) void k_encode(size_t begin, size_t count, uint32_t *hit,
                                                 uint32_t *total, int32_t *state, uint32_t *chit,
-                                                uint32_t *ctotal, uint32_t *cminh)
+                                                uint32_t *ctotal, uint32_t *cminh, uint32_t *counters,
+                                                unsigned long long *host_flag, uint32_t seq)
 {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // k_trace has completed: the scan's row count is final.  Publish {seq, count} as ONE
+        // 8-byte system-scope store to host-mapped memory (the host spins on it and returns to
+        // its caller while this kernel and k_minh still run) and re-arm the counter.
+        const uint32_t c = counters[0];
+        counters[0] = 0;
+        __hip_atomic_store(host_flag, ((unsigned long long)seq << 32) | c, __ATOMIC_RELEASE,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     const size_t nvec = count / VEC;
     for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec;
          v += (size_t)gridDim.x * blockDim.x) {
@@ -280,14 +290,9 @@ __global__ __launch_bounds__(256) void k_encode(size_t begin, size_t count, uint
 template <typename T>
 __global__ __launch_bounds__(256) void k_minh(const ScanParams P, const T *__restrict__ world,
                                               long n, const int32_t *__restrict__ state,
-                                              uint32_t *cminh, uint32_t *counters,
-                                              volatile uint32_t *host_counters)
+                                              uint32_t *cminh)
 {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i == 0) {          // k_trace is complete: publish the scan's row count (host-mapped) and re-arm
-        host_counters[0] = counters[0];
-        counters[0] = 0;
-    }
     if (i >= n) return;
     const T x = world[3 * i + 0], y = world[3 * i + 1], z = world[3 * i + 2];
     const T d2 = (x * x + y * y) + z * z;
@@ -515,16 +520,18 @@ __global__ __launch_bounds__(1024) void k_fuse(const FuseParams P, const FuseDes
 // ------------------------------------------------------------------------------------------
 // k_map2d: every 2-D output of combine_maps from height/inferred height, one lane per cell.
 //
-// Workgroup = a 32 x 8 tile of WINDOW cells.  The height map of the tile plus a 15-cell halo
+// Workgroup = an 8 (x) x 32 (y) tile of WINDOW cells.  The height map of the tile plus a 15-cell halo
 // (the reach of __guess_height) is staged once in LDS together with two sets of validity
 // bitmasks (one 64-bit word per tile row over x, one per tile column over y).  The reference's
 // expanding-ring search (up to 15 rings x 4 directions x 30 cells of dependent global loads
 // per cell) becomes at most 60 LDS word reads + count-trailing-zeros per cell.
-// Internal maps are [sy][sx] storage order; the four returned maps are written in the
-// reference's [x][y] window order (or left in storage order for sharded runs).
+// Internal maps are [sy][sx] storage order.  The four returned maps are transposed through LDS
+// and written in the reference's [x][y] window order as runs of 32 consecutive y (128/256 B)
+// -- straight into host-mapped memory on the single-GPU path (no D2H copy command) -- or left
+// in storage order for sharded runs.
 // ------------------------------------------------------------------------------------------
-#define M2_TX 32
-#define M2_TY 8
+#define M2_TX 8
+#define M2_TY 32
 #define M2_HALO 15
 #define M2_W (M2_TX + 2 * M2_HALO)   // 62
 #define M2_H (M2_TY + 2 * M2_HALO)   // 38
@@ -543,9 +550,12 @@ __global__ __launch_bounds__(256) void k_map2d(const Map2dParams P, const int32_
     __shared__ double ht[M2_H][M2_W];
     __shared__ unsigned long long rowm[M2_H];
     __shared__ unsigned long long colm[M2_W];
+    __shared__ int o_pos[M2_TX][M2_TY + 1], o_neg[M2_TX][M2_TY + 1], o_vis[M2_TX][M2_TY + 1];
+    __shared__ double o_rgh[M2_TX][M2_TY + 1];
 
     const int xy = P.xy;
-    const int tid = threadIdx.y * M2_TX + threadIdx.x;
+    const int tid = threadIdx.x;
+    const int tx = tid & (M2_TX - 1), ty = tid >> 3;
     const int lane = tid & 63, wv = tid >> 6;
     const int X0 = blockIdx.x * M2_TX, Y0 = blockIdx.y * M2_TY;
     if (host_counter && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
@@ -571,11 +581,12 @@ __global__ __launch_bounds__(256) void k_map2d(const Map2dParams P, const int32_
     }
     __syncthreads();
 
-    const int x0 = X0 + threadIdx.x, y0 = Y0 + threadIdx.y;          // window cell
-    if (x0 >= xy || y0 >= xy) return;
-    const int sx0 = wrap_add(x0, P.om[0], xy), sy0 = wrap_add(y0, P.om[1], xy);
-    if (sy0 < P.y_lo || sy0 >= P.y_hi) return;                        // another rank's row
-    const int lx = threadIdx.x + M2_HALO, ly = threadIdx.y + M2_HALO;
+    const int x0 = X0 + tx, y0 = Y0 + ty;                            // window cell
+    bool mine = x0 < xy && y0 < xy;
+    const int sx0 = wrap_add(mine ? x0 : 0, P.om[0], xy), sy0 = wrap_add(mine ? y0 : 0, P.om[1], xy);
+    mine = mine && sy0 >= P.y_lo && sy0 < P.y_hi;                      // else: another rank's row
+    const int lx = tx + M2_HALO, ly = ty + M2_HALO;
+    if (mine) {
     const double h00 = ht[ly][lx];
 
     // ---- slope / roughness: 3x3 least-squares plane (gvom.py:665-734) ---------------------
@@ -646,9 +657,7 @@ __global__ __launch_bounds__(256) void k_map2d(const Map2dParams P, const int32_
         }
     }
     const size_t c_yx = (size_t)sy0 * xy + sx0;
-    const size_t c_xy = P.out_storage_order ? c_yx : (size_t)x0 * xy + y0;
     slope_x[c_yx] = sxv; slope_y[c_yx] = syv; rough[c_yx] = rv;
-    out_rough[c_xy] = rv;
 
     // ---- guess height (gvom.py:558-661), typos at :581 and :655 reproduced ---------------
     // ring i, direction +x: first valid cell of column x0+i for dy in [-i, i)   -> colm bit-scan
@@ -697,8 +706,8 @@ __global__ __launch_bounds__(256) void k_map2d(const Map2dParams P, const int32_
         if (dh > 0) dh_out = dh;
     }
     guessed[c_yx] = dh_out;
-    out_neg[c_xy] = dh_out > P.neg_thr ? 100 : 0;            // gvom.py:479-485
-    out_vis[c_xy] = h00 > -1000 ? 1 : 0;                     // gvom.py:414-422
+    const int negv = dh_out > P.neg_thr ? 100 : 0;           // gvom.py:479-485
+    const int visv = h00 > -1000 ? 1 : 0;                    // gvom.py:414-422
 
     // ---- positive obstacles (gvom.py:489-521) ------------------------------------------
     int pos = 0;
@@ -722,7 +731,22 @@ __global__ __launch_bounds__(256) void k_map2d(const Map2dParams P, const int32_
             pos = (int)(density * 100);
         }
     }
-    out_pos[c_xy] = pos;
+    if (P.out_storage_order) {
+        out_pos[c_yx] = pos; out_neg[c_yx] = negv; out_vis[c_yx] = visv; out_rough[c_yx] = rv;
+    } else {
+        o_pos[tx][ty] = pos; o_neg[tx][ty] = negv; o_vis[tx][ty] = visv; o_rgh[tx][ty] = rv;
+    }
+    }   // mine
+    if (!P.out_storage_order) {
+        __syncthreads();
+        const int ox = tid >> 5, oy = tid & 31;              // 32 consecutive lanes -> 32 consecutive y
+        const int gx = X0 + ox, gy = Y0 + oy;
+        if (gx < xy && gy < xy) {
+            const size_t c_xy = (size_t)gx * xy + gy;
+            out_pos[c_xy] = o_pos[ox][oy]; out_neg[c_xy] = o_neg[ox][oy];
+            out_vis[c_xy] = o_vis[ox][oy]; out_rough[c_xy] = o_rgh[ox][oy];
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -820,35 +844,34 @@ hipError_t gvom_launch_trace(hipStream_t s, const ScanParams &P, int dtype, cons
 
 hipError_t gvom_launch_encode(hipStream_t s, int xy, int zs, int sy_lo, int sy_hi, uint32_t *hit,
                               uint32_t *total, int32_t *state, uint32_t *chit, uint32_t *ctotal,
-                              uint32_t *cminh, unsigned long long *)
+                              uint32_t *cminh, uint32_t *counters, unsigned long long *host_flag,
+                              uint32_t seq)
 {
     const size_t plane = (size_t)xy * zs;
     const size_t begin = (size_t)sy_lo * plane, count = (size_t)(sy_hi - sy_lo) * plane;
-    if (count == 0) return hipSuccess;
     if (plane % 4 == 0) {
         const size_t nvec = count / 4;
-        const unsigned blocks = (unsigned)min((size_t)8192, (nvec + 255) / 256);
+        const unsigned blocks = (unsigned)max((size_t)1, min((size_t)8192, (nvec + 255) / 256));
         hipLaunchKernelGGL(k_encode<4>, dim3(blocks), dim3(256), 0, s, begin, count, hit, total,
-                           state, chit, ctotal, cminh);
+                           state, chit, ctotal, cminh, counters, host_flag, seq);
     } else {
-        const unsigned blocks = (unsigned)min((size_t)8192, (count + 255) / 256);
+        const unsigned blocks = (unsigned)max((size_t)1, min((size_t)8192, (count + 255) / 256));
         hipLaunchKernelGGL(k_encode<1>, dim3(blocks), dim3(256), 0, s, begin, count, hit, total,
-                           state, chit, ctotal, cminh);
+                           state, chit, ctotal, cminh, counters, host_flag, seq);
     }
     return hipGetLastError();
 }
 
 hipError_t gvom_launch_minh(hipStream_t s, const ScanParams &P, int dtype, const void *world,
-                            int64_t n, const int32_t *state, uint32_t *cminh, uint32_t *counters,
-                            uint32_t *host_counters)
+                            int64_t n, const int32_t *state, uint32_t *cminh)
 {
     const unsigned blocks = (unsigned)((n + 255) / 256);
     if (dtype == 0)
         hipLaunchKernelGGL(k_minh<float>, dim3(blocks), dim3(256), 0, s, P, (const float *)world,
-                           (long)n, state, cminh, counters, host_counters);
+                           (long)n, state, cminh);
     else
         hipLaunchKernelGGL(k_minh<double>, dim3(blocks), dim3(256), 0, s, P, (const double *)world,
-                           (long)n, state, cminh, counters, host_counters);
+                           (long)n, state, cminh);
     return hipGetLastError();
 }
 
@@ -876,7 +899,7 @@ hipError_t gvom_launch_map2d(hipStream_t s, const Map2dParams &P, const int32_t 
 {
     const dim3 grid((P.xy + M2_TX - 1) / M2_TX, (P.xy + M2_TY - 1) / M2_TY);
     if (P.y_hi <= P.y_lo) return hipSuccess;
-    hipLaunchKernelGGL(k_map2d, grid, dim3(M2_TX, M2_TY), 0, s, P, fstate, fhit, ftotal, height, inferred,
+    hipLaunchKernelGGL(k_map2d, grid, dim3(M2_TX * M2_TY), 0, s, P, fstate, fhit, ftotal, height, inferred,
                        slope_x, slope_y, rough, guessed, out_pos, out_neg, out_rough, out_vis, counter,
                        host_counter);
     return hipGetLastError();

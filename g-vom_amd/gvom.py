@@ -81,6 +81,9 @@ ABI = [
     ("gvom_process_pointcloud", _I, [_P, _P, _I64, _I64, _I, _DP, _P]),
     ("gvom_process_pointcloud_device", _I, [_P, _P, _I64, _I64, _I, _DP, _P]),
     ("gvom_combine_maps", _I, [_P, _P, _P, _P, _P, _P]),
+    ("gvom_output_buffer_alloc", _I, [_P, ctypes.POINTER(_P)]),
+    ("gvom_output_buffer_free", _I, [_P, _P]),
+    ("gvom_combine_maps_into", _I, [_P, _P, _P]),
     ("gvom_scan_begin", _I, [_P, _P, _I, _I64, _I64, _I, _DP, _P, ctypes.POINTER(_I64)]),
     ("gvom_scan_commit", _I, [_P, _I]),
     ("gvom_combine_fuse", _I, [_P, ctypes.POINTER(_I64)]),
@@ -99,6 +102,7 @@ ABI = [
     ("gvom_read_map2d", _I, [_P, _I, _P]),
     ("gvom_last_stage_ms", _I, [_P, ctypes.POINTER(ctypes.c_float * N_STAGES)]),
     ("gvom_set_profiling", _I, [_P, _I]),
+    ("gvom_host_timing", _I, [_P, ctypes.POINTER(ctypes.c_double * 8)]),
     ("gvom_stream", _P, [_P]),
     ("gvom_last_error", ctypes.c_char_p, [_P]),
     ("gvom_backend_info", _I, [ctypes.c_char_p, ctypes.c_size_t]),
@@ -152,6 +156,23 @@ class _DeviceArrayView(object):
         return a if dtype is None else a.astype(dtype)
 
 
+class _PinnedOutput(object):
+    """One pinned, device-mapped output buffer of combine_maps.  The four returned numpy arrays
+    are views whose base chain ends here; when the caller drops them all, the buffer goes back to
+    the owning Gvom's pool (so every call still returns FRESH arrays, as the reference does)."""
+
+    def __init__(self, owner_pool, ptr, nbytes):
+        self._pool = owner_pool
+        self.ptr = ptr
+        self.__array_interface__ = {"data": (ptr, False), "shape": (nbytes,), "typestr": "|u1",
+                                    "version": 3}
+
+    def __del__(self):
+        pool = self._pool
+        if pool is not None:
+            pool.append(self.ptr)           # recycled by the next combine_maps (or freed on close)
+
+
 class Gvom(object):
     """A class to convert lidar pointclouds into a cost map (reference gvom.py:12-27)."""
 
@@ -192,6 +213,7 @@ class Gvom(object):
         else:
             rc = self._lib.gvom_create_sharded(ctypes.byref(prm), int(device), int(_shard[0]),
                                                int(_shard[1]), ctypes.byref(self._h))
+        self._out_pool = []                 # free pinned output buffers (host pointers)
         if rc != GVOM_OK:
             info = ctypes.create_string_buffer(256)
             self._lib.gvom_backend_info(info, 256)
@@ -203,6 +225,10 @@ class Gvom(object):
         h, self._h = getattr(self, "_h", None), None
         if h:
             try:
+                # buffers still referenced by live arrays are left to the OS (pinned host memory
+                # is not tied to the handle); free the idle ones
+                for p in getattr(self, "_out_pool", []):
+                    self._lib.gvom_output_buffer_free(h, ctypes.c_void_p(p))
                 self._lib.gvom_destroy(h)
             except Exception:
                 pass
@@ -269,17 +295,27 @@ class Gvom(object):
         (reference gvom.py:177-354).  Returns None or (origin_world f64[3], positive i32[xy,xy],
         negative i32[xy,xy], roughness f64[xy,xy], visibility i32[xy,xy])."""
         xy = self.xy_size
+        n2 = xy * xy
         origin = np.zeros(3, np.float64)
-        positive = np.empty((xy, xy), np.int32)
-        negative = np.empty((xy, xy), np.int32)
-        roughness = np.empty((xy, xy), np.float64)
-        visibility = np.empty((xy, xy), np.int32)
-        rc = self._check(self._lib.gvom_combine_maps(self._h, _ptr(origin), _ptr(positive),
-                                                     _ptr(negative), _ptr(roughness),
-                                                     _ptr(visibility)))
+        # the GPU writes the four maps straight into a pinned, device-mapped host buffer; the
+        # returned arrays are views of it (fresh per call: a buffer is reused only after every
+        # array of an earlier call has been garbage-collected)
+        if self._out_pool:
+            ptr = self._out_pool.pop()
+        else:
+            p = ctypes.c_void_p()
+            self._check(self._lib.gvom_output_buffer_alloc(self._h, ctypes.byref(p)))
+            ptr = p.value
+        holder = _PinnedOutput(self._out_pool, ptr, n2 * 20)
+        rc = self._check(self._lib.gvom_combine_maps_into(self._h, _ptr(origin), ctypes.c_void_p(ptr)))
         if rc == GVOM_EMPTY_BUFFER:
             print("[WARNING] The map buffer is empty, nothing will happen!")
             return None
+        raw = np.asarray(holder)
+        positive = raw[0:4 * n2].view(np.int32).reshape(xy, xy)
+        negative = raw[4 * n2:8 * n2].view(np.int32).reshape(xy, xy)
+        visibility = raw[8 * n2:12 * n2].view(np.int32).reshape(xy, xy)
+        roughness = raw[12 * n2:20 * n2].view(np.float64).reshape(xy, xy)
         return (origin, positive, negative, roughness, visibility)
 
     # ---- accessors / debug API (reference gvom.py:356-410) ------------------------------
@@ -439,6 +475,12 @@ class Gvom(object):
         ms = (ctypes.c_float * N_STAGES)()
         self._check(self._lib.gvom_last_stage_ms(self._h, ctypes.byref(ms)))
         return dict(zip(STAGE_NAMES, [float(v) for v in ms]))
+
+    def host_timing(self):
+        us = (ctypes.c_double * 8)()
+        self._check(self._lib.gvom_host_timing(self._h, ctypes.byref(us)))
+        return dict(zip(("scan_launch", "scan_wait", "combine_launch", "combine_wait", "output_copy"),
+                        [float(v) for v in us][:5]))
 
     def scan_stats(self):
         st = GvomScanStats()

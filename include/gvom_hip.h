@@ -107,6 +107,14 @@ int gvom_process_pointcloud_device(gvom_t *h, const void *xyz_dev, int64_t n,
 int gvom_combine_maps(gvom_t *h, double origin_world[3], int32_t *positive, int32_t *negative,
                       double *roughness, int32_t *visibility);
 
+/* Zero-copy variant of combine_maps: the four maps are written by the GPU straight into a
+ * pinned, device-mapped host buffer obtained from gvom_output_buffer_alloc (20*xy*xy bytes:
+ * [positive i32 | negative i32 | visibility i32 | roughness f64], each xy*xy in [x][y] order).
+ * The caller owns the buffer (and may keep several alive) until gvom_output_buffer_free. */
+int gvom_output_buffer_alloc(gvom_t *h, void **host_ptr);
+int gvom_output_buffer_free(gvom_t *h, void *host_ptr);
+int gvom_combine_maps_into(gvom_t *h, double origin_world[3], void *pinned_out);
+
 /* --- split entry points for slab-sharded (multi-GPU) runs ---------------------------------
  * Used by g-vom_amd/gvom_sharded.py; each rank holds a gvom_create_sharded() handle and
  * drives these between its torch.distributed (RCCL) collectives.  Single-GPU callers never
@@ -183,6 +191,9 @@ int gvom_read_map2d(gvom_t *h, int which2d, double *out);
 int gvom_last_stage_ms(gvom_t *h, float ms[GVOM_N_STAGES]);
 /* Enables/disables per-stage event timing (adds one host sync per call when on). */
 int gvom_set_profiling(gvom_t *h, int on);
+/* Host-side phase times (microseconds per call, averaged; enabled by GVOM_HOST_TIMING=1):
+ * [0] scan launches [1] scan wait [2] combine launches [3] combine wait [4] output copies. */
+int gvom_host_timing(gvom_t *h, double us[8]);
 /* Raw HIP stream the library launches on (hipStream_t as void*), for external event timing. */
 void *gvom_stream(gvom_t *h);
 
