@@ -33,6 +33,8 @@ struct Buf {                                   // grow-only device buffer
 
 struct Slot {                                  // one scan in sparse form
     int32_t *state = nullptr;                  // [V] storage order
+    uint32_t *tags = nullptr;                  // [ntiles] tile epochs (live iff == epoch)
+    uint32_t epoch = 0;
     Buf chit, ctotal, cminh;                   // compact rows
     int64_t origin[3] = {0, 0, 0};
     int64_t count = 0;
@@ -43,6 +45,8 @@ struct Slot {                                  // one scan in sparse form
 
 struct Fused {
     int32_t *state = nullptr;
+    uint32_t *tags = nullptr;
+    uint32_t epoch = 0;
     Buf hit, total, minh;
     int64_t origin[3] = {0, 0, 0};
     int64_t count = 0;                         // rows on THIS rank
@@ -56,7 +60,9 @@ struct gvom_handle {
     int device = 0;
     int rank = 0, world = 1;
     int sy_lo = 0, sy_hi = 0;
-    size_t V = 0, slabV = 0, cells2d = 0;
+    size_t V = 0, slabV = 0, cells2d = 0, ntiles = 0;
+    int nseg = 1;
+    uint32_t epoch = 0;                                 // last tile epoch handed out
     hipStream_t stream = nullptr;
     std::mutex mu;
     std::string err;
@@ -81,6 +87,8 @@ struct gvom_handle {
     bool has_combined = false;
     int64_t combined_cell_count = 0;                    // global count if set by the sharded layer
     MapDesc *descs_dev = nullptr, *descs_host = nullptr;
+    uint32_t *blockcounts = nullptr;                    // per-workgroup occupied counts of k_fuse
+    int fuse_blocks = 0;
 
     double *height = nullptr, *inferred = nullptr, *slope_x = nullptr, *slope_y = nullptr,
            *rough = nullptr, *guessed = nullptr;        // [sy][sx] storage order
@@ -157,6 +165,8 @@ void fill_scan_params(const gvom_handle *h, const int64_t origin[3], const doubl
     P.om[1] = (int)floor_mod(origin[1], p.xy_size);
     P.om[2] = (int)floor_mod(origin[2], p.z_size);
     P.sy_lo = h->sy_lo; P.sy_hi = h->sy_hi;
+    P.nseg = h->nseg;
+    P.epoch = 0;
 }
 
 int create_impl(const gvom_params *params, int device_id, int rank, int world, gvom_t **out)
@@ -185,6 +195,8 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, g
     h->V = (size_t)xy * xy * zs;
     h->slabV = (size_t)(h->sy_hi - h->sy_lo) * xy * zs;
     h->cells2d = (size_t)xy * xy;
+    h->nseg = (xy + 63) / 64;
+    h->ntiles = (size_t)xy * zs * h->nseg;
 #define CK(call)                                                                                \
     do {                                                                                        \
         hipError_t e_ = (call);                                                                 \
@@ -201,11 +213,19 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, g
     CK(hipMemsetAsync(h->hit, 0, h->V * 4, h->stream));
     CK(hipMemsetAsync(h->total, 0, h->V * 4, h->stream));
     h->slots.resize(params->buffer_size + 1);
-    for (auto &s : h->slots) CK(hipMalloc((void **)&s.state, h->V * 4));
+    for (auto &s : h->slots) {
+        CK(hipMalloc((void **)&s.state, h->V * 4));
+        CK(hipMalloc((void **)&s.tags, h->ntiles * 4));
+        CK(hipMemsetAsync(s.tags, 0, h->ntiles * 4, h->stream));
+    }
     h->ring.resize(params->buffer_size);
     for (int i = 0; i < params->buffer_size; ++i) h->ring[i] = i;
     h->staging = params->buffer_size;
-    for (int k = 0; k < 2; ++k) CK(hipMalloc((void **)&h->fused[k].state, h->V * 4));
+    for (int k = 0; k < 2; ++k) {
+        CK(hipMalloc((void **)&h->fused[k].state, h->V * 4));
+        CK(hipMalloc((void **)&h->fused[k].tags, h->ntiles * 4));
+        CK(hipMemsetAsync(h->fused[k].tags, 0, h->ntiles * 4, h->stream));
+    }
     CK(hipMalloc((void **)&h->counters, 64));
     CK(hipHostMalloc((void **)&h->counters_host, 64, hipHostMallocMapped | hipHostMallocCoherent));
     CK(hipHostGetDevicePointer((void **)&h->counters_host_dev, h->counters_host, 0));
@@ -213,6 +233,9 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, g
     CK(hipMemsetAsync(h->counters, 0, 64, h->stream));
     CK(hipMalloc((void **)&h->descs_dev, sizeof(MapDesc) * (GVOM_MAX_SLOTS + 1)));
     CK(hipHostMalloc((void **)&h->descs_host, sizeof(MapDesc) * (GVOM_MAX_SLOTS + 1)));
+    h->fuse_blocks = ((xy + 63) / 64) * (h->sy_hi - h->sy_lo);
+    CK(hipMalloc((void **)&h->blockcounts, (size_t)(h->fuse_blocks > 0 ? h->fuse_blocks : 1) * 4));
+    CK(hipMemsetAsync(h->blockcounts, 0, (size_t)(h->fuse_blocks > 0 ? h->fuse_blocks : 1) * 4, h->stream));
     double **maps[6] = {&h->height, &h->inferred, &h->slope_x, &h->slope_y, &h->rough, &h->guessed};
     for (auto m : maps) CK(hipMalloc((void **)m, h->cells2d * 8));
     CK(hipMalloc((void **)&h->out_pos, h->cells2d * 20));              // [pos | neg | vis | rough] packed:
@@ -241,6 +264,8 @@ int scan_launch(gvom_handle *h, const void *dev_pts, int64_t n, int64_t stride_e
     ScanParams P;
     fill_scan_params(h, origin, tf, P);
     Slot &st = h->slots[h->staging];
+    st.epoch = ++h->epoch;                                 // tiles stamped by this scan
+    P.epoch = st.epoch;
     const size_t esz = dtype == GVOM_DTYPE_F32 ? 4 : 8;
     int rc;
     if ((rc = ensure(h, h->world_pts, (size_t)n * 3 * esz))) return rc;
@@ -252,11 +277,11 @@ int scan_launch(gvom_handle *h, const void *dev_pts, int64_t n, int64_t stride_e
     const uint32_t seq = ++h->scan_seq;
     if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
     HIPCHK(h, gvom_launch_trace(h->stream, P, dtype, dev_pts, stride_elems, n, h->world_pts.p, h->hit,
-                                h->total, st.state, h->counters, h->trace_variant));
+                                h->total, st.state, st.tags, h->counters, h->trace_variant));
     if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
     HIPCHK(h, gvom_launch_encode(h->stream, p.xy_size, p.z_size, h->sy_lo, h->sy_hi, h->hit, h->total,
                                  st.state, (uint32_t *)st.chit.p, (uint32_t *)st.ctotal.p,
-                                 (uint32_t *)st.cminh.p, h->counters,
+                                 (uint32_t *)st.cminh.p, st.tags, st.epoch, h->counters,
                                  (unsigned long long *)h->counters_host_dev, seq));
     if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
     HIPCHK(h, gvom_launch_minh(h->stream, P, dtype, h->world_pts.p, n, st.state, (uint32_t *)st.cminh.p));
@@ -369,7 +394,7 @@ int fuse_impl(gvom_handle *h, bool publish_now)
         d.d[0] = clamp_delta(F.origin[0] - s.origin[0], p.xy_size);
         d.d[1] = clamp_delta(F.origin[1] - s.origin[1], p.xy_size);
         d.d[2] = clamp_delta(F.origin[2] - s.origin[2], p.z_size);
-        d.pad = 0;
+        d.epoch = s.epoch; d.tags = s.tags; d.pad = 0;
         bound += s.count;
     }
     P.nslots = ns;
@@ -381,16 +406,22 @@ int fuse_impl(gvom_handle *h, bool publish_now)
         d.d[0] = clamp_delta(F.origin[0] - prev->origin[0], p.xy_size);
         d.d[1] = clamp_delta(F.origin[1] - prev->origin[1], p.xy_size);
         d.d[2] = clamp_delta(F.origin[2] - prev->origin[2], p.z_size);
-        d.pad = 0;
+        d.epoch = prev->epoch; d.tags = prev->tags; d.pad = 0;
         bound += prev->count;
     }
-    if ((size_t)bound > h->slabV) bound = (int64_t)h->slabV;
-    int rc;
-    if ((rc = ensure(h, F.hit, (size_t)bound * 4))) return rc;
-    if ((rc = ensure(h, F.total, (size_t)bound * 4))) return rc;
-    if ((rc = ensure(h, F.minh, (size_t)bound * 4))) return rc;
+    (void)bound;
     P.sy_lo = h->sy_lo; P.sy_hi = h->sy_hi;
     P.nz = choose_nz(p.z_size, &P.zc);
+    P.nseg = h->nseg;
+    F.epoch = ++h->epoch;
+    P.epoch = F.epoch;
+    // every wave of k_fuse owns a static range of 64*zc compact rows (no global reservation)
+    const size_t row_cap = (size_t)h->fuse_blocks * P.nz * 64 * P.zc;
+    if (row_cap >= 2147483648ull) { h->err = "fused row space exceeds 31 bits"; return GVOM_ERR_CAPACITY; }
+    int rc;
+    if ((rc = ensure(h, F.hit, row_cap * 4))) return rc;
+    if ((rc = ensure(h, F.total, row_cap * 4))) return rc;
+    if ((rc = ensure(h, F.minh, row_cap * 4))) return rc;
     for (int k = 0; k < 3; ++k) { P.origin[k] = (double)F.origin[k]; P.ego[k] = h->ego[k]; }
     P.xy_res = p.xy_resolution; P.z_res = p.z_resolution;
     P.radius2 = p.robot_radius * p.robot_radius;
@@ -407,12 +438,12 @@ int fuse_impl(gvom_handle *h, bool publish_now)
     }
     if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[4], h->stream));
     HIPCHK(h, gvom_launch_fuse(h->stream, P, KD, descs_mem, F.state, (uint32_t *)F.hit.p,
-                               (uint32_t *)F.total.p, (uint32_t *)F.minh.p,
-                               (unsigned long long *)(h->counters + 2), h->height, h->inferred));
+                               (uint32_t *)F.total.p, (uint32_t *)F.minh.p, F.tags, h->blockcounts,
+                               h->height, h->inferred));
     if (h->profiling) { HIPCHK(h, hipEventRecord(h->ev[5], h->stream)); h->ev_fuse = true; }
     if (publish_now)
-        HIPCHK(h, gvom_launch_publish_u64(h->stream, (unsigned long long *)(h->counters + 2),
-                                          (unsigned long long *)(h->counters_host_dev + 2)));
+        HIPCHK(h, gvom_launch_publish_count(h->stream, h->blockcounts, h->fuse_blocks,
+                                            (unsigned long long *)(h->counters_host_dev + 2)));
     F.valid = true;
     h->cur = nxt;
     h->has_combined = true;
@@ -437,6 +468,8 @@ int map2d_impl(gvom_handle *h, bool storage_order_out, bool publish, bool zero_c
     P.pos_thr = p.positive_obstacle_threshold; P.neg_thr = p.negative_obstacle_threshold;
     P.slope_thr = p.slope_obstacle_threshold; P.robot_height = p.robot_height;
     P.out_storage_order = storage_order_out ? 1 : 0;
+    P.nseg = h->nseg;
+    P.epoch = F.epoch;
     if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[6], h->stream));
     const size_t n2 = h->cells2d;
     int32_t *o_pos = h->out_pos, *o_neg = h->out_neg, *o_vis = h->out_vis;
@@ -445,10 +478,10 @@ int map2d_impl(gvom_handle *h, bool storage_order_out, bool publish, bool zero_c
         o_pos = (int32_t *)h->out_host_dev; o_neg = o_pos + n2; o_vis = o_neg + n2;
         o_rgh = (double *)(o_vis + n2);
     }
-    HIPCHK(h, gvom_launch_map2d(h->stream, P, F.state, (const uint32_t *)F.hit.p,
+    HIPCHK(h, gvom_launch_map2d(h->stream, P, F.state, F.tags, (const uint32_t *)F.hit.p,
                                 (const uint32_t *)F.total.p, h->height, h->inferred, h->slope_x,
                                 h->slope_y, h->rough, h->guessed, o_pos, o_neg, o_rgh, o_vis,
-                                (unsigned long long *)(h->counters + 2),
+                                h->blockcounts, h->fuse_blocks,
                                 publish ? (unsigned long long *)(h->counters_host_dev + 2) : nullptr));
     if (h->profiling) { HIPCHK(h, hipEventRecord(h->ev[7], h->stream)); h->ev_map = true; }
     h->maps_valid = true;
@@ -505,11 +538,12 @@ VIS void gvom_destroy(gvom_t *h)
     if (h->stream) hipStreamSynchronize(h->stream);
     auto fb = [](Buf &b) { if (b.p) hipFree(b.p); b.p = nullptr; b.bytes = 0; };
     hipFree(h->hit); hipFree(h->total);
-    for (auto &s : h->slots) { hipFree(s.state); fb(s.chit); fb(s.ctotal); fb(s.cminh); }
-    for (auto &f : h->fused) { hipFree(f.state); fb(f.hit); fb(f.total); fb(f.minh); }
+    for (auto &s : h->slots) { hipFree(s.state); hipFree(s.tags); fb(s.chit); fb(s.ctotal); fb(s.cminh); }
+    for (auto &f : h->fused) { hipFree(f.state); hipFree(f.tags); fb(f.hit); fb(f.total); fb(f.minh); }
     fb(h->in_pts); fb(h->world_pts);
     hipFree(h->counters); if (h->counters_host) hipHostFree(h->counters_host);
     hipFree(h->descs_dev); if (h->descs_host) hipHostFree(h->descs_host);
+    hipFree(h->blockcounts);
     hipFree(h->height); hipFree(h->inferred); hipFree(h->slope_x); hipFree(h->slope_y);
     hipFree(h->rough); hipFree(h->guessed);
     hipFree(h->out_pos);
@@ -749,25 +783,26 @@ VIS int gvom_read_dense(gvom_t *h, int which, int32_t *state, int32_t *hit, int3
     if (!h) return GVOM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->device));
-    const int32_t *st; const uint32_t *ch, *ct, *cm; const int64_t *org; int64_t cnt;
+    const int32_t *st; const uint32_t *ch, *ct, *cm, *tg; uint32_t ep; const int64_t *org; int64_t cnt;
     if (which == GVOM_WHICH_FUSED) {
         if (!h->has_combined) return GVOM_NO_DATA;
         const Fused &F = h->fused[h->cur];
         st = F.state; ch = (const uint32_t *)F.hit.p; ct = (const uint32_t *)F.total.p;
-        cm = (const uint32_t *)F.minh.p; org = F.origin; cnt = F.count;
+        cm = (const uint32_t *)F.minh.p; org = F.origin; cnt = F.count; tg = F.tags; ep = F.epoch;
     } else {
         if (which < 0 || which >= h->prm.buffer_size) return GVOM_ERR_INVALID;
         const Slot &s = h->slots[h->ring[which]];
         if (!s.filled) return GVOM_NO_DATA;
         st = s.state; ch = (const uint32_t *)s.chit.p; ct = (const uint32_t *)s.ctotal.p;
-        cm = (const uint32_t *)s.cminh.p; org = s.origin; cnt = s.count;
+        cm = (const uint32_t *)s.cminh.p; org = s.origin; cnt = s.count; tg = s.tags; ep = s.epoch;
     }
     const size_t V = h->V;
     int32_t *tmp = nullptr;
     HIPCHK(h, hipMalloc((void **)&tmp, V * 16));
     int om[3] = {(int)floor_mod(org[0], h->prm.xy_size), (int)floor_mod(org[1], h->prm.xy_size),
                  (int)floor_mod(org[2], h->prm.z_size)};
-    hipError_t e = gvom_launch_read_dense(h->stream, h->prm.xy_size, h->prm.z_size, om, st, ch, ct, cm,
+    hipError_t e = gvom_launch_read_dense(h->stream, h->prm.xy_size, h->prm.z_size, om, h->sy_lo, h->sy_hi,
+                                          tg, ep, st, ch, ct, cm,
                                           tmp, tmp + V, tmp + 2 * V, (float *)(tmp + 3 * V));
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e == hipSuccess && state) e = hipMemcpy(state, tmp, V * 4, hipMemcpyDeviceToHost);

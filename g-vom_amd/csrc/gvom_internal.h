@@ -19,6 +19,11 @@
 
 #define GVOM_MAX_SLOTS 64
 
+// TILES: 64 consecutive sx of one (sy, sz) row = 256 bytes of every per-voxel array.  Tile index
+// T = (sy*zs + sz)*nseg + (sx >> 6), nseg = ceil(xy/64).  Every scan / fused map carries one
+// uint32 tag per tile; a tile holds valid data iff tag == the map's epoch, otherwise all its
+// voxels read as "never observed" (-1) and their stored bytes are stale and never read.  Epochs
+// only grow, so tag arrays are never cleared.
 struct ScanParams {
     double xy_res, z_res;
     double min_d2;        // min_distance * min_distance (f64 product, gvom.py:1067)
@@ -29,6 +34,8 @@ struct ScanParams {
     int    xy, zs;
     int    om[3];         // origin mod size (storage offset)
     int    sy_lo, sy_hi;  // storage rows owned by this rank: [sy_lo, sy_hi)
+    int    nseg;          // tiles per (sy, sz) row
+    uint32_t epoch;       // this scan's tile epoch
 };
 
 struct MapDesc {          // one source map of the fusion (ring slot or previous fused map)
@@ -37,7 +44,9 @@ struct MapDesc {          // one source map of the fusion (ring slot or previous
     const uint32_t *total;
     const uint32_t *minh;   // float bits
     int d[3];               // fused origin - this map's origin (window shift), clamped
-    int pad;
+    uint32_t epoch;         // tile (T) of this map is live iff tags[T] == epoch
+    const uint32_t *tags;
+    uint64_t pad;
 };
 
 #define GVOM_KARG_DESCS 17   // ring slots + previous map passed by kernel argument when they fit
@@ -49,6 +58,8 @@ struct FuseParams {
     int nslots;             // number of non-empty ring slots (descs[0..nslots))
     int has_prev;           // descs[nslots] is the previous fused map
     int sy_lo, sy_hi;
+    int nseg;               // tiles per (sy, sz) row
+    uint32_t epoch;         // epoch of the fused map being written
     int nz;                 // z-chunks per workgroup (block = 64 * nz threads)
     int zc;                 // window-z cells per chunk (<= 64)
     double origin[3];       // fused origin (voxels)
@@ -62,6 +73,8 @@ struct Map2dParams {
     int xy, zs;
     int om[3];
     int y_lo, y_hi;         // STORAGE rows [sy] computed by this rank
+    int nseg;
+    uint32_t epoch;         // epoch of the fused map (tile liveness of fstate)
     int out_storage_order;  // 1: the four outputs stay [sy][sx] (sharded runs); 0: reference [x][y]
     double origin_z;        // fused origin z (voxels)
     double xy_res, z_res;
@@ -71,26 +84,28 @@ struct Map2dParams {
 // ---- launchers (gvom_kernels.hip) --------------------------------------------------------
 hipError_t gvom_launch_trace(hipStream_t s, const ScanParams &P, int dtype, const void *pts,
                              int64_t stride_elems, int64_t n, void *world, uint32_t *hit,
-                             uint32_t *total, int32_t *state, uint32_t *counters, int variant);
+                             uint32_t *total, int32_t *state, uint32_t *tags, uint32_t *counters,
+                             int variant);
 hipError_t gvom_launch_encode(hipStream_t s, int xy, int zs, int sy_lo, int sy_hi, uint32_t *hit,
                               uint32_t *total, int32_t *state, uint32_t *chit, uint32_t *ctotal,
-                              uint32_t *cminh, uint32_t *counters, unsigned long long *host_flag,
-                              uint32_t seq);
+                              uint32_t *cminh, const uint32_t *tags, uint32_t epoch,
+                              uint32_t *counters, unsigned long long *host_flag, uint32_t seq);
 hipError_t gvom_launch_minh(hipStream_t s, const ScanParams &P, int dtype, const void *world,
                             int64_t n, const int32_t *state, uint32_t *cminh);
-hipError_t gvom_launch_publish_u64(hipStream_t s, unsigned long long *counter, unsigned long long *host_counter);
+hipError_t gvom_launch_publish_count(hipStream_t s, const uint32_t *blockcounts, int nblocks,
+                                     unsigned long long *host_counter);
 hipError_t gvom_launch_fuse(hipStream_t s, const FuseParams &P, const FuseDescs &KD,
                             const MapDesc *descs_dev, int32_t *fstate, uint32_t *fhit, uint32_t *ftotal, uint32_t *fminh,
-                            unsigned long long *counter, double *height, double *inferred);
-hipError_t gvom_launch_map2d(hipStream_t s, const Map2dParams &P, const int32_t *fstate,
+                            uint32_t *ftags, uint32_t *blockcounts, double *height, double *inferred);
+hipError_t gvom_launch_map2d(hipStream_t s, const Map2dParams &P, const int32_t *fstate, const uint32_t *ftags,
                              const uint32_t *fhit, const uint32_t *ftotal, const double *height,
                              const double *inferred, double *slope_x, double *slope_y,
                              double *rough, double *guessed, int32_t *out_pos, int32_t *out_neg,
-                             double *out_rough, int32_t *out_vis, unsigned long long *counter,
-                             unsigned long long *host_counter);
+                             double *out_rough, int32_t *out_vis, const uint32_t *blockcounts,
+                             int nblocks, unsigned long long *host_counter);
 // test hooks / debug accessors
-hipError_t gvom_launch_read_dense(hipStream_t s, int xy, int zs, const int om[3],
-                                  const int32_t *state, const uint32_t *chit,
+hipError_t gvom_launch_read_dense(hipStream_t s, int xy, int zs, const int om[3], int sy_lo, int sy_hi,
+                                  const uint32_t *tags, uint32_t epoch, const int32_t *state, const uint32_t *chit,
                                   const uint32_t *ctotal, const uint32_t *cminh, int32_t *o_state,
                                   int32_t *o_hit, int32_t *o_total, float *o_minh);
 // storage order [sy][sx] -> reference order [x][y] (window coordinates)

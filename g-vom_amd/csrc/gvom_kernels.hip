@@ -24,6 +24,11 @@
 
 #define WAVE 64
 
+// Pointers read out of a descriptor table are generic ("flat") to the compiler; these casts tell
+// it they point to global memory so it emits global_load (vmcnt only) instead of flat_load.
+typedef const __attribute__((address_space(1))) int32_t *gptr_i32;
+typedef const __attribute__((address_space(1))) uint32_t *gptr_u32;
+
 __device__ __forceinline__ int wrap_add(int a, int b, int n) { int s = a + b; return s >= n ? s - n : s; }
 __device__ __forceinline__ int wrap_sub(int a, int b, int n) { int s = a - b; return s < 0 ? s + n : s; }
 // Python's max(a, b): a unless b > a  (gvom.py:1116; differs from fmaxf only for NaN)
@@ -59,7 +64,7 @@ template <typename T, int VAR>
 __global__ __launch_bounds__(256) void k_trace(const ScanParams P, const T *__restrict__ in,
                                                long stride, long n, T *__restrict__ world,
                                                uint32_t *hit, uint32_t *total, int32_t *state,
-                                               uint32_t *counters)
+                                               uint32_t *tags, uint32_t *counters)
 {
     const int lane = threadIdx.x & (WAVE - 1);
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -102,6 +107,8 @@ __global__ __launch_bounds__(256) void k_trace(const ScanParams P, const T *__re
     if (ingrid) {
         old = atomicAdd(&hit[L], 1u);
         atomicAdd(&total[L], 1u);
+        const uint32_t tile = (L / P.xy) * P.nseg + ((L % P.xy) >> 6);  // stamp the tile (idempotent)
+        tags[tile] = P.epoch;
     }
     const bool claim = ingrid && old == 0;
     const unsigned long long cm = __ballot(claim);
@@ -162,8 +169,11 @@ __global__ __launch_bounds__(256) void k_trace(const ScanParams P, const T *__re
                 const int sx = wrap_add((int)fx, P.om[0], P.xy);
                 const int sz = wrap_add((int)fz, P.om[2], P.zs);
                 const uint32_t Ls = ((uint32_t)sy * P.zs + sz) * P.xy + sx;
-                if (VAR == 0) atomicAdd(&total[Ls], 1u);
-                else sink += Ls;
+                if (VAR == 0) {
+                    atomicAdd(&total[Ls], 1u);
+                    const uint32_t tile = ((uint32_t)sy * P.zs + sz) * P.nseg + (sx >> 6);
+                    tags[tile] = P.epoch;
+                } else sink += Ls;
             }
             length += step_len;
         }
@@ -175,7 +185,7 @@ __global__ __launch_bounds__(256) void k_trace(const ScanParams P, const T *__re
     bool active = pass && (length < lim);
     while (__any(active)) {
         bool commit = false;
-        uint32_t Ls = 0;
+        uint32_t Ls = 0, Ts = 0;
         if (active) {
             pd = pd + dir; p1 = p1 + inc1; p2 = p2 + inc2;
             const float px = si == 0 ? pd : (si == 1 ? p2 : p1);
@@ -190,6 +200,7 @@ __global__ __launch_bounds__(256) void k_trace(const ScanParams P, const T *__re
                     const int sx = wrap_add((int)fx, P.om[0], P.xy);
                     const int sz = wrap_add((int)fz, P.om[2], P.zs);
                     Ls = ((uint32_t)sy * P.zs + sz) * P.xy + sx;
+                    Ts = ((uint32_t)sy * P.zs + sz) * P.nseg + (sx >> 6);
                     commit = true;
                 }
                 length += step_len;
@@ -208,23 +219,27 @@ __global__ __launch_bounds__(256) void k_trace(const ScanParams P, const T *__re
             const unsigned long long after = (nh >> lane) >> 1;
             const uint32_t run = (uint32_t)__ffsll((long long)~after);       // 1 + followers
             atomicAdd(&total[Ls], run);
+            tags[Ts] = P.epoch;                                              // stamp the tile (idempotent store)
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// k_encode: one streaming pass over the slab's accumulators.
+// k_encode: visits only the tiles k_trace stamped with this scan's epoch (one wave per tile, four
+// tiles in flight per wave).  Per voxel of a dirty tile:
 //   occupied (hit > 0): row was claimed in k_trace -> move hit/total to the compact arrays,
 //                       initialise min-height to 1.0f                  gvom.py:1164-1168,1014
 //   else              : state = -total - 1                             gvom.py:1160
 //   and the accumulators are zeroed for the next scan (replaces the fills of gvom.py:114-121).
-// 4 voxels per lane (16-byte loads/stores) when the slab is 16-byte tileable.
+// Untouched tiles are neither read nor written: their tag != epoch makes every consumer treat
+// them as "never observed" (-1), which is what the reference's -1 fill + __assign_indices yield.
 // ------------------------------------------------------------------------------------------
-template <int VEC>
-__global__ __launch_bounds__(256) void k_encode(size_t begin, size_t count, uint32_t *hit,
-                                                uint32_t *total, int32_t *state, uint32_t *chit,
-                                                uint32_t *ctotal, uint32_t *cminh, uint32_t *counters,
-                                                unsigned long long *host_flag, uint32_t seq)
+__global__ __launch_bounds__(256) void k_encode(int xy, int nseg, uint32_t t_begin, uint32_t t_end,
+                                                uint32_t *hit, uint32_t *total, int32_t *state,
+                                                uint32_t *chit, uint32_t *ctotal, uint32_t *cminh,
+                                                const uint32_t *__restrict__ tags, uint32_t epoch,
+                                                uint32_t *counters, unsigned long long *host_flag,
+                                                uint32_t seq)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         // k_trace has completed: the scan's row count is final.  Publish {seq, count} as ONE
@@ -235,49 +250,39 @@ __global__ __launch_bounds__(256) void k_encode(size_t begin, size_t count, uint
         __hip_atomic_store(host_flag, ((unsigned long long)seq << 32) | c, __ATOMIC_RELEASE,
                            __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    const size_t nvec = count / VEC;
-    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec;
-         v += (size_t)gridDim.x * blockDim.x) {
-        const size_t L0 = begin + v * VEC;
-        uint32_t h[VEC], t[VEC];
-        int32_t st[VEC];
-        if (VEC == 4) {
-            const uint4 hv = *reinterpret_cast<const uint4 *>(hit + L0);
-            const uint4 tv = *reinterpret_cast<const uint4 *>(total + L0);
-            h[0] = hv.x; h[1 % VEC] = hv.y; h[2 % VEC] = hv.z; h[3 % VEC] = hv.w;
-            t[0] = tv.x; t[1 % VEC] = tv.y; t[2 % VEC] = tv.z; t[3 % VEC] = tv.w;
-        } else {
-            h[0] = hit[L0]; t[0] = total[L0];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const uint32_t wid = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const uint32_t nw = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t T0 = t_begin + wid * 4; T0 < t_end; T0 += nw * 4) {
+        // lane j (< 4) fetches the tag of tile T0 + j; ballot -> wave-uniform dirty mask
+        const uint32_t Tl = T0 + (lane & 3);
+        const uint32_t tagv = tags[Tl < t_end ? Tl : t_begin];
+        const uint32_t dmask = (uint32_t)__ballot(lane < 4 && Tl < t_end && tagv == epoch);
+        if (dmask == 0) continue;                                    // wave-uniform
+        bool dirty[4];
+        uint32_t L[4], h[4], t[4];
+        int32_t rowv[4];
+        // unconditional loads (clean tiles read the always-valid first row and are ignored)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t T = T0 + j;
+            const uint32_t sx = (T % nseg) * 64 + lane;
+            dirty[j] = ((dmask >> j) & 1u) && sx < (uint32_t)xy;
+            L[j] = dirty[j] ? (T / nseg) * xy + sx : (uint32_t)lane;
         }
-        uint32_t any_h = 0, any_t = 0;
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) { any_h |= h[k]; any_t |= t[k]; }
-        if (any_h) {                                   // rare: some voxel of the vector is occupied
-            int32_t rows[VEC];
-            if (VEC == 4) {
-                const int4 sv = *reinterpret_cast<const int4 *>(state + L0);
-                rows[0] = sv.x; rows[1 % VEC] = sv.y; rows[2 % VEC] = sv.z; rows[3 % VEC] = sv.w;
-            } else rows[0] = state[L0];
+        for (int j = 0; j < 4; ++j) { h[j] = hit[L[j]]; t[j] = total[L[j]]; rowv[j] = state[L[j]]; }
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) {
-                if (h[k] > 0) {
-                    const int32_t row = rows[k];
-                    chit[row] = h[k]; ctotal[row] = t[k]; cminh[row] = 0x3f800000u;
-                    st[k] = row;
-                } else st[k] = -(int32_t)t[k] - 1;
+        for (int j = 0; j < 4; ++j) {
+            if (!dirty[j]) continue;
+            if (h[j] > 0) {
+                const int32_t row = rowv[j];
+                chit[row] = h[j]; ctotal[row] = t[j]; cminh[row] = 0x3f800000u;
+                hit[L[j]] = 0;
+            } else {
+                state[L[j]] = -(int32_t)t[j] - 1;
             }
-        } else {
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) st[k] = -(int32_t)t[k] - 1;
-        }
-        if (VEC == 4) {
-            *reinterpret_cast<int4 *>(state + L0) = make_int4(st[0], st[1 % VEC], st[2 % VEC], st[3 % VEC]);
-            if (any_h) *reinterpret_cast<uint4 *>(hit + L0) = make_uint4(0, 0, 0, 0);
-            if (any_t) *reinterpret_cast<uint4 *>(total + L0) = make_uint4(0, 0, 0, 0);
-        } else {
-            state[L0] = st[0];
-            if (any_h) hit[L0] = 0;
-            if (any_t) total[L0] = 0;
+            if (t[j]) total[L[j]] = 0;
         }
     }
 }
@@ -317,35 +322,40 @@ __global__ __launch_bounds__(256) void k_minh(const ScanParams P, const T *__res
 // k_fuse: temporal fusion + per-column height reductions in ONE pass over the fused grid.
 //
 // Workgroup = 64 storage columns (consecutive sx of one storage row sy) x all z, as nz waves
-// that each own a chunk of <= 64 consecutive WINDOW z levels.  Storage is world-anchored, so
+// that each own a chunk of zc consecutive WINDOW z levels.  Storage is world-anchored, so
 // every source map holds the voxel at the same linear index L and only a window test
 // (is this world voxel inside the source's window?) replaces the reference's shifted gather.
 //
-// Pass A  per voxel: fold the ring slots in slot order, then the previous fused map
-//         (gvom.py:963-968, 992-997) into "occupied" or a free/unknown code; non-occupied
-//         codes are stored right away; occupied voxels are remembered in a 64-bit mask.
-//         Wave popcounts -> LDS scan -> ONE global atomic per workgroup reserves its rows.
-// Pass B  per occupied voxel: ballot/prefix-sum row assignment, hit/total sums and min-height
-//         min over every source where the voxel is occupied (gvom.py:910-912).
-// Tail    lowest occupied z (+ its min-height) and lowest observed-free z per column are
-//         combined across the nz waves through LDS -> height_map / inferred_height_map.
+//  * per voxel: fold the ring slots in slot order, then the previous fused map
+//    (gvom.py:963-968, 992-997) into "occupied" or a free/unknown code.  For zc <= 16 the 16
+//    state words of a source are loaded back to back (predicated, independent) before folding.
+//  * compact rows: every WAVE owns a static row range [wave_id * 64*zc, ...) of the fused compact
+//    arrays and numbers its occupied voxels inside it by ballot + prefix popcount.  Rows are
+//    therefore not globally dense (the reference's are, gvom.py:964,993 -- value-neutral: every
+//    consumer goes through the state map) and NO global atomic or row-reservation barrier
+//    exists; the occupied-voxel count is the sum of per-workgroup counts (blockcounts[]).
+//  * occupied voxel: hit/total sums and min-height min over every source where it is occupied
+//    (gvom.py:910-912).
+//  * column tail: lowest occupied z (+ its min-height) and lowest observed-free z per column
+//    are combined across the nz waves through LDS (the kernel's only barrier)
+//    -> height_map (gvom.py:525-540) / inferred_height_map (gvom.py:544-554).
 // ------------------------------------------------------------------------------------------
 template <bool ZC16>
 __global__ __launch_bounds__(1024) void k_fuse(const FuseParams P, const FuseDescs KD,
                                                const MapDesc *__restrict__ descs_mem,
                                                int32_t *fstate, uint32_t *fhit, uint32_t *ftotal,
-                                               uint32_t *fminh, unsigned long long *counter,
+                                               uint32_t *fminh, uint32_t *ftags, uint32_t *blockcounts,
                                                double *height, double *inferred)
 {
-    __shared__ uint32_t s_wave_tot[16];
-    __shared__ uint32_t s_base;
+    __shared__ uint32_t s_cnt[16];
     __shared__ int s_zocc[16][WAVE];
     __shared__ uint32_t s_hocc[16][WAVE];
     __shared__ int s_zfree[16][WAVE];
 
     // source descriptors: by kernel argument when they fit (no H2D copy per combine)
     const MapDesc *__restrict__ descs = descs_mem ? descs_mem : KD.d;
-    const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform by construction
     const int sx = blockIdx.x * WAVE + lane;
     const int sy = P.sy_lo + blockIdx.y;
     const bool col_ok = sx < P.xy;
@@ -363,13 +373,33 @@ __global__ __launch_bounds__(1024) void k_fuse(const FuseParams P, const FuseDes
     const int z0 = w * P.zc;
     const int z1 = min(z0 + P.zc, P.zs);
     const uint32_t colbase = (uint32_t)sy * P.zs * P.xy + (col_ok ? sx : 0);
-    unsigned long long occmask = 0ull;
+    const uint32_t rbase = ((blockIdx.y * gridDim.x + blockIdx.x) * (uint32_t)P.nz + w) * (uint32_t)(WAVE * P.zc);
+    const uint32_t tbase = (uint32_t)sy * P.zs * P.nseg + blockIdx.x;   // tile of (sy, sz=0, this segment)
+    uint32_t running = 0;                                // rows used by this wave so far
     int zocc = INT_MAX, zfree = INT_MAX;
+    uint32_t hocc = 0x3f800000u;
 
-    // ---- pass A ----------------------------------------------------------------------------
+    // one occupied voxel: gather over the sources, store its compact row
+    auto emit = [&](int z, uint32_t L, uint32_t row) {
+        uint32_t h = 0, t = 0, m = 0x3f800000u;          // gvom.py:222-228 (0, 0, 1.0f)
+        for (int s = 0; s < nsrc; ++s) {
+            const int zz = z + descs[s].d[2];
+            if (((okmask >> s) & 1ull) && zz >= 0 && zz < P.zs &&
+                descs[s].tags[tbase + (L - colbase) / P.xy * P.nseg] == descs[s].epoch) {   // live tile
+                const int st = descs[s].state[L];
+                if (st >= 0) {                                            // gvom.py:841,910-912
+                    h += descs[s].hit[st];
+                    t += descs[s].total[st];
+                    m = min(m, descs[s].minh[st]);
+                }
+            }
+        }
+        fstate[L] = (int32_t)row;
+        fhit[row] = h; ftotal[row] = t; fminh[row] = m;
+        if (z == zocc) hocc = m;
+    };
+
     if (ZC16) {
-        // chunk of exactly <= 16 z levels: per source, 16 independent predicated loads are
-        // issued back to back (memory-level parallelism), then folded in source order.
         int c[16];
         uint32_t occbits = 0;
 #pragma unroll
@@ -377,14 +407,38 @@ __global__ __launch_bounds__(1024) void k_fuse(const FuseParams P, const FuseDes
         for (int s = 0; s < nsrc; ++s) {
             const int dz = descs[s].d[2];
             const bool okxy = (okmask >> s) & 1ull;
-            const int32_t *__restrict__ sp = descs[s].state;
+            const gptr_i32 sp = (gptr_i32)descs[s].state;
+            const gptr_u32 tg = (gptr_u32)descs[s].tags;
+            const uint32_t ep = descs[s].epoch;
             int st[16];
+            // Tile liveness first: lane k fetches the tag of the wave's k-th tile (ONE vector load
+            // for all 16), a ballot turns them into a wave-uniform bit mask.  Then 16 UNCONDITIONAL
+            // independent 256-byte row loads are issued back to back so all of them are in flight
+            // together; a dead tile (tag != epoch) redirects its load to the first row of the
+            // array -- one always-hot cache line set -- so it costs no HBM traffic.  No branches:
+            // a branch-guarded load makes hipcc emit `s_waitcnt vmcnt(0)` in front of every load
+            // (no memory-level parallelism).  The window test is applied to the value afterwards.
+            uint32_t live;
+            {
+                const int zl = z0 + (lane & 15);
+                const int szl = wrap_add(zl < P.zs ? zl : 0, P.om[2], P.zs);
+                const uint32_t tagv = tg[tbase + (uint32_t)szl * P.nseg];
+                live = (uint32_t)__ballot(lane < 16 && zl < z1 && tagv == ep);
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int z = z0 + k;
+                const int sz = wrap_add(z < P.zs ? z : 0, P.om[2], P.zs);
+                const uint32_t addr = ((live >> k) & 1u) ? colbase + (uint32_t)sz * P.xy : (uint32_t)lane;
+                st[k] = sp[addr];
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) st[k] = ((live >> k) & 1u) ? st[k] : -1;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const int z = z0 + k, zz = z + dz;
                 const bool ok = okxy && z < z1 && zz >= 0 && zz < P.zs;
-                const int sz = wrap_add(z < P.zs ? z : 0, P.om[2], P.zs);
-                st[k] = ok ? sp[colbase + (uint32_t)sz * P.xy] : -1;   // -1 == "never observed": no effect
+                st[k] = ok ? st[k] : -1;                  // -1 == "never observed": no effect
             }
             if (s < P.nslots) {
 #pragma unroll
@@ -402,102 +456,93 @@ __global__ __launch_bounds__(1024) void k_fuse(const FuseParams P, const FuseDes
                 }
             }
         }
-        if (col_ok) {
+        if (!col_ok) occbits = 0;
+        // free / unknown codes, first free z, first occupied z.  A tile in which every voxel is
+        // still "never observed" is not written at all (its tag stays != epoch).
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int z = z0 + k;
-                if (z < z1) {
-                    if ((occbits >> k) & 1u) {
+        for (int k = 0; k < 16; ++k) {
+            const int z = z0 + k;
+            const bool occ = (occbits >> k) & 1u;
+            const bool inside = col_ok && z < z1;
+            if (__any(inside && (occ || c[k] != -1))) {
+                const int sz = wrap_add(z < P.zs ? z : 0, P.om[2], P.zs);
+                if (lane == 0) ftags[tbase + (uint32_t)sz * P.nseg] = P.epoch;
+                if (inside) {
+                    if (occ) {
                         if (zocc == INT_MAX) zocc = z;
                     } else {
-                        const int sz = wrap_add(z, P.om[2], P.zs);
                         fstate[colbase + (uint32_t)sz * P.xy] = c[k];
                         if (c[k] < -1 && zfree == INT_MAX) zfree = z;                     // gvom.py:551
                     }
                 }
             }
-            occmask = occbits;
         }
-    } else
-    for (int z = z0; z < z1; ++z) {
-        const int sz = wrap_add(z, P.om[2], P.zs);
-        const uint32_t L = colbase + (uint32_t)sz * P.xy;
-        int c = -1;
-        bool occ = false;
-        for (int s = 0; s < P.nslots; ++s) {
-            const int zs_ = z + descs[s].d[2];
-            if (((okmask >> s) & 1ull) && zs_ >= 0 && zs_ < P.zs) {
-                const int st = descs[s].state[L];
-                if (st >= 0) occ = true;                                  // gvom.py:963
-                else if (st < -1 && !occ) c += st + 1;                    // gvom.py:967
+        // occupied voxels (sparse): rows by ballot + prefix popcount inside the wave's range
+        if (__any(occbits != 0)) {
+            for (int k = 0; k < 16; ++k) {
+                const bool occ = (occbits >> k) & 1u;
+                const unsigned long long b = __ballot(occ);
+                if (b == 0ull) continue;
+                if (occ) {
+                    const int z = z0 + k;
+                    const int sz = wrap_add(z, P.om[2], P.zs);
+                    emit(z, colbase + (uint32_t)sz * P.xy, rbase + running + (uint32_t)__popcll(b & lanemask_lt()));
+                }
+                running += (uint32_t)__popcll(b);
             }
         }
-        if (P.has_prev) {
-            const int s = P.nslots;
-            const int zs_ = z + descs[s].d[2];
-            if (((okmask >> s) & 1ull) && zs_ >= 0 && zs_ < P.zs && !occ) {
-                const int p = descs[s].state[L];
-                if (p >= 0 && c >= -11) occ = true;                       // gvom.py:992
-                else if (p < -1) c += p + 1;                              // gvom.py:996
+    } else {
+        for (int z = z0; z < z1; ++z) {
+            const int sz = wrap_add(z, P.om[2], P.zs);
+            const uint32_t L = colbase + (uint32_t)sz * P.xy;
+            int c = -1;
+            bool occ = false;
+            const uint32_t T = tbase + (uint32_t)sz * P.nseg;
+            for (int s = 0; s < P.nslots; ++s) {
+                const int zz = z + descs[s].d[2];
+                if (((okmask >> s) & 1ull) && zz >= 0 && zz < P.zs && descs[s].tags[T] == descs[s].epoch) {
+                    const int st = descs[s].state[L];
+                    if (st >= 0) occ = true;                              // gvom.py:963
+                    else if (st < -1 && !occ) c += st + 1;                // gvom.py:967
+                }
             }
-        }
-        if (col_ok) {
-            if (occ) {
-                occmask |= 1ull << (z - z0);
-                if (zocc == INT_MAX) zocc = z;
-            } else {
+            if (P.has_prev) {
+                const int s = P.nslots;
+                const int zz = z + descs[s].d[2];
+                if (((okmask >> s) & 1ull) && zz >= 0 && zz < P.zs && !occ &&
+                    descs[s].tags[T] == descs[s].epoch) {
+                    const int p = descs[s].state[L];
+                    if (p >= 0 && c >= -11) occ = true;                   // gvom.py:992
+                    else if (p < -1) c += p + 1;                          // gvom.py:996
+                }
+            }
+            occ = occ && col_ok;
+            const bool nonempty = __any(col_ok && (occ || c != -1));
+            if (nonempty && lane == 0) ftags[T] = P.epoch;
+            if (nonempty && col_ok && !occ) {
                 fstate[L] = c;
                 if (c < -1 && zfree == INT_MAX) zfree = z;                // gvom.py:551
             }
-        }
-    }
-
-    // ---- reserve rows: one atomic per workgroup ------------------------------------------
-    const uint32_t wt = wave_sum((uint32_t)__popcll(occmask));
-    if (lane == 0) s_wave_tot[w] = wt;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t tot = 0;
-        for (int k = 0; k < P.nz; ++k) { const uint32_t t = s_wave_tot[k]; s_wave_tot[k] = tot; tot += t; }
-        s_base = tot ? (uint32_t)atomicAdd(counter, (unsigned long long)tot) : 0u;
-    }
-    __syncthreads();
-    uint32_t running = s_base + s_wave_tot[w];
-
-    // ---- pass B ----------------------------------------------------------------------------
-    uint32_t hocc = 0x3f800000u;
-    if (wt != 0) {                                       // wave-uniform
-        for (int z = z0; z < z1; ++z) {
-            const bool occ = (occmask >> (z - z0)) & 1ull;
             const unsigned long long b = __ballot(occ);
-            if (b == 0ull) continue;
-            if (occ) {
-                const int sz = wrap_add(z, P.om[2], P.zs);
-                const uint32_t L = colbase + (uint32_t)sz * P.xy;
-                const uint32_t row = running + (uint32_t)__popcll(b & lanemask_lt());
-                uint32_t h = 0, t = 0, m = 0x3f800000u;  // gvom.py:222-228 (0, 0, 1.0f)
-                for (int s = 0; s < nsrc; ++s) {
-                    const int zs_ = z + descs[s].d[2];
-                    if (((okmask >> s) & 1ull) && zs_ >= 0 && zs_ < P.zs) {
-                        const int st = descs[s].state[L];
-                        if (st >= 0) {                                    // gvom.py:841,910-912
-                            h += descs[s].hit[st];
-                            t += descs[s].total[st];
-                            m = min(m, descs[s].minh[st]);
-                        }
-                    }
+            if (b != 0ull) {
+                if (occ) {
+                    if (zocc == INT_MAX) zocc = z;
+                    emit(z, L, rbase + running + (uint32_t)__popcll(b & lanemask_lt()));
                 }
-                fstate[L] = (int32_t)row;
-                fhit[row] = h; ftotal[row] = t; fminh[row] = m;
-                if (z == zocc) hocc = m;
+                running += (uint32_t)__popcll(b);
             }
-            running += (uint32_t)__popcll(b);
         }
     }
 
     // ---- column tail: height (gvom.py:525-540) and inferred height (gvom.py:544-554) ------
     s_zocc[w][lane] = zocc; s_hocc[w][lane] = hocc; s_zfree[w][lane] = zfree;
+    if (lane == 0) s_cnt[w] = running;
     __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int k = 0; k < P.nz; ++k) tot += s_cnt[k];
+        blockcounts[blockIdx.y * gridDim.x + blockIdx.x] = tot;
+    }
     if (w == 0 && col_ok) {
         int zo = INT_MAX, zf = INT_MAX;
         uint32_t hb = 0x3f800000u;
@@ -515,6 +560,28 @@ __global__ __launch_bounds__(1024) void k_fuse(const FuseParams P, const FuseDes
         inferred[(size_t)sy * P.xy + sx] =
             (zf != INT_MAX) ? ((double)zf + P.origin[2]) * P.z_res : -1000.0;
     }
+}
+
+// sum of the per-workgroup occupied-voxel counts of k_fuse -> host-mapped memory
+__device__ __forceinline__ void publish_block_counts(const uint32_t *blockcounts, int nblocks,
+                                                     volatile unsigned long long *host_counter,
+                                                     unsigned long long *s_red, int tid, int nthreads)
+{
+    unsigned long long a = 0;
+    for (int i = tid; i < nblocks; i += nthreads) a += blockcounts[i];
+    s_red[tid] = a;
+    __syncthreads();
+    for (int o = nthreads >> 1; o > 0; o >>= 1) {
+        if (tid < o) s_red[tid] += s_red[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) *host_counter = s_red[0];
+}
+
+__global__ void k_publish_count(const uint32_t *blockcounts, int nblocks, unsigned long long *host_counter)
+{
+    __shared__ unsigned long long s_red[256];
+    publish_block_counts(blockcounts, nblocks, host_counter, s_red, threadIdx.x, 256);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -537,6 +604,7 @@ __global__ __launch_bounds__(1024) void k_fuse(const FuseParams P, const FuseDes
 #define M2_H (M2_TY + 2 * M2_HALO)   // 38
 
 __global__ __launch_bounds__(256) void k_map2d(const Map2dParams P, const int32_t *__restrict__ fstate,
+                                               const uint32_t *__restrict__ ftags,
                                                const uint32_t *__restrict__ fhit,
                                                const uint32_t *__restrict__ ftotal,
                                                const double *__restrict__ height,
@@ -544,8 +612,8 @@ __global__ __launch_bounds__(256) void k_map2d(const Map2dParams P, const int32_
                                                double *slope_x, double *slope_y, double *rough,
                                                double *guessed, int32_t *out_pos, int32_t *out_neg,
                                                double *out_rough, int32_t *out_vis,
-                                               unsigned long long *counter,
-                                               volatile unsigned long long *host_counter)
+                                               const uint32_t *blockcounts, int nblocks,
+                                               unsigned long long *host_counter)
 {
     __shared__ double ht[M2_H][M2_W];
     __shared__ unsigned long long rowm[M2_H];
@@ -558,9 +626,10 @@ __global__ __launch_bounds__(256) void k_map2d(const Map2dParams P, const int32_
     const int tx = tid & (M2_TX - 1), ty = tid >> 3;
     const int lane = tid & 63, wv = tid >> 6;
     const int X0 = blockIdx.x * M2_TX, Y0 = blockIdx.y * M2_TY;
-    if (host_counter && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
-        *host_counter = *counter;      // k_fuse is complete: publish its row count (host-mapped)
-        *counter = 0ull;
+    if (host_counter && blockIdx.x == 0 && blockIdx.y == 0) {
+        // k_fuse is complete: publish the fused occupied-voxel count (host-mapped memory)
+        __shared__ unsigned long long s_red[M2_TX * M2_TY];
+        publish_block_counts(blockcounts, nblocks, host_counter, s_red, tid, M2_TX * M2_TY);
     }
 
     // ---- stage the tile (+halo) and its row masks ------------------------------------------
@@ -721,7 +790,9 @@ __global__ __launch_bounds__(256) void k_map2d(const Map2dParams P, const int32_
             double density = 0.0, nn = 0.0;
             for (int z = zmin; z <= zmax; ++z) {
                 const int sz = wrap_add(z, P.om[2], P.zs);
-                const int32_t row = fstate[((uint32_t)sy0 * P.zs + sz) * xy + sx0];
+                const uint32_t rz = (uint32_t)sy0 * P.zs + sz;
+                int32_t row = -1;
+                if (ftags[rz * P.nseg + (sx0 >> 6)] == P.epoch) row = fstate[rz * xy + sx0];   // live tile
                 if (row >= 0) {
                     const uint32_t hc = fhit[row];
                     if ((int32_t)hc > 10) { nn += (double)(int32_t)ftotal[row]; density += (double)(int32_t)hc; }
@@ -753,7 +824,8 @@ __global__ __launch_bounds__(256) void k_map2d(const Map2dParams P, const int32_
 // Test hooks / debug accessors (not on the hot path)
 // ------------------------------------------------------------------------------------------
 // storage order + compact rows -> dense arrays in the reference's x + y*xy + z*xy*xy order
-__global__ void k_read_dense(int xy, int zs, int om0, int om1, int om2,
+__global__ void k_read_dense(int xy, int zs, int om0, int om1, int om2, int sy_lo, int sy_hi,
+                             const uint32_t *__restrict__ tags, uint32_t epoch,
                              const int32_t *__restrict__ state, const uint32_t *__restrict__ chit,
                              const uint32_t *__restrict__ ctotal, const uint32_t *__restrict__ cminh,
                              int32_t *o_state, int32_t *o_hit, int32_t *o_total, float *o_minh)
@@ -763,7 +835,10 @@ __global__ void k_read_dense(int xy, int zs, int om0, int om1, int om2,
          idx += (size_t)gridDim.x * blockDim.x) {
         const int x = (int)(idx % xy), y = (int)((idx / xy) % xy), z = (int)(idx / ((size_t)xy * xy));
         const int sx = wrap_add(x, om0, xy), sy = wrap_add(y, om1, xy), sz = wrap_add(z, om2, zs);
-        const int32_t st = state[((size_t)sy * zs + sz) * xy + sx];
+        const int nseg = (xy + 63) / 64;
+        int32_t st = -1;
+        if (sy >= sy_lo && sy < sy_hi && tags[((size_t)sy * zs + sz) * nseg + (sx >> 6)] == epoch)
+            st = state[((size_t)sy * zs + sz) * xy + sx];
         if (st >= 0) {
             o_state[idx] = 0; o_hit[idx] = (int32_t)chit[st]; o_total[idx] = (int32_t)ctotal[st];
             o_minh[idx] = __uint_as_float(cminh[st]);
@@ -806,15 +881,10 @@ __global__ void k_debug_height(int xy, int om0, int om1, double o0, double o1, d
     }
 }
 
-__global__ void k_publish_u64(unsigned long long *counter, volatile unsigned long long *host_counter)
+hipError_t gvom_launch_publish_count(hipStream_t s, const uint32_t *blockcounts, int nblocks,
+                                     unsigned long long *host_counter)
 {
-    *host_counter = *counter;
-    *counter = 0ull;
-}
-
-hipError_t gvom_launch_publish_u64(hipStream_t s, unsigned long long *counter, unsigned long long *host_counter)
-{
-    hipLaunchKernelGGL(k_publish_u64, dim3(1), dim3(1), 0, s, counter, host_counter);
+    hipLaunchKernelGGL(k_publish_count, dim3(1), dim3(256), 0, s, blockcounts, nblocks, host_counter);
     return hipGetLastError();
 }
 
@@ -823,12 +893,13 @@ hipError_t gvom_launch_publish_u64(hipStream_t s, unsigned long long *counter, u
 // ------------------------------------------------------------------------------------------
 hipError_t gvom_launch_trace(hipStream_t s, const ScanParams &P, int dtype, const void *pts,
                              int64_t stride_elems, int64_t n, void *world, uint32_t *hit,
-                             uint32_t *total, int32_t *state, uint32_t *counters, int variant)
+                             uint32_t *total, int32_t *state, uint32_t *tags, uint32_t *counters,
+                             int variant)
 {
     const unsigned blocks = (unsigned)((n + 255) / 256);
 #define TRACE_LAUNCH(TT, VV)                                                                     \
     hipLaunchKernelGGL((k_trace<TT, VV>), dim3(blocks), dim3(256), 0, s, P, (const TT *)pts,      \
-                       (long)stride_elems, (long)n, (TT *)world, hit, total, state, counters)
+                       (long)stride_elems, (long)n, (TT *)world, hit, total, state, tags, counters)
     if (dtype == 0) {
         if (variant == 0) TRACE_LAUNCH(float, 0);
         else if (variant == 9) TRACE_LAUNCH(float, 9);
@@ -844,21 +915,18 @@ hipError_t gvom_launch_trace(hipStream_t s, const ScanParams &P, int dtype, cons
 
 hipError_t gvom_launch_encode(hipStream_t s, int xy, int zs, int sy_lo, int sy_hi, uint32_t *hit,
                               uint32_t *total, int32_t *state, uint32_t *chit, uint32_t *ctotal,
-                              uint32_t *cminh, uint32_t *counters, unsigned long long *host_flag,
-                              uint32_t seq)
+                              uint32_t *cminh, const uint32_t *tags, uint32_t epoch,
+                              uint32_t *counters, unsigned long long *host_flag, uint32_t seq)
 {
-    const size_t plane = (size_t)xy * zs;
-    const size_t begin = (size_t)sy_lo * plane, count = (size_t)(sy_hi - sy_lo) * plane;
-    if (plane % 4 == 0) {
-        const size_t nvec = count / 4;
-        const unsigned blocks = (unsigned)max((size_t)1, min((size_t)8192, (nvec + 255) / 256));
-        hipLaunchKernelGGL(k_encode<4>, dim3(blocks), dim3(256), 0, s, begin, count, hit, total,
-                           state, chit, ctotal, cminh, counters, host_flag, seq);
-    } else {
-        const unsigned blocks = (unsigned)max((size_t)1, min((size_t)8192, (count + 255) / 256));
-        hipLaunchKernelGGL(k_encode<1>, dim3(blocks), dim3(256), 0, s, begin, count, hit, total,
-                           state, chit, ctotal, cminh, counters, host_flag, seq);
-    }
+    const int nseg = (xy + 63) / 64;
+    const uint32_t t_begin = (uint32_t)sy_lo * zs * nseg, t_end = (uint32_t)sy_hi * zs * nseg;
+    const uint32_t ntiles = t_end - t_begin;
+    // one wave handles 4 tiles per iteration; 4 waves per block
+    unsigned blocks = (ntiles + 15) / 16;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_encode, dim3(blocks), dim3(256), 0, s, xy, nseg, t_begin, t_end, hit, total,
+                       state, chit, ctotal, cminh, tags, epoch, counters, host_flag, seq);
     return hipGetLastError();
 }
 
@@ -876,41 +944,43 @@ hipError_t gvom_launch_minh(hipStream_t s, const ScanParams &P, int dtype, const
 }
 
 hipError_t gvom_launch_fuse(hipStream_t s, const FuseParams &P, const FuseDescs &KD,
-                            const MapDesc *descs_dev, int32_t *fstate, uint32_t *fhit, uint32_t *ftotal, uint32_t *fminh,
-                            unsigned long long *counter, double *height, double *inferred)
+                            const MapDesc *descs_dev, int32_t *fstate, uint32_t *fhit,
+                            uint32_t *ftotal, uint32_t *fminh, uint32_t *ftags, uint32_t *blockcounts,
+                            double *height, double *inferred)
 {
     const dim3 grid((P.xy + 63) / 64, P.sy_hi - P.sy_lo);
     if (grid.y == 0) return hipSuccess;
     if (P.zc <= 16)
         hipLaunchKernelGGL(k_fuse<true>, grid, dim3(64 * P.nz), 0, s, P, KD, descs_dev, fstate, fhit,
-                           ftotal, fminh, counter, height, inferred);
+                           ftotal, fminh, ftags, blockcounts, height, inferred);
     else
         hipLaunchKernelGGL(k_fuse<false>, grid, dim3(64 * P.nz), 0, s, P, KD, descs_dev, fstate, fhit,
-                           ftotal, fminh, counter, height, inferred);
+                           ftotal, fminh, ftags, blockcounts, height, inferred);
     return hipGetLastError();
 }
 
 hipError_t gvom_launch_map2d(hipStream_t s, const Map2dParams &P, const int32_t *fstate,
-                             const uint32_t *fhit, const uint32_t *ftotal, const double *height,
+                             const uint32_t *ftags, const uint32_t *fhit, const uint32_t *ftotal, const double *height,
                              const double *inferred, double *slope_x, double *slope_y,
                              double *rough, double *guessed, int32_t *out_pos, int32_t *out_neg,
-                             double *out_rough, int32_t *out_vis, unsigned long long *counter,
-                             unsigned long long *host_counter)
+                             double *out_rough, int32_t *out_vis, const uint32_t *blockcounts,
+                             int nblocks, unsigned long long *host_counter)
 {
     const dim3 grid((P.xy + M2_TX - 1) / M2_TX, (P.xy + M2_TY - 1) / M2_TY);
     if (P.y_hi <= P.y_lo) return hipSuccess;
-    hipLaunchKernelGGL(k_map2d, grid, dim3(M2_TX * M2_TY), 0, s, P, fstate, fhit, ftotal, height, inferred,
-                       slope_x, slope_y, rough, guessed, out_pos, out_neg, out_rough, out_vis, counter,
-                       host_counter);
+    hipLaunchKernelGGL(k_map2d, grid, dim3(M2_TX * M2_TY), 0, s, P, fstate, ftags, fhit, ftotal, height, inferred,
+                       slope_x, slope_y, rough, guessed, out_pos, out_neg, out_rough, out_vis, blockcounts,
+                       nblocks, host_counter);
     return hipGetLastError();
 }
 
-hipError_t gvom_launch_read_dense(hipStream_t s, int xy, int zs, const int om[3],
-                                  const int32_t *state, const uint32_t *chit,
+hipError_t gvom_launch_read_dense(hipStream_t s, int xy, int zs, const int om[3], int sy_lo, int sy_hi,
+                                  const uint32_t *tags, uint32_t epoch, const int32_t *state, const uint32_t *chit,
                                   const uint32_t *ctotal, const uint32_t *cminh, int32_t *o_state,
                                   int32_t *o_hit, int32_t *o_total, float *o_minh)
 {
-    hipLaunchKernelGGL(k_read_dense, dim3(2048), dim3(256), 0, s, xy, zs, om[0], om[1], om[2], state,
+    hipLaunchKernelGGL(k_read_dense, dim3(2048), dim3(256), 0, s, xy, zs, om[0], om[1], om[2], sy_lo, sy_hi,
+                       tags, epoch, state,
                        chit, ctotal, cminh, o_state, o_hit, o_total, o_minh);
     return hipGetLastError();
 }
