@@ -83,6 +83,23 @@ def cpu_baseline(params, scans, budget_s=20.0):
             "ms_per_step": el / steps * 1e3}
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/
+    *_traffic.json, written by tools/summarize_pmc.py: separate FETCH_SIZE / WRITE_SIZE passes,
+    corrected with the factors calibrated on known-byte kernels in the same session), newest
+    file first.  None if no profile covers the kernel."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
+        try:
+            k = json.load(open(f))["kernels"].get(kernel)
+        except Exception:
+            k = None
+        if k and k.get("hbm_bytes_corrected"):
+            return {"bytes_per_launch": k["hbm_bytes_corrected"], "source": os.path.basename(f),
+                    "atomic_requests_per_launch": k.get("TCC_EA0_ATOMIC_sum")}
+    return None
+
+
 def run_single(args):
     import gvom
     import synth
@@ -121,17 +138,28 @@ def run_single(args):
                 acc[s] += ms[s]
     elapsed = time.perf_counter() - t0
     stage_ms = {s: acc[s] / n_sampled for s in acc}
+    # PCIe-inclusive rate (never `value`): the same steps with the cloud handed over as a HOST
+    # buffer, the reference's own calling convention (gvom.py:110 cuda.to_device)
+    n_pcie = max(10, args.steps // 4)
+    t1 = time.perf_counter()
+    for k in range(n_pcie):
+        pc, ego, tf = scans[k % len(scans)]
+        g.process_pointcloud(pc, ego, tf)
+        g.combine_maps()
+    pcie_elapsed = time.perf_counter() - t1
 
     V = params[2] * params[2] * params[3]
     P = 12 if scans[0][0].dtype == np.float32 else 24
     n_in = stats["sum_hit"]
     alg = {                                                          # bytes per launch
         "trace": n_pts * P + 4 * (stats["sum_hit"] + stats["sum_total"]),
-        "encode": 20 * V,
-        "min_height": n_pts * P + 4 * n_in,
+        "encode": 20 * V + n_pts * P + 4 * n_in,          # min-height pass rides in the k_encode launch
+        "min_height": 0,
         "fuse": 4 * V * (min(args.poses, params[4]) + 1) + 4 * V + 4 * V,
         "map2d": 68 * params[2] * params[2],
     }
+    stage_ms.pop("min_height", None)
+    alg.pop("min_height", None)
     dom = max(stage_ms, key=lambda s: stage_ms[s])
     achieved = alg[dom] / (stage_ms[dom] * 1e-3) / 1e9
     out = {
@@ -148,11 +176,14 @@ def run_single(args):
                    "poses": len(scans), "input": "device-resident f32 xyz",
                    "step": "1 scan + 1 combine incl. D2H of the 4 maps"},
         "map_hz": args.steps / elapsed,
+        "value_pcie_inclusive": n_pts * n_pcie / pcie_elapsed / 1e6,
         "stage_ms": stage_ms,
         "host_us": g.host_timing(),
         "sum_hit": stats["sum_hit"], "sum_total": stats["sum_total"], "cells": stats["cells"],
         "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": (pmc_traffic("k_" + dom) or {}).get("bytes_per_launch"),
+                     "traffic_detail": pmc_traffic("k_" + dom),
                      "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": stage_ms[dom],
                      "all_stages_GBs": {s: alg[s] / (stage_ms[s] * 1e-3) / 1e9 if stage_ms[s] > 0 else None
                                         for s in alg}},

@@ -277,15 +277,13 @@ int scan_launch(gvom_handle *h, const void *dev_pts, int64_t n, int64_t stride_e
     const uint32_t seq = ++h->scan_seq;
     if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
     HIPCHK(h, gvom_launch_trace(h->stream, P, dtype, dev_pts, stride_elems, n, h->world_pts.p, h->hit,
-                                h->total, st.state, st.tags, h->counters, h->trace_variant));
+                                h->total, st.state, st.tags, (uint32_t *)st.cminh.p, h->counters,
+                                h->trace_variant));
     if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
-    HIPCHK(h, gvom_launch_encode(h->stream, p.xy_size, p.z_size, h->sy_lo, h->sy_hi, h->hit, h->total,
-                                 st.state, (uint32_t *)st.chit.p, (uint32_t *)st.ctotal.p,
-                                 (uint32_t *)st.cminh.p, st.tags, st.epoch, h->counters,
-                                 (unsigned long long *)h->counters_host_dev, seq));
-    if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
-    HIPCHK(h, gvom_launch_minh(h->stream, P, dtype, h->world_pts.p, n, st.state, (uint32_t *)st.cminh.p));
-    if (h->profiling) { HIPCHK(h, hipEventRecord(h->ev[3], h->stream)); h->ev_scan = true; }
+    HIPCHK(h, gvom_launch_encode(h->stream, P, dtype, h->world_pts.p, n, h->hit, h->total, st.state,
+                                 (uint32_t *)st.chit.p, (uint32_t *)st.ctotal.p, (uint32_t *)st.cminh.p,
+                                 st.tags, h->counters, (unsigned long long *)h->counters_host_dev, seq));
+    if (h->profiling) { HIPCHK(h, hipEventRecord(h->ev[2], h->stream)); h->ev_scan = true; }
     HT(h, 0, t0);                                        // scan: launches
     // Wait only for k_trace: k_encode's first thread publishes {seq, count} to host-mapped memory.
     // The caller gets control back while k_encode / k_minh still run; everything it can do next
@@ -358,13 +356,21 @@ int process_impl(gvom_handle *h, const void *xyz, bool on_device, int64_t n, int
     return accept ? GVOM_OK : GVOM_NO_OVERLAP;
 }
 
-int choose_nz(int zs, int *zc)
+// z decomposition of k_fuse: chunks of zc levels (16 whenever z_size <= 256), cpw chunks per wave,
+// nz waves per workgroup.  Small workgroups (<= 4 waves when possible) keep several of them
+// resident per CU, so one workgroup's end-of-column barrier never idles the CU.
+int choose_nz(int zs, int *zc, int *cpw)
 {
-    int nz = (zs + 15) / 16;
-    if (nz < 1) nz = 1;
-    if (nz > 16) nz = 16;
-    *zc = (zs + nz - 1) / nz;
-    return nz;
+    int nchunks = (zs + 15) / 16;
+    if (nchunks < 1) nchunks = 1;
+    if (nchunks > 16) nchunks = 16;
+    *zc = (zs + nchunks - 1) / nchunks;
+    nchunks = (zs + *zc - 1) / *zc;
+    int want_waves = 4;
+    if (const char *v = getenv("GVOM_FUSE_WAVES")) want_waves = atoi(v) > 0 ? atoi(v) : 4;
+    *cpw = (nchunks + want_waves - 1) / want_waves;
+    if (*cpw < 1) *cpw = 1;
+    return (nchunks + *cpw - 1) / *cpw;
 }
 
 // fusion + column reductions (k_fuse) into fused[1 - cur]
@@ -411,12 +417,12 @@ int fuse_impl(gvom_handle *h, bool publish_now)
     }
     (void)bound;
     P.sy_lo = h->sy_lo; P.sy_hi = h->sy_hi;
-    P.nz = choose_nz(p.z_size, &P.zc);
+    P.nz = choose_nz(p.z_size, &P.zc, &P.cpw);
     P.nseg = h->nseg;
     F.epoch = ++h->epoch;
     P.epoch = F.epoch;
     // every wave of k_fuse owns a static range of 64*zc compact rows (no global reservation)
-    const size_t row_cap = (size_t)h->fuse_blocks * P.nz * 64 * P.zc;
+    const size_t row_cap = (size_t)h->fuse_blocks * P.nz * 64 * P.zc * P.cpw;
     if (row_cap >= 2147483648ull) { h->err = "fused row space exceeds 31 bits"; return GVOM_ERR_CAPACITY; }
     int rc;
     if ((rc = ensure(h, F.hit, row_cap * 4))) return rc;
@@ -494,7 +500,7 @@ void collect_stage_ms(gvom_handle *h)
     if (h->ev_scan) {
         hipEventElapsedTime(&h->stage_ms[0], h->ev[0], h->ev[1]);
         hipEventElapsedTime(&h->stage_ms[1], h->ev[1], h->ev[2]);
-        hipEventElapsedTime(&h->stage_ms[2], h->ev[2], h->ev[3]);
+        h->stage_ms[2] = 0.0f;             // min-height runs inside the k_encode launch
     }
     if (h->ev_fuse) hipEventElapsedTime(&h->stage_ms[3], h->ev[4], h->ev[5]);
     if (h->ev_map) hipEventElapsedTime(&h->stage_ms[4], h->ev[6], h->ev[7]);
@@ -963,6 +969,18 @@ VIS int gvom_host_timing(gvom_t *h, double us[8])
     if (!h || !us) return GVOM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     for (int k = 0; k < 8; ++k) us[k] = h->host_calls ? h->host_ns[k] / h->host_calls / 1e3 : 0.0;
+    return GVOM_OK;
+}
+
+// diagnostic (GVOM_TRACE_VARIANT=2): cumulative {run heads, distinct-64B-line heads, atomic wave
+// instructions} of k_trace since creation
+VIS int gvom_debug_trace_counters(gvom_t *h, uint32_t out[3])
+{
+    if (!h || !out) return GVOM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(out, h->counters + 4, 12, hipMemcpyDeviceToHost));
     return GVOM_OK;
 }
 

@@ -62,6 +62,7 @@ struct FuseParams {
     uint32_t epoch;         // epoch of the fused map being written
     int nz;                 // z-chunks per workgroup (block = 64 * nz threads)
     int zc;                 // window-z cells per chunk (<= 64)
+    int cpw;                // chunks per wave (a wave walks them in ascending z)
     double origin[3];       // fused origin (voxels)
     double ego[3];          // latest ego (gvom.py:294-295)
     double xy_res, z_res;
@@ -84,14 +85,12 @@ struct Map2dParams {
 // ---- launchers (gvom_kernels.hip) --------------------------------------------------------
 hipError_t gvom_launch_trace(hipStream_t s, const ScanParams &P, int dtype, const void *pts,
                              int64_t stride_elems, int64_t n, void *world, uint32_t *hit,
-                             uint32_t *total, int32_t *state, uint32_t *tags, uint32_t *counters,
-                             int variant);
-hipError_t gvom_launch_encode(hipStream_t s, int xy, int zs, int sy_lo, int sy_hi, uint32_t *hit,
-                              uint32_t *total, int32_t *state, uint32_t *chit, uint32_t *ctotal,
-                              uint32_t *cminh, const uint32_t *tags, uint32_t epoch,
+                             uint32_t *total, int32_t *state, uint32_t *tags, uint32_t *cminh,
+                             uint32_t *counters, int variant);
+hipError_t gvom_launch_encode(hipStream_t s, const ScanParams &P, int dtype, const void *world,
+                              int64_t n, uint32_t *hit, uint32_t *total, int32_t *state,
+                              uint32_t *chit, uint32_t *ctotal, uint32_t *cminh, const uint32_t *tags,
                               uint32_t *counters, unsigned long long *host_flag, uint32_t seq);
-hipError_t gvom_launch_minh(hipStream_t s, const ScanParams &P, int dtype, const void *world,
-                            int64_t n, const int32_t *state, uint32_t *cminh);
 hipError_t gvom_launch_publish_count(hipStream_t s, const uint32_t *blockcounts, int nblocks,
                                      unsigned long long *host_counter);
 hipError_t gvom_launch_fuse(hipStream_t s, const FuseParams &P, const FuseDescs &KD,

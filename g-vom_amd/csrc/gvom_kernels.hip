@@ -1,13 +1,14 @@
 // gvom_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the G-VOM hot path.
 //
-// Five kernels replace the reference's ~55 Numba-CUDA launches per scan+combine
+// Four kernels replace the reference's ~55 Numba-CUDA launches per scan+combine
 // (reference: /root/reference/scripts/gvom.py, cited as "gvom.py:NNN"):
 //
 //   k_trace   gvom.py:1040-1056 (transform) + :1060-1150 (hit + dominant-axis DDA)
 //             + the row-claim half of :1154-1160 (first hit of a voxel claims its compact row)
 //   k_encode  gvom.py:1154-1168 (state code + dense->compact move) + the three V-sized clears
-//             of :114-121 (accumulators are cleared as they are read; no separate fill)
-//   k_minh    gvom.py:1303-1329 (+ fill :1014-1015 folded into k_encode)
+//             of :114-121 (accumulators are cleared as they are read; no separate fill), only on
+//             the 64-voxel tiles the scan touched; its trailing blocks run the min-height pass
+//             gvom.py:1303-1329 (fill :1014-1015 folded into k_trace's row claim)
 //   k_fuse    gvom.py:943-968 x slots, :972-997, :821-912 (count/min lines 910-912) x (slots+1),
 //             :525-540 (height) and :544-554 (inferred height): ONE pass over the fused grid
 //   k_map2d   gvom.py:665-734 (slope/roughness), :558-661 (guess height), :489-521 (positive),
@@ -64,7 +65,7 @@ template <typename T, int VAR>
 __global__ __launch_bounds__(256) void k_trace(const ScanParams P, const T *__restrict__ in,
                                                long stride, long n, T *__restrict__ world,
                                                uint32_t *hit, uint32_t *total, int32_t *state,
-                                               uint32_t *tags, uint32_t *counters)
+                                               uint32_t *tags, uint32_t *cminh, uint32_t *counters)
 {
     const int lane = threadIdx.x & (WAVE - 1);
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -117,7 +118,11 @@ __global__ __launch_bounds__(256) void k_trace(const ScanParams P, const T *__re
         uint32_t base = 0;
         if (lane == leader) base = atomicAdd(&counters[0], (uint32_t)__popcll(cm));
         base = __shfl(base, leader);
-        if (claim) state[L] = (int32_t)(base + (uint32_t)__popcll(cm & lanemask_lt()));
+        if (claim) {
+            const uint32_t row = base + (uint32_t)__popcll(cm & lanemask_lt());
+            state[L] = (int32_t)row;
+            cminh[row] = 0x3f800000u;                   // min-height starts at 1.0f (gvom.py:1014-1015)
+        }
     }
     if (VAR == 0 && !pass) return;
 
@@ -181,8 +186,9 @@ __global__ __launch_bounds__(256) void k_trace(const ScanParams P, const T *__re
         return;
     }
 
-    // ---- VAR 1: lock-step, run-merged ----------------------------------------------------
+    // ---- VAR 1: lock-step, run-merged (VAR 2: same + diagnostic counters) -------------------
     bool active = pass && (length < lim);
+    uint32_t n_heads = 0, n_lines = 0, n_instr = 0;      // VAR 2 only
     while (__any(active)) {
         bool commit = false;
         uint32_t Ls = 0, Ts = 0;
@@ -221,7 +227,19 @@ __global__ __launch_bounds__(256) void k_trace(const ScanParams P, const T *__re
             atomicAdd(&total[Ls], run);
             tags[Ts] = P.epoch;                                              // stamp the tile (idempotent store)
         }
+        if (VAR == 2) {                                   // diagnostic: heads, distinct 64-B lines, instructions
+            const unsigned long long hm = __ballot(head);
+            const uint32_t lkey = head ? (Ls >> 4) : (0xFFFFFF00u | (uint32_t)lane);
+            // previous head's line: scan left for the nearest head lane
+            const unsigned long long below = hm & lanemask_lt();
+            const int prev = below ? 63 - __clzll((long long)below) : lane;
+            const uint32_t pl = (uint32_t)__shfl((int)lkey, prev);
+            const bool newline = head && (below == 0ull || pl != lkey);
+            const unsigned long long nlm = __ballot(newline);
+            n_heads += (uint32_t)__popcll(hm); n_lines += (uint32_t)__popcll(nlm); n_instr += hm ? 1u : 0u;
+        }
     }
+    if (VAR == 2 && lane == 0) { atomicAdd(&counters[4], n_heads); atomicAdd(&counters[5], n_lines); atomicAdd(&counters[6], n_instr); }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -233,14 +251,47 @@ __global__ __launch_bounds__(256) void k_trace(const ScanParams P, const T *__re
 //   and the accumulators are zeroed for the next scan (replaces the fills of gvom.py:114-121).
 // Untouched tiles are neither read nor written: their tag != epoch makes every consumer treat
 // them as "never observed" (-1), which is what the reference's -1 fill + __assign_indices yield.
+//
+// The same launch also carries the min-height pass (gvom.py:1303-1329) in its trailing blocks
+// [enc_blocks, gridDim.x): one lane per return, f32 atomic-min of the fractional z inside its
+// voxel, keyed by the voxel's compact row.  The value is a - floor(a) >= 0, so the float order
+// equals the order of its bit pattern and an unsigned atomicMin is exact.  It only needs what
+// k_trace left behind (row ids of occupied voxels, rows initialised to 1.0f), and the encode
+// blocks never write those words, so both parts run concurrently.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_encode(int xy, int nseg, uint32_t t_begin, uint32_t t_end,
+template <typename T>
+__global__ __launch_bounds__(256) void k_encode(const ScanParams P, unsigned enc_blocks,
+                                                uint32_t t_begin, uint32_t t_end,
                                                 uint32_t *hit, uint32_t *total, int32_t *state,
                                                 uint32_t *chit, uint32_t *ctotal, uint32_t *cminh,
                                                 const uint32_t *__restrict__ tags, uint32_t epoch,
+                                                const T *__restrict__ world, long n,
                                                 uint32_t *counters, unsigned long long *host_flag,
                                                 uint32_t seq)
 {
+    const int xy = P.xy, nseg = P.nseg;
+    if (blockIdx.x >= enc_blocks) {                      // ---- min-height blocks ----
+        const long i = (long)(blockIdx.x - enc_blocks) * 256 + threadIdx.x;
+        if (i >= n) return;
+        const T x = world[3 * i + 0], y = world[3 * i + 1], z = world[3 * i + 2];
+        const T d2 = (x * x + y * y) + z * z;
+        if ((double)d2 < P.min_d2) return;
+        const double fx = floor((double)x / P.xy_res - P.origin[0]);
+        if (!(fx >= 0.0 && fx < (double)P.xy)) return;
+        const double fy = floor((double)y / P.xy_res - P.origin[1]);
+        if (!(fy >= 0.0 && fy < (double)P.xy)) return;
+        const double az = (double)z / P.z_res - P.origin[2];
+        const double fz = floor(az);
+        if (!(fz >= 0.0 && fz < (double)P.zs)) return;
+        const int sy = wrap_add((int)fy, P.om[1], P.xy);
+        if (sy < P.sy_lo || sy >= P.sy_hi) return;
+        const int sx = wrap_add((int)fx, P.om[0], P.xy);
+        const int sz = wrap_add((int)fz, P.om[2], P.zs);
+        const int32_t row = state[((uint32_t)sy * P.zs + sz) * P.xy + sx];
+        const float v = (float)(az - fz);               // local_point[2], f64 -> f32 (gvom.py:1326,1329)
+        if (row >= 0) atomicMin(&cminh[row], __float_as_uint(v));
+        return;
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         // k_trace has completed: the scan's row count is final.  Publish {seq, count} as ONE
         // 8-byte system-scope store to host-mapped memory (the host spins on it and returns to
@@ -252,7 +303,7 @@ __global__ __launch_bounds__(256) void k_encode(int xy, int nseg, uint32_t t_beg
     }
     const int lane = threadIdx.x & (WAVE - 1);
     const uint32_t wid = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    const uint32_t nw = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t nw = (enc_blocks * blockDim.x) >> 6;
     for (uint32_t T0 = t_begin + wid * 4; T0 < t_end; T0 += nw * 4) {
         // lane j (< 4) fetches the tag of tile T0 + j; ballot -> wave-uniform dirty mask
         const uint32_t Tl = T0 + (lane & 3);
@@ -265,10 +316,10 @@ __global__ __launch_bounds__(256) void k_encode(int xy, int nseg, uint32_t t_beg
         // unconditional loads (clean tiles read the always-valid first row and are ignored)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const uint32_t T = T0 + j;
-            const uint32_t sx = (T % nseg) * 64 + lane;
+            const uint32_t tile = T0 + j;
+            const uint32_t sx = (tile % nseg) * 64 + lane;
             dirty[j] = ((dmask >> j) & 1u) && sx < (uint32_t)xy;
-            L[j] = dirty[j] ? (T / nseg) * xy + sx : (uint32_t)lane;
+            L[j] = dirty[j] ? (tile / nseg) * xy + sx : (uint32_t)lane;
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) { h[j] = hit[L[j]]; t[j] = total[L[j]]; rowv[j] = state[L[j]]; }
@@ -277,7 +328,7 @@ __global__ __launch_bounds__(256) void k_encode(int xy, int nseg, uint32_t t_beg
             if (!dirty[j]) continue;
             if (h[j] > 0) {
                 const int32_t row = rowv[j];
-                chit[row] = h[j]; ctotal[row] = t[j]; cminh[row] = 0x3f800000u;
+                chit[row] = h[j]; ctotal[row] = t[j];
                 hit[L[j]] = 0;
             } else {
                 state[L[j]] = -(int32_t)t[j] - 1;
@@ -285,37 +336,6 @@ __global__ __launch_bounds__(256) void k_encode(int xy, int nseg, uint32_t t_beg
             if (t[j]) total[L[j]] = 0;
         }
     }
-}
-
-// ------------------------------------------------------------------------------------------
-// k_minh: per in-grid return, f32 atomic-min of the fractional z inside its voxel, keyed by
-// the voxel's compact row (gvom.py:1303-1329).  The value is a - floor(a) >= 0, so the float
-// order equals the order of its bit pattern and an unsigned atomicMin is exact.
-// ------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void k_minh(const ScanParams P, const T *__restrict__ world,
-                                              long n, const int32_t *__restrict__ state,
-                                              uint32_t *cminh)
-{
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const T x = world[3 * i + 0], y = world[3 * i + 1], z = world[3 * i + 2];
-    const T d2 = (x * x + y * y) + z * z;
-    if ((double)d2 < P.min_d2) return;
-    const double fx = floor((double)x / P.xy_res - P.origin[0]);
-    if (!(fx >= 0.0 && fx < (double)P.xy)) return;
-    const double fy = floor((double)y / P.xy_res - P.origin[1]);
-    if (!(fy >= 0.0 && fy < (double)P.xy)) return;
-    const double az = (double)z / P.z_res - P.origin[2];
-    const double fz = floor(az);
-    if (!(fz >= 0.0 && fz < (double)P.zs)) return;
-    const int sy = wrap_add((int)fy, P.om[1], P.xy);
-    if (sy < P.sy_lo || sy >= P.sy_hi) return;
-    const int sx = wrap_add((int)fx, P.om[0], P.xy);
-    const int sz = wrap_add((int)fz, P.om[2], P.zs);
-    const int32_t row = state[((uint32_t)sy * P.zs + sz) * P.xy + sx];
-    const float v = (float)(az - fz);                   // local_point[2], f64 -> f32 (gvom.py:1326,1329)
-    if (row >= 0) atomicMin(&cminh[row], __float_as_uint(v));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -370,14 +390,19 @@ __global__ __launch_bounds__(1024) void k_fuse(const FuseParams P, const FuseDes
     }
     if (!col_ok) okmask = 0ull;
 
-    const int z0 = w * P.zc;
-    const int z1 = min(z0 + P.zc, P.zs);
     const uint32_t colbase = (uint32_t)sy * P.zs * P.xy + (col_ok ? sx : 0);
-    const uint32_t rbase = ((blockIdx.y * gridDim.x + blockIdx.x) * (uint32_t)P.nz + w) * (uint32_t)(WAVE * P.zc);
     const uint32_t tbase = (uint32_t)sy * P.zs * P.nseg + blockIdx.x;   // tile of (sy, sz=0, this segment)
     uint32_t running = 0;                                // rows used by this wave so far
     int zocc = INT_MAX, zfree = INT_MAX;
     uint32_t hocc = 0x3f800000u;
+    // this wave owns window-z chunks [w*cpw, (w+1)*cpw) of zc levels each (ascending z) and the
+    // static compact-row range starting at rbase
+    const uint32_t rbase = ((blockIdx.y * gridDim.x + blockIdx.x) * (uint32_t)P.nz + w) *
+                           (uint32_t)(WAVE * P.zc * P.cpw);
+    for (int cc = 0; cc < P.cpw; ++cc) {
+    const int z0 = (w * P.cpw + cc) * P.zc;
+    if (z0 >= P.zs) break;
+    const int z1 = min(z0 + P.zc, P.zs);
 
     // one occupied voxel: gather over the sources, store its compact row
     auto emit = [&](int z, uint32_t L, uint32_t row) {
@@ -533,6 +558,8 @@ __global__ __launch_bounds__(1024) void k_fuse(const FuseParams P, const FuseDes
             }
         }
     }
+
+    }   // chunks of this wave
 
     // ---- column tail: height (gvom.py:525-540) and inferred height (gvom.py:544-554) ------
     s_zocc[w][lane] = zocc; s_hocc[w][lane] = hocc; s_zfree[w][lane] = zfree;
@@ -893,16 +920,17 @@ hipError_t gvom_launch_publish_count(hipStream_t s, const uint32_t *blockcounts,
 // ------------------------------------------------------------------------------------------
 hipError_t gvom_launch_trace(hipStream_t s, const ScanParams &P, int dtype, const void *pts,
                              int64_t stride_elems, int64_t n, void *world, uint32_t *hit,
-                             uint32_t *total, int32_t *state, uint32_t *tags, uint32_t *counters,
-                             int variant)
+                             uint32_t *total, int32_t *state, uint32_t *tags, uint32_t *cminh,
+                             uint32_t *counters, int variant)
 {
     const unsigned blocks = (unsigned)((n + 255) / 256);
 #define TRACE_LAUNCH(TT, VV)                                                                     \
     hipLaunchKernelGGL((k_trace<TT, VV>), dim3(blocks), dim3(256), 0, s, P, (const TT *)pts,      \
-                       (long)stride_elems, (long)n, (TT *)world, hit, total, state, tags, counters)
+                       (long)stride_elems, (long)n, (TT *)world, hit, total, state, tags, cminh, counters)
     if (dtype == 0) {
         if (variant == 0) TRACE_LAUNCH(float, 0);
         else if (variant == 9) TRACE_LAUNCH(float, 9);
+        else if (variant == 2) TRACE_LAUNCH(float, 2);
         else TRACE_LAUNCH(float, 1);
     } else {
         if (variant == 0) TRACE_LAUNCH(double, 0);
@@ -913,33 +941,26 @@ hipError_t gvom_launch_trace(hipStream_t s, const ScanParams &P, int dtype, cons
     return hipGetLastError();
 }
 
-hipError_t gvom_launch_encode(hipStream_t s, int xy, int zs, int sy_lo, int sy_hi, uint32_t *hit,
-                              uint32_t *total, int32_t *state, uint32_t *chit, uint32_t *ctotal,
-                              uint32_t *cminh, const uint32_t *tags, uint32_t epoch,
+hipError_t gvom_launch_encode(hipStream_t s, const ScanParams &P, int dtype, const void *world,
+                              int64_t n, uint32_t *hit, uint32_t *total, int32_t *state,
+                              uint32_t *chit, uint32_t *ctotal, uint32_t *cminh, const uint32_t *tags,
                               uint32_t *counters, unsigned long long *host_flag, uint32_t seq)
 {
-    const int nseg = (xy + 63) / 64;
-    const uint32_t t_begin = (uint32_t)sy_lo * zs * nseg, t_end = (uint32_t)sy_hi * zs * nseg;
+    const uint32_t t_begin = (uint32_t)P.sy_lo * P.zs * P.nseg, t_end = (uint32_t)P.sy_hi * P.zs * P.nseg;
     const uint32_t ntiles = t_end - t_begin;
-    // one wave handles 4 tiles per iteration; 4 waves per block
-    unsigned blocks = (ntiles + 15) / 16;
-    if (blocks > 4096) blocks = 4096;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_encode, dim3(blocks), dim3(256), 0, s, xy, nseg, t_begin, t_end, hit, total,
-                       state, chit, ctotal, cminh, tags, epoch, counters, host_flag, seq);
-    return hipGetLastError();
-}
-
-hipError_t gvom_launch_minh(hipStream_t s, const ScanParams &P, int dtype, const void *world,
-                            int64_t n, const int32_t *state, uint32_t *cminh)
-{
-    const unsigned blocks = (unsigned)((n + 255) / 256);
+    // encode part: one wave handles 4 tiles per iteration, 4 waves per block
+    unsigned enc_blocks = (ntiles + 15) / 16;
+    if (enc_blocks > 4096) enc_blocks = 4096;
+    if (enc_blocks < 1) enc_blocks = 1;
+    const unsigned mh_blocks = (unsigned)((n + 255) / 256);          // min-height part
     if (dtype == 0)
-        hipLaunchKernelGGL(k_minh<float>, dim3(blocks), dim3(256), 0, s, P, (const float *)world,
-                           (long)n, state, cminh);
+        hipLaunchKernelGGL(k_encode<float>, dim3(enc_blocks + mh_blocks), dim3(256), 0, s, P, enc_blocks,
+                           t_begin, t_end, hit, total, state, chit, ctotal, cminh, tags, P.epoch,
+                           (const float *)world, (long)n, counters, host_flag, seq);
     else
-        hipLaunchKernelGGL(k_minh<double>, dim3(blocks), dim3(256), 0, s, P, (const double *)world,
-                           (long)n, state, cminh);
+        hipLaunchKernelGGL(k_encode<double>, dim3(enc_blocks + mh_blocks), dim3(256), 0, s, P, enc_blocks,
+                           t_begin, t_end, hit, total, state, chit, ctotal, cminh, tags, P.epoch,
+                           (const double *)world, (long)n, counters, host_flag, seq);
     return hipGetLastError();
 }
 
