@@ -75,7 +75,7 @@ def cpu_baseline(params, scans, budget_s=20.0):
         pts += pc.shape[0]
         steps += 1
         el = time.perf_counter() - t0
-        if el > budget_s or steps >= 2 * len(scans) + 8:
+        if el > budget_s and steps >= 3:
             break
     return {"value": pts / el / 1e6, "unit": "M points/s", "cores": 1, "kind": "port",
             "sample": "%d whole steps (scan+combine) of the same workload, %.1f s, "
@@ -196,13 +196,13 @@ def run_single(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--config", default="m256", choices=["c2", "c3", "m256", "m256b8"])
     ap.add_argument("--poses", type=int, default=1, help="distinct sensor poses cycled through")
     ap.add_argument("--sample", type=int, default=8, help="HIP-event-time the kernels on every n-th timed step")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 or world > 1 or os.environ.get("GVOM_BENCH_FORCE_SHARDED"):
