@@ -73,8 +73,9 @@ def run(args):
             "config": {"workload": desc + "; %d sensors, one shared map, grid sharded into %d y-slabs"
                        % (world, world), "name": name, "points_per_step": n_total,
                        "points_per_gpu": n_local, "grid": [params[2], params[2], params[3]],
-                       "buffer_size": params[4], "collectives": "all_gather(cloud), all_reduce(count), "
-                       "all_gather(height, inferred, 4 output maps) over RCCL; none on per-voxel data"},
+                       "buffer_size": params[4],
+                       "collectives": "per step: all_gather(cloud, 12 B/pt) + in-place all_gather(height|inferred|"
+                       "density rows, 24 B/cell) over RCCL; none on per-voxel data"},
             "map_hz": args.steps / elapsed,
             "stage_ms_rank0": stage_ms,
             "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": None, "peak": 8000.0,

@@ -79,6 +79,7 @@ struct gvom_handle {
 
     // pending (uncommitted) scan
     bool pending = false;
+    bool pending_any = false;
     int64_t pending_origin[3] = {0, 0, 0};
     int64_t pending_n = 0;
 
@@ -90,8 +91,12 @@ struct gvom_handle {
     uint32_t *blockcounts = nullptr;                    // per-workgroup occupied counts of k_fuse
     int fuse_blocks = 0;
 
-    double *height = nullptr, *inferred = nullptr, *slope_x = nullptr, *slope_y = nullptr,
-           *rough = nullptr, *guessed = nullptr;        // [sy][sx] storage order
+    double *hmaps = nullptr;                            // [sy][3][sx]: height | inferred height | positive density
+    double *height = nullptr, *inferred = nullptr;      // = hmaps, hmaps + xy  (row stride hs = 3*xy)
+    int hs = 0;
+    double *slope_x = nullptr, *slope_y = nullptr, *rough = nullptr, *guessed = nullptr;   // [sy][sx]
+    hipStream_t own_stream = nullptr;                   // created by the library (stream may be attached)
+    bool blocking = true;                               // split entry points synchronize before returning
     int32_t *out_pos = nullptr, *out_neg = nullptr, *out_vis = nullptr;
     double *out_rough = nullptr;
     void *out_host = nullptr;                           // pinned, device-mapped staging for the 4 outputs
@@ -167,6 +172,17 @@ void fill_scan_params(const gvom_handle *h, const int64_t origin[3], const doubl
     P.sy_lo = h->sy_lo; P.sy_hi = h->sy_hi;
     P.nseg = h->nseg;
     P.epoch = 0;
+    // slab rows as intervals of window y (storage row sy <-> window row (sy - om1) mod xy)
+    P.cull = 0;
+    P.wlo[0] = 0; P.whi[0] = p.xy_size; P.wlo[1] = 1 << 30; P.whi[1] = -(1 << 30);
+    const int len = h->sy_hi - h->sy_lo;
+    if (len < p.xy_size) {
+        P.cull = 1;
+        const int a = (int)floor_mod((int64_t)h->sy_lo - P.om[1], p.xy_size);
+        if (a + len <= p.xy_size) { P.wlo[0] = a; P.whi[0] = a + len; }
+        else { P.wlo[0] = a; P.whi[0] = p.xy_size; P.wlo[1] = 0; P.whi[1] = a + len - p.xy_size; }
+        if (len == 0) { P.wlo[0] = 1 << 30; P.whi[0] = -(1 << 30); }
+    }
 }
 
 int create_impl(const gvom_params *params, int device_id, int rank, int world, gvom_t **out)
@@ -208,6 +224,7 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, g
     } while (0)
     CK(hipSetDevice(device_id));
     CK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->own_stream = h->stream;
     CK(hipMalloc((void **)&h->hit, h->V * 4));
     CK(hipMalloc((void **)&h->total, h->V * 4));
     CK(hipMemsetAsync(h->hit, 0, h->V * 4, h->stream));
@@ -236,8 +253,12 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, g
     h->fuse_blocks = ((xy + 63) / 64) * (h->sy_hi - h->sy_lo);
     CK(hipMalloc((void **)&h->blockcounts, (size_t)(h->fuse_blocks > 0 ? h->fuse_blocks : 1) * 4));
     CK(hipMemsetAsync(h->blockcounts, 0, (size_t)(h->fuse_blocks > 0 ? h->fuse_blocks : 1) * 4, h->stream));
-    double **maps[6] = {&h->height, &h->inferred, &h->slope_x, &h->slope_y, &h->rough, &h->guessed};
+    h->hs = 3 * xy;
+    CK(hipMalloc((void **)&h->hmaps, h->cells2d * 24));
+    h->height = h->hmaps; h->inferred = h->hmaps + xy;
+    double **maps[4] = {&h->slope_x, &h->slope_y, &h->rough, &h->guessed};
     for (auto m : maps) CK(hipMalloc((void **)m, h->cells2d * 8));
+
     CK(hipMalloc((void **)&h->out_pos, h->cells2d * 20));              // [pos | neg | vis | rough] packed:
     h->out_neg = h->out_pos + h->cells2d;                              // one D2H copy per combine
     h->out_vis = h->out_neg + h->cells2d;
@@ -302,7 +323,11 @@ int scan_launch(gvom_handle *h, const void *dev_pts, int64_t n, int64_t stride_e
     }
     HT(h, 1, t0);                                        // scan: wait
     if (h->host_timing) h->host_calls++;
-    st.count = (int64_t)(uint32_t)(*(volatile unsigned long long *)h->counters_host & 0xffffffffull);
+    {
+        const unsigned long long fl = *(volatile unsigned long long *)h->counters_host;
+        st.count = (int64_t)(fl & 0x7fffffffull);          // occupied voxels of THIS rank's slab
+        h->pending_any = (fl & 0x80000000ull) != 0;        // some return landed in the grid on ANY rank
+    }
     st.origin[0] = origin[0]; st.origin[1] = origin[1]; st.origin[2] = origin[2];
     st.stats_valid = false;
     st.stats.points = n;
@@ -351,7 +376,7 @@ int process_impl(gvom_handle *h, const void *xyz, bool on_device, int64_t n, int
     int rc = scan_launch(h, dev, n, row_stride_bytes / (int64_t)esz, dtype, tf);
     if (rc) return rc;
     if (defer) return GVOM_OK;
-    const bool accept = h->slots[h->staging].count > 0;
+    const bool accept = h->pending_any;                   // == (global occupied-voxel count > 0), gvom.py:147-150
     scan_commit(h, accept);
     return accept ? GVOM_OK : GVOM_NO_OVERLAP;
 }
@@ -419,6 +444,7 @@ int fuse_impl(gvom_handle *h, bool publish_now)
     P.sy_lo = h->sy_lo; P.sy_hi = h->sy_hi;
     P.nz = choose_nz(p.z_size, &P.zc, &P.cpw);
     P.nseg = h->nseg;
+    P.hs = h->hs;
     F.epoch = ++h->epoch;
     P.epoch = F.epoch;
     // every wave of k_fuse owns a static range of 64*zc compact rows (no global reservation)
@@ -449,7 +475,8 @@ int fuse_impl(gvom_handle *h, bool publish_now)
     if (h->profiling) { HIPCHK(h, hipEventRecord(h->ev[5], h->stream)); h->ev_fuse = true; }
     if (publish_now)
         HIPCHK(h, gvom_launch_publish_count(h->stream, h->blockcounts, h->fuse_blocks,
-                                            (unsigned long long *)(h->counters_host_dev + 2)));
+                                            (unsigned long long *)(h->counters_host_dev + 2),
+                                            (unsigned long long *)(h->counters + 10)));
     F.valid = true;
     h->cur = nxt;
     h->has_combined = true;
@@ -458,7 +485,10 @@ int fuse_impl(gvom_handle *h, bool publish_now)
 }
 
 // 2-D maps (k_map2d) from height/inferred of the whole window (all rows must be present)
-int map2d_impl(gvom_handle *h, bool storage_order_out, bool publish, bool zero_copy = false)
+// 2-D maps (k_map2d) from height/inferred of the whole window (all rows must be present).
+// gathered: sharded run -- every row of the interleaved height buffer (heights + owner-computed
+// positive densities) has been all-gathered and this rank computes ALL rows of the outputs.
+int map2d_impl(gvom_handle *h, bool gathered, bool publish, char *out_dev)
 {
     const gvom_params &p = h->prm;
     const Fused &F = h->fused[h->cur];
@@ -468,22 +498,20 @@ int map2d_impl(gvom_handle *h, bool storage_order_out, bool publish, bool zero_c
     P.om[0] = (int)floor_mod(F.origin[0], p.xy_size);
     P.om[1] = (int)floor_mod(F.origin[1], p.xy_size);
     P.om[2] = (int)floor_mod(F.origin[2], p.z_size);
-    P.y_lo = h->sy_lo; P.y_hi = h->sy_hi;
+    P.y_lo = gathered ? 0 : h->sy_lo; P.y_hi = gathered ? p.xy_size : h->sy_hi;
     P.origin_z = (double)F.origin[2];
     P.xy_res = p.xy_resolution; P.z_res = p.z_resolution;
     P.pos_thr = p.positive_obstacle_threshold; P.neg_thr = p.negative_obstacle_threshold;
     P.slope_thr = p.slope_obstacle_threshold; P.robot_height = p.robot_height;
-    P.out_storage_order = storage_order_out ? 1 : 0;
+    P.out_storage_order = 0;
+    P.gathered_pos = gathered ? 1 : 0;
     P.nseg = h->nseg;
+    P.hs = h->hs;
     P.epoch = F.epoch;
-    if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[6], h->stream));
     const size_t n2 = h->cells2d;
-    int32_t *o_pos = h->out_pos, *o_neg = h->out_neg, *o_vis = h->out_vis;
-    double *o_rgh = h->out_rough;
-    if (zero_copy) {                                     // k_map2d writes straight into pinned host memory
-        o_pos = (int32_t *)h->out_host_dev; o_neg = o_pos + n2; o_vis = o_neg + n2;
-        o_rgh = (double *)(o_vis + n2);
-    }
+    int32_t *o_pos = (int32_t *)out_dev, *o_neg = o_pos + n2, *o_vis = o_neg + n2;
+    double *o_rgh = (double *)(o_vis + n2);
+    if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[6], h->stream));
     HIPCHK(h, gvom_launch_map2d(h->stream, P, F.state, F.tags, (const uint32_t *)F.hit.p,
                                 (const uint32_t *)F.total.p, h->height, h->inferred, h->slope_x,
                                 h->slope_y, h->rough, h->guessed, o_pos, o_neg, o_rgh, o_vis,
@@ -491,6 +519,25 @@ int map2d_impl(gvom_handle *h, bool storage_order_out, bool publish, bool zero_c
                                 publish ? (unsigned long long *)(h->counters_host_dev + 2) : nullptr));
     if (h->profiling) { HIPCHK(h, hipEventRecord(h->ev[7], h->stream)); h->ev_map = true; }
     h->maps_valid = true;
+    return GVOM_OK;
+}
+
+// sharded runs: positive-obstacle densities of this rank's rows into the height buffer
+int posdens_impl(gvom_handle *h)
+{
+    const gvom_params &p = h->prm;
+    const Fused &F = h->fused[h->cur];
+    Map2dParams P;
+    memset(&P, 0, sizeof P);
+    P.xy = p.xy_size; P.zs = p.z_size;
+    P.om[2] = (int)floor_mod(F.origin[2], p.z_size);
+    P.y_lo = h->sy_lo; P.y_hi = h->sy_hi;
+    P.origin_z = (double)F.origin[2];
+    P.z_res = p.z_resolution;
+    P.pos_thr = p.positive_obstacle_threshold; P.robot_height = p.robot_height;
+    P.nseg = h->nseg; P.hs = h->hs; P.epoch = F.epoch;
+    HIPCHK(h, gvom_launch_posdens(h->stream, P, F.state, F.tags, (const uint32_t *)F.hit.p,
+                                  (const uint32_t *)F.total.p, h->hmaps));
     return GVOM_OK;
 }
 
@@ -550,12 +597,12 @@ VIS void gvom_destroy(gvom_t *h)
     hipFree(h->counters); if (h->counters_host) hipHostFree(h->counters_host);
     hipFree(h->descs_dev); if (h->descs_host) hipHostFree(h->descs_host);
     hipFree(h->blockcounts);
-    hipFree(h->height); hipFree(h->inferred); hipFree(h->slope_x); hipFree(h->slope_y);
+    hipFree(h->hmaps); hipFree(h->slope_x); hipFree(h->slope_y);
     hipFree(h->rough); hipFree(h->guessed);
     hipFree(h->out_pos);
     if (h->out_host) hipHostFree(h->out_host);
     for (auto &e : h->ev) if (e) hipEventDestroy(e);
-    if (h->stream) hipStreamDestroy(h->stream);
+    if (h->own_stream) hipStreamDestroy(h->own_stream);
     delete h;
 }
 
@@ -600,7 +647,7 @@ VIS int gvom_combine_maps(gvom_t *h, double origin_world[3], int32_t *positive, 
     double t0 = now_ns();
     int rc = fuse_impl(h, false);
     if (rc) return rc;
-    if ((rc = map2d_impl(h, false, true, h->zero_copy))) return rc;
+    if ((rc = map2d_impl(h, false, true, h->zero_copy ? h->out_host_dev : (char *)h->out_pos))) return rc;
     const size_t n2 = h->cells2d;
     char *stage = (char *)h->out_host;
     if (!h->zero_copy && (positive || negative || visibility || roughness))
@@ -657,11 +704,7 @@ VIS int gvom_combine_maps_into(gvom_t *h, double origin_world[3], void *pinned_o
     if (rc) return rc;
     char *dev = nullptr;
     HIPCHK(h, hipHostGetDevicePointer((void **)&dev, pinned_out, 0));
-    char *saved = h->out_host_dev;
-    h->out_host_dev = dev;
-    rc = map2d_impl(h, false, true, true);
-    h->out_host_dev = saved;
-    if (rc) return rc;
+    if ((rc = map2d_impl(h, false, true, dev))) return rc;
     HT(h, 2, t0);
     if ((rc = finish_combine(h))) return rc;
     HT(h, 3, t0);
@@ -688,6 +731,11 @@ VIS int gvom_combine_fuse(gvom_t *h, int64_t *local_cells)
     HIPCHK(h, hipSetDevice(h->device));
     int rc = fuse_impl(h, true);
     if (rc) return rc;
+    if ((rc = posdens_impl(h))) return rc;                // third row of the height buffer
+    if (!h->blocking) {                                   // count stays on the device (GVOM_BUF_FUSED_CELLS)
+        if (local_cells) *local_cells = -1;
+        return GVOM_OK;
+    }
     if ((rc = finish_combine(h))) return rc;
     if (local_cells) *local_cells = h->fused[h->cur].count;
     return GVOM_OK;
@@ -701,65 +749,90 @@ VIS int gvom_set_combined_cell_count(gvom_t *h, int64_t global_cells)
     return GVOM_OK;
 }
 
-static void *map_ptr(gvom_handle *h, int which, size_t *esz)
+static void *map_ptr(gvom_handle *h, int which, size_t *esz, int *stride)
 {
-    *esz = 8;
+    *esz = 8; *stride = h->prm.xy_size;
     switch (which) {
-    case GVOM_MAP_HEIGHT: return h->height;
-    case GVOM_MAP_INFERRED_HEIGHT: return h->inferred;
+    case GVOM_MAP_HEIGHT: *stride = h->hs; return h->height;
+    case GVOM_MAP_INFERRED_HEIGHT: *stride = h->hs; return h->inferred;
     case GVOM_MAP_SLOPE_X: return h->slope_x;
     case GVOM_MAP_SLOPE_Y: return h->slope_y;
     case GVOM_MAP_ROUGHNESS: return h->rough;
     case GVOM_MAP_GUESSED_DELTA: return h->guessed;
-    case 100: *esz = 4; return h->out_pos;
-    case 101: *esz = 4; return h->out_neg;
-    case 102: return h->out_rough;
-    case 103: *esz = 4; return h->out_vis;
     default: return nullptr;
     }
 }
 
-// copies storage rows [row_lo, row_hi) of map `which` (100..103 = the four outputs) between
-// the library's buffer and dev_buf (which holds exactly those rows, densely).
-VIS int gvom_rows_export(gvom_t *h, int which, int row_lo, int row_hi, void *dev_buf)
-{
-    if (!h || !dev_buf) return GVOM_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(h->mu);
-    size_t esz; char *m = (char *)map_ptr(h, which, &esz);
-    if (!m || row_lo < 0 || row_hi > h->prm.xy_size || row_lo > row_hi) return GVOM_ERR_INVALID;
-    const size_t rb = (size_t)h->prm.xy_size * esz;
-    HIPCHK(h, hipMemcpyAsync(dev_buf, m + row_lo * rb, (row_hi - row_lo) * rb, hipMemcpyDeviceToDevice, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    return GVOM_OK;
-}
-
-VIS int gvom_rows_import(gvom_t *h, int which, int row_lo, int row_hi, const void *dev_buf)
-{
-    if (!h || !dev_buf) return GVOM_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(h->mu);
-    size_t esz; char *m = (char *)map_ptr(h, which, &esz);
-    if (!m || row_lo < 0 || row_hi > h->prm.xy_size || row_lo > row_hi) return GVOM_ERR_INVALID;
-    const size_t rb = (size_t)h->prm.xy_size * esz;
-    HIPCHK(h, hipMemcpyAsync(m + row_lo * rb, dev_buf, (row_hi - row_lo) * rb, hipMemcpyDeviceToDevice, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    return GVOM_OK;
-}
-
-VIS int gvom_combine_map2d(gvom_t *h)
+// ---- plumbing for the sharded layer: the library's own device buffers take part in the caller's
+// collectives directly (a rank's rows are one contiguous block of each buffer), on the caller's
+// stream, without host synchronisation in between.
+VIS int gvom_attach_stream(gvom_t *h, void *hip_stream)
 {
     if (!h) return GVOM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
-    if (!h->has_combined) return GVOM_NO_DATA;
     HIPCHK(h, hipSetDevice(h->device));
-    int rc = map2d_impl(h, true, false);
-    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    // NULL is a real stream (HIP's legacy default stream -- PyTorch's default); GVOM_OWN_STREAM detaches
+    h->stream = (hip_stream == GVOM_OWN_STREAM) ? h->own_stream : (hipStream_t)hip_stream;
+    return GVOM_OK;
+}
+
+VIS int gvom_set_blocking(gvom_t *h, int on)
+{
+    if (!h) return GVOM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->blocking = on != 0;
+    return GVOM_OK;
+}
+
+VIS int gvom_sync(gvom_t *h)
+{
+    if (!h) return GVOM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     collect_stage_ms(h);
     return GVOM_OK;
 }
 
-VIS int gvom_finalize_outputs(gvom_t *h, double origin_world[3], int32_t *positive, int32_t *negative,
-                              double *roughness, int32_t *visibility);
+VIS int gvom_device_buffer(gvom_t *h, int which, void **ptr, int64_t *bytes, int64_t *row_stride_bytes)
+{
+    if (!h || !ptr) return GVOM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    int64_t b = 0, rs = 0;
+    switch (which) {
+    case GVOM_BUF_HEIGHT_MAPS: *ptr = h->hmaps; rs = (int64_t)h->hs * 8; b = rs * h->prm.xy_size; break;
+    case GVOM_BUF_SCAN_CELLS: *ptr = h->counters + 8; b = 8; rs = 8; break;
+    case GVOM_BUF_FUSED_CELLS: *ptr = h->counters + 10; b = 8; rs = 8; break;
+    default: return GVOM_ERR_INVALID;
+    }
+    if (bytes) *bytes = b;
+    if (row_stride_bytes) *row_stride_bytes = rs;
+    return GVOM_OK;
+}
+
+// sharded runs, after the in-place all_gather of GVOM_BUF_HEIGHT_MAPS: all rows of the four
+// outputs, written by the GPU straight into a pinned buffer from gvom_output_buffer_alloc
+// (same layout as gvom_combine_maps_into).  Synchronises.
+VIS int gvom_combine_map2d_into(gvom_t *h, double origin_world[3], void *pinned_out)
+{
+    if (!h || !pinned_out) return GVOM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!h->has_combined) return GVOM_NO_DATA;
+    HIPCHK(h, hipSetDevice(h->device));
+    char *dev = nullptr;
+    HIPCHK(h, hipHostGetDevicePointer((void **)&dev, pinned_out, 0));
+    int rc = map2d_impl(h, true, false, dev);
+    if (rc) return rc;
+    if ((rc = finish_combine(h))) return rc;
+    if (origin_world) {
+        const Fused &F = h->fused[h->cur];
+        origin_world[0] = (double)F.origin[0] * h->prm.xy_resolution;
+        origin_world[1] = (double)F.origin[1] * h->prm.xy_resolution;
+        origin_world[2] = (double)F.origin[2] * h->prm.z_resolution;
+    }
+    return GVOM_OK;
+}
 
 VIS int gvom_get_state(gvom_t *h, gvom_state *out)
 {
@@ -828,49 +901,17 @@ VIS int gvom_read_map2d(gvom_t *h, int which2d, double *out)
     std::lock_guard<std::mutex> lk(h->mu);
     if (!h->has_combined || !h->maps_valid) return GVOM_NO_DATA;
     HIPCHK(h, hipSetDevice(h->device));
-    size_t esz; const double *src = (const double *)map_ptr(h, which2d, &esz);
-    if (!src || esz != 8 || which2d >= 100) return GVOM_ERR_INVALID;
+    size_t esz; int stride; const double *src = (const double *)map_ptr(h, which2d, &esz, &stride);
+    if (!src) return GVOM_ERR_INVALID;
     const Fused &F = h->fused[h->cur];
     double *tmp = nullptr;
     HIPCHK(h, hipMalloc((void **)&tmp, h->cells2d * 8));
     hipError_t e = gvom_launch_unwrap_f64(h->stream, h->prm.xy_size, (int)floor_mod(F.origin[0], h->prm.xy_size),
-                                          (int)floor_mod(F.origin[1], h->prm.xy_size), src, tmp);
+                                          (int)floor_mod(F.origin[1], h->prm.xy_size), src, stride, tmp);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e == hipSuccess) e = hipMemcpy(out, tmp, h->cells2d * 8, hipMemcpyDeviceToHost);
     hipFree(tmp);
     HIPCHK(h, e);
-    return GVOM_OK;
-}
-
-VIS int gvom_finalize_outputs(gvom_t *h, double origin_world[3], int32_t *positive, int32_t *negative,
-                              double *roughness, int32_t *visibility)
-{
-    if (!h) return GVOM_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(h->mu);
-    if (!h->has_combined) return GVOM_NO_DATA;
-    HIPCHK(h, hipSetDevice(h->device));
-    const Fused &F = h->fused[h->cur];
-    const int om0 = (int)floor_mod(F.origin[0], h->prm.xy_size), om1 = (int)floor_mod(F.origin[1], h->prm.xy_size);
-    const size_t n2 = h->cells2d;
-    void *tmp = nullptr;
-    HIPCHK(h, hipMalloc(&tmp, n2 * 8));
-    hipError_t e = hipSuccess;
-    struct { void *src; void *dst; int esz; } jobs[4] = {
-        {h->out_pos, positive, 4}, {h->out_neg, negative, 4}, {h->out_rough, roughness, 8}, {h->out_vis, visibility, 4}};
-    for (auto &j : jobs) {
-        if (!j.dst || e != hipSuccess) continue;
-        if (j.esz == 8) e = gvom_launch_unwrap_f64(h->stream, h->prm.xy_size, om0, om1, (const double *)j.src, (double *)tmp);
-        else e = gvom_launch_unwrap_i32(h->stream, h->prm.xy_size, om0, om1, (const int32_t *)j.src, (int32_t *)tmp);
-        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-        if (e == hipSuccess) e = hipMemcpy(j.dst, tmp, n2 * j.esz, hipMemcpyDeviceToHost);
-    }
-    hipFree(tmp);
-    HIPCHK(h, e);
-    if (origin_world) {
-        origin_world[0] = (double)F.origin[0] * h->prm.xy_resolution;
-        origin_world[1] = (double)F.origin[1] * h->prm.xy_resolution;
-        origin_world[2] = (double)F.origin[2] * h->prm.z_resolution;
-    }
     return GVOM_OK;
 }
 
@@ -907,7 +948,7 @@ static int debug_maps(gvom_t *h, float *out7, float *out3)
     double org[3] = {(double)F.origin[0], (double)F.origin[1], (double)F.origin[2]};
     hipError_t e = gvom_launch_debug_height(h->stream, h->prm.xy_size, (int)floor_mod(F.origin[0], h->prm.xy_size),
                                             (int)floor_mod(F.origin[1], h->prm.xy_size), org,
-                                            h->prm.xy_resolution, h->prm.z_resolution, h->height, h->rough,
+                                            h->prm.xy_resolution, h->prm.z_resolution, h->height, h->hs, h->rough,
                                             h->slope_x, h->slope_y, out7 ? tmp : nullptr, h->guessed,
                                             out3 ? tmp : nullptr);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);

@@ -36,6 +36,9 @@ struct ScanParams {
     int    sy_lo, sy_hi;  // storage rows owned by this rank: [sy_lo, sy_hi)
     int    nseg;          // tiles per (sy, sz) row
     uint32_t epoch;       // this scan's tile epoch
+    // slab-sharded runs: the slab's rows as (up to two) intervals of WINDOW y, for ray culling
+    int    cull;          // 1: skip rays that cannot reach the slab, stop rays that have left it
+    int    wlo[2], whi[2];
 };
 
 struct MapDesc {          // one source map of the fusion (ring slot or previous fused map)
@@ -59,6 +62,7 @@ struct FuseParams {
     int has_prev;           // descs[nslots] is the previous fused map
     int sy_lo, sy_hi;
     int nseg;               // tiles per (sy, sz) row
+    int hs;                 // row stride (elements) of the height / inferred-height maps
     uint32_t epoch;         // epoch of the fused map being written
     int nz;                 // z-chunks per workgroup (block = 64 * nz threads)
     int zc;                 // window-z cells per chunk (<= 64)
@@ -75,6 +79,8 @@ struct Map2dParams {
     int om[3];
     int y_lo, y_hi;         // STORAGE rows [sy] computed by this rank
     int nseg;
+    int hs;                 // row stride (elements) of the height / inferred-height maps
+    int gathered_pos;       // 1: positive-obstacle densities come from the gathered height buffer (sharded)
     uint32_t epoch;         // epoch of the fused map (tile liveness of fstate)
     int out_storage_order;  // 1: the four outputs stay [sy][sx] (sharded runs); 0: reference [x][y]
     double origin_z;        // fused origin z (voxels)
@@ -92,7 +98,7 @@ hipError_t gvom_launch_encode(hipStream_t s, const ScanParams &P, int dtype, con
                               uint32_t *chit, uint32_t *ctotal, uint32_t *cminh, const uint32_t *tags,
                               uint32_t *counters, unsigned long long *host_flag, uint32_t seq);
 hipError_t gvom_launch_publish_count(hipStream_t s, const uint32_t *blockcounts, int nblocks,
-                                     unsigned long long *host_counter);
+                                     unsigned long long *host_counter, unsigned long long *dev_counter);
 hipError_t gvom_launch_fuse(hipStream_t s, const FuseParams &P, const FuseDescs &KD,
                             const MapDesc *descs_dev, int32_t *fstate, uint32_t *fhit, uint32_t *ftotal, uint32_t *fminh,
                             uint32_t *ftags, uint32_t *blockcounts, double *height, double *inferred);
@@ -108,9 +114,11 @@ hipError_t gvom_launch_read_dense(hipStream_t s, int xy, int zs, const int om[3]
                                   const uint32_t *ctotal, const uint32_t *cminh, int32_t *o_state,
                                   int32_t *o_hit, int32_t *o_total, float *o_minh);
 // storage order [sy][sx] -> reference order [x][y] (window coordinates)
-hipError_t gvom_launch_unwrap_f64(hipStream_t s, int xy, int om0, int om1, const double *in, double *out_xy);
-hipError_t gvom_launch_unwrap_i32(hipStream_t s, int xy, int om0, int om1, const int32_t *in, int32_t *out_xy);
+hipError_t gvom_launch_unwrap_f64(hipStream_t s, int xy, int om0, int om1, const double *in, int in_stride, double *out_xy);
+hipError_t gvom_launch_posdens(hipStream_t s, const Map2dParams &P, const int32_t *fstate,
+                               const uint32_t *ftags, const uint32_t *fhit, const uint32_t *ftotal,
+                               double *hmaps);
 hipError_t gvom_launch_debug_height(hipStream_t s, int xy, int om0, int om1, const double origin[3], double xy_res,
-                                    double z_res, const double *height, const double *rough,
+                                    double z_res, const double *height, int hs, const double *rough,
                                     const double *sx, const double *sy, float *out7,
                                     const double *guessed, float *out3);

@@ -88,13 +88,14 @@ __global__ __launch_bounds__(256) void k_trace(const ScanParams P, const T *__re
     const double dxy = (double)P.xy, dzs = (double)P.zs;
 
     // ---- endpoint ------------------------------------------------------------------------
-    bool ingrid = false;
+    bool ingrid = false, ingrid_any = false;
     uint32_t L = 0;
     if (pass) {
         const double fx = floor((double)x / P.xy_res - P.origin[0]);
         const double fy = floor((double)y / P.xy_res - P.origin[1]);
         const double fz = floor((double)z / P.z_res - P.origin[2]);
         if (fx >= 0.0 && fx < dxy && fy >= 0.0 && fy < dxy && fz >= 0.0 && fz < dzs) {
+            ingrid_any = true;                           // in the grid, whichever rank owns the row
             const int sx = wrap_add((int)fx, P.om[0], P.xy);
             const int sy = wrap_add((int)fy, P.om[1], P.xy);
             const int sz = wrap_add((int)fz, P.om[2], P.zs);
@@ -111,6 +112,10 @@ __global__ __launch_bounds__(256) void k_trace(const ScanParams P, const T *__re
         const uint32_t tile = (L / P.xy) * P.nseg + ((L % P.xy) >> 6);  // stamp the tile (idempotent)
         tags[tile] = P.epoch;
     }
+    // every rank sees every point, so each can count the GLOBAL number of in-grid returns: the
+    // reference's "no overlap" test (gvom.py:147-150) then needs no collective in sharded runs
+    const unsigned long long gm = __ballot(ingrid_any);
+    if (gm != 0ull && lane == (__ffsll((long long)gm) - 1)) atomicAdd(&counters[1], (uint32_t)__popcll(gm));
     const bool claim = ingrid && old == 0;
     const unsigned long long cm = __ballot(claim);
     if (cm != 0ull) {                                   // wave-uniform
@@ -188,6 +193,23 @@ __global__ __launch_bounds__(256) void k_trace(const ScanParams P, const T *__re
 
     // ---- VAR 1: lock-step, run-merged (VAR 2: same + diagnostic counters) -------------------
     bool active = pass && (length < lim);
+    // slab-sharded runs: a ray whose window-y range cannot touch this rank's rows is not traced
+    // at all, and a ray is dropped once it has moved past them (y is monotone along a ray); both
+    // tests are conservative (+-1 row), so the committed updates are unchanged.
+    const float sy_dir = si == 1 ? sd : (si == 0 ? so1 : so2);           // slope of the y axis
+    int ystop_lo = INT_MIN, ystop_hi = INT_MAX;
+    if (P.cull && active) {
+        const float yend_f = e1 - (float)P.origin[1];
+        const float ybeg_f = P.pt0[1] - (float)P.origin[1];
+        const int y0i = (int)floorf(fminf(ybeg_f, yend_f)) - 2, y1i = (int)floorf(fmaxf(ybeg_f, yend_f)) + 2;
+        const bool hit0 = y1i >= P.wlo[0] && y0i < P.whi[0];
+        const bool hit1 = y1i >= P.wlo[1] && y0i < P.whi[1];
+        if (!hit0 && !hit1) active = false;
+        const int lo = min(P.wlo[0], P.wlo[1] < P.whi[1] ? P.wlo[1] : P.wlo[0]);
+        const int hi = max(P.whi[0], P.wlo[1] < P.whi[1] ? P.whi[1] : P.whi[0]);
+        if (sy_dir > 0.0f) ystop_hi = hi + 1;            // moving towards +y: done beyond the last owned row
+        else if (sy_dir < 0.0f) ystop_lo = lo - 2;
+    }
     uint32_t n_heads = 0, n_lines = 0, n_instr = 0;      // VAR 2 only
     while (__any(active)) {
         bool commit = false;
@@ -210,11 +232,12 @@ __global__ __launch_bounds__(256) void k_trace(const ScanParams P, const T *__re
                     commit = true;
                 }
                 length += step_len;
-                active = length < lim;
+                active = length < lim && (int)fy < ystop_hi && (int)fy > ystop_lo;
             } else {
                 active = false;                           // ray left the grid (gvom.py:1135-1144)
             }
         }
+        if (!__any(commit)) continue;                     // nothing to add in this step (wave-uniform)
         // merge runs of equal voxel indices among neighbouring lanes
         const uint32_t key = commit ? Ls : (0xFFFFFF00u | (uint32_t)lane);   // > any voxel index
         const uint32_t left = (uint32_t)__shfl_up((int)key, 1);
@@ -297,8 +320,10 @@ __global__ __launch_bounds__(256) void k_encode(const ScanParams P, unsigned enc
         // 8-byte system-scope store to host-mapped memory (the host spins on it and returns to
         // its caller while this kernel and k_minh still run) and re-arm the counter.
         const uint32_t c = counters[0];
-        counters[0] = 0;
-        __hip_atomic_store(host_flag, ((unsigned long long)seq << 32) | c, __ATOMIC_RELEASE,
+        const uint32_t any = counters[1] ? 0x80000000u : 0u;     // some return landed in the grid (any rank)
+        counters[0] = 0; counters[1] = 0;
+        counters[8] = c; counters[9] = 0;               // device-side copy (int64) for sharded runs
+        __hip_atomic_store(host_flag, ((unsigned long long)seq << 32) | any | c, __ATOMIC_RELEASE,
                            __HIP_MEMORY_SCOPE_SYSTEM);
     }
     const int lane = threadIdx.x & (WAVE - 1);
@@ -583,8 +608,8 @@ __global__ __launch_bounds__(1024) void k_fuse(const FuseParams P, const FuseDes
         if (xp * xp + yp * yp <= P.radius2) hval = P.ego[2] - P.ground_to_lidar_height;
         if (zo != INT_MAX)
             hval = (((double)__uint_as_float(hb) + (double)zo) + P.origin[2]) * P.z_res;
-        height[(size_t)sy * P.xy + sx] = hval;
-        inferred[(size_t)sy * P.xy + sx] =
+        height[(size_t)sy * P.hs + sx] = hval;
+        inferred[(size_t)sy * P.hs + sx] =
             (zf != INT_MAX) ? ((double)zf + P.origin[2]) * P.z_res : -1000.0;
     }
 }
@@ -605,10 +630,12 @@ __device__ __forceinline__ void publish_block_counts(const uint32_t *blockcounts
     if (tid == 0) *host_counter = s_red[0];
 }
 
-__global__ void k_publish_count(const uint32_t *blockcounts, int nblocks, unsigned long long *host_counter)
+__global__ void k_publish_count(const uint32_t *blockcounts, int nblocks, unsigned long long *host_counter,
+                                unsigned long long *dev_counter)
 {
     __shared__ unsigned long long s_red[256];
     publish_block_counts(blockcounts, nblocks, host_counter, s_red, threadIdx.x, 256);
+    if (threadIdx.x == 0) *dev_counter = s_red[0];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -630,6 +657,7 @@ __global__ void k_publish_count(const uint32_t *blockcounts, int nblocks, unsign
 #define M2_W (M2_TX + 2 * M2_HALO)   // 62
 #define M2_H (M2_TY + 2 * M2_HALO)   // 38
 
+template <bool GATHERED_POS>
 __global__ __launch_bounds__(256) void k_map2d(const Map2dParams P, const int32_t *__restrict__ fstate,
                                                const uint32_t *__restrict__ ftags,
                                                const uint32_t *__restrict__ fhit,
@@ -664,7 +692,7 @@ __global__ __launch_bounds__(256) void k_map2d(const Map2dParams P, const int32_
         const int gy = Y0 - M2_HALO + r, gx = X0 - M2_HALO + lane;
         double v = -1000.0;
         if (lane < M2_W && gy >= 0 && gy < xy && gx >= 0 && gx < xy)
-            v = height[(size_t)wrap_add(gy, P.om[1], xy) * xy + wrap_add(gx, P.om[0], xy)];
+            v = height[(size_t)wrap_add(gy, P.om[1], xy) * P.hs + wrap_add(gx, P.om[0], xy)];
         if (lane < M2_W) ht[r][lane] = v;
         const unsigned long long m = __ballot(v > -1000);
         if (lane == 0) rowm[r] = m;
@@ -760,7 +788,7 @@ __global__ __launch_bounds__(256) void k_map2d(const Map2dParams P, const int32_
     //                   -x: column x0-i, dy in [-i+1, i];  +y: row y0+i, dx in [-i+1, i];
     //                   -y: row y0-i, dx in [-i, i)                               (gvom.py:588-638)
     double dh_out = 0.0;
-    const double inf00 = inferred[c_yx];
+    const double inf00 = inferred[(size_t)sy0 * P.hs + sx0];
     if (!(h00 > -1000 || inf00 == -1000.0)) {
         bool x_p_done = false, x_n_done = false, y_p_done = false, y_n_done = false;
         double x_ph = -1000, x_nh = -1000, y_ph = -1000, y_nh = -1000;
@@ -809,6 +837,9 @@ __global__ __launch_bounds__(256) void k_map2d(const Map2dParams P, const int32_
     int pos = 0;
     if (sqrt(sxv * sxv + syv * syv) >= P.slope_thr) {
         pos = 100;
+    } else if (GATHERED_POS) {
+        // sharded runs: the slab owner computed the density (k_posdens), all-gathered with the heights
+        pos = (int)height[(size_t)sy0 * P.hs + 2 * (size_t)xy + sx0];
     } else {
         const double fmin = floor(((h00 + P.pos_thr) / P.z_res) - P.origin_z) + 1.0;
         const double fmax = floor(((h00 + P.robot_height) / P.z_res) - P.origin_z);
@@ -829,13 +860,9 @@ __global__ __launch_bounds__(256) void k_map2d(const Map2dParams P, const int32_
             pos = (int)(density * 100);
         }
     }
-    if (P.out_storage_order) {
-        out_pos[c_yx] = pos; out_neg[c_yx] = negv; out_vis[c_yx] = visv; out_rough[c_yx] = rv;
-    } else {
-        o_pos[tx][ty] = pos; o_neg[tx][ty] = negv; o_vis[tx][ty] = visv; o_rgh[tx][ty] = rv;
-    }
+    o_pos[tx][ty] = pos; o_neg[tx][ty] = negv; o_vis[tx][ty] = visv; o_rgh[tx][ty] = rv;
     }   // mine
-    if (!P.out_storage_order) {
+    {
         __syncthreads();
         const int ox = tid >> 5, oy = tid & 31;              // 32 consecutive lanes -> 32 consecutive y
         const int gx = X0 + ox, gy = Y0 + oy;
@@ -876,16 +903,50 @@ __global__ void k_read_dense(int xy, int zs, int om0, int om1, int om2, int sy_l
 }
 
 template <typename E>
-__global__ void k_unwrap(int xy, int om0, int om1, const E *__restrict__ in, E *out_xy)
+__global__ void k_unwrap(int xy, int om0, int om1, const E *__restrict__ in, int in_stride, E *out_xy)
 {
     const int sx = blockIdx.x * 64 + threadIdx.x, sy = blockIdx.y * 4 + threadIdx.y;
     if (sx < xy && sy < xy)
-        out_xy[(size_t)wrap_sub(sx, om0, xy) * xy + wrap_sub(sy, om1, xy)] = in[(size_t)sy * xy + sx];
+        out_xy[(size_t)wrap_sub(sx, om0, xy) * xy + wrap_sub(sy, om1, xy)] = in[(size_t)sy * in_stride + sx];
+}
+
+// Sharded runs: positive-obstacle density of the slab's own cells (the z-range gather of
+// gvom.py:502-521, everything of __make_positive_obstacle_map except the slope override),
+// stored as the third row of the interleaved height buffer so that it travels with the heights.
+__global__ __launch_bounds__(256) void k_posdens(const Map2dParams P, const int32_t *__restrict__ fstate,
+                                                 const uint32_t *__restrict__ ftags,
+                                                 const uint32_t *__restrict__ fhit,
+                                                 const uint32_t *__restrict__ ftotal, double *hmaps)
+{
+    const int xy = P.xy;
+    const int sx0 = blockIdx.x * 64 + threadIdx.x, sy0 = P.y_lo + blockIdx.y * 4 + threadIdx.y;
+    if (sx0 >= xy || sy0 >= P.y_hi) return;
+    const double h00 = hmaps[(size_t)sy0 * P.hs + sx0];
+    int pos = 0;
+    const double fmin = floor(((h00 + P.pos_thr) / P.z_res) - P.origin_z) + 1.0;
+    const double fmax = floor(((h00 + P.robot_height) / P.z_res) - P.origin_z);
+    if (fmin >= 0 && fmin < (double)P.zs && fmax >= 0 && fmax < (double)P.zs) {
+        const int zmin = (int)fmin, zmax = (int)fmax;
+        double density = 0.0, nn = 0.0;
+        for (int z = zmin; z <= zmax; ++z) {
+            const int sz = wrap_add(z, P.om[2], P.zs);
+            const uint32_t rz = (uint32_t)sy0 * P.zs + sz;
+            int32_t row = -1;
+            if (ftags[rz * P.nseg + (sx0 >> 6)] == P.epoch) row = fstate[rz * xy + sx0];
+            if (row >= 0) {
+                const uint32_t hc = fhit[row];
+                if ((int32_t)hc > 10) { nn += (double)(int32_t)ftotal[row]; density += (double)(int32_t)hc; }
+            }
+        }
+        if (nn > 0.0) density /= nn;
+        pos = (int)(density * 100);
+    }
+    hmaps[(size_t)sy0 * P.hs + 2 * (size_t)xy + sx0] = (double)pos;
 }
 
 // gvom.py:426-438 (7 columns) and :442-450 (3 columns, fed with guessed_height_delta :407)
 __global__ void k_debug_height(int xy, int om0, int om1, double o0, double o1, double xy_res,
-                               double z_res, const double *height, const double *rough,
+                               double z_res, const double *height, int hs, const double *rough,
                                const double *sx, const double *sy, float *out7,
                                const double *guessed, float *out3)
 {
@@ -897,7 +958,7 @@ __global__ void k_debug_height(int xy, int om0, int om1, double o0, double o1, d
     if (out7) {
         const double a = sx[g], b = sy[g];
         out7[c * 7 + 0] = wx; out7[c * 7 + 1] = wy;
-        out7[c * 7 + 2] = (float)(height[g] - z_res);
+        out7[c * 7 + 2] = (float)(height[(size_t)wrap_add(y, om1, xy) * hs + wrap_add(x, om0, xy)] - z_res);
         out7[c * 7 + 3] = (float)rough[g];
         out7[c * 7 + 4] = (float)a; out7[c * 7 + 5] = (float)b;
         out7[c * 7 + 6] = (float)sqrt(a * a + b * b);
@@ -909,9 +970,9 @@ __global__ void k_debug_height(int xy, int om0, int om1, double o0, double o1, d
 }
 
 hipError_t gvom_launch_publish_count(hipStream_t s, const uint32_t *blockcounts, int nblocks,
-                                     unsigned long long *host_counter)
+                                     unsigned long long *host_counter, unsigned long long *dev_counter)
 {
-    hipLaunchKernelGGL(k_publish_count, dim3(1), dim3(256), 0, s, blockcounts, nblocks, host_counter);
+    hipLaunchKernelGGL(k_publish_count, dim3(1), dim3(256), 0, s, blockcounts, nblocks, host_counter, dev_counter);
     return hipGetLastError();
 }
 
@@ -989,9 +1050,14 @@ hipError_t gvom_launch_map2d(hipStream_t s, const Map2dParams &P, const int32_t 
 {
     const dim3 grid((P.xy + M2_TX - 1) / M2_TX, (P.xy + M2_TY - 1) / M2_TY);
     if (P.y_hi <= P.y_lo) return hipSuccess;
-    hipLaunchKernelGGL(k_map2d, grid, dim3(M2_TX * M2_TY), 0, s, P, fstate, ftags, fhit, ftotal, height, inferred,
-                       slope_x, slope_y, rough, guessed, out_pos, out_neg, out_rough, out_vis, blockcounts,
-                       nblocks, host_counter);
+    if (P.gathered_pos)
+        hipLaunchKernelGGL(k_map2d<true>, grid, dim3(M2_TX * M2_TY), 0, s, P, fstate, ftags, fhit, ftotal, height,
+                           inferred, slope_x, slope_y, rough, guessed, out_pos, out_neg, out_rough, out_vis,
+                           blockcounts, nblocks, host_counter);
+    else
+        hipLaunchKernelGGL(k_map2d<false>, grid, dim3(M2_TX * M2_TY), 0, s, P, fstate, ftags, fhit, ftotal, height,
+                           inferred, slope_x, slope_y, rough, guessed, out_pos, out_neg, out_rough, out_vis,
+                           blockcounts, nblocks, host_counter);
     return hipGetLastError();
 }
 
@@ -1006,26 +1072,36 @@ hipError_t gvom_launch_read_dense(hipStream_t s, int xy, int zs, const int om[3]
     return hipGetLastError();
 }
 
-hipError_t gvom_launch_unwrap_f64(hipStream_t s, int xy, int om0, int om1, const double *in, double *out_xy)
+hipError_t gvom_launch_unwrap_f64(hipStream_t s, int xy, int om0, int om1, const double *in, int in_stride, double *out_xy)
 {
     hipLaunchKernelGGL(k_unwrap<double>, dim3((xy + 63) / 64, (xy + 3) / 4), dim3(64, 4), 0, s, xy,
-                       om0, om1, in, out_xy);
+                       om0, om1, in, in_stride, out_xy);
+    return hipGetLastError();
+}
+
+hipError_t gvom_launch_posdens(hipStream_t s, const Map2dParams &P, const int32_t *fstate,
+                               const uint32_t *ftags, const uint32_t *fhit, const uint32_t *ftotal,
+                               double *hmaps)
+{
+    if (P.y_hi <= P.y_lo) return hipSuccess;
+    hipLaunchKernelGGL(k_posdens, dim3((P.xy + 63) / 64, (P.y_hi - P.y_lo + 3) / 4), dim3(64, 4), 0, s, P,
+                       fstate, ftags, fhit, ftotal, hmaps);
     return hipGetLastError();
 }
 
 hipError_t gvom_launch_unwrap_i32(hipStream_t s, int xy, int om0, int om1, const int32_t *in, int32_t *out_xy)
 {
     hipLaunchKernelGGL(k_unwrap<int32_t>, dim3((xy + 63) / 64, (xy + 3) / 4), dim3(64, 4), 0, s, xy,
-                       om0, om1, in, out_xy);
+                       om0, om1, in, xy, out_xy);
     return hipGetLastError();
 }
 
 hipError_t gvom_launch_debug_height(hipStream_t s, int xy, int om0, int om1, const double origin[3],
-                                    double xy_res, double z_res, const double *height,
+                                    double xy_res, double z_res, const double *height, int hs,
                                     const double *rough, const double *sx, const double *sy,
                                     float *out7, const double *guessed, float *out3)
 {
     hipLaunchKernelGGL(k_debug_height, dim3((xy + 63) / 64, (xy + 3) / 4), dim3(64, 4), 0, s, xy, om0,
-                       om1, origin[0], origin[1], xy_res, z_res, height, rough, sx, sy, out7, guessed, out3);
+                       om1, origin[0], origin[1], xy_res, z_res, height, hs, rough, sx, sy, out7, guessed, out3);
     return hipGetLastError();
 }

@@ -30,7 +30,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 GVOM_OK, GVOM_EMPTY_CLOUD, GVOM_NO_OVERLAP, GVOM_EMPTY_BUFFER, GVOM_NO_DATA = 0, 1, 2, 3, 4
 GVOM_WHICH_FUSED = -1
 MAP_HEIGHT, MAP_INFERRED, MAP_SLOPE_X, MAP_SLOPE_Y, MAP_ROUGHNESS, MAP_GUESSED = range(6)
-OUT_POSITIVE, OUT_NEGATIVE, OUT_ROUGHNESS, OUT_VISIBILITY = 100, 101, 102, 103
+BUF_HEIGHT_MAPS, BUF_SCAN_CELLS, BUF_FUSED_CELLS = 0, 2, 3
 N_STAGES = 5
 STAGE_NAMES = ("trace", "encode", "min_height", "fuse", "map2d")
 
@@ -88,10 +88,11 @@ ABI = [
     ("gvom_scan_commit", _I, [_P, _I]),
     ("gvom_combine_fuse", _I, [_P, ctypes.POINTER(_I64)]),
     ("gvom_set_combined_cell_count", _I, [_P, _I64]),
-    ("gvom_rows_export", _I, [_P, _I, _I, _I, _P]),
-    ("gvom_rows_import", _I, [_P, _I, _I, _I, _P]),
-    ("gvom_combine_map2d", _I, [_P]),
-    ("gvom_finalize_outputs", _I, [_P, _P, _P, _P, _P, _P]),
+    ("gvom_attach_stream", _I, [_P, _P]),
+    ("gvom_set_blocking", _I, [_P, _I]),
+    ("gvom_sync", _I, [_P]),
+    ("gvom_device_buffer", _I, [_P, _I, ctypes.POINTER(_P), ctypes.POINTER(_I64), ctypes.POINTER(_I64)]),
+    ("gvom_combine_map2d_into", _I, [_P, _P, _P]),
     ("gvom_slot_filled", _I, [_P, _I]),
     ("gvom_get_state", _I, [_P, ctypes.POINTER(GvomState)]),
     ("gvom_get_scan_stats", _I, [_P, ctypes.POINTER(GvomScanStats)]),
@@ -103,6 +104,7 @@ ABI = [
     ("gvom_last_stage_ms", _I, [_P, ctypes.POINTER(ctypes.c_float * N_STAGES)]),
     ("gvom_set_profiling", _I, [_P, _I]),
     ("gvom_host_timing", _I, [_P, ctypes.POINTER(ctypes.c_double * 8)]),
+    ("gvom_debug_trace_counters", _I, [_P, _P]),
     ("gvom_stream", _P, [_P]),
     ("gvom_last_error", ctypes.c_char_p, [_P]),
     ("gvom_backend_info", _I, [ctypes.c_char_p, ctypes.c_size_t]),
@@ -294,12 +296,20 @@ class Gvom(object):
         """Combines all maps in the buffer and processes the resultant map into 2D maps
         (reference gvom.py:177-354).  Returns None or (origin_world f64[3], positive i32[xy,xy],
         negative i32[xy,xy], roughness f64[xy,xy], visibility i32[xy,xy])."""
+        rc, out = self._combine_into(self._lib.gvom_combine_maps_into)
+        if rc == GVOM_EMPTY_BUFFER:
+            print("[WARNING] The map buffer is empty, nothing will happen!")
+            return None
+        return out
+
+    def _combine_into(self, entry_point):
+        """Runs `entry_point(handle, origin, pinned_buffer)` and wraps the pinned buffer as the
+        reference's return tuple.  The GPU writes the four maps straight into a pinned,
+        device-mapped host buffer; the returned arrays are views of it (fresh per call: a buffer
+        is reused only after every array of an earlier call has been garbage-collected)."""
         xy = self.xy_size
         n2 = xy * xy
         origin = np.zeros(3, np.float64)
-        # the GPU writes the four maps straight into a pinned, device-mapped host buffer; the
-        # returned arrays are views of it (fresh per call: a buffer is reused only after every
-        # array of an earlier call has been garbage-collected)
         if self._out_pool:
             ptr = self._out_pool.pop()
         else:
@@ -307,16 +317,15 @@ class Gvom(object):
             self._check(self._lib.gvom_output_buffer_alloc(self._h, ctypes.byref(p)))
             ptr = p.value
         holder = _PinnedOutput(self._out_pool, ptr, n2 * 20)
-        rc = self._check(self._lib.gvom_combine_maps_into(self._h, _ptr(origin), ctypes.c_void_p(ptr)))
-        if rc == GVOM_EMPTY_BUFFER:
-            print("[WARNING] The map buffer is empty, nothing will happen!")
-            return None
+        rc = self._check(entry_point(self._h, _ptr(origin), ctypes.c_void_p(ptr)))
+        if rc != GVOM_OK:
+            return rc, None
         raw = np.asarray(holder)
         positive = raw[0:4 * n2].view(np.int32).reshape(xy, xy)
         negative = raw[4 * n2:8 * n2].view(np.int32).reshape(xy, xy)
         visibility = raw[8 * n2:12 * n2].view(np.int32).reshape(xy, xy)
         roughness = raw[12 * n2:20 * n2].view(np.float64).reshape(xy, xy)
-        return (origin, positive, negative, roughness, visibility)
+        return GVOM_OK, (origin, positive, negative, roughness, visibility)
 
     # ---- accessors / debug API (reference gvom.py:356-410) ------------------------------
     def get_map_as_occupancy_grid(self):

@@ -3,21 +3,28 @@
 Partitioning (DESIGN.md "Multi-GPU"): the voxel grid is stored world-anchored (toroidal),
 so its storage y axis is cut into `world` contiguous slabs that NEVER migrate when the
 robot-centred window moves.  Rank r owns storage rows [r*xy/world, (r+1)*xy/world) of every
-per-voxel array (accumulators, ring slots, fused map) and of every 2-D map.
+per-voxel array (accumulators, ring slots, fused map).
 
-Per scan (process_pointcloud):
-    all_gather      every rank's share of the cloud (N_r x 3 floats; 1.5 MB per 131k points)
-    local           each rank traces ALL rays but commits only voxels of its slab
-                    (integer atomics commute -> bit-identical to one GPU), encodes its slab
-    all_reduce(sum) occupied-voxel count -> the reference's "no overlap" test is global
-Per combine (combine_maps):
-    local           temporal fusion + column reductions of the slab -> its rows of the
-                    height / inferred-height maps
-    all_gather      height + inferred rows (2 x 8 B x xy^2: 1 MB at xy=256): the slope stencil
-                    needs +-1 row, __guess_height +-15 rows
-    local           slope / roughness / guess / positive / negative / visibility rows
-    all_gather      the four output maps' rows; every rank returns the full maps
-There is NO collective on per-voxel data: the only exchanged bytes are the cloud and 2-D maps.
+Per scan (process_pointcloud) -- ONE collective:
+    all_gather      every rank's share of the cloud (12 B/point; 1.5 MB per 131k points)
+    local           each rank traces the rays that can reach its slab (window-y culling + early
+                    exit in k_trace) and commits only voxels of its slab; integer atomics commute,
+                    so the result is bit-identical to one GPU.  Every rank sees every point, so
+                    each counts the in-grid returns of ALL slabs itself: the reference's "no
+                    overlap" test (gvom.py:147-150) needs no collective.
+Per combine (combine_maps) -- ONE collective:
+    local           temporal fusion + column reductions of the slab -> its rows of the height and
+                    inferred-height maps, plus the positive-obstacle density of its cells (the only
+                    2-D quantity that needs voxel data)
+    all_gather      IN PLACE on the library's row-interleaved buffer [sy][height | inferred |
+                    density] (24 B x xy^2 = 1.5 MB at xy=256): the slope stencil needs +-1 row,
+                    __guess_height +-15 rows
+    local           every rank computes ALL rows of slope / roughness / guess / positive /
+                    negative / visibility (20 us of redundant 2-D work instead of a second
+                    collective) straight into pinned host memory; every rank returns the maps
+There is NO collective on per-voxel data: the only exchanged bytes are the cloud and 2-D rows.
+The library runs on the caller's (torch) stream and its own buffer is the collective buffer,
+so a combine has no host synchronisation before the final one.
 
 The collectives are torch.distributed calls (backend "nccl" == RCCL over xGMI on ROCm; "gloo"
 in the CPU tests); the compute is behind a small backend interface: `HipShardBackend` (the
@@ -30,79 +37,62 @@ import numpy as np
 import gvom as _gvom
 
 
+class _DevBuf(object):
+    """Exposes a raw device pointer to torch (zero-copy) through __cuda_array_interface__."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"data": (int(ptr), False), "shape": tuple(shape),
+                                         "typestr": typestr, "version": 2}
+
+
 class HipShardBackend(object):
-    """Per-rank compute on one MI355X through the C ABI (include/gvom_hip.h, sharded entry
-    points).  Tensors handed to the collectives are torch CUDA tensors; the library copies
-    rows device-to-device into/out of them (gvom_rows_export / gvom_rows_import)."""
+    """Per-rank compute on one MI355X through the C ABI (include/gvom_hip.h, split entry points).
+    The library is attached to torch's current stream and set non-blocking; its own device
+    buffer is wrapped as a torch tensor and used directly by the collective."""
 
     def __init__(self, params, rank, world, device):
         import torch
         self.torch = torch
         self.rank, self.world = rank, world
         self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
         self.g = _gvom.Gvom(*params, device=device, _shard=(rank, world))
         self.lib, self.h = self.g._lib, self.g._h
         self.xy = params[2]
-        self.rows = self.xy // world
-        self.lo, self.hi = rank * self.rows, (rank + 1) * self.rows
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self.g._check(self.lib.gvom_attach_stream(self.h, ctypes.c_void_p(stream)))
+        self.g._check(self.lib.gvom_set_blocking(self.h, 0))
+        self.height_full = self._wrap(_gvom.BUF_HEIGHT_MAPS, np.float64)      # [xy, 3*xy]
+        self.fused_cells = self._wrap(_gvom.BUF_FUSED_CELLS, np.int64)        # [1]
 
-    def empty_rows(self, which, full=False):
-        dt = self.torch.float64 if which in (_gvom.MAP_HEIGHT, _gvom.MAP_INFERRED, _gvom.OUT_ROUGHNESS) \
-            else self.torch.int32
-        return self.torch.empty(((self.xy if full else self.rows), self.xy), dtype=dt, device=self.device)
+    def _wrap(self, which, dtype):
+        p, nbytes, rs = ctypes.c_void_p(), ctypes.c_int64(), ctypes.c_int64()
+        self.g._check(self.lib.gvom_device_buffer(self.h, which, ctypes.byref(p), ctypes.byref(nbytes),
+                                                  ctypes.byref(rs)))
+        item = np.dtype(dtype).itemsize
+        shape = (nbytes.value // rs.value, rs.value // item) if nbytes.value > rs.value else (nbytes.value // item,)
+        return self.torch.as_tensor(_DevBuf(p.value, shape, np.dtype(dtype).str), device=self.device)
 
     def cloud_tensor(self, pc):
-        t = self.torch.from_numpy(np.ascontiguousarray(pc[:, :3]))
-        return t.to(self.device)
+        return self.torch.from_numpy(np.ascontiguousarray(pc[:, :3])).to(self.device)
 
-    def scan_begin(self, cloud, ego, tf):
-        """cloud: torch CUDA tensor (n,3) f32/f64, contiguous.  Returns (rc, local_cells)."""
-        code = 0 if cloud.dtype == self.torch.float32 else 1
-        egoc = (ctypes.c_double * 3)(*[float(e) for e in ego])
-        tfp = None
-        if tf is not None:
-            tf = np.ascontiguousarray(np.asarray(tf, np.float64))
-            tfp = tf.ctypes.data_as(ctypes.c_void_p)
-        cells = ctypes.c_int64(0)
-        n = int(cloud.shape[0])
-        rc = self.g._check(self.lib.gvom_scan_begin(
-            self.h, ctypes.c_void_p(cloud.data_ptr()) if n else None, 1, n, 3 * cloud.element_size(),
-            code, egoc, tfp, ctypes.byref(cells)))
+    def process(self, cloud, ego, tf):
+        """The whole cloud (torch CUDA tensor (n,3), contiguous, on the attached stream) against
+        this rank's slab.  Returns the reference's outcome code (same on every rank)."""
         self.g.ego_position = ego
-        return rc, int(cells.value)
-
-    def scan_commit(self, accept):
-        self.g._check(self.lib.gvom_scan_commit(self.h, 1 if accept else 0))
+        return self.g.process_pointcloud_device(cloud.data_ptr(), int(cloud.shape[0]),
+                                                np.float32 if cloud.dtype == self.torch.float32 else np.float64,
+                                                ego, tf)
 
     def combine_fuse(self):
-        cells = ctypes.c_int64(0)
-        rc = self.g._check(self.lib.gvom_combine_fuse(self.h, ctypes.byref(cells)))
-        return rc, int(cells.value)
+        return self.g._check(self.lib.gvom_combine_fuse(self.h, None))
 
     def set_cell_count(self, n):
         self.g._check(self.lib.gvom_set_combined_cell_count(self.h, int(n)))
 
-    def rows_export(self, which):
-        t = self.empty_rows(which)
-        self.g._check(self.lib.gvom_rows_export(self.h, which, self.lo, self.hi, ctypes.c_void_p(t.data_ptr())))
-        return t
-
-    def rows_import(self, which, full):
-        self.g._check(self.lib.gvom_rows_import(self.h, which, 0, self.xy, ctypes.c_void_p(full.data_ptr())))
-
     def combine_map2d(self):
-        self.g._check(self.lib.gvom_combine_map2d(self.h))
-
-    def finalize(self):
-        xy = self.xy
-        origin = np.zeros(3); pos = np.empty((xy, xy), np.int32); neg = np.empty((xy, xy), np.int32)
-        rough = np.empty((xy, xy), np.float64); vis = np.empty((xy, xy), np.int32)
-        p = _gvom._ptr
-        self.g._check(self.lib.gvom_finalize_outputs(self.h, p(origin), p(pos), p(neg), p(rough), p(vis)))
-        return origin, pos, neg, rough, vis
-
-    def sync(self):
-        self.torch.cuda.synchronize(self.device)
+        rc, out = self.g._combine_into(self.lib.gvom_combine_map2d_into)
+        return out
 
 
 class ShardedGvom(object):
@@ -112,8 +102,9 @@ class ShardedGvom(object):
     result equals gvom.Gvom fed with the concatenated cloud, bit for bit."""
 
     def __init__(self, *params, **kw):
+        import torch
         import torch.distributed as dist
-        self.dist = dist
+        self.torch, self.dist = torch, dist
         self.group = kw.pop("group", None)
         self.rank = dist.get_rank(self.group)
         self.world = dist.get_world_size(self.group)
@@ -127,69 +118,69 @@ class ShardedGvom(object):
         if backend is None:
             backend = HipShardBackend(params, self.rank, self.world, 0 if device is None else device)
         self.b = backend
+        self.rows = self.xy_size // self.world
         self.ego_position = [0, 0, 0]
-        self.combined_cell_count_cpu = None
+        self._cells_dirty = False
+        self._cell_count = None
+        self._staged = self.dist.get_backend(self.group) == "gloo"
 
-    # -- helpers -------------------------------------------------------------------------
-    def _all_gather_rows(self, local):
-        torch = __import__("torch")
+    # -- collectives ------------------------------------------------------------------------
+    def _all_gather_cloud(self, local):
+        torch = self.torch
         dev = local.device
-        if local.is_cuda and self.dist.get_backend(self.group) == "gloo":
+        if local.is_cuda and self._staged:
             local = local.cpu()          # gloo has no GPU all_gather: stage through the host (tests only)
         out = torch.empty((self.world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype,
                           device=local.device)
         self.dist.all_gather_into_tensor(out, local.contiguous(), group=self.group)
         return out.to(dev)
 
-    def _all_reduce_sum(self, value, like):
-        torch = __import__("torch")
-        dev = like.device if (like is not None and self.dist.get_backend(self.group) != "gloo") else "cpu"
-        t = torch.tensor([int(value)], dtype=torch.int64, device=dev)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
-        return int(t.item())
+    def _all_gather_rows_inplace(self, full):
+        """full: [xy, width] tensor whose rows [rank*rows, (rank+1)*rows) are valid on this rank."""
+        lo = self.rank * self.rows
+        if full.is_cuda and self._staged:
+            mine = full[lo:lo + self.rows].cpu()
+            out = self.torch.empty((full.shape[0],) + tuple(full.shape[1:]), dtype=full.dtype)
+            self.dist.all_gather_into_tensor(out, mine.contiguous(), group=self.group)
+            full.copy_(out.to(full.device))
+        else:
+            self.dist.all_gather_into_tensor(full, full[lo:lo + self.rows], group=self.group)
+
+    @property
+    def combined_cell_count_cpu(self):
+        """Global occupied-voxel count of the fused map (gvom.py:217).  Collective: every rank
+        must read it (it is not needed on the hot path, so it costs nothing unless asked for)."""
+        if self._cells_dirty:
+            t = self.b.fused_cells.clone()
+            if t.is_cuda and self._staged:
+                t = t.cpu()
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+            self._cell_count = int(t.item())
+            self.b.set_cell_count(self._cell_count)
+            self._cells_dirty = False
+        return self._cell_count
 
     # -- API -----------------------------------------------------------------------------
     def process_pointcloud(self, pointcloud, ego_position, transform=None):
         """pointcloud: this rank's share, numpy (n,>=3) or a torch tensor already on the
         backend's device ((n,3) contiguous; every rank must pass the same n and dtype)."""
-        torch = __import__("torch")
         self.ego_position = ego_position
-        local = pointcloud if isinstance(pointcloud, torch.Tensor) else self.b.cloud_tensor(pointcloud)
-        full = self._all_gather_rows(local)                       # exchange step 1: the cloud
-        if hasattr(self.b, "sync"):
-            self.b.sync()
-        rc, cells = self.b.scan_begin(full, ego_position, transform)
-        if rc == _gvom.GVOM_EMPTY_CLOUD:
-            if self.rank == 0:
+        local = pointcloud if isinstance(pointcloud, self.torch.Tensor) else self.b.cloud_tensor(pointcloud)
+        full = self._all_gather_cloud(local)                      # the scan's only collective
+        rc = self.b.process(full, ego_position, transform)
+        if self.rank == 0:
+            if rc == _gvom.GVOM_EMPTY_CLOUD:
                 print("[WARNING] Processing an empty pointcloud, nothing will happen!")
-            return None
-        total = self._all_reduce_sum(cells, full)                 # global "no overlap" test
-        self.b.scan_commit(total > 0)
-        if total == 0 and self.rank == 0:
-            print("[WARNING] The pointcloud points don't overlap with any voxels, nothing will happen!")
+            elif rc == _gvom.GVOM_NO_OVERLAP:
+                print("[WARNING] The pointcloud points don't overlap with any voxels, nothing will happen!")
         return None
 
     def combine_maps(self):
-        rc, cells = self.b.combine_fuse()
+        rc = self.b.combine_fuse()
         if rc == _gvom.GVOM_EMPTY_BUFFER:
             if self.rank == 0:
                 print("[WARNING] The map buffer is empty, nothing will happen!")
             return None
-        h_loc = self.b.rows_export(_gvom.MAP_HEIGHT)
-        i_loc = self.b.rows_export(_gvom.MAP_INFERRED)
-        total = self._all_reduce_sum(cells, h_loc)
-        self.combined_cell_count_cpu = total
-        self.b.set_cell_count(total)
-        h_full = self._all_gather_rows(h_loc)                     # exchange step 2: height rows
-        i_full = self._all_gather_rows(i_loc)
-        if hasattr(self.b, "sync"):
-            self.b.sync()
-        self.b.rows_import(_gvom.MAP_HEIGHT, h_full)
-        self.b.rows_import(_gvom.MAP_INFERRED, i_full)
-        self.b.combine_map2d()
-        for which in (_gvom.OUT_POSITIVE, _gvom.OUT_NEGATIVE, _gvom.OUT_ROUGHNESS, _gvom.OUT_VISIBILITY):
-            full = self._all_gather_rows(self.b.rows_export(which))   # exchange step 3: outputs
-            if hasattr(self.b, "sync"):
-                self.b.sync()
-            self.b.rows_import(which, full)
-        return self.b.finalize()
+        self._cells_dirty = True
+        self._all_gather_rows_inplace(self.b.height_full)         # the combine's only collective
+        return self.b.combine_map2d()

@@ -127,29 +127,37 @@ int gvom_combine_maps_into(gvom_t *h, double origin_world[3], void *pinned_out);
  *                   reference's "no overlap" test (gvom.py:147-150) is on the GLOBAL count.
  * gvom_combine_fuse fusion + column reductions of this rank's slab (gvom.py:183-304); the
  *                   rank's rows of the height / inferred-height maps become valid.
- * gvom_rows_export / gvom_rows_import
- *                   device-to-device copy of storage rows [row_lo,row_hi) of a 2-D map (the
- *                   GVOM_MAP_* ids, or GVOM_OUT_* for the four returned maps) to/from a
- *                   caller-owned device buffer holding exactly those rows -- the collectives
- *                   (all_gather over RCCL) run on the caller's buffers.
- * gvom_combine_map2d  slope/roughness/guess/positive/negative/visibility for this rank's rows
- *                   (needs all rows of height + inferred height), outputs in storage order.
- * gvom_finalize_outputs  storage order -> the reference's [x][y] order, to host (rank 0). */
+ * gvom_attach_stream / gvom_set_blocking / gvom_sync / gvom_device_buffer
+ *                   the sharded layer runs the library on ITS stream (e.g. torch's current stream)
+ *                   and hands the library's own device buffer to the collective: a rank's rows are
+ *                   one contiguous block of GVOM_BUF_HEIGHT_MAPS ([sy][height row | inferred-height
+ *                   row | positive-obstacle density row], f64), so all_gather over RCCL works in
+ *                   place with no pack/unpack copies; with blocking off, gvom_combine_fuse does not
+ *                   synchronise the host and the cell counts stay on the device
+ *                   (GVOM_BUF_SCAN_CELLS / GVOM_BUF_FUSED_CELLS, one int64 each).
+ * gvom_combine_map2d_into  after that all_gather: ALL rows of slope/roughness/guess/positive/
+ *                   negative/visibility on every rank (20 us of redundant 2-D work instead of a
+ *                   second collective), written straight into a pinned output buffer.
+ * In sharded handles gvom_process_pointcloud[_device] needs no collective for the reference's
+ * "no overlap" test: every rank is handed the whole cloud, so each counts the in-grid returns of
+ * ALL slabs and takes the same commit decision. */
 int gvom_scan_begin(gvom_t *h, const void *xyz, int on_device, int64_t n, int64_t row_stride_bytes,
                     int dtype, const double ego[3], const double *transform_4x4,
                     int64_t *local_cells);
 int gvom_scan_commit(gvom_t *h, int accept);
 int gvom_combine_fuse(gvom_t *h, int64_t *local_cells);
 int gvom_set_combined_cell_count(gvom_t *h, int64_t global_cells);
-#define GVOM_OUT_POSITIVE   100
-#define GVOM_OUT_NEGATIVE   101
-#define GVOM_OUT_ROUGHNESS  102
-#define GVOM_OUT_VISIBILITY 103
-int gvom_rows_export(gvom_t *h, int which, int row_lo, int row_hi, void *dev_buf);
-int gvom_rows_import(gvom_t *h, int which, int row_lo, int row_hi, const void *dev_buf);
-int gvom_combine_map2d(gvom_t *h);
-int gvom_finalize_outputs(gvom_t *h, double origin_world[3], int32_t *positive, int32_t *negative,
-                          double *roughness, int32_t *visibility);
+#define GVOM_BUF_HEIGHT_MAPS  0
+#define GVOM_BUF_SCAN_CELLS   2
+#define GVOM_BUF_FUSED_CELLS  3
+#define GVOM_OWN_STREAM ((void *)(intptr_t)-1)
+/* hip_stream: a hipStream_t; NULL is HIP's legacy default stream (PyTorch's default stream);
+ * GVOM_OWN_STREAM returns to the library's private stream. */
+int gvom_attach_stream(gvom_t *h, void *hip_stream);
+int gvom_set_blocking(gvom_t *h, int on);
+int gvom_sync(gvom_t *h);
+int gvom_device_buffer(gvom_t *h, int which, void **ptr, int64_t *bytes, int64_t *row_stride_bytes);
+int gvom_combine_map2d_into(gvom_t *h, double origin_world[3], void *pinned_out);
 
 /* --- accessors of the reference object ------------------------------------------------- */
 /* 1 if ring slot `slot` holds a scan (origin_buffer[slot] is not None, gvom.py:201). */
@@ -194,6 +202,9 @@ int gvom_set_profiling(gvom_t *h, int on);
 /* Host-side phase times (microseconds per call, averaged; enabled by GVOM_HOST_TIMING=1):
  * [0] scan launches [1] scan wait [2] combine launches [3] combine wait [4] output copies. */
 int gvom_host_timing(gvom_t *h, double us[8]);
+/* Diagnostic (GVOM_TRACE_VARIANT=2): cumulative {merged-run heads, distinct-64B-line heads, atomic
+ * wave instructions} issued by k_trace since creation. */
+int gvom_debug_trace_counters(gvom_t *h, uint32_t out[3]);
 /* Raw HIP stream the library launches on (hipStream_t as void*), for external event timing. */
 void *gvom_stream(gvom_t *h);
 

@@ -31,12 +31,13 @@ def main():
             shares = [s + 900.0 for s in shares]                 # globally rejected scan
         sh.process_pointcloud(shares[rank], ego)
         got = sh.combine_maps()
+        cnt = sh.combined_cell_count_cpu          # collective-backed: every rank must ask
         if rank == 0:
             ref.process_pointcloud(np.concatenate(shares, 0), ego)
             want = ref.combine_maps()
             for a, b in zip(got, want):
                 assert a.dtype == b.dtype and np.array_equal(a, b), "step %d" % k
-            assert sh.combined_cell_count_cpu == ref.combined_cell_count_cpu
+            assert cnt == ref.combined_cell_count_cpu, (k, cnt, ref.combined_cell_count_cpu)
     dist.barrier()
     dist.destroy_process_group()
     print("rank %d ok" % rank)

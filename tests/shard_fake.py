@@ -1,11 +1,11 @@
 """Test double for the per-rank compute of g-vom_amd/gvom_sharded.py: the CPU oracle stands in
-for the HIP library so that the SHARDING LOGIC (cloud all-gather, global cell count, height
-row all-gather in storage order, output reassembly) runs under gloo on CPU.
+for the HIP library so that the SHARDING LOGIC (cloud all-gather, asynchronous global cell
+count + lazy commit, in-place all-gather of the row-interleaved height buffer and of the packed
+output rows, storage<->window reordering) runs under gloo on CPU.
 
-Each rank computes with the full oracle but only ever EXPORTS the rows of its own slab
-(everything else is poisoned), and derives its 2-D outputs from the IMPORTED (gathered)
-height maps -- so a wrong row order / wrong window<->storage conversion / missing gather
-changes the final maps."""
+Each rank computes with the full oracle but only ever PUBLISHES the rows of its own slab
+(everything else is poisoned), and derives its 2-D outputs from the GATHERED height rows -- so a
+wrong row order / wrong window<->storage conversion / missing gather changes the final maps."""
 import contextlib
 import io
 
@@ -26,7 +26,9 @@ class OracleShardBackend(object):
         self.xy, self.zs = params[2], params[3]
         self.rows = self.xy // world
         self.lo, self.hi = rank * self.rows, (rank + 1) * self.rows
-        self.maps = {}
+        xy = self.xy
+        self.height_full = torch.full((xy, 3 * xy), POISON, dtype=torch.float64)
+        self.fused_cells = torch.zeros(1, dtype=torch.int64)
 
     # -- layout helpers ---------------------------------------------------------------------
     def _om(self, origin):
@@ -48,76 +50,57 @@ class OracleShardBackend(object):
         return int(occ[:, own, :].sum())
 
     # -- interface used by ShardedGvom ----------------------------------------------------------
-    def empty_rows(self, which, full=False):
-        dt = torch.float64 if which in (_gvom.MAP_HEIGHT, _gvom.MAP_INFERRED, _gvom.OUT_ROUGHNESS) else torch.int32
-        return torch.empty(((self.xy if full else self.rows), self.xy), dtype=dt)
-
     def cloud_tensor(self, pc):
         return torch.from_numpy(np.ascontiguousarray(pc[:, :3]))
 
-    def scan_begin(self, cloud, ego, tf):
+    def process(self, cloud, ego, tf):
         pc = cloud.numpy()
         if pc.shape[0] == 0:
             self.g.ego_position = ego
-            return _gvom.GVOM_EMPTY_CLOUD, 0
+            return _gvom.GVOM_EMPTY_CLOUD
         slot = self.g.buffer_index
         was = self.g.origin_buffer[slot]
         with contextlib.redirect_stdout(io.StringIO()):
             self.g.process_pointcloud(pc, ego, tf)
-        if self.g.origin_buffer[slot] is was:          # rejected by the oracle's own global test
-            return _gvom.GVOM_OK, 0
-        return _gvom.GVOM_OK, self._local_scan_cells(slot)
-
-    def _local_scan_cells(self, slot):
-        if self.g.origin_buffer[slot] is None:
-            return 0
-        return self._own_cells(self.g.index_buffer[slot], self.g.origin_buffer[slot])
-
-    def scan_commit(self, accept):
-        pass                                       # the oracle applied the same global rule itself
+        return _gvom.GVOM_NO_OVERLAP if self.g.origin_buffer[slot] is was else _gvom.GVOM_OK
 
     def combine_fuse(self):
         with contextlib.redirect_stdout(io.StringIO()):
             out = self.g.combine_maps()
         if out is None:
-            return _gvom.GVOM_EMPTY_BUFFER, 0
-        self.origin = self.g.combined_origin
-        for which, m in ((_gvom.MAP_HEIGHT, self.g.height_map), (_gvom.MAP_INFERRED, self.g.inferred_height_map)):
-            s = self._to_storage(m, self.origin)
-            s[:self.lo] = POISON; s[self.hi:] = POISON          # only own rows are "computed"
-            self.maps[which] = s
-        return _gvom.GVOM_OK, self._own_cells(self.g.combined_index_map, self.origin)
+            return _gvom.GVOM_EMPTY_BUFFER
+        g, xy = self.g, self.xy
+        self.origin = g.combined_origin
+        # positive-obstacle DENSITY (no slope override): the oracle kernel with zero slopes
+        zero = np.zeros((xy, xy))
+        dens = oracle.make_positive_obstacle_map(g.combined_index_map, g.height_map, xy, self.zs, g.z_resolution,
+                                                 g.positive_obstacle_threshold, g.combined_hit_count,
+                                                 g.combined_total_count, g.robot_height, self.origin,
+                                                 zero, zero, 1e300)
+        hf = self.height_full.numpy()
+        hf[:] = POISON                                           # other ranks' rows: garbage
+        hf[self.lo:self.hi, :xy] = self._to_storage(g.height_map, self.origin)[self.lo:self.hi]
+        hf[self.lo:self.hi, xy:2 * xy] = self._to_storage(g.inferred_height_map, self.origin)[self.lo:self.hi]
+        hf[self.lo:self.hi, 2 * xy:] = self._to_storage(dens.astype(np.float64), self.origin)[self.lo:self.hi]
+        self.fused_cells[0] = self._own_cells(g.combined_index_map, self.origin)
+        return _gvom.GVOM_OK
 
     def set_cell_count(self, n):
         self.cell_count = n
 
-    def rows_export(self, which):
-        return torch.from_numpy(np.ascontiguousarray(self.maps[which][self.lo:self.hi]))
-
-    def rows_import(self, which, full):
-        self.maps[which] = full.numpy().copy()
-
     def combine_map2d(self):
-        g = self.g
-        h = self._to_window(self.maps[_gvom.MAP_HEIGHT], self.origin)
-        inf = self._to_window(self.maps[_gvom.MAP_INFERRED], self.origin)
+        """ALL rows of the outputs from the gathered [height | inferred | density] rows."""
+        g, xy = self.g, self.xy
+        hf = self.height_full.numpy()
+        h = self._to_window(hf[:, :xy].copy(), self.origin)
+        inf = self._to_window(hf[:, xy:2 * xy].copy(), self.origin)
+        dens = self._to_window(hf[:, 2 * xy:].copy(), self.origin)
         sx, sy, r = oracle.calculate_slope(h, g.xy_resolution)
         dh = oracle.guess_height(h, inf)
-        pos = oracle.make_positive_obstacle_map(g.combined_index_map, h, self.xy, self.zs, g.z_resolution,
-                                                g.positive_obstacle_threshold, g.combined_hit_count,
-                                                g.combined_total_count, g.robot_height, self.origin,
-                                                sx, sy, g.slope_obstacle_threshold)
+        steep = np.sqrt(sx * sx + sy * sy) >= g.slope_obstacle_threshold
+        pos = np.where(steep, 100, dens.astype(np.int32)).astype(np.int32)
         neg = np.where(dh > g.negative_obstacle_threshold, 100, 0).astype(np.int32)
         vis = (h > -1000).astype(np.int32)
-        for which, m in ((_gvom.OUT_POSITIVE, pos), (_gvom.OUT_NEGATIVE, neg), (_gvom.OUT_ROUGHNESS, r),
-                         (_gvom.OUT_VISIBILITY, vis)):
-            s = self._to_storage(m, self.origin)
-            s[:self.lo] = -7777; s[self.hi:] = -7777
-            self.maps[which] = s
-
-    def finalize(self):
         o = self.origin.copy()
-        o[0] *= self.g.xy_resolution; o[1] *= self.g.xy_resolution; o[2] *= self.g.z_resolution
-        return (o,) + tuple(self._to_window(self.maps[w], self.origin)
-                            for w in (_gvom.OUT_POSITIVE, _gvom.OUT_NEGATIVE, _gvom.OUT_ROUGHNESS,
-                                      _gvom.OUT_VISIBILITY))
+        o[0] *= g.xy_resolution; o[1] *= g.xy_resolution; o[2] *= g.z_resolution
+        return (o, pos, neg, r, vis)
