@@ -395,6 +395,7 @@ int choose_nz(int zs, int *zc, int *cpw)
     if (const char *v = getenv("GVOM_FUSE_WAVES")) want_waves = atoi(v) > 0 ? atoi(v) : 4;
     *cpw = (nchunks + want_waves - 1) / want_waves;
     if (*cpw < 1) *cpw = 1;
+    if (*cpw > 4) *cpw = 4;                               // a wave's tiles (16 per chunk) fit one 64-bit mask
     return (nchunks + *cpw - 1) / *cpw;
 }
 
@@ -443,6 +444,7 @@ int fuse_impl(gvom_handle *h, bool publish_now)
     (void)bound;
     P.sy_lo = h->sy_lo; P.sy_hi = h->sy_hi;
     P.nz = choose_nz(p.z_size, &P.zc, &P.cpw);
+    if (const char *v = getenv("GVOM_FUSE_DEBUG")) P.debug = atoi(v);
     P.nseg = h->nseg;
     P.hs = h->hs;
     F.epoch = ++h->epoch;

@@ -67,6 +67,7 @@ struct FuseParams {
     int nz;                 // z-chunks per workgroup (block = 64 * nz threads)
     int zc;                 // window-z cells per chunk (<= 64)
     int cpw;                // chunks per wave (a wave walks them in ascending z)
+    int debug;              // GVOM_FUSE_DEBUG bits (timing experiments only): 1 no code stores, 2 no emit, 4 all tiles dead
     double origin[3];       // fused origin (voxels)
     double ego[3];          // latest ego (gvom.py:294-295)
     double xy_res, z_res;

@@ -393,6 +393,7 @@ __global__ __launch_bounds__(1024) void k_fuse(const FuseParams P, const FuseDes
                                                double *height, double *inferred)
 {
     __shared__ uint32_t s_cnt[16];
+    __shared__ unsigned long long s_live[16][GVOM_MAX_SLOTS + 1];   // [wave][source]: live-tile masks
     __shared__ int s_zocc[16][WAVE];
     __shared__ uint32_t s_hocc[16][WAVE];
     __shared__ int s_zfree[16][WAVE];
@@ -424,10 +425,41 @@ __global__ __launch_bounds__(1024) void k_fuse(const FuseParams P, const FuseDes
     // static compact-row range starting at rbase
     const uint32_t rbase = ((blockIdx.y * gridDim.x + blockIdx.x) * (uint32_t)P.nz + w) *
                            (uint32_t)(WAVE * P.zc * P.cpw);
+    if (ZC16) {
+        // Phase 0: tile liveness of EVERY source for all (<= 64) tiles this wave will visit: lane
+        // (16*cc + k) fetches the tag of tile k of chunk cc -- one vector load per source, four
+        // sources in flight -- and a ballot turns each into a wave-uniform 64-bit mask kept in LDS.
+        const int cc_l = lane >> 4, k_l = lane & 15;
+        const int zl = (w * P.cpw + cc_l) * P.zc + k_l;
+        const bool valid_l = cc_l < P.cpw && k_l < P.zc && zl < P.zs;
+        const uint32_t tl = tbase + (uint32_t)wrap_add(valid_l ? zl : 0, P.om[2], P.zs) * P.nseg;
+        for (int s0 = 0; s0 < nsrc; s0 += 4) {
+            uint32_t tv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ss = min(s0 + j, nsrc - 1);
+                tv[j] = ((gptr_u32)descs[ss].tags)[tl];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ss = min(s0 + j, nsrc - 1);
+                const unsigned long long m = (P.debug & 4) ? 0ull : __ballot(valid_l && tv[j] == descs[ss].epoch);
+                if (lane == 0 && s0 + j < nsrc) s_live[w][s0 + j] = m;
+            }
+        }
+    }
     for (int cc = 0; cc < P.cpw; ++cc) {
     const int z0 = (w * P.cpw + cc) * P.zc;
     if (z0 >= P.zs) break;
     const int z1 = min(z0 + P.zc, P.zs);
+    if (ZC16) {
+        // a chunk whose 16 tiles are dead in EVERY source is "never observed" throughout: nothing
+        // to read, fold or write (wave-uniform early-out; most chunks above/below the lidar's
+        // vertical field of view take it)
+        uint32_t anylive = 0;
+        for (int s = 0; s < nsrc; ++s) anylive |= (uint32_t)(s_live[w][s] >> (16 * cc)) & 0xffffu;
+        if (__builtin_amdgcn_readfirstlane(anylive) == 0) continue;
+    }
 
     // one occupied voxel: gather over the sources, store its compact row
     auto emit = [&](int z, uint32_t L, uint32_t row) {
@@ -454,49 +486,19 @@ __global__ __launch_bounds__(1024) void k_fuse(const FuseParams P, const FuseDes
         uint32_t occbits = 0;
 #pragma unroll
         for (int k = 0; k < 16; ++k) c[k] = -1;
-        for (int s = 0; s < nsrc; ++s) {
-            const int dz = descs[s].d[2];
-            const bool okxy = (okmask >> s) & 1ull;
-            const gptr_i32 sp = (gptr_i32)descs[s].state;
-            const gptr_u32 tg = (gptr_u32)descs[s].tags;
-            const uint32_t ep = descs[s].epoch;
-            int st[16];
-            // Tile liveness first: lane k fetches the tag of the wave's k-th tile (ONE vector load
-            // for all 16), a ballot turns them into a wave-uniform bit mask.  Then 16 UNCONDITIONAL
-            // independent 256-byte row loads are issued back to back so all of them are in flight
-            // together; a dead tile (tag != epoch) redirects its load to the first row of the
-            // array -- one always-hot cache line set -- so it costs no HBM traffic.  No branches:
-            // a branch-guarded load makes hipcc emit `s_waitcnt vmcnt(0)` in front of every load
-            // (no memory-level parallelism).  The window test is applied to the value afterwards.
-            uint32_t live;
-            {
-                const int zl = z0 + (lane & 15);
-                const int szl = wrap_add(zl < P.zs ? zl : 0, P.om[2], P.zs);
-                const uint32_t tagv = tg[tbase + (uint32_t)szl * P.nseg];
-                live = (uint32_t)__ballot(lane < 16 && zl < z1 && tagv == ep);
-            }
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int z = z0 + k;
-                const int sz = wrap_add(z < P.zs ? z : 0, P.om[2], P.zs);
-                const uint32_t addr = ((live >> k) & 1u) ? colbase + (uint32_t)sz * P.xy : (uint32_t)lane;
-                st[k] = sp[addr];
-            }
-#pragma unroll
-            for (int k = 0; k < 16; ++k) st[k] = ((live >> k) & 1u) ? st[k] : -1;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int z = z0 + k, zz = z + dz;
-                const bool ok = okxy && z < z1 && zz >= 0 && zz < P.zs;
-                st[k] = ok ? st[k] : -1;                  // -1 == "never observed": no effect
-            }
-            if (s < P.nslots) {
+        // sources two at a time: 32 UNCONDITIONAL independent 256-byte row loads in flight (a dead
+        // tile redirects its load to the always-hot first row of the array, costing no HBM
+        // traffic; a branch-guarded load would make hipcc emit `s_waitcnt vmcnt(0)` in front of
+        // every load).  The window test is applied to the loaded value afterwards; folding is
+        // in source order (ring slots, then the previous fused map).
+        auto fold = [&](const int (&st)[16], bool is_prev) {
+            if (!is_prev) {
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
                     if (st[k] >= 0) occbits |= 1u << k;                                   // gvom.py:963
                     else if (st[k] < -1 && !((occbits >> k) & 1u)) c[k] += st[k] + 1;     // gvom.py:967
                 }
-            } else {                                     // previous fused map
+            } else {
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
                     if (!((occbits >> k) & 1u)) {
@@ -505,6 +507,34 @@ __global__ __launch_bounds__(1024) void k_fuse(const FuseParams P, const FuseDes
                     }
                 }
             }
+        };
+        for (int s0 = 0; s0 < nsrc; s0 += 2) {
+            const int sA = s0, sB = min(s0 + 1, nsrc - 1);
+            const bool hasB = s0 + 1 < nsrc;
+            const gptr_i32 spA = (gptr_i32)descs[sA].state, spB = (gptr_i32)descs[sB].state;
+            const uint32_t liveA = (uint32_t)(s_live[w][sA] >> (16 * cc)) & 0xffffu;
+            const uint32_t liveB = hasB ? ((uint32_t)(s_live[w][sB] >> (16 * cc)) & 0xffffu) : 0u;
+            int stA[16], stB[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int z = z0 + k;
+                const int sz = wrap_add(z < P.zs ? z : 0, P.om[2], P.zs);
+                const uint32_t real = colbase + (uint32_t)sz * P.xy;
+                stA[k] = spA[((liveA >> k) & 1u) ? real : (uint32_t)lane];
+                stB[k] = spB[((liveB >> k) & 1u) ? real : (uint32_t)lane];
+            }
+            const int dzA = descs[sA].d[2], dzB = descs[sB].d[2];
+            const bool okA = (okmask >> sA) & 1ull, okB = hasB && ((okmask >> sB) & 1ull);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int z = z0 + k;
+                const bool inA = okA && ((liveA >> k) & 1u) && z < z1 && z + dzA >= 0 && z + dzA < P.zs;
+                const bool inB = okB && ((liveB >> k) & 1u) && z < z1 && z + dzB >= 0 && z + dzB < P.zs;
+                stA[k] = inA ? stA[k] : -1;               // -1 == "never observed": no effect
+                stB[k] = inB ? stB[k] : -1;
+            }
+            fold(stA, sA >= P.nslots);
+            if (hasB) fold(stB, sB >= P.nslots);
         }
         if (!col_ok) occbits = 0;
         // free / unknown codes, first free z, first occupied z.  A tile in which every voxel is
@@ -514,7 +544,7 @@ __global__ __launch_bounds__(1024) void k_fuse(const FuseParams P, const FuseDes
             const int z = z0 + k;
             const bool occ = (occbits >> k) & 1u;
             const bool inside = col_ok && z < z1;
-            if (__any(inside && (occ || c[k] != -1))) {
+            if (!(P.debug & 1) && __any(inside && (occ || c[k] != -1))) {
                 const int sz = wrap_add(z < P.zs ? z : 0, P.om[2], P.zs);
                 if (lane == 0) ftags[tbase + (uint32_t)sz * P.nseg] = P.epoch;
                 if (inside) {
@@ -527,16 +557,55 @@ __global__ __launch_bounds__(1024) void k_fuse(const FuseParams P, const FuseDes
                 }
             }
         }
-        // occupied voxels (sparse): rows by ballot + prefix popcount inside the wave's range
-        if (__any(occbits != 0)) {
-            for (int k = 0; k < 16; ++k) {
-                const bool occ = (occbits >> k) & 1u;
+        // occupied voxels (sparse, skipped by most waves): hit/total sums and min-height min over
+        // every source where the voxel is occupied (gvom.py:841,910-912).  Per source, the state
+        // rows of all occupied z levels are fetched together, then the three compact arrays are
+        // gathered in batches of 16 independent loads -- not one dependent chain per voxel.
+        for (int kg = 0; kg < 16; kg += 4) {             // groups of 4 z levels keep the registers low
+            const uint32_t gbits = (P.debug & 2) ? 0u : (occbits >> kg) & 0xfu;
+            if (!__any(gbits != 0)) continue;               // wave-uniform: most groups are empty
+            uint32_t hh[4], tt[4], mm[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { hh[j] = 0; tt[j] = 0; mm[j] = 0x3f800000u; }    // gvom.py:222-228
+            for (int s = 0; s < nsrc; ++s) {
+                const gptr_i32 sp = (gptr_i32)descs[s].state;
+                const gptr_u32 hp = (gptr_u32)descs[s].hit, tp = (gptr_u32)descs[s].total, mp = (gptr_u32)descs[s].minh;
+                const uint32_t live = ((uint32_t)(s_live[w][s] >> (16 * cc)) >> kg) & 0xfu;
+                const int dz = descs[s].d[2];
+                const bool okS = (okmask >> s) & 1ull;
+                int st[4];
+                bool use[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int z = z0 + kg + j;
+                    use[j] = ((gbits >> j) & 1u) && okS && ((live >> j) & 1u) && z + dz >= 0 && z + dz < P.zs;
+                    const int sz = wrap_add(z < P.zs ? z : 0, P.om[2], P.zs);
+                    st[j] = sp[use[j] ? colbase + (uint32_t)sz * P.xy : (uint32_t)lane];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) st[j] = (use[j] && st[j] >= 0) ? st[j] : -1;
+                uint32_t gh[4], gt[4], gm[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t r = st[j] >= 0 ? (uint32_t)st[j] : 0u;
+                    gh[j] = hp[r]; gt[j] = tp[r]; gm[j] = mp[r];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (st[j] >= 0) { hh[j] += gh[j]; tt[j] += gt[j]; mm[j] = min(mm[j], gm[j]); }
+            }
+            // rows by ballot + prefix popcount inside the wave's static range
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool occ = (gbits >> j) & 1u;
                 const unsigned long long b = __ballot(occ);
-                if (b == 0ull) continue;
                 if (occ) {
-                    const int z = z0 + k;
+                    const int z = z0 + kg + j;
                     const int sz = wrap_add(z, P.om[2], P.zs);
-                    emit(z, colbase + (uint32_t)sz * P.xy, rbase + running + (uint32_t)__popcll(b & lanemask_lt()));
+                    const uint32_t row = rbase + running + (uint32_t)__popcll(b & lanemask_lt());
+                    fstate[colbase + (uint32_t)sz * P.xy] = (int32_t)row;
+                    fhit[row] = hh[j]; ftotal[row] = tt[j]; fminh[row] = mm[j];
+                    if (z == zocc) hocc = mm[j];
                 }
                 running += (uint32_t)__popcll(b);
             }
