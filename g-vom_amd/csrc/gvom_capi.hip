@@ -171,6 +171,16 @@ void fill_scan_params(const gvom_handle *h, const int64_t origin[3], const doubl
     P.om[2] = (int)floor_mod(origin[2], p.z_size);
     P.sy_lo = h->sy_lo; P.sy_hi = h->sy_hi;
     P.nseg = h->nseg;
+    P.sxq = (p.xy_size + 3) / 4;
+    // DDA segments: the ego sits at the window centre, so a ray takes at most size/2 + 2 steps
+    {
+        int nsegs = 4;
+        if (const char *v = getenv("GVOM_TRACE_SEGMENTS")) nsegs = atoi(v) > 0 ? atoi(v) : 4;
+        const int maxsteps = (p.xy_size > p.z_size ? p.xy_size : p.z_size) / 2 + 2;
+        P.nsegs = nsegs;
+        P.seg_len = (maxsteps + nsegs - 1) / nsegs;
+        if (P.seg_len < 8) { P.seg_len = 8; }
+    }
     P.epoch = 0;
     // slab rows as intervals of window y (storage row sy <-> window row (sy - om1) mod xy)
     P.cull = 0;
@@ -225,10 +235,12 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, g
     CK(hipSetDevice(device_id));
     CK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     h->own_stream = h->stream;
-    CK(hipMalloc((void **)&h->hit, h->V * 4));
-    CK(hipMalloc((void **)&h->total, h->V * 4));
-    CK(hipMemsetAsync(h->hit, 0, h->V * 4, h->stream));
-    CK(hipMemsetAsync(h->total, 0, h->V * 4, h->stream));
+    // accumulators are micro-tiled in 4x4 (x,y) patches (gvom_internal.h "ACCUMULATOR LAYOUT")
+    const size_t acc_elems = (size_t)((xy + 3) / 4) * ((xy + 3) / 4) * zs * 16 + 256;
+    CK(hipMalloc((void **)&h->hit, acc_elems * 4));
+    CK(hipMalloc((void **)&h->total, acc_elems * 4));
+    CK(hipMemsetAsync(h->hit, 0, acc_elems * 4, h->stream));
+    CK(hipMemsetAsync(h->total, 0, acc_elems * 4, h->stream));
     h->slots.resize(params->buffer_size + 1);
     for (auto &s : h->slots) {
         CK(hipMalloc((void **)&s.state, h->V * 4));

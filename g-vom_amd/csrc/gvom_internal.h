@@ -24,6 +24,13 @@
 // uint32 tag per tile; a tile holds valid data iff tag == the map's epoch, otherwise all its
 // voxels read as "never observed" (-1) and their stored bytes are stale and never read.  Epochs
 // only grow, so tag arrays are never cleared.
+// ACCUMULATOR LAYOUT (hit[], total[] only -- private to k_trace / k_encode): micro-tiled so that one
+// 64-byte line holds a 4 (x) x 4 (y) patch of voxels at one z:
+//   A(sx, sy, sz) = ((((sy >> 2) * zs + sz) * sxq + (sx >> 2)) << 4) + ((sy & 3) << 2) + (sx & 3)
+// The hardware merges the lanes of one atomic instruction that fall into the same 64-B line into
+// one memory-side request, and k_trace runs at that request rate; with rows of 16 consecutive x
+// per line an x-dominant ray bundle (all lanes at the same x, spread over y) needed one request
+// per distinct y.  Patches make x- and y-dominant bundles equally cheap (about half the requests).
 struct ScanParams {
     double xy_res, z_res;
     double min_d2;        // min_distance * min_distance (f64 product, gvom.py:1067)
@@ -35,6 +42,8 @@ struct ScanParams {
     int    om[3];         // origin mod size (storage offset)
     int    sy_lo, sy_hi;  // storage rows owned by this rank: [sy_lo, sy_hi)
     int    nseg;          // tiles per (sy, sz) row
+    int    nsegs, seg_len; // DDA steps are split into nsegs segments of seg_len steps (last: open-ended)
+    int    sxq;           // accumulator layout: 4x4 (x,y) patches per row of patches = ceil(xy/4)
     uint32_t epoch;       // this scan's tile epoch
     // slab-sharded runs: the slab's rows as (up to two) intervals of WINDOW y, for ray culling
     int    cull;          // 1: skip rays that cannot reach the slab, stop rays that have left it

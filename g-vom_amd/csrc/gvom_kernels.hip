@@ -32,6 +32,10 @@ typedef const __attribute__((address_space(1))) uint32_t *gptr_u32;
 
 __device__ __forceinline__ int wrap_add(int a, int b, int n) { int s = a + b; return s >= n ? s - n : s; }
 __device__ __forceinline__ int wrap_sub(int a, int b, int n) { int s = a - b; return s < 0 ? s + n : s; }
+// accumulator (hit/total) index of storage voxel (sx, sy, sz): 4x4 (x,y) patches per 64-B line
+__device__ __forceinline__ uint32_t acc_idx(int sx, int sy, int sz, int zs, int sxq) {
+    return (((((uint32_t)sy >> 2) * zs + sz) * sxq + ((uint32_t)sx >> 2)) << 4) + (((uint32_t)sy & 3u) << 2) + ((uint32_t)sx & 3u);
+}
 // Python's max(a, b): a unless b > a  (gvom.py:1116; differs from fmaxf only for NaN)
 __device__ __forceinline__ float py_maxf(float a, float b) { return (b > a) ? b : a; }
 __device__ __forceinline__ double py_maxd(double a, double b) { return (b > a) ? b : a; }
@@ -53,6 +57,15 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 //      voxel's compact row with ONE wave-aggregated atomic (ballot + popcount)  gvom.py:1070-1090,1158
 //   4. dominant-axis DDA from the ego position, total += 1 per step             gvom.py:1093-1150
 // Only voxels whose storage row sy lies in [sy_lo, sy_hi) are committed (multi-GPU slabs).
+//
+// SEGMENTS.  A 131k-point scan is only 2 waves per SIMD and the step body is a long dependent
+// chain (f32 add -> f64 floor/compare -> index -> shuffle/ballot -> atomic), so the kernel would
+// be latency-bound.  Each coordinate advances by a constant-sign f32 increment, i.e. monotonically,
+// and so does `length`; therefore "the ray has already ended before step k" is decided by the
+// state AT step k alone, and a ray's steps can be split into nsegs segments handled by different
+// waves (blockIdx.y): a lane first replays the skipped steps with the reference's exact f32/f64
+// accumulation (3 f32 adds + 1 f64 add per step, no floor, no memory traffic), then runs the full
+// step body for its own seg_len steps.  Results are bit-identical; there are nsegs x more waves.
 // ------------------------------------------------------------------------------------------
 // VAR selects the accumulation strategy of the DDA loop (A/B-able at run time through the
 // GVOM_TRACE_VARIANT environment variable, read by gvom_create):
@@ -69,6 +82,9 @@ __global__ __launch_bounds__(256) void k_trace(const ScanParams P, const T *__re
 {
     const int lane = threadIdx.x & (WAVE - 1);
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int seg = (VAR == 1 || VAR == 2) ? (int)blockIdx.y : 0;      // step segment of this wave
+    if ((VAR == 0 || VAR == 9) && blockIdx.y != 0) return;
+    const bool first = seg == 0;                                       // segment 0 also does the endpoint
     const bool live = i < n;
     T x = 0, y = 0, z = 0;
     if (live) {
@@ -81,7 +97,7 @@ __global__ __launch_bounds__(256) void k_trace(const ScanParams P, const T *__re
             const double o2 = ((dx * P.tf[8] + dy * P.tf[9]) + dz * P.tf[10]) + P.tf[11];
             x = (T)o0; y = (T)o1; z = (T)o2;
         }
-        world[3 * i + 0] = x; world[3 * i + 1] = y; world[3 * i + 2] = z;
+        if (first) { world[3 * i + 0] = x; world[3 * i + 1] = y; world[3 * i + 2] = z; }
     }
     const T d2 = (x * x + y * y) + z * z;
     const bool pass = live && !((double)d2 < P.min_d2);
@@ -89,8 +105,8 @@ __global__ __launch_bounds__(256) void k_trace(const ScanParams P, const T *__re
 
     // ---- endpoint ------------------------------------------------------------------------
     bool ingrid = false, ingrid_any = false;
-    uint32_t L = 0;
-    if (pass) {
+    uint32_t L = 0, A = 0;
+    if (pass && first) {
         const double fx = floor((double)x / P.xy_res - P.origin[0]);
         const double fy = floor((double)y / P.xy_res - P.origin[1]);
         const double fz = floor((double)z / P.z_res - P.origin[2]);
@@ -102,13 +118,14 @@ __global__ __launch_bounds__(256) void k_trace(const ScanParams P, const T *__re
             if (sy >= P.sy_lo && sy < P.sy_hi) {
                 ingrid = true;
                 L = ((uint32_t)sy * P.zs + sz) * P.xy + sx;
+                A = acc_idx(sx, sy, sz, P.zs, P.sxq);
             }
         }
     }
     uint32_t old = 1;
     if (ingrid) {
-        old = atomicAdd(&hit[L], 1u);
-        atomicAdd(&total[L], 1u);
+        old = atomicAdd(&hit[A], 1u);
+        atomicAdd(&total[A], 1u);
         const uint32_t tile = (L / P.xy) * P.nseg + ((L % P.xy) >> 6);  // stamp the tile (idempotent)
         tags[tile] = P.epoch;
     }
@@ -178,7 +195,7 @@ __global__ __launch_bounds__(256) void k_trace(const ScanParams P, const T *__re
             if (sy >= P.sy_lo && sy < P.sy_hi) {
                 const int sx = wrap_add((int)fx, P.om[0], P.xy);
                 const int sz = wrap_add((int)fz, P.om[2], P.zs);
-                const uint32_t Ls = ((uint32_t)sy * P.zs + sz) * P.xy + sx;
+                const uint32_t Ls = acc_idx(sx, sy, sz, P.zs, P.sxq);
                 if (VAR == 0) {
                     atomicAdd(&total[Ls], 1u);
                     const uint32_t tile = ((uint32_t)sy * P.zs + sz) * P.nseg + (sx >> 6);
@@ -192,6 +209,12 @@ __global__ __launch_bounds__(256) void k_trace(const ScanParams P, const T *__re
     }
 
     // ---- VAR 1: lock-step, run-merged (VAR 2: same + diagnostic counters) -------------------
+    // replay the steps of earlier segments (exact accumulation; see SEGMENTS above)
+    for (int j = seg * P.seg_len; j > 0; --j) {
+        pd = pd + dir; p1 = p1 + inc1; p2 = p2 + inc2;
+        length += step_len;
+    }
+    int left = (seg == P.nsegs - 1) ? INT_MAX : P.seg_len;             // steps this wave may take
     bool active = pass && (length < lim);
     // slab-sharded runs: a ray whose window-y range cannot touch this rank's rows is not traced
     // at all, and a ray is dropped once it has moved past them (y is monotone along a ray); both
@@ -227,12 +250,12 @@ __global__ __launch_bounds__(256) void k_trace(const ScanParams P, const T *__re
                 if (sy >= P.sy_lo && sy < P.sy_hi) {
                     const int sx = wrap_add((int)fx, P.om[0], P.xy);
                     const int sz = wrap_add((int)fz, P.om[2], P.zs);
-                    Ls = ((uint32_t)sy * P.zs + sz) * P.xy + sx;
+                    Ls = acc_idx(sx, sy, sz, P.zs, P.sxq);   // accumulator index: the merge key and the atomic's target
                     Ts = ((uint32_t)sy * P.zs + sz) * P.nseg + (sx >> 6);
                     commit = true;
                 }
                 length += step_len;
-                active = length < lim && (int)fy < ystop_hi && (int)fy > ystop_lo;
+                active = length < lim && --left > 0 && (int)fy < ystop_hi && (int)fy > ystop_lo;
             } else {
                 active = false;                           // ray left the grid (gvom.py:1135-1144)
             }
@@ -326,39 +349,62 @@ __global__ __launch_bounds__(256) void k_encode(const ScanParams P, unsigned enc
         __hip_atomic_store(host_flag, ((unsigned long long)seq << 32) | any | c, __ATOMIC_RELEASE,
                            __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    // ---- encode blocks: one wave per QUAD = 4 storage rows (sy = 4q .. 4q+3) x 64 sx at one sz,
+    // i.e. 4 tiles = 16 accumulator lines.  Lane (p = lane >> 2, r = lane & 3) owns the 4 voxels
+    // sx = 64*seg + 4p .. +3 of row sy = 4q + r: one 16-byte load of hit and of total (its quarter of
+    // a 4x4 patch line) and one 16-byte store of state.
     const int lane = threadIdx.x & (WAVE - 1);
     const uint32_t wid = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const uint32_t nw = (enc_blocks * blockDim.x) >> 6;
-    for (uint32_t T0 = t_begin + wid * 4; T0 < t_end; T0 += nw * 4) {
-        // lane j (< 4) fetches the tag of tile T0 + j; ballot -> wave-uniform dirty mask
-        const uint32_t Tl = T0 + (lane & 3);
-        const uint32_t tagv = tags[Tl < t_end ? Tl : t_begin];
-        const uint32_t dmask = (uint32_t)__ballot(lane < 4 && Tl < t_end && tagv == epoch);
-        if (dmask == 0) continue;                                    // wave-uniform
-        bool dirty[4];
-        uint32_t L[4], h[4], t[4];
-        int32_t rowv[4];
-        // unconditional loads (clean tiles read the always-valid first row and are ignored)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t tile = T0 + j;
-            const uint32_t sx = (tile % nseg) * 64 + lane;
-            dirty[j] = ((dmask >> j) & 1u) && sx < (uint32_t)xy;
-            L[j] = dirty[j] ? (tile / nseg) * xy + sx : (uint32_t)lane;
+    const int p4 = lane >> 2, r = lane & 3;
+    const bool vec_state = (xy & 3) == 0;                // 16-byte aligned state rows
+    for (uint32_t u0 = t_begin + wid * 2; u0 < t_end; u0 += nw * 2) {
+        // two quads per iteration; lane j (< 8) fetches the tag of row (j & 3) of quad (j >> 2)
+        uint32_t dmask;
+        {
+            const uint32_t u = u0 + ((lane >> 2) & 1);
+            const uint32_t seg = u % nseg, sz = (u / nseg) % P.zs, q = u / (nseg * P.zs);
+            const uint32_t syl = q * 4 + (lane & 3);
+            const bool ok = lane < 8 && u < t_end && syl < (uint32_t)xy && (int)syl >= P.sy_lo && (int)syl < P.sy_hi;
+            const uint32_t tagv = tags[ok ? (syl * P.zs + sz) * nseg + seg : 0];
+            dmask = (uint32_t)__ballot(ok && tagv == epoch);
         }
+        if (dmask == 0) continue;                                    // wave-uniform
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { h[j] = hit[L[j]]; t[j] = total[L[j]]; rowv[j] = state[L[j]]; }
+        for (int j = 0; j < 2; ++j) {
+            if (((dmask >> (4 * j)) & 0xfu) == 0) continue;          // wave-uniform
+            const uint32_t u = u0 + j;
+            const uint32_t seg = u % nseg, sz = (u / nseg) % P.zs, q = u / (nseg * P.zs);
+            const uint32_t sy = q * 4 + r, sx0 = seg * 64 + p4 * 4;
+            const bool dirty = ((dmask >> (4 * j + r)) & 1u) && sx0 < (uint32_t)xy;
+            const uint32_t A0 = dirty ? acc_idx((int)sx0, (int)sy, (int)sz, P.zs, P.sxq) : (uint32_t)(lane * 4);
+            const uint32_t L0 = dirty ? (sy * P.zs + sz) * xy + sx0 : 0u;
+            const uint4 hv = *reinterpret_cast<const uint4 *>(hit + A0);
+            const uint4 tv = *reinterpret_cast<const uint4 *>(total + A0);
+            if (!dirty) continue;
+            const uint32_t h[4] = {hv.x, hv.y, hv.z, hv.w}, t[4] = {tv.x, tv.y, tv.z, tv.w};
+            int32_t st[4];
+            const uint32_t any_h = h[0] | h[1] | h[2] | h[3], any_t = t[0] | t[1] | t[2] | t[3];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (!dirty[j]) continue;
-            if (h[j] > 0) {
-                const int32_t row = rowv[j];
-                chit[row] = h[j]; ctotal[row] = t[j];
-                hit[L[j]] = 0;
-            } else {
-                state[L[j]] = -(int32_t)t[j] - 1;
+            for (int i = 0; i < 4; ++i) st[i] = -(int32_t)t[i] - 1;
+            if (any_h) {                                 // rare: an occupied voxel; its row was claimed in k_trace
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (h[i] > 0 && sx0 + i < (uint32_t)xy) {
+                        const int32_t row = state[L0 + i];
+                        chit[row] = h[i]; ctotal[row] = t[i];
+                        st[i] = row;
+                    }
+                }
+                *reinterpret_cast<uint4 *>(hit + A0) = make_uint4(0, 0, 0, 0);
             }
-            if (t[j]) total[L[j]] = 0;
+            if (any_t) *reinterpret_cast<uint4 *>(total + A0) = make_uint4(0, 0, 0, 0);
+            if (vec_state) {
+                *reinterpret_cast<int4 *>(state + L0) = make_int4(st[0], st[1], st[2], st[3]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (sx0 + i < (uint32_t)xy) state[L0 + i] = st[i];
+            }
         }
     }
 }
@@ -1054,8 +1100,9 @@ hipError_t gvom_launch_trace(hipStream_t s, const ScanParams &P, int dtype, cons
                              uint32_t *counters, int variant)
 {
     const unsigned blocks = (unsigned)((n + 255) / 256);
+    const unsigned nsegs = (variant == 0 || variant == 9) ? 1u : (unsigned)P.nsegs;
 #define TRACE_LAUNCH(TT, VV)                                                                     \
-    hipLaunchKernelGGL((k_trace<TT, VV>), dim3(blocks), dim3(256), 0, s, P, (const TT *)pts,      \
+    hipLaunchKernelGGL((k_trace<TT, VV>), dim3(blocks, nsegs), dim3(256), 0, s, P, (const TT *)pts, \
                        (long)stride_elems, (long)n, (TT *)world, hit, total, state, tags, cminh, counters)
     if (dtype == 0) {
         if (variant == 0) TRACE_LAUNCH(float, 0);
@@ -1076,10 +1123,12 @@ hipError_t gvom_launch_encode(hipStream_t s, const ScanParams &P, int dtype, con
                               uint32_t *chit, uint32_t *ctotal, uint32_t *cminh, const uint32_t *tags,
                               uint32_t *counters, unsigned long long *host_flag, uint32_t seq)
 {
-    const uint32_t t_begin = (uint32_t)P.sy_lo * P.zs * P.nseg, t_end = (uint32_t)P.sy_hi * P.zs * P.nseg;
+    // encode part: units = quads (4 rows x 64 sx at one sz) that intersect the slab; one wave handles
+    // 2 quads per iteration, 4 waves per block
+    const uint32_t q_lo = (uint32_t)P.sy_lo >> 2, q_hi = ((uint32_t)P.sy_hi + 3) >> 2;
+    const uint32_t t_begin = q_lo * P.zs * P.nseg, t_end = q_hi * P.zs * P.nseg;
     const uint32_t ntiles = t_end - t_begin;
-    // encode part: one wave handles 4 tiles per iteration, 4 waves per block
-    unsigned enc_blocks = (ntiles + 15) / 16;
+    unsigned enc_blocks = (ntiles + 7) / 8;
     if (enc_blocks > 4096) enc_blocks = 4096;
     if (enc_blocks < 1) enc_blocks = 1;
     const unsigned mh_blocks = (unsigned)((n + 255) / 256);          // min-height part
