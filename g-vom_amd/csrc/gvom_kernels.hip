@@ -149,8 +149,21 @@ __global__ __launch_bounds__(256) void k_trace(const ScanParams P, const T *__re
     if (VAR == 0 && !pass) return;
 
     // ---- ray ------------------------------------------------------------------------------
-    const float e0 = (float)((double)x / P.xy_res);
     const float e1 = (float)((double)y / P.xy_res);
+    // slab-sharded runs: a ray whose window-y range cannot touch this rank's rows is not traced at
+    // all (conservative +-2 rows, so the committed updates are unchanged); waves without any
+    // reaching ray leave before the DDA setup.
+    bool reach = pass;
+    if (P.cull && (VAR == 1 || VAR == 2)) {
+        const float yend_f = e1 - (float)P.origin[1];
+        const float ybeg_f = P.pt0[1] - (float)P.origin[1];
+        const int y0i = (int)floorf(fminf(ybeg_f, yend_f)) - 2, y1i = (int)floorf(fmaxf(ybeg_f, yend_f)) + 2;
+        const bool hit0 = y1i >= P.wlo[0] && y0i < P.whi[0];
+        const bool hit1 = y1i >= P.wlo[1] && y0i < P.whi[1];
+        reach = pass && (hit0 || hit1);
+        if (!__any(reach)) return;                       // wave-uniform
+    }
+    const float e0 = (float)((double)x / P.xy_res);
     const float e2 = (float)((double)z / P.z_res);
     float s0 = e0 - P.pt0[0], s1 = e1 - P.pt0[1], s2 = e2 - P.pt0[2];
     const float ss = (s0 * s0 + s1 * s1) + s2 * s2;
@@ -215,19 +228,23 @@ __global__ __launch_bounds__(256) void k_trace(const ScanParams P, const T *__re
         length += step_len;
     }
     int left = (seg == P.nsegs - 1) ? INT_MAX : P.seg_len;             // steps this wave may take
-    bool active = pass && (length < lim);
-    // slab-sharded runs: a ray whose window-y range cannot touch this rank's rows is not traced
-    // at all, and a ray is dropped once it has moved past them (y is monotone along a ray); both
-    // tests are conservative (+-1 row), so the committed updates are unchanged.
+    bool active = reach && (length < lim);
+    // ... and a ray is dropped once it has moved past the slab's rows (y is monotone along a ray)
     const float sy_dir = si == 1 ? sd : (si == 0 ? so1 : so2);           // slope of the y axis
     int ystop_lo = INT_MIN, ystop_hi = INT_MAX;
+    if (P.cull) {
+        // this SEGMENT's window-y range (conservative +-2 rows): segments that only cross other
+        // ranks' rows are dropped, so a rank steps (almost) only through its own slab
+        const float ynow = (si == 1 ? pd : (si == 0 ? p1 : p2)) - (float)P.origin[1];
+        const float yinc = si == 1 ? dir : (si == 0 ? inc1 : inc2);
+        const float yseg = (seg == P.nsegs - 1) ? (e1 - (float)P.origin[1]) : ynow + yinc * (float)(P.seg_len + 1);
+        const int a0 = (int)floorf(fminf(ynow, yseg)) - 2, a1 = (int)floorf(fmaxf(ynow, yseg)) + 2;
+        const bool h0 = a1 >= P.wlo[0] && a0 < P.whi[0];
+        const bool h1 = a1 >= P.wlo[1] && a0 < P.whi[1];
+        active = active && (h0 || h1);
+        if (!__any(active)) return;                      // wave-uniform
+    }
     if (P.cull && active) {
-        const float yend_f = e1 - (float)P.origin[1];
-        const float ybeg_f = P.pt0[1] - (float)P.origin[1];
-        const int y0i = (int)floorf(fminf(ybeg_f, yend_f)) - 2, y1i = (int)floorf(fmaxf(ybeg_f, yend_f)) + 2;
-        const bool hit0 = y1i >= P.wlo[0] && y0i < P.whi[0];
-        const bool hit1 = y1i >= P.wlo[1] && y0i < P.whi[1];
-        if (!hit0 && !hit1) active = false;
         const int lo = min(P.wlo[0], P.wlo[1] < P.whi[1] ? P.wlo[1] : P.wlo[0]);
         const int hi = max(P.whi[0], P.wlo[1] < P.whi[1] ? P.whi[1] : P.whi[0]);
         if (sy_dir > 0.0f) ystop_hi = hi + 1;            // moving towards +y: done beyond the last owned row
