@@ -100,6 +100,21 @@ def pmc_traffic(kernel):
     return None
 
 
+def atomic_ceiling(kernel, ms):
+    """k_trace is bound by the memory-side atomic REQUEST rate, not by bytes: report it beside the
+    HBM roofline (SURVEY 8d).  Requests per launch come from the committed TCC_EA0_ATOMIC_sum pass;
+    the ceiling is the scattered int32 atomic rate calibrated with tools/pmc_calib on the same part."""
+    if kernel != "trace":
+        return None
+    t = pmc_traffic("k_trace") or {}
+    req = t.get("atomic_requests_per_launch")
+    if not req:
+        return None
+    return {"bound": "memory-side atomic requests", "requests_per_launch": req,
+            "achieved": req / (ms * 1e-3) / 1e9, "peak": 16.0, "unit": "G requests/s",
+            "frac": req / (ms * 1e-3) / 1e9 / 16.0, "source": t.get("source")}
+
+
 def run_single(args):
     import gvom
     import synth
@@ -185,6 +200,7 @@ def run_single(args):
                      "traffic": (pmc_traffic("k_" + dom) or {}).get("bytes_per_launch"),
                      "traffic_detail": pmc_traffic("k_" + dom),
                      "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": stage_ms[dom],
+                     "secondary_ceiling": atomic_ceiling(dom, stage_ms[dom]),
                      "all_stages_GBs": {s: alg[s] / (stage_ms[s] * 1e-3) / 1e9 if stage_ms[s] > 0 else None
                                         for s in alg}},
     }
