@@ -29,6 +29,8 @@
 // it they point to global memory so it emits global_load (vmcnt only) instead of flat_load.
 typedef const __attribute__((address_space(1))) int32_t *gptr_i32;
 typedef const __attribute__((address_space(1))) uint32_t *gptr_u32;
+typedef int v4i __attribute__((ext_vector_type(4)));                       // 16-byte vector of 4 ints
+typedef const __attribute__((address_space(1))) v4i *gptr_v4i;
 
 __device__ __forceinline__ int wrap_add(int a, int b, int n) { int s = a + b; return s >= n ? s - n : s; }
 __device__ __forceinline__ int wrap_sub(int a, int b, int n) { int s = a - b; return s < 0 ? s + n : s; }
@@ -746,6 +748,238 @@ __global__ __launch_bounds__(1024) void k_fuse(const FuseParams P, const FuseDes
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_fuse4: the same fusion as k_fuse<true> with 16-byte accesses (xy % 4 == 0, 16-level chunks).
+// Lane (g = lane & 15, q = lane >> 4) owns the 4 columns sx = 64*seg + 4g .. +3 and, in every
+// chunk, the 4 levels z = z0 + 4j + q (j = 0..3): one int4 load per source and j covers 4 tiles
+// (4 levels x 64 columns) of the wave -- 4 loads instead of 16 per source, at the 16-B/lane rate
+// (6.5 TB/s vs 4.0 TB/s for 4-B/lane loads on this part) -- and the codes go out as int4 stores.
+// Cell (j, i) of a lane is voxel (sx = 4g + i, z = z0 + 4j + q); its fold state lives in
+// c[4j + i] / bit 4j + i of occbits.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_fuse4(const FuseParams P, const FuseDescs KD,
+                                                const MapDesc *__restrict__ descs_mem,
+                                                int32_t *fstate, uint32_t *fhit, uint32_t *ftotal,
+                                                uint32_t *fminh, uint32_t *ftags, uint32_t *blockcounts,
+                                                double *height, double *inferred)
+{
+    __shared__ uint32_t s_cnt[16];
+    __shared__ unsigned long long s_live[16][GVOM_MAX_SLOTS + 1];
+    __shared__ int s_zocc[16][WAVE];
+    __shared__ uint32_t s_hocc[16][WAVE];
+    __shared__ int s_zfree[16][WAVE];
+
+    const MapDesc *__restrict__ descs = descs_mem ? descs_mem : KD.d;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane & 15, q = lane >> 4;
+    const int sxb = blockIdx.x * WAVE + 4 * g;            // first of this lane's 4 columns
+    const int sy = P.sy_lo + blockIdx.y;
+    const bool col_ok = sxb < P.xy;                        // xy % 4 == 0: all four or none
+    const int y = wrap_sub(sy, P.om[1], P.xy);
+    const int nsrc = P.nslots + P.has_prev;
+
+    unsigned long long okm[4] = {0ull, 0ull, 0ull, 0ull};   // per column: sources whose window contains (x, y)
+    int xw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xw[i] = wrap_sub(col_ok ? sxb + i : 0, P.om[0], P.xy);
+    for (int s = 0; s < nsrc; ++s) {
+        const int ys = y + descs[s].d[1];
+        const bool yok = ys >= 0 && ys < P.xy;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int xs = xw[i] + descs[s].d[0];
+            if (col_ok && yok && xs >= 0 && xs < P.xy) okm[i] |= 1ull << s;
+        }
+    }
+
+    const uint32_t colbase = (uint32_t)sy * P.zs * P.xy + (col_ok ? sxb : 0);
+    const uint32_t tbase = (uint32_t)sy * P.zs * P.nseg + blockIdx.x;
+    uint32_t running = 0;
+    int zocc[4] = {INT_MAX, INT_MAX, INT_MAX, INT_MAX}, zfree[4] = {INT_MAX, INT_MAX, INT_MAX, INT_MAX};
+    uint32_t hocc[4] = {0x3f800000u, 0x3f800000u, 0x3f800000u, 0x3f800000u};
+    const uint32_t rbase = ((blockIdx.y * gridDim.x + blockIdx.x) * (uint32_t)P.nz + w) *
+                           (uint32_t)(WAVE * P.zc * P.cpw);
+
+    {   // phase 0: live-tile masks of every source for the (<= 64) tiles of this wave
+        const int cc_l = lane >> 4, k_l = lane & 15;
+        const int zl = (w * P.cpw + cc_l) * P.zc + k_l;
+        const bool valid_l = cc_l < P.cpw && k_l < P.zc && zl < P.zs;
+        const uint32_t tl = tbase + (uint32_t)wrap_add(valid_l ? zl : 0, P.om[2], P.zs) * P.nseg;
+        for (int s0 = 0; s0 < nsrc; s0 += 4) {
+            uint32_t tv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tv[j] = ((gptr_u32)descs[min(s0 + j, nsrc - 1)].tags)[tl];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned long long m = __ballot(valid_l && tv[j] == descs[min(s0 + j, nsrc - 1)].epoch);
+                if (lane == 0 && s0 + j < nsrc) s_live[w][s0 + j] = m;
+            }
+        }
+    }
+
+    for (int cc = 0; cc < P.cpw; ++cc) {
+        const int z0 = (w * P.cpw + cc) * P.zc;
+        if (z0 >= P.zs) break;
+        const int z1 = min(z0 + P.zc, P.zs);
+        uint32_t anylive = 0;
+        for (int s = 0; s < nsrc; ++s) anylive |= (uint32_t)(s_live[w][s] >> (16 * cc)) & 0xffffu;
+        if (__builtin_amdgcn_readfirstlane(anylive) == 0) continue;     // chunk dead in every source
+
+        int zq[4];                                        // this lane's 4 levels and their row offsets
+        uint32_t roff[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            zq[j] = z0 + 4 * j + q;
+            roff[j] = colbase + (uint32_t)wrap_add(zq[j] < P.zs ? zq[j] : 0, P.om[2], P.zs) * P.xy;
+        }
+        int c[16];
+        uint32_t occbits = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) c[k] = -1;
+
+        auto fold = [&](const v4i (&v)[4], uint32_t live, int dz, int s, bool is_prev) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool zin = ((live >> (4 * j + q)) & 1u) && zq[j] < z1 && zq[j] + dz >= 0 && zq[j] + dz < P.zs;
+                const int vv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int st = (zin && ((okm[i] >> s) & 1ull)) ? vv[i] : -1;     // -1: no effect
+                    const int k = 4 * j + i;
+                    if (!is_prev) {
+                        if (st >= 0) occbits |= 1u << k;                                  // gvom.py:963
+                        else if (st < -1 && !((occbits >> k) & 1u)) c[k] += st + 1;       // gvom.py:967
+                    } else if (!((occbits >> k) & 1u)) {
+                        if (st >= 0 && c[k] >= -11) occbits |= 1u << k;                   // gvom.py:992
+                        else if (st < -1) c[k] += st + 1;                                 // gvom.py:996
+                    }
+                }
+            }
+        };
+        for (int s0 = 0; s0 < nsrc; s0 += 2) {
+            const int sA = s0, sB = min(s0 + 1, nsrc - 1);
+            const bool hasB = s0 + 1 < nsrc;
+            const gptr_i32 spA = (gptr_i32)descs[sA].state, spB = (gptr_i32)descs[sB].state;
+            const uint32_t liveA = (uint32_t)(s_live[w][sA] >> (16 * cc)) & 0xffffu;
+            const uint32_t liveB = hasB ? ((uint32_t)(s_live[w][sB] >> (16 * cc)) & 0xffffu) : 0u;
+            v4i vA[4], vB[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {               // 8 unconditional 16-byte loads in flight
+                const uint32_t aA = ((liveA >> (4 * j + q)) & 1u) ? roff[j] : (uint32_t)(4 * lane);
+                const uint32_t aB = ((liveB >> (4 * j + q)) & 1u) ? roff[j] : (uint32_t)(4 * lane);
+                vA[j] = *(gptr_v4i)(spA + aA);
+                vB[j] = *(gptr_v4i)(spB + aB);
+            }
+            fold(vA, liveA, descs[sA].d[2], sA, sA >= P.nslots);
+            if (hasB) fold(vB, liveB, descs[sB].d[2], sB, sB >= P.nslots);
+        }
+        if (!col_ok) occbits = 0;
+
+        // codes: one int4 store per live-or-new tile row segment; first free / occupied z per column
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool inside = col_ok && zq[j] < z1;
+            bool nonempty = false;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) nonempty = nonempty || ((occbits >> (4 * j + i)) & 1u) || c[4 * j + i] != -1;
+            const unsigned long long nb = __ballot(inside && nonempty);
+            if ((nb >> (16 * q)) & 0xffffull) {           // some lane of MY tile (same q) has content
+                if (g == 0 && zq[j] < z1)
+                    ftags[tbase + (uint32_t)wrap_add(zq[j], P.om[2], P.zs) * P.nseg] = P.epoch;
+                if (inside) {
+                    *reinterpret_cast<int4 *>(fstate + roff[j]) = make_int4(c[4 * j], c[4 * j + 1], c[4 * j + 2], c[4 * j + 3]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if ((occbits >> (4 * j + i)) & 1u) { if (zocc[i] == INT_MAX) zocc[i] = zq[j]; }
+                        else if (c[4 * j + i] < -1 && zfree[i] == INT_MAX) zfree[i] = zq[j];   // gvom.py:551
+                    }
+                }
+            }
+        }
+
+        // occupied voxels (sparse): per j (4 levels x 64 columns of the wave), batched gathers
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t gbits = (occbits >> (4 * j)) & 0xfu;
+            if (!__any(gbits != 0)) continue;               // wave-uniform
+            uint32_t hh[4] = {0, 0, 0, 0}, tt[4] = {0, 0, 0, 0}, mm[4] = {0x3f800000u, 0x3f800000u, 0x3f800000u, 0x3f800000u};
+            for (int s = 0; s < nsrc; ++s) {
+                const gptr_i32 sp = (gptr_i32)descs[s].state;
+                const gptr_u32 hp = (gptr_u32)descs[s].hit, tp = (gptr_u32)descs[s].total, mp = (gptr_u32)descs[s].minh;
+                const uint32_t live = (uint32_t)(s_live[w][s] >> (16 * cc)) & 0xffffu;
+                const int dz = descs[s].d[2];
+                const bool zin = gbits && ((live >> (4 * j + q)) & 1u) && zq[j] + dz >= 0 && zq[j] + dz < P.zs;
+                const v4i v = *(gptr_v4i)(sp + (zin ? roff[j] : (uint32_t)(4 * lane)));
+                const int vv[4] = {v.x, v.y, v.z, v.w};
+                int st[4];
+                uint32_t gh[4], gt[4], gm[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    st[i] = (zin && ((gbits >> i) & 1u) && ((okm[i] >> s) & 1ull) && vv[i] >= 0) ? vv[i] : -1;
+                    const uint32_t r = st[i] >= 0 ? (uint32_t)st[i] : 0u;
+                    gh[i] = hp[r]; gt[i] = tp[r]; gm[i] = mp[r];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (st[i] >= 0) { hh[i] += gh[i]; tt[i] += gt[i]; mm[i] = min(mm[i], gm[i]); }   // gvom.py:910-912
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool occ = (gbits >> i) & 1u;
+                const unsigned long long b = __ballot(occ);
+                if (occ) {
+                    const uint32_t row = rbase + running + (uint32_t)__popcll(b & lanemask_lt());
+                    fstate[roff[j] + i] = (int32_t)row;
+                    fhit[row] = hh[i]; ftotal[row] = tt[i]; fminh[row] = mm[i];
+                    if (zq[j] == zocc[i]) hocc[i] = mm[i];
+                }
+                running += (uint32_t)__popcll(b);
+            }
+        }
+    }   // chunks
+
+    // ---- column tail: lowest occupied z (+ its min-height) / lowest free z per column.  A column's
+    // levels are spread over the 4 lanes {g, g+16, g+32, g+48}: reduce them first, then across waves.
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+            const int oz = __shfl_xor(zocc[i], o);
+            const uint32_t oh = (uint32_t)__shfl_xor((int)hocc[i], o);
+            if (oz < zocc[i]) { zocc[i] = oz; hocc[i] = oh; }
+            zfree[i] = min(zfree[i], __shfl_xor(zfree[i], o));
+        }
+        if (q == 0) { s_zocc[w][4 * g + i] = zocc[i]; s_hocc[w][4 * g + i] = hocc[i]; s_zfree[w][4 * g + i] = zfree[i]; }
+    }
+    if (lane == 0) s_cnt[w] = running;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int k = 0; k < P.nz; ++k) tot += s_cnt[k];
+        blockcounts[blockIdx.y * gridDim.x + blockIdx.x] = tot;
+    }
+    const int sx = blockIdx.x * WAVE + lane;
+    if (w == 0 && sx < P.xy) {
+        const int x = wrap_sub(sx, P.om[0], P.xy);
+        int zo = INT_MAX, zf = INT_MAX;
+        uint32_t hb = 0x3f800000u;
+        for (int k = 0; k < P.nz; ++k) {
+            if (zo == INT_MAX && s_zocc[k][lane] != INT_MAX) { zo = s_zocc[k][lane]; hb = s_hocc[k][lane]; }
+            if (zf == INT_MAX && s_zfree[k][lane] != INT_MAX) zf = s_zfree[k][lane];
+        }
+        double hval = -1000.0;
+        const double xp = ((P.origin[0] + (double)x) * P.xy_res) - P.ego[0];
+        const double yp = ((P.origin[1] + (double)y) * P.xy_res) - P.ego[1];
+        if (xp * xp + yp * yp <= P.radius2) hval = P.ego[2] - P.ground_to_lidar_height;
+        if (zo != INT_MAX)
+            hval = (((double)__uint_as_float(hb) + (double)zo) + P.origin[2]) * P.z_res;
+        height[(size_t)sy * P.hs + sx] = hval;
+        inferred[(size_t)sy * P.hs + sx] =
+            (zf != INT_MAX) ? ((double)zf + P.origin[2]) * P.z_res : -1000.0;
+    }
+}
+
 // sum of the per-workgroup occupied-voxel counts of k_fuse -> host-mapped memory
 __device__ __forceinline__ void publish_block_counts(const uint32_t *blockcounts, int nblocks,
                                                      volatile unsigned long long *host_counter,
@@ -1167,7 +1401,10 @@ hipError_t gvom_launch_fuse(hipStream_t s, const FuseParams &P, const FuseDescs 
 {
     const dim3 grid((P.xy + 63) / 64, P.sy_hi - P.sy_lo);
     if (grid.y == 0) return hipSuccess;
-    if (P.zc <= 16)
+    if (P.zc == 16 && (P.xy & 3) == 0 && !(P.debug & 8))
+        hipLaunchKernelGGL(k_fuse4, grid, dim3(64 * P.nz), 0, s, P, KD, descs_dev, fstate, fhit,
+                           ftotal, fminh, ftags, blockcounts, height, inferred);
+    else if (P.zc <= 16)
         hipLaunchKernelGGL(k_fuse<true>, grid, dim3(64 * P.nz), 0, s, P, KD, descs_dev, fstate, fhit,
                            ftotal, fminh, ftags, blockcounts, height, inferred);
     else
