@@ -36,6 +36,7 @@ struct Slot {                                  // one scan in sparse form
     uint32_t *tags = nullptr;                  // [ntiles] tile epochs (live iff == epoch)
     uint32_t epoch = 0;
     Buf chit, ctotal, cminh;                   // compact rows
+    Buf metrics;                               // optional statistics: double[rows][10]
     int64_t origin[3] = {0, 0, 0};
     int64_t count = 0;
     bool filled = false;
@@ -48,6 +49,7 @@ struct Fused {
     uint32_t *tags = nullptr;
     uint32_t epoch = 0;
     Buf hit, total, minh;
+    Buf metrics;                               // optional statistics: float[rows][10]
     int64_t origin[3] = {0, 0, 0};
     int64_t count = 0;                         // rows on THIS rank
     bool valid = false;
@@ -111,6 +113,7 @@ struct gvom_handle {
     double host_ns[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // host-side phase timing (GVOM_HOST_TIMING)
     long host_calls = 0;
     bool host_timing = false;
+    bool stats = false;                                 // per-voxel statistics enabled (gvom_params.reserved0 bit 0)
     int trace_variant = 1;                              // GVOM_TRACE_VARIANT (k_trace strategy)
     bool profiling = false;
     hipEvent_t ev[8] = {nullptr};
@@ -214,6 +217,8 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, g
     h->device = device_id;
     h->rank = rank; h->world = world;
     if (const char *v = getenv("GVOM_TRACE_VARIANT")) h->trace_variant = atoi(v);
+    h->stats = (params->reserved0 & GVOM_FLAG_VOXEL_STATISTICS) != 0;
+    if (const char *v = getenv("GVOM_VOXEL_STATISTICS")) h->stats = atoi(v) != 0;
     if (const char *v = getenv("GVOM_HOST_TIMING")) h->host_timing = atoi(v) != 0;
     const int xy = params->xy_size, zs = params->z_size;
     h->sy_lo = (int)((int64_t)xy * rank / world);
@@ -306,17 +311,23 @@ int scan_launch(gvom_handle *h, const void *dev_pts, int64_t n, int64_t stride_e
     if ((rc = ensure(h, st.chit, cap * 4))) return rc;
     if ((rc = ensure(h, st.ctotal, cap * 4))) return rc;
     if ((rc = ensure(h, st.cminh, cap * 4))) return rc;
+    if (h->stats && (rc = ensure(h, st.metrics, cap * 80))) return rc;
     double t0 = now_ns();
     const uint32_t seq = ++h->scan_seq;
     if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
     HIPCHK(h, gvom_launch_trace(h->stream, P, dtype, dev_pts, stride_elems, n, h->world_pts.p, h->hit,
                                 h->total, st.state, st.tags, (uint32_t *)st.cminh.p, h->counters,
-                                h->trace_variant));
+                                h->trace_variant, h->stats ? (double *)st.metrics.p : nullptr));
     if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
     HIPCHK(h, gvom_launch_encode(h->stream, P, dtype, h->world_pts.p, n, h->hit, h->total, st.state,
                                  (uint32_t *)st.chit.p, (uint32_t *)st.ctotal.p, (uint32_t *)st.cminh.p,
                                  st.tags, h->counters, (unsigned long long *)h->counters_host_dev, seq));
     if (h->profiling) { HIPCHK(h, hipEventRecord(h->ev[2], h->stream)); h->ev_scan = true; }
+    if (h->stats) {                                      // optional per-voxel statistics
+        HIPCHK(h, gvom_launch_stats(h->stream, P, dtype, h->world_pts.p, n, st.state, st.tags,
+                                    p.xy_eigen_dist, p.z_eigen_dist, (double *)st.metrics.p));
+        HIPCHK(h, gvom_launch_stats_finalize(h->stream, (double *)st.metrics.p, h->counters + 8, (int64_t)cap));
+    }
     HT(h, 0, t0);                                        // scan: launches
     // Wait only for k_trace: k_encode's first thread publishes {seq, count} to host-mapped memory.
     // The caller gets control back while k_encode / k_minh still run; everything it can do next
@@ -438,7 +449,7 @@ int fuse_impl(gvom_handle *h, bool publish_now)
         d.d[0] = clamp_delta(F.origin[0] - s.origin[0], p.xy_size);
         d.d[1] = clamp_delta(F.origin[1] - s.origin[1], p.xy_size);
         d.d[2] = clamp_delta(F.origin[2] - s.origin[2], p.z_size);
-        d.epoch = s.epoch; d.tags = s.tags; d.pad = 0;
+        d.epoch = s.epoch; d.tags = s.tags; d.metrics = h->stats ? s.metrics.p : nullptr;
         bound += s.count;
     }
     P.nslots = ns;
@@ -450,7 +461,7 @@ int fuse_impl(gvom_handle *h, bool publish_now)
         d.d[0] = clamp_delta(F.origin[0] - prev->origin[0], p.xy_size);
         d.d[1] = clamp_delta(F.origin[1] - prev->origin[1], p.xy_size);
         d.d[2] = clamp_delta(F.origin[2] - prev->origin[2], p.z_size);
-        d.epoch = prev->epoch; d.tags = prev->tags; d.pad = 0;
+        d.epoch = prev->epoch; d.tags = prev->tags; d.metrics = h->stats ? prev->metrics.p : nullptr;
         bound += prev->count;
     }
     (void)bound;
@@ -468,6 +479,7 @@ int fuse_impl(gvom_handle *h, bool publish_now)
     if ((rc = ensure(h, F.hit, row_cap * 4))) return rc;
     if ((rc = ensure(h, F.total, row_cap * 4))) return rc;
     if ((rc = ensure(h, F.minh, row_cap * 4))) return rc;
+    if (h->stats && (rc = ensure(h, F.metrics, row_cap * 40))) return rc;
     for (int k = 0; k < 3; ++k) { P.origin[k] = (double)F.origin[k]; P.ego[k] = h->ego[k]; }
     P.xy_res = p.xy_resolution; P.z_res = p.z_resolution;
     P.radius2 = p.robot_radius * p.robot_radius;
@@ -487,6 +499,8 @@ int fuse_impl(gvom_handle *h, bool publish_now)
                                (uint32_t *)F.total.p, (uint32_t *)F.minh.p, F.tags, h->blockcounts,
                                h->height, h->inferred));
     if (h->profiling) { HIPCHK(h, hipEventRecord(h->ev[5], h->stream)); h->ev_fuse = true; }
+    if (h->stats)
+        HIPCHK(h, gvom_launch_fuse_stats(h->stream, P, KD, descs_mem, F.state, F.tags, (float *)F.metrics.p));
     if (publish_now)
         HIPCHK(h, gvom_launch_publish_count(h->stream, h->blockcounts, h->fuse_blocks,
                                             (unsigned long long *)(h->counters_host_dev + 2),
@@ -605,8 +619,8 @@ VIS void gvom_destroy(gvom_t *h)
     if (h->stream) hipStreamSynchronize(h->stream);
     auto fb = [](Buf &b) { if (b.p) hipFree(b.p); b.p = nullptr; b.bytes = 0; };
     hipFree(h->hit); hipFree(h->total);
-    for (auto &s : h->slots) { hipFree(s.state); hipFree(s.tags); fb(s.chit); fb(s.ctotal); fb(s.cminh); }
-    for (auto &f : h->fused) { hipFree(f.state); hipFree(f.tags); fb(f.hit); fb(f.total); fb(f.minh); }
+    for (auto &s : h->slots) { hipFree(s.state); hipFree(s.tags); fb(s.chit); fb(s.ctotal); fb(s.cminh); fb(s.metrics); }
+    for (auto &f : h->fused) { hipFree(f.state); hipFree(f.tags); fb(f.hit); fb(f.total); fb(f.minh); fb(f.metrics); }
     fb(h->in_pts); fb(h->world_pts);
     hipFree(h->counters); if (h->counters_host) hipHostFree(h->counters_host);
     hipFree(h->descs_dev); if (h->descs_host) hipHostFree(h->descs_host);
@@ -969,6 +983,43 @@ static int debug_maps(gvom_t *h, float *out7, float *out3)
     if (e == hipSuccess) e = hipMemcpy(out7 ? out7 : out3, tmp, n2 * (out7 ? 7 : 3) * 4, hipMemcpyDeviceToHost);
     hipFree(tmp);
     HIPCHK(h, e);
+    return GVOM_OK;
+}
+
+// Gvom.make_debug_voxel_map (gvom.py:363-378, kernels :1333-1378, :454-473)
+VIS int gvom_debug_voxel_map(gvom_t *h, float *out, int64_t max_rows, int64_t *rows)
+{
+    if (!h || !out || max_rows < 0) return GVOM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!h->has_combined || !h->stats) return GVOM_NO_DATA;
+    HIPCHK(h, hipSetDevice(h->device));
+    const gvom_params &p = h->prm;
+    const Fused &F = h->fused[h->cur];
+    Map2dParams P;
+    memset(&P, 0, sizeof P);
+    P.xy = p.xy_size; P.zs = p.z_size;
+    P.om[0] = (int)floor_mod(F.origin[0], p.xy_size);
+    P.om[1] = (int)floor_mod(F.origin[1], p.xy_size);
+    P.om[2] = (int)floor_mod(F.origin[2], p.z_size);
+    P.y_lo = h->sy_lo; P.y_hi = h->sy_hi;
+    P.xy_res = p.xy_resolution; P.z_res = p.z_resolution;
+    P.nseg = h->nseg; P.epoch = F.epoch;
+    float *tmp = nullptr;
+    HIPCHK(h, hipMalloc((void **)&tmp, (size_t)(max_rows > 0 ? max_rows : 1) * 32));
+    hipError_t e = hipMemsetAsync(h->counters + 12, 0, 8, h->stream);
+    if (e == hipSuccess)
+        e = gvom_launch_voxel_cloud(h->stream, P, (double)F.origin[0], (double)F.origin[1], (double)F.origin[2],
+                                    F.state, F.tags, (const uint32_t *)F.hit.p, (const uint32_t *)F.total.p,
+                                    (const float *)F.metrics.p, tmp, max_rows,
+                                    (unsigned long long *)(h->counters + 12));
+    unsigned long long cnt = 0;
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) e = hipMemcpy(&cnt, h->counters + 12, 8, hipMemcpyDeviceToHost);
+    const int64_t nrows = (int64_t)cnt < max_rows ? (int64_t)cnt : max_rows;
+    if (e == hipSuccess && nrows > 0) e = hipMemcpy(out, tmp, (size_t)nrows * 32, hipMemcpyDeviceToHost);
+    hipFree(tmp);
+    HIPCHK(h, e);
+    if (rows) *rows = (int64_t)cnt;
     return GVOM_OK;
 }
 

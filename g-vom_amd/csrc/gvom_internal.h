@@ -58,7 +58,7 @@ struct MapDesc {          // one source map of the fusion (ring slot or previous
     int d[3];               // fused origin - this map's origin (window shift), clamped
     uint32_t epoch;         // tile (T) of this map is live iff tags[T] == epoch
     const uint32_t *tags;
-    uint64_t pad;
+    const void *metrics;    // optional per-row statistics: double[rows][10] (ring slot) or float[rows][10] (fused)
 };
 
 #define GVOM_KARG_DESCS 17   // ring slots + previous map passed by kernel argument when they fit
@@ -102,7 +102,7 @@ struct Map2dParams {
 hipError_t gvom_launch_trace(hipStream_t s, const ScanParams &P, int dtype, const void *pts,
                              int64_t stride_elems, int64_t n, void *world, uint32_t *hit,
                              uint32_t *total, int32_t *state, uint32_t *tags, uint32_t *cminh,
-                             uint32_t *counters, int variant);
+                             uint32_t *counters, int variant, double *stat_sums);
 hipError_t gvom_launch_encode(hipStream_t s, const ScanParams &P, int dtype, const void *world,
                               int64_t n, uint32_t *hit, uint32_t *total, int32_t *state,
                               uint32_t *chit, uint32_t *ctotal, uint32_t *cminh, const uint32_t *tags,
@@ -118,6 +118,16 @@ hipError_t gvom_launch_map2d(hipStream_t s, const Map2dParams &P, const int32_t 
                              double *rough, double *guessed, int32_t *out_pos, int32_t *out_neg,
                              double *out_rough, int32_t *out_vis, const uint32_t *blockcounts,
                              int nblocks, unsigned long long *host_counter);
+// ---- optional per-voxel statistics (gvom.py:1172-1299, 858-909, 1333-1378, 454-473)
+hipError_t gvom_launch_stats(hipStream_t s, const ScanParams &P, int dtype, const void *world, int64_t n,
+                             const int32_t *state, const uint32_t *tags, int xy_e, int z_e, double *sums);
+hipError_t gvom_launch_stats_finalize(hipStream_t s, double *sums, const uint32_t *row_count_dev, int64_t cap);
+hipError_t gvom_launch_fuse_stats(hipStream_t s, const FuseParams &P, const FuseDescs &KD, const MapDesc *descs_dev,
+                                  const int32_t *fstate, const uint32_t *ftags, float *fmetrics);
+hipError_t gvom_launch_voxel_cloud(hipStream_t s, const Map2dParams &P, double o0, double o1, double o2,
+                                   const int32_t *fstate, const uint32_t *ftags, const uint32_t *fhit,
+                                   const uint32_t *ftotal, const float *fmetrics, float *out, int64_t max_rows,
+                                   unsigned long long *row_counter);
 // test hooks / debug accessors
 hipError_t gvom_launch_read_dense(hipStream_t s, int xy, int zs, const int om[3], int sy_lo, int sy_hi,
                                   const uint32_t *tags, uint32_t epoch, const int32_t *state, const uint32_t *chit,

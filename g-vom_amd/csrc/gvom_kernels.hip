@@ -80,7 +80,8 @@ template <typename T, int VAR>
 __global__ __launch_bounds__(256) void k_trace(const ScanParams P, const T *__restrict__ in,
                                                long stride, long n, T *__restrict__ world,
                                                uint32_t *hit, uint32_t *total, int32_t *state,
-                                               uint32_t *tags, uint32_t *cminh, uint32_t *counters)
+                                               uint32_t *tags, uint32_t *cminh, uint32_t *counters,
+                                               double *stat_sums)
 {
     const int lane = threadIdx.x & (WAVE - 1);
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -146,6 +147,8 @@ __global__ __launch_bounds__(256) void k_trace(const ScanParams P, const T *__re
             const uint32_t row = base + (uint32_t)__popcll(cm & lanemask_lt());
             state[L] = (int32_t)row;
             cminh[row] = 0x3f800000u;                   // min-height starts at 1.0f (gvom.py:1014-1015)
+            if (stat_sums)                              // optional statistics: zeroed metrics (gvom.py:1011-1012)
+                for (int m = 0; m < 10; ++m) stat_sums[(size_t)row * 10 + m] = 0.0;
         }
     }
     if (VAR == 0 && !pass) return;
@@ -1241,6 +1244,258 @@ __global__ __launch_bounds__(256) void k_map2d(const Map2dParams P, const int32_
 }
 
 // ------------------------------------------------------------------------------------------
+// Optional per-voxel statistics.  Off the north-star path; enabled per handle.
+// Float accumulation order is unspecified on a GPU (as in the reference's f64 atomics), so these
+// results match the reference to a tolerance, not bit for bit.
+// ------------------------------------------------------------------------------------------
+
+// k_stats: gvom.py:1172-1220 + :1234-1285 in ONE pass over the points: every return adds the raw
+// moments of its position relative to each OCCUPIED voxel of its (2*xy_e+1)^2 x (2*z_e+1)
+// neighbourhood (voxel units, f64): sums[row] = {Sx, Sy, Sz, Sxx, Sxy, Sxz, Syy, Syz, Szz, n}.
+// (The reference makes two passes -- mean, then centred products; raw moments in f64 give the
+// same covariance to ~1e-13 for coordinates in [-1, 2).)  Runs after k_encode: state >= 0 in a
+// live tile identifies an occupied voxel and its row.
+template <typename T>
+__global__ __launch_bounds__(256) void k_stats(const ScanParams P, const T *__restrict__ world, long n,
+                                               const int32_t *__restrict__ state,
+                                               const uint32_t *__restrict__ tags, int xy_e, int z_e,
+                                               double *sums)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const T x = world[3 * i + 0], y = world[3 * i + 1], z = world[3 * i + 2];
+    const T d2 = (x * x + y * y) + z * z;
+    if ((double)d2 < P.min_d2) return;
+    const double ax = (double)x / P.xy_res - P.origin[0];
+    const double ay = (double)y / P.xy_res - P.origin[1];
+    const double az = (double)z / P.z_res - P.origin[2];
+    const double bx = floor(ax), by = floor(ay), bz = floor(az);
+    if (!(fabs(bx) < 1e9) || !(fabs(by) < 1e9) || !(fabs(bz) < 1e9)) return;
+    const int xb = (int)bx, yb = (int)by, zb = (int)bz;
+    for (int xi = xb - xy_e; xi <= xb + xy_e; ++xi) {
+        if (xi < 0 || xi >= P.xy) continue;
+        for (int yi = yb - xy_e; yi <= yb + xy_e; ++yi) {
+            if (yi < 0 || yi >= P.xy) continue;
+            const int sy = wrap_add(yi, P.om[1], P.xy);
+            if (sy < P.sy_lo || sy >= P.sy_hi) continue;
+            const int sx = wrap_add(xi, P.om[0], P.xy);
+            for (int zi = zb - z_e; zi <= zb + z_e; ++zi) {
+                if (zi < 0 || zi >= P.zs) continue;
+                const int sz = wrap_add(zi, P.om[2], P.zs);
+                const uint32_t rz = (uint32_t)sy * P.zs + sz;
+                if (tags[rz * P.nseg + (sx >> 6)] != P.epoch) continue;      // untouched tile
+                const int32_t row = state[rz * P.xy + sx];
+                if (row < 0) continue;
+                const double lx = ax - (double)xi, ly = ay - (double)yi, lz = az - (double)zi;
+                double *m = sums + (size_t)row * 10;
+                unsafeAtomicAdd(m + 0, lx); unsafeAtomicAdd(m + 1, ly); unsafeAtomicAdd(m + 2, lz);
+                unsafeAtomicAdd(m + 3, lx * lx); unsafeAtomicAdd(m + 4, lx * ly); unsafeAtomicAdd(m + 5, lx * lz);
+                unsafeAtomicAdd(m + 6, ly * ly); unsafeAtomicAdd(m + 7, ly * lz); unsafeAtomicAdd(m + 8, lz * lz);
+                unsafeAtomicAdd(m + 9, 1.0);
+            }
+        }
+    }
+}
+
+// raw moments -> the reference's per-scan metrics layout: mean xyz, covariance xx xy xz yy yz zz
+// (population covariance, gvom.py:1224-1230, 1289-1299), count
+__global__ void k_stats_finalize(double *sums, const uint32_t *row_count, long cap)
+{
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= cap || r >= (long)row_count[0]) return;
+    double *m = sums + r * 10;
+    const double nn = m[9];
+    if (!(nn > 0.0)) { for (int k = 0; k < 9; ++k) m[k] = 0.0; return; }
+    const double mx = m[0] / nn, my = m[1] / nn, mz = m[2] / nn;
+    const double cxx = m[3] / nn - mx * mx, cxy = m[4] / nn - mx * my, cxz = m[5] / nn - mx * mz;
+    const double cyy = m[6] / nn - my * my, cyz = m[7] / nn - my * mz, czz = m[8] / nn - mz * mz;
+    m[0] = mx; m[1] = my; m[2] = mz; m[3] = cxx; m[4] = cxy; m[5] = cxz; m[6] = cyy; m[7] = cyz; m[8] = czz;
+}
+
+// gvom.py:858-909: pooled mean / covariance merge of one voxel; the fused metrics are float32, a ring
+// slot's float64, the previous fused map's float32; TO selects the reference's arithmetic (f32*f32
+// stays f32, anything touching an f64 operand is f64 -- numpy scalar rules of the simulator).
+template <typename TO>
+__device__ __forceinline__ void merge_metrics(float (&c)[10], const TO *o)
+{
+    typedef decltype((float)1 * (TO)1) W;
+    const float c0 = c[0], c1 = c[1], c2 = c[2], c9 = c[9];
+    const TO o0 = o[0], o1 = o[1], o2 = o[2], o9 = o[9];
+    const W nn = (W)c9 + (W)o9;
+    const W cm[3] = {((W)(c0 * c9) + (W)(o0 * o9)) / nn, ((W)(c1 * c9) + (W)(o1 * o9)) / nn,
+                     ((W)(c2 * c9) + (W)(o2 * o9)) / nn};
+    const float cmean[3] = {c0, c1, c2};
+    const TO omean[3] = {o0, o1, o2};
+    const int A[6] = {0, 0, 0, 1, 1, 2}, B[6] = {0, 1, 2, 1, 2, 2};
+    float out[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int a = A[k], b = B[k];
+        W t = (W)(c9 * c[3 + k]) + (W)(o9 * o[3 + k]);
+        t = t + ((W)c9 * ((W)cmean[a] - cm[a])) * ((W)cmean[b] - cm[b]);
+        t = t + ((W)o9 * ((W)omean[a] - cm[a])) * ((W)omean[b] - cm[b]);
+        out[k] = (float)(t / nn);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) c[3 + k] = out[k];
+    c[0] = (float)cm[0]; c[1] = (float)cm[1]; c[2] = (float)cm[2];
+    c[9] = (float)nn;
+}
+
+// k_fuse_stats: the covariance half of gvom.py:821-912 for every occupied voxel of the fused map
+// written by k_fuse: sources in the reference's order (ring slots, then the previous fused map).
+__global__ __launch_bounds__(256) void k_fuse_stats(const FuseParams P, const FuseDescs KD,
+                                                    const MapDesc *__restrict__ descs_mem,
+                                                    const int32_t *__restrict__ fstate,
+                                                    const uint32_t *__restrict__ ftags, float *fmetrics)
+{
+    const MapDesc *__restrict__ descs = descs_mem ? descs_mem : KD.d;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const uint32_t wid = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const uint32_t nw = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t t0 = (uint32_t)P.sy_lo * P.zs * P.nseg, t1 = (uint32_t)P.sy_hi * P.zs * P.nseg;
+    const int nsrc = P.nslots + P.has_prev;
+    for (uint32_t tile = t0 + wid; tile < t1; tile += nw) {
+        if (ftags[tile] != P.epoch) continue;                            // wave-uniform
+        const uint32_t rz = tile / P.nseg;
+        const int sx = (int)(tile % P.nseg) * 64 + lane, sy = (int)(rz / P.zs), sz = (int)(rz % P.zs);
+        if (sx >= P.xy) continue;
+        const uint32_t L = rz * P.xy + sx;
+        const int32_t row = fstate[L];
+        if (row < 0) continue;
+        const int x = wrap_sub(sx, P.om[0], P.xy), y = wrap_sub(sy, P.om[1], P.xy), z = wrap_sub(sz, P.om[2], P.zs);
+        float c[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) c[k] = 0.0f;                        // gvom.py:234-236
+        for (int s = 0; s < nsrc; ++s) {
+            const int xs = x + descs[s].d[0], ys = y + descs[s].d[1], zs_ = z + descs[s].d[2];
+            if (xs < 0 || xs >= P.xy || ys < 0 || ys >= P.xy || zs_ < 0 || zs_ >= P.zs) continue;
+            if (descs[s].tags[tile] != descs[s].epoch) continue;
+            const int st = descs[s].state[L];
+            if (st < 0 || !descs[s].metrics) continue;
+            if (s < P.nslots) merge_metrics<double>(c, (const double *)descs[s].metrics + (size_t)st * 10);
+            else merge_metrics<float>(c, (const float *)descs[s].metrics + (size_t)st * 10);
+        }
+#pragma unroll
+        for (int k = 0; k < 10; ++k) fmetrics[(size_t)row * 10 + k] = c[k];
+    }
+}
+
+// gvom.py:1333-1378 (eigenvalues) + :454-473 (debug voxel cloud): one output row of 8 floats per
+// occupied fused voxel; output position from an atomic counter (row order is unspecified).
+__global__ __launch_bounds__(256) void k_voxel_cloud(const Map2dParams P, double o0, double o1, double o2,
+                                                     const int32_t *__restrict__ fstate,
+                                                     const uint32_t *__restrict__ ftags,
+                                                     const uint32_t *__restrict__ fhit,
+                                                     const uint32_t *__restrict__ ftotal,
+                                                     const float *__restrict__ fmetrics, float *out,
+                                                     long max_rows, unsigned long long *row_counter)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+    const uint32_t wid = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const uint32_t nw = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t t0 = (uint32_t)P.y_lo * P.zs * P.nseg, t1 = (uint32_t)P.y_hi * P.zs * P.nseg;
+    const double PI = 3.141592653589793;
+    for (uint32_t tile = t0 + wid; tile < t1; tile += nw) {
+        if (ftags[tile] != P.epoch) continue;
+        const uint32_t rz = tile / P.nseg;
+        const int sx = (int)(tile % P.nseg) * 64 + lane, sy = (int)(rz / P.zs), sz = (int)(rz % P.zs);
+        int32_t row = -1;
+        if (sx < P.xy) row = fstate[rz * P.xy + sx];
+        const unsigned long long b = __ballot(row >= 0);
+        if (b == 0ull) continue;
+        unsigned long long base = 0;
+        const int leader = __ffsll((long long)b) - 1;
+        if (lane == leader) base = atomicAdd(row_counter, (unsigned long long)__popcll(b));
+        base = __shfl((long long)base, leader);
+        if (row < 0) continue;
+        const long pos = (long)base + __popcll(b & lanemask_lt());
+        if (pos >= max_rows) continue;
+        const float *m = fmetrics + (size_t)row * 10;
+        const float xx = m[3], xy = m[4], xz = m[5], yy = m[6], yz = m[7], zz = m[8];
+        const float p1 = (xy * xy + xz * xz) + yz * yz;
+        const double q = (double)((xx + yy) + zz) / 3.0;
+        float e0, e1, e2;
+        if (p1 == 0) {
+            e0 = py_maxf(xx, py_maxf(yy, zz));
+            const float mn = (zz < yy) ? zz : yy;
+            e2 = (mn < xx) ? mn : xx;
+            e1 = (float)((3.0 * q - (double)e0) - (double)e2);
+        } else {
+            const double p2 = ((((double)xx - q) * ((double)xx - q) + ((double)yy - q) * ((double)yy - q))
+                               + ((double)zz - q) * ((double)zz - q)) + 2.0 * (double)p1;
+            const double p = sqrt(p2 / 6.0);
+            const double B0 = ((double)xx - q) / p, B1 = (double)xy / p, B2 = (double)xz / p;
+            const double B3 = ((double)yy - q) / p, B4 = (double)yz / p, B5 = ((double)zz - q) / p;
+            double r = (B0 * (B3 * B5 - B4 * B4) - B1 * (B1 * B5 - B4 * B2)) + B2 * (B1 * B4 - B3 * B2);
+            r = r / 2;
+            double phi;
+            if (r <= -1) phi = PI / 3.0;
+            else if (r >= 1) phi = 0.0;
+            else phi = acos(r) / 3.0;
+            e0 = (float)(q + 2.0 * p * cos(phi));
+            e2 = (float)(q + 2.0 * p * cos(phi + (2.0 * PI / 3.0)));
+            e1 = (float)((3.0 * q - (double)e0) - (double)e2);
+        }
+        const int x = wrap_sub(sx, P.om[0], P.xy), y = wrap_sub(sy, P.om[1], P.xy), z = wrap_sub(sz, P.om[2], P.zs);
+        float *o = out + pos * 8;
+        const uint32_t hc = fhit[row], tc = ftotal[row];
+        o[0] = (float)(((double)x + o0) * P.xy_res);
+        o[1] = (float)(((double)y + o1) * P.xy_res);
+        o[2] = (float)(((double)z + o2) * P.z_res);
+        o[3] = (float)((double)(int32_t)hc / (double)(int32_t)tc);
+        o[4] = (float)(int32_t)hc;
+        o[5] = e0 - e1; o[6] = e1 - e2; o[7] = e2;
+    }
+}
+
+hipError_t gvom_launch_stats(hipStream_t s, const ScanParams &P, int dtype, const void *world, int64_t n,
+                             const int32_t *state, const uint32_t *tags, int xy_e, int z_e, double *sums)
+{
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    if (dtype == 0)
+        hipLaunchKernelGGL(k_stats<float>, dim3(blocks), dim3(256), 0, s, P, (const float *)world, (long)n, state,
+                           tags, xy_e, z_e, sums);
+    else
+        hipLaunchKernelGGL(k_stats<double>, dim3(blocks), dim3(256), 0, s, P, (const double *)world, (long)n, state,
+                           tags, xy_e, z_e, sums);
+    return hipGetLastError();
+}
+
+hipError_t gvom_launch_stats_finalize(hipStream_t s, double *sums, const uint32_t *row_count_dev, int64_t cap)
+{
+    if (cap <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_stats_finalize, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, s, sums, row_count_dev,
+                       (long)cap);
+    return hipGetLastError();
+}
+
+hipError_t gvom_launch_fuse_stats(hipStream_t s, const FuseParams &P, const FuseDescs &KD, const MapDesc *descs_dev,
+                                  const int32_t *fstate, const uint32_t *ftags, float *fmetrics)
+{
+    const uint32_t ntiles = (uint32_t)(P.sy_hi - P.sy_lo) * P.zs * P.nseg;
+    if (ntiles == 0) return hipSuccess;
+    unsigned blocks = (ntiles + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_fuse_stats, dim3(blocks), dim3(256), 0, s, P, KD, descs_dev, fstate, ftags, fmetrics);
+    return hipGetLastError();
+}
+
+hipError_t gvom_launch_voxel_cloud(hipStream_t s, const Map2dParams &P, double o0, double o1, double o2,
+                                   const int32_t *fstate, const uint32_t *ftags, const uint32_t *fhit,
+                                   const uint32_t *ftotal, const float *fmetrics, float *out, int64_t max_rows,
+                                   unsigned long long *row_counter)
+{
+    const uint32_t ntiles = (uint32_t)(P.y_hi - P.y_lo) * P.zs * P.nseg;
+    if (ntiles == 0) return hipSuccess;
+    unsigned blocks = (ntiles + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_voxel_cloud, dim3(blocks), dim3(256), 0, s, P, o0, o1, o2, fstate, ftags, fhit, ftotal,
+                       fmetrics, out, (long)max_rows, row_counter);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // Test hooks / debug accessors (not on the hot path)
 // ------------------------------------------------------------------------------------------
 // storage order + compact rows -> dense arrays in the reference's x + y*xy + z*xy*xy order
@@ -1348,13 +1603,14 @@ hipError_t gvom_launch_publish_count(hipStream_t s, const uint32_t *blockcounts,
 hipError_t gvom_launch_trace(hipStream_t s, const ScanParams &P, int dtype, const void *pts,
                              int64_t stride_elems, int64_t n, void *world, uint32_t *hit,
                              uint32_t *total, int32_t *state, uint32_t *tags, uint32_t *cminh,
-                             uint32_t *counters, int variant)
+                             uint32_t *counters, int variant, double *stat_sums)
 {
     const unsigned blocks = (unsigned)((n + 255) / 256);
     const unsigned nsegs = (variant == 0 || variant == 9) ? 1u : (unsigned)P.nsegs;
 #define TRACE_LAUNCH(TT, VV)                                                                     \
     hipLaunchKernelGGL((k_trace<TT, VV>), dim3(blocks, nsegs), dim3(256), 0, s, P, (const TT *)pts, \
-                       (long)stride_elems, (long)n, (TT *)world, hit, total, state, tags, cminh, counters)
+                       (long)stride_elems, (long)n, (TT *)world, hit, total, state, tags, cminh, counters, \
+                       stat_sums)
     if (dtype == 0) {
         if (variant == 0) TRACE_LAUNCH(float, 0);
         else if (variant == 9) TRACE_LAUNCH(float, 9);

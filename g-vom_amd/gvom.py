@@ -97,6 +97,7 @@ ABI = [
     ("gvom_get_state", _I, [_P, ctypes.POINTER(GvomState)]),
     ("gvom_get_scan_stats", _I, [_P, ctypes.POINTER(GvomScanStats)]),
     ("gvom_get_occupancy", _I, [_P, _P]),
+    ("gvom_debug_voxel_map", _I, [_P, _P, _I64, ctypes.POINTER(_I64)]),
     ("gvom_debug_height_map", _I, [_P, _P]),
     ("gvom_debug_inferred_height_map", _I, [_P, _P]),
     ("gvom_read_dense", _I, [_P, _I, _P, _P, _P, _P, _P, ctypes.POINTER(_I64)]),
@@ -181,7 +182,7 @@ class Gvom(object):
     def __init__(self, xy_resolution, z_resolution, xy_size, z_size, buffer_size, min_distance,
                  positive_obstacle_threshold, negative_obstacle_threshold, slope_obstacle_threshold,
                  robot_height, robot_radius, ground_to_lidar_height, xy_eigen_dist, z_eigen_dist,
-                 device=0, _shard=None):
+                 device=0, voxel_statistics=False, _shard=None):
         self.xy_resolution = xy_resolution
         self.z_resolution = z_resolution
         self.xy_size = xy_size
@@ -206,7 +207,7 @@ class Gvom(object):
         self._lib = load_library()
         self._h = ctypes.c_void_p()
         prm = GvomParams(float(xy_resolution), float(z_resolution), int(xy_size), int(z_size),
-                         int(buffer_size), 0, float(min_distance),
+                         int(buffer_size), 1 if voxel_statistics else 0, float(min_distance),
                          float(positive_obstacle_threshold), float(negative_obstacle_threshold),
                          float(slope_obstacle_threshold), float(robot_height), float(robot_radius),
                          float(ground_to_lidar_height), int(xy_eigen_dist), int(z_eigen_dist))
@@ -336,11 +337,19 @@ class Gvom(object):
         return out.astype(bool)
 
     def make_debug_voxel_map(self):
-        # per-voxel eigenvalue statistics are a "next" row; the reference's
-        # caller tolerates None (gvom_ros.py:171-172)
-        if self.combined_cell_count_cpu is None:
+        """float32[Cc, 8] rows {x, y, z, hit/total, hit, l0-l1, l1-l2, l2} (reference gvom.py:363-378)
+        when the mapper was created with voxel_statistics=True (or GVOM_VOXEL_STATISTICS=1); else
+        None, which the reference's caller tolerates (gvom_ros.py:171-172)."""
+        n = self.combined_cell_count_cpu
+        if n is None:
             print("No data")
-        return None
+            return None
+        out = np.empty((max(n, 1), 8), np.float32)
+        rows = ctypes.c_int64(0)
+        rc = self._check(self._lib.gvom_debug_voxel_map(self._h, _ptr(out), n, ctypes.byref(rows)))
+        if rc == GVOM_NO_DATA:
+            return None
+        return out[:min(n, int(rows.value))]
 
     def make_debug_height_map(self):
         out = np.empty((self.xy_size * self.xy_size, 7), np.float32)

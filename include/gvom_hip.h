@@ -51,7 +51,7 @@ typedef struct gvom_params {
     int32_t xy_size;
     int32_t z_size;
     int32_t buffer_size;
-    int32_t reserved0;
+    int32_t reserved0;             /* flags: GVOM_FLAG_* */
     double  min_distance;
     double  positive_obstacle_threshold;
     double  negative_obstacle_threshold;
@@ -62,6 +62,12 @@ typedef struct gvom_params {
     int32_t xy_eigen_dist;
     int32_t z_eigen_dist;
 } gvom_params;
+
+/* gvom_params.reserved0 flags */
+#define GVOM_FLAG_VOXEL_STATISTICS 1   /* also run the per-voxel mean/covariance path (gvom.py:1172-1299,
+                                        * 858-909, 1333-1378) that feeds only make_debug_voxel_map; off by
+                                        * default: it is not on the north-star path and costs scan time.
+                                        * The environment variable GVOM_VOXEL_STATISTICS=0/1 overrides. */
 
 /* Ring-buffer bookkeeping visible on the reference object (gvom.py:56-58,172-175). */
 typedef struct gvom_state {
@@ -167,6 +173,11 @@ int gvom_get_scan_stats(gvom_t *h, gvom_scan_stats *out);
 /* Gvom.get_map_as_occupancy_grid (gvom.py:356-361): uint8[xy][xy][z] C-order (== the
  * reference's order='F' reshape of the lookup table), 1 where occupied. */
 int gvom_get_occupancy(gvom_t *h, uint8_t *out_xyz);
+/* Gvom.make_debug_voxel_map (gvom.py:363-378; kernels :1333-1378 eigenvalues, :454-473): one row of
+ * 8 float32 per occupied fused voxel {x, y, z, hit/total, hit, l0-l1, l1-l2, l2}; row order is
+ * unspecified (as in the reference).  *rows = number of occupied voxels; at most max_rows are written.
+ * GVOM_NO_DATA unless the handle was created with GVOM_FLAG_VOXEL_STATISTICS and has combined. */
+int gvom_debug_voxel_map(gvom_t *h, float *out, int64_t max_rows, int64_t *rows);
 /* Gvom.make_debug_height_map (gvom.py:380-394, kernel :426-438): float32[xy*xy][7]. */
 int gvom_debug_height_map(gvom_t *h, float *out);
 /* Gvom.make_debug_inferred_height_map (gvom.py:396-410, kernel :442-450): float32[xy*xy][3]. */

@@ -154,6 +154,51 @@ ORC_API int64_t orc_calculate_min_height_##SUF(double xy_res, double z_res, int6
         if (row >= 0) { if (v < min_height[row]) min_height[row] = v; ++n_in; }                 \
     }                                                                                           \
     return n_in;                                                                                \
+}                                                                                               \
+                                                                                                \
+/* gvom.py:1172-1220 __calculate_mean (pass = 0) and :1234-1285 __calculate_covariance        \
+ * (pass = 1): every point adds to each OCCUPIED voxel of its (2*xy_e+1)^2*(2*z_e+1)           \
+ * neighbourhood its coordinates relative to that voxel's corner (voxel units, f64).           \
+ * metrics: double[C][10] = mean xyz, cov xx xy xz yy yz zz, count. */                         \
+ORC_API void orc_calculate_stats_##SUF(int pass, double xy_res, double z_res, int64_t xy,       \
+        int64_t zs, double min_distance, const int32_t *index_map, const T *pts, int64_t n,     \
+        int64_t stride, double *metrics, const double *origin, int64_t xy_e, int64_t z_e)       \
+{                                                                                               \
+    const double md2 = min_distance * min_distance;                                             \
+    for (int64_t i = 0; i < n; ++i) {                                                           \
+        const T *p = pts + i * stride;                                                          \
+        T d2 = (T)((T)((T)(p[0] * p[0]) + (T)(p[1] * p[1])) + (T)(p[2] * p[2]));                \
+        if ((double)d2 < md2) continue;                                                         \
+        const double ax = (double)p[0] / xy_res - origin[0];                                    \
+        const double ay = (double)p[1] / xy_res - origin[1];                                    \
+        const double az = (double)p[2] / z_res - origin[2];                                     \
+        const double bx = floor(ax), by = floor(ay), bz = floor(az);                            \
+        if (!(fabs(bx) < 1e15) || !(fabs(by) < 1e15) || !(fabs(bz) < 1e15)) continue;           \
+        const int64_t xb = (int64_t)bx, yb = (int64_t)by, zb = (int64_t)bz;                     \
+        for (int64_t xi = xb - xy_e; xi < xb + 1 + xy_e; ++xi) {                                \
+            if (xi < 0 || xi >= xy) continue;                                                   \
+            for (int64_t yi = yb - xy_e; yi < yb + 1 + xy_e; ++yi) {                            \
+                if (yi < 0 || yi >= xy) continue;                                               \
+                for (int64_t zi = zb - z_e; zi < zb + 1 + z_e; ++zi) {                          \
+                    if (zi < 0 || zi >= zs) continue;                                           \
+                    const int32_t row = index_map[xi + yi * xy + zi * xy * xy];                 \
+                    if (row < 0) continue;                                                      \
+                    const double lx = ax - (double)xi, ly = ay - (double)yi, lz = az - (double)zi; \
+                    double *m = metrics + (int64_t)row * 10;                                    \
+                    if (pass == 0) {                                                            \
+                        m[0] += lx; m[1] += ly; m[2] += lz; m[9] += 1.0;                        \
+                    } else {                                                                    \
+                        m[3] += (lx - m[0]) * (lx - m[0]);                                      \
+                        m[4] += (lx - m[0]) * (ly - m[1]);                                      \
+                        m[5] += (lx - m[0]) * (lz - m[2]);                                      \
+                        m[6] += (ly - m[1]) * (ly - m[1]);                                      \
+                        m[7] += (ly - m[1]) * (lz - m[2]);                                      \
+                        m[8] += (lz - m[2]) * (lz - m[2]);                                      \
+                    }                                                                           \
+                }                                                                               \
+            }                                                                                   \
+        }                                                                                       \
+    }                                                                                           \
 }
 
 GEN_POINT_KERNELS(float, f32)
@@ -512,6 +557,138 @@ ORC_API void orc_make_inferred_height_map_pointcloud(const double *map, const do
             out[index * 3 + 1] = (float)(((double)y + origin[1]) * xy_res);
             out[index * 3 + 2] = (float)(map[x * xy + y] - z_res);
         }
+}
+
+/* ------------------------------------------------------------------------------------
+ * "Next" rows: per-voxel statistics, their temporal merge, eigenvalues and
+ * the debug voxel cloud.  Float accumulation order is unspecified on a GPU, so everything
+ * below is compared to a tolerance, not bit for bit.
+ * ---------------------------------------------------------------------------------- */
+
+/* gvom.py:1224-1230 __normalize_mean and :1289-1299 __normalize_covariance */
+ORC_API void orc_normalize_stats(int pass, double *metrics, int64_t cell_count)
+{
+    for (int64_t i = 0; i < cell_count; ++i) {
+        double *m = metrics + i * 10;
+        if (pass == 0) { m[0] /= m[9]; m[1] /= m[9]; m[2] /= m[9]; }
+        else for (int j = 3; j < 9; ++j) m[j] = (m[9] <= 0) ? 0.0 : m[j] / m[9];
+    }
+}
+
+/* gvom.py:858-909 pooled mean / covariance merge of one voxel.  The fused metrics are float32
+ * (gvom.py:234); a ring slot's are float64 (gvom.py:1011), the previous fused map's float32.
+ * Under the simulator's numpy scalar rules f32*f32 stays f32 and anything touching an f64
+ * operand is f64 -- TO is the old map's type and selects exactly that arithmetic. */
+#define GEN_MERGE(TO, SUF)                                                                      \
+static void merge_metrics_##SUF(float *c, const TO *o)                                          \
+{                                                                                               \
+    typedef __typeof__((float)1 * (TO)1) W;          /* float or double */                       \
+    const float c0 = c[0], c1 = c[1], c2 = c[2], c9 = c[9];                                     \
+    const TO o0 = o[0], o1 = o[1], o2 = o[2], o9 = o[9];                                        \
+    const W n = (W)c9 + (W)o9;                                                                  \
+    const W mx = ((W)(c0 * c9) + (W)(o0 * o9)) / n;                                             \
+    const W my = ((W)(c1 * c9) + (W)(o1 * o9)) / n;                                             \
+    const W mz = ((W)(c2 * c9) + (W)(o2 * o9)) / n;                                             \
+    const W cm[3] = {mx, my, mz};                                                               \
+    const float cmean[3] = {c0, c1, c2};                                                        \
+    const TO omean[3] = {o0, o1, o2};                                                           \
+    static const int A[6] = {0, 0, 0, 1, 1, 2}, B[6] = {0, 1, 2, 1, 2, 2};                      \
+    float out[6];                                                                               \
+    for (int k = 0; k < 6; ++k) {                                                               \
+        const int a = A[k], b = B[k];                                                           \
+        W t = (W)(c9 * c[3 + k]) + (W)(o9 * o[3 + k]);                                          \
+        t = t + ((W)c9 * ((W)cmean[a] - cm[a])) * ((W)cmean[b] - cm[b]);                        \
+        t = t + ((W)o9 * ((W)omean[a] - cm[a])) * ((W)omean[b] - cm[b]);                        \
+        out[k] = (float)(t / n);                                                                \
+    }                                                                                           \
+    for (int k = 0; k < 6; ++k) c[3 + k] = out[k];                                              \
+    c[0] = (float)mx; c[1] = (float)my; c[2] = (float)mz;                                       \
+    c[9] = (float)n;                                                                            \
+}                                                                                               \
+/* gvom.py:821-912 __combine_metrics, complete (covariance merge + lines 910-912) */           \
+ORC_API void orc_combine_metrics_full_##SUF(float *combined_metrics, int32_t *combined_hit,     \
+        int32_t *combined_total, float *combined_min_height, const int32_t *combined_index_map, \
+        const double *combined_origin, const TO *old_metrics, const int32_t *old_hit,           \
+        const int32_t *old_total, const float *old_min_height, const int32_t *old_index_map,    \
+        const double *old_origin, int64_t xy, int64_t zs)                                       \
+{                                                                                               \
+    double d[3] = { combined_origin[0] - old_origin[0], combined_origin[1] - old_origin[1],     \
+                    combined_origin[2] - old_origin[2] };                                       \
+    for (int64_t z = 0; z < zs; ++z)                                                            \
+        for (int64_t y = 0; y < xy; ++y)                                                        \
+            for (int64_t x = 0; x < xy; ++x) {                                                  \
+                int64_t io;                                                                     \
+                if (!shifted_index(x, y, z, d, xy, zs, &io)) continue;                          \
+                int32_t index = combined_index_map[x + y * xy + z * xy * xy];                   \
+                int32_t index_old = old_index_map[io];                                          \
+                if (index < 0 || index_old < 0) continue;                                       \
+                merge_metrics_##SUF(combined_metrics + (int64_t)index * 10,                     \
+                                    old_metrics + (int64_t)index_old * 10);                     \
+                combined_hit[index] = combined_hit[index] + old_hit[index_old];                 \
+                combined_total[index] = combined_total[index] + old_total[index_old];           \
+                float a = combined_min_height[index], b = old_min_height[index_old];            \
+                combined_min_height[index] = (b < a) ? b : a;                                   \
+            }                                                                                   \
+}
+GEN_MERGE(double, f64)
+GEN_MERGE(float, f32)
+
+/* gvom.py:1333-1378 __calculate_eigenvalues: closed-form eigenvalues of the symmetric 3x3
+ * covariance (trigonometric method); metrics float32[C][10] -> eigenvalues float32[C][3]. */
+ORC_API void orc_calculate_eigenvalues(float *ev, const float *metrics, int64_t cell_count)
+{
+    const double PI = 3.141592653589793;
+    for (int64_t i = 0; i < cell_count; ++i) {
+        const float *m = metrics + i * 10;
+        const float xx = m[3], xy = m[4], xz = m[5], yy = m[6], yz = m[7], zz = m[8];
+        const float p1 = (float)((float)(xy * xy) + (float)(xz * xz)) + (float)(yz * yz);   /* f32 */
+        const double q = (double)((float)((float)(xx + yy) + zz)) / 3.0;
+        float *e = ev + i * 3;
+        if (p1 == 0) {
+            e[0] = py_maxf(xx, py_maxf(yy, zz));
+            const float mn_yz = (zz < yy) ? zz : yy;          /* Python min(yy, zz) */
+            e[2] = (mn_yz < xx) ? mn_yz : xx;                 /* Python min(xx, .) */
+            e[1] = (float)((3.0 * q - (double)e[0]) - (double)e[2]);
+        } else {
+            const double p2 = ((((double)xx - q) * ((double)xx - q) + ((double)yy - q) * ((double)yy - q))
+                               + ((double)zz - q) * ((double)zz - q)) + 2.0 * (double)p1;
+            const double p = sqrt(p2 / 6.0);
+            const double B0 = ((double)xx - q) / p, B1 = (double)xy / p, B2 = (double)xz / p;
+            const double B3 = ((double)yy - q) / p, B4 = (double)yz / p, B5 = ((double)zz - q) / p;
+            double r = (B0 * (B3 * B5 - B4 * B4) - B1 * (B1 * B5 - B4 * B2)) + B2 * (B1 * B4 - B3 * B2);
+            r = r / 2;
+            double phi;
+            if (r <= -1) phi = PI / 3.0;
+            else if (r >= 1) phi = 0.0;
+            else phi = acos(r) / 3.0;
+            e[0] = (float)(q + 2.0 * p * cos(phi));
+            e[2] = (float)(q + 2.0 * p * cos(phi + (2.0 * PI / 3.0)));
+            e[1] = (float)((3.0 * q - (double)e[0]) - (double)e[2]);
+        }
+    }
+}
+
+/* gvom.py:454-473 __make_voxel_pointcloud -> float32[Cc][8], one row per occupied fused voxel,
+ * row = its compact index (order unspecified on a GPU; tests sort the rows). */
+ORC_API void orc_make_voxel_pointcloud(const int32_t *combined_index_map, const int32_t *hit,
+        const int32_t *total, const float *ev, const double *origin, float *out, int64_t xy,
+        int64_t zs, double xy_res, double z_res)
+{
+    for (int64_t z = 0; z < zs; ++z)
+        for (int64_t y = 0; y < xy; ++y)
+            for (int64_t x = 0; x < xy; ++x) {
+                const int32_t index = combined_index_map[x + y * xy + z * xy * xy];
+                if (index < 0) continue;
+                float *o = out + (int64_t)index * 8;
+                o[0] = (float)(((double)x + origin[0]) * xy_res);
+                o[1] = (float)(((double)y + origin[1]) * xy_res);
+                o[2] = (float)(((double)z + origin[2]) * z_res);
+                o[3] = (float)((double)hit[index] / (double)total[index]);
+                o[4] = (float)hit[index];
+                o[5] = ev[index * 3 + 0] - ev[index * 3 + 1];
+                o[6] = ev[index * 3 + 1] - ev[index * 3 + 2];
+                o[7] = ev[index * 3 + 2];
+            }
 }
 
 ORC_API int orc_abi_version(void) { return 1; }

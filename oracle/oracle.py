@@ -50,6 +50,15 @@ def lib():
             f = getattr(L, "orc_calculate_min_height_" + suf)
             f.argtypes = [_f64, _f64, _i64, _i64, _f64, _P, _P, _i64, _i64, _P, _P]
             f.restype = _i64
+            f = getattr(L, "orc_calculate_stats_" + suf)
+            f.argtypes = [_c.c_int, _f64, _f64, _i64, _i64, _f64, _P, _P, _i64, _i64, _P, _P, _i64, _i64]
+            f.restype = None
+            f = getattr(L, "orc_combine_metrics_full_" + suf)
+            f.argtypes = [_P] * 12 + [_i64, _i64]; f.restype = None
+        L.orc_normalize_stats.argtypes = [_c.c_int, _P, _i64]; L.orc_normalize_stats.restype = None
+        L.orc_calculate_eigenvalues.argtypes = [_P, _P, _i64]; L.orc_calculate_eigenvalues.restype = None
+        L.orc_make_voxel_pointcloud.argtypes = [_P, _P, _P, _P, _P, _P, _i64, _i64, _f64, _f64]
+        L.orc_make_voxel_pointcloud.restype = None
         L.orc_assign_indices.argtypes = [_P, _P, _P, _i64]; L.orc_assign_indices.restype = _c.c_int32
         L.orc_move_data.argtypes = [_P, _P, _P, _i64]; L.orc_move_data.restype = None
         for name in ("orc_combine_indices", "orc_combine_old_indices"):
@@ -156,7 +165,16 @@ class OracleGvom:
 
     def __init__(self, xy_resolution, z_resolution, xy_size, z_size, buffer_size, min_distance,
                  positive_obstacle_threshold, negative_obstacle_threshold, slope_obstacle_threshold,
-                 robot_height, robot_radius, ground_to_lidar_height, xy_eigen_dist, z_eigen_dist):
+                 robot_height, robot_radius, ground_to_lidar_height, xy_eigen_dist, z_eigen_dist,
+                 voxel_statistics=False):
+        # voxel_statistics: also restate the per-voxel mean/covariance/eigenvalue path (SURVEY 8f
+        # rank 2: gvom.py:1172-1299, 858-909, 1333-1378, 363-378).  Off by default so that the
+        # timed CPU baseline covers the same work as the GPU hot path.
+        self.voxel_statistics = voxel_statistics
+        self.metrics_buffer = [None] * buffer_size
+        self.combined_metrics = None
+        self.last_combined_metrics = None
+        self.voxels_eigenvalues = None
         self.xy_resolution = xy_resolution
         self.z_resolution = z_resolution
         self.xy_size = xy_size
@@ -237,7 +255,17 @@ class OracleGvom:
         self.last_scan_points_in_grid = getattr(L, "orc_calculate_min_height_" + suf)(      # :1032
             self.xy_resolution, self.z_resolution, self.xy_size, self.z_size, self.min_distance,
             _p(index_map), _p(pc), point_count, pc.shape[1], _p(min_height), _p(origin))
+        metrics = None
+        if self.voxel_statistics:                                                            # :1011-1030
+            metrics = np.zeros((cell_count, 10), np.float64)
+            for ps in (0, 1):
+                getattr(L, "orc_calculate_stats_" + suf)(
+                    ps, self.xy_resolution, self.z_resolution, self.xy_size, self.z_size,
+                    self.min_distance, _p(index_map), _p(pc), point_count, pc.shape[1], _p(metrics),
+                    _p(origin), self.xy_eigen_dist, self.z_eigen_dist)
+                L.orc_normalize_stats(ps, _p(metrics), cell_count)
         b = self.buffer_index                                                                # :163
+        self.metrics_buffer[b] = metrics
         self.index_buffer[b] = index_map
         self.hit_count_buffer[b] = hit
         self.total_count_buffer[b] = total
@@ -276,7 +304,9 @@ class OracleGvom:
         self.combined_hit_count = np.zeros(Cc, np.int32)
         self.combined_total_count = np.zeros(Cc, np.int32)
         self.combined_min_height = np.ones(Cc, np.float32)
-        for i in range(self.buffer_size):                                                    # :238
+        if self.voxel_statistics:
+            self._combine_with_statistics(Cc)
+        for i in range(self.buffer_size if not self.voxel_statistics else 0):                # :238
             if self.origin_buffer[i] is None:
                 continue
             L.orc_combine_metrics(_p(self.combined_hit_count), _p(self.combined_total_count),
@@ -284,7 +314,7 @@ class OracleGvom:
                                   _p(self.combined_origin), _p(self.hit_count_buffer[i]),
                                   _p(self.total_count_buffer[i]), _p(self.min_height_buffer[i]),
                                   _p(self.index_buffer[i]), _p(self.origin_buffer[i]), xy, zs)
-        if self.last_combined_origin is not None:                                            # :254
+        if self.last_combined_origin is not None and not self.voxel_statistics:              # :254
             L.orc_combine_metrics(_p(self.combined_hit_count), _p(self.combined_total_count),
                                   _p(self.combined_min_height), _p(self.combined_index_map),
                                   _p(self.combined_origin), _p(self.last_combined_hit_count),
@@ -328,6 +358,45 @@ class OracleGvom:
         visibility = np.zeros((xy, xy), np.int32)                                            # :348
         L.orc_make_visibility_map(_p(visibility), _p(self.height_map), xy)
         return (origin_world, positive, negative, self.roughness_map.copy(), visibility)
+
+    def _combine_with_statistics(self, Cc):
+        """gvom.py:234-284 with the covariance merge: slots (float64 metrics) in slot order, then
+        the previous fused map (float32 metrics), then the eigenvalues."""
+        L = lib()
+        xy, zs = self.xy_size, self.z_size
+        self.combined_metrics = np.zeros((Cc, 10), np.float32)
+        for i in range(self.buffer_size):
+            if self.origin_buffer[i] is None:
+                continue
+            L.orc_combine_metrics_full_f64(
+                _p(self.combined_metrics), _p(self.combined_hit_count), _p(self.combined_total_count),
+                _p(self.combined_min_height), _p(self.combined_index_map), _p(self.combined_origin),
+                _p(self.metrics_buffer[i]), _p(self.hit_count_buffer[i]), _p(self.total_count_buffer[i]),
+                _p(self.min_height_buffer[i]), _p(self.index_buffer[i]), _p(self.origin_buffer[i]), xy, zs)
+        if self.last_combined_origin is not None:
+            L.orc_combine_metrics_full_f32(
+                _p(self.combined_metrics), _p(self.combined_hit_count), _p(self.combined_total_count),
+                _p(self.combined_min_height), _p(self.combined_index_map), _p(self.combined_origin),
+                _p(self.last_combined_metrics), _p(self.last_combined_hit_count),
+                _p(self.last_combined_total_count), _p(self.last_combined_min_height),
+                _p(self.last_combined_index_map), _p(self.last_combined_origin), xy, zs)
+        self.last_combined_metrics = self.combined_metrics
+        self.voxels_eigenvalues = np.zeros((Cc, 3), np.float32)
+        L.orc_calculate_eigenvalues(_p(self.voxels_eigenvalues), _p(self.combined_metrics), Cc)
+
+    # gvom.py:363-378
+    def make_debug_voxel_map(self):
+        if self.combined_cell_count_cpu is None:
+            print("No data")
+            return None
+        if not self.voxel_statistics:
+            return None
+        out = np.zeros([self.combined_cell_count_cpu, 8], np.float32)
+        lib().orc_make_voxel_pointcloud(_p(self.combined_index_map), _p(self.combined_hit_count),
+                                        _p(self.combined_total_count), _p(self.voxels_eigenvalues),
+                                        _p(self.combined_origin), _p(out), self.xy_size, self.z_size,
+                                        self.xy_resolution, self.z_resolution)
+        return out
 
     # gvom.py:356-361
     def get_map_as_occupancy_grid(self):

@@ -253,6 +253,11 @@ def run_and_record(make_gvom, scenario, record_debug=True):
                 rec[pre + "occupancy"] = np.asarray(g.get_map_as_occupancy_grid())
                 rec[pre + "debug_height_map"] = np.asarray(g.make_debug_height_map())
                 rec[pre + "debug_inferred_height_map"] = np.asarray(g.make_debug_inferred_height_map())
+                vox = g.make_debug_voxel_map()
+                if vox is not None:                  # rows = compact index (unspecified order): sort by xyz
+                    vox = np.asarray(vox)
+                    order = np.lexsort((vox[:, 2], vox[:, 1], vox[:, 0]))
+                    rec[pre + "debug_voxel_map"] = vox[order]
     return rec
 
 

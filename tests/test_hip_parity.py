@@ -41,6 +41,33 @@ def test_hip_reproduces_reference_golden(gvom_mod, name):
     assert compare_records(got, want, float_tol=1e-5) > 5
 
 
+@pytest.mark.parametrize("name", ["f1", "f2", "f3", "f4", "f5", "f6"])
+def test_hip_voxel_statistics_match_reference_golden(gvom_mod, name):
+    """Opt-in per-voxel statistics: make_debug_voxel_map against the rows the
+    reference produced (sorted by voxel; f64 atomic accumulation order is unspecified on both
+    sides, so eigenvalue columns are held to 1e-4 relative / 2e-5 absolute), everything else as in
+    the default configuration."""
+    want = np.load(os.path.join(G, name + ".npz"))
+    sc = scenarios.scenario_from_record(want)
+    got = scenarios.run_and_record(lambda *p: gvom_mod.Gvom(*p, voxel_statistics=True), sc)
+    assert compare_records(got, want, float_tol=1e-5, stats_rtol=1e-4, stats_atol=2e-5) > 5
+    assert any(k.endswith("debug_voxel_map") for k in got) == any(k.endswith("debug_voxel_map") for k in want.files)
+
+
+def test_hip_voxel_statistics_match_oracle_c2(gvom_mod):
+    """Statistics at full c2 size over 3 scans with a moving sensor and buffer=2 (ring slots in
+    float64, previous fused map in float32, as in the reference)."""
+    params, scans = synth.config_inputs("c2", n_scans=3)
+    params = params[:4] + (2,) + params[5:]
+    steps = []
+    for s in scans:
+        steps += [("scan",) + s, ("combine",)]
+    sc = {"params": params, "steps": steps}
+    want = scenarios.run_and_record(lambda *p: oracle.OracleGvom(*p, voxel_statistics=True), sc)
+    got = scenarios.run_and_record(lambda *p: gvom_mod.Gvom(*p, voxel_statistics=True), sc)
+    assert compare_records(got, want, float_tol=1e-5, stats_rtol=1e-4, stats_atol=2e-5) > 20
+
+
 def _run_both(gvom_mod, params, steps, record_debug=True):
     sc = {"params": params, "steps": steps}
     want = scenarios.run_and_record(oracle.OracleGvom, sc, record_debug=record_debug)
