@@ -102,7 +102,7 @@ struct Map2dParams {
 hipError_t gvom_launch_trace(hipStream_t s, const ScanParams &P, int dtype, const void *pts,
                              int64_t stride_elems, int64_t n, void *world, uint32_t *hit,
                              uint32_t *total, int32_t *state, uint32_t *tags, uint32_t *cminh,
-                             uint32_t *counters, int variant, double *stat_sums);
+                             uint32_t *counters, int variant, double *stat_sums, double *stat_base);
 hipError_t gvom_launch_encode(hipStream_t s, const ScanParams &P, int dtype, const void *world,
                               int64_t n, uint32_t *hit, uint32_t *total, int32_t *state,
                               uint32_t *chit, uint32_t *ctotal, uint32_t *cminh, const uint32_t *tags,
@@ -120,8 +120,8 @@ hipError_t gvom_launch_map2d(hipStream_t s, const Map2dParams &P, const int32_t 
                              int nblocks, unsigned long long *host_counter);
 // ---- optional per-voxel statistics (gvom.py:1172-1299, 858-909, 1333-1378, 454-473)
 hipError_t gvom_launch_stats(hipStream_t s, const ScanParams &P, int dtype, const void *world, int64_t n,
-                             const int32_t *state, const uint32_t *tags, int xy_e, int z_e, double *sums);
-hipError_t gvom_launch_stats_finalize(hipStream_t s, double *sums, const uint32_t *row_count_dev, int64_t cap);
+                             const int32_t *state, const uint32_t *tags, int xy_e, int z_e, double *base,
+                             double *sums);
 hipError_t gvom_launch_fuse_stats(hipStream_t s, const FuseParams &P, const FuseDescs &KD, const MapDesc *descs_dev,
                                   const int32_t *fstate, const uint32_t *ftags, float *fmetrics);
 hipError_t gvom_launch_voxel_cloud(hipStream_t s, const Map2dParams &P, double o0, double o1, double o2,

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void k_trace(const ScanParams P, const T *__re
                                                long stride, long n, T *__restrict__ world,
                                                uint32_t *hit, uint32_t *total, int32_t *state,
                                                uint32_t *tags, uint32_t *cminh, uint32_t *counters,
-                                               double *stat_sums)
+                                               double *stat_sums, double *stat_base)
 {
     const int lane = threadIdx.x & (WAVE - 1);
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void k_trace(const ScanParams P, const T *__re
             state[L] = (int32_t)row;
             cminh[row] = 0x3f800000u;                   // min-height starts at 1.0f (gvom.py:1014-1015)
             if (stat_sums)                              // optional statistics: zeroed metrics (gvom.py:1011-1012)
-                for (int m = 0; m < 10; ++m) stat_sums[(size_t)row * 10 + m] = 0.0;
+                for (int m = 0; m < 10; ++m) { stat_sums[(size_t)row * 10 + m] = 0.0; stat_base[(size_t)row * 10 + m] = 0.0; }
         }
     }
     if (VAR == 0 && !pass) return;
@@ -1249,17 +1249,21 @@ __global__ __launch_bounds__(256) void k_map2d(const Map2dParams P, const int32_
 // results match the reference to a tolerance, not bit for bit.
 // ------------------------------------------------------------------------------------------
 
-// k_stats: gvom.py:1172-1220 + :1234-1285 in ONE pass over the points: every return adds the raw
-// moments of its position relative to each OCCUPIED voxel of its (2*xy_e+1)^2 x (2*z_e+1)
-// neighbourhood (voxel units, f64): sums[row] = {Sx, Sy, Sz, Sxx, Sxy, Sxz, Syy, Syz, Szz, n}.
-// (The reference makes two passes -- mean, then centred products; raw moments in f64 give the
-// same covariance to ~1e-13 for coordinates in [-1, 2).)  Runs after k_encode: state >= 0 in a
-// live tile identifies an occupied voxel and its row.
+// k_stats: gvom.py:1172-1220 + :1234-1285.  The reference adds every return to each OCCUPIED
+// voxel of its (2*xy_e+1)^2 x (2*z_e+1) neighbourhood (up to 270 f64 atomics per point).  Here a
+// return whose own voxel lies in the grid adds the raw moments of its in-voxel position l in
+// [0,1)^3 to ITS OWN voxel only (10 atomics): base[row] = {Sx, Sy, Sz, Sxx, Sxy, Sxz, Syy, Syz,
+// Szz, n}; k_stats_gather then gives every occupied voxel the moments of its neighbours, shifted
+// by the voxel offset d (l' = l + d):  S l' = S l + n d,  S l'l'^T = S l l^T + d (S l)^T +
+// (S l) d^T + n d d^T -- the same sums, 27x fewer atomics.  Returns whose own voxel is outside the
+// grid (they can still touch border voxels) and slab-sharded handles (a neighbour's moments may
+// live on another rank) use the direct form into `sums`.  Both buffers are zeroed at row claim.
+// Runs after k_encode: state >= 0 in a live tile identifies an occupied voxel and its row.
 template <typename T>
 __global__ __launch_bounds__(256) void k_stats(const ScanParams P, const T *__restrict__ world, long n,
                                                const int32_t *__restrict__ state,
                                                const uint32_t *__restrict__ tags, int xy_e, int z_e,
-                                               double *sums)
+                                               double *base, double *sums, int direct_only)
 {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -1272,6 +1276,19 @@ __global__ __launch_bounds__(256) void k_stats(const ScanParams P, const T *__re
     const double bx = floor(ax), by = floor(ay), bz = floor(az);
     if (!(fabs(bx) < 1e9) || !(fabs(by) < 1e9) || !(fabs(bz) < 1e9)) return;
     const int xb = (int)bx, yb = (int)by, zb = (int)bz;
+    const bool base_in = xb >= 0 && xb < P.xy && yb >= 0 && yb < P.xy && zb >= 0 && zb < P.zs;
+    if (base_in && !direct_only) {
+        const int sx = wrap_add(xb, P.om[0], P.xy), sy = wrap_add(yb, P.om[1], P.xy), sz = wrap_add(zb, P.om[2], P.zs);
+        const int32_t row = state[((uint32_t)sy * P.zs + sz) * P.xy + sx];      // >= 0: this voxel has a hit
+        if (row < 0) return;
+        const double lx = ax - bx, ly = ay - by, lz = az - bz;
+        double *m = base + (size_t)row * 10;
+        unsafeAtomicAdd(m + 0, lx); unsafeAtomicAdd(m + 1, ly); unsafeAtomicAdd(m + 2, lz);
+        unsafeAtomicAdd(m + 3, lx * lx); unsafeAtomicAdd(m + 4, lx * ly); unsafeAtomicAdd(m + 5, lx * lz);
+        unsafeAtomicAdd(m + 6, ly * ly); unsafeAtomicAdd(m + 7, ly * lz); unsafeAtomicAdd(m + 8, lz * lz);
+        unsafeAtomicAdd(m + 9, 1.0);
+        return;
+    }
     for (int xi = xb - xy_e; xi <= xb + xy_e; ++xi) {
         if (xi < 0 || xi >= P.xy) continue;
         for (int yi = yb - xy_e; yi <= yb + xy_e; ++yi) {
@@ -1297,19 +1314,73 @@ __global__ __launch_bounds__(256) void k_stats(const ScanParams P, const T *__re
     }
 }
 
-// raw moments -> the reference's per-scan metrics layout: mean xyz, covariance xx xy xz yy yz zz
-// (population covariance, gvom.py:1224-1230, 1289-1299), count
-__global__ void k_stats_finalize(double *sums, const uint32_t *row_count, long cap)
+// k_stats_gather: per occupied voxel of the scan (dirty tiles only): add the shifted moments of the
+// occupied voxels of its neighbourhood (see k_stats) to the directly accumulated ones, then turn the
+// raw moments into the reference's per-scan metrics layout: mean xyz, population covariance
+// xx xy xz yy yz zz (gvom.py:1224-1230, 1289-1299), count.
+__global__ __launch_bounds__(256) void k_stats_gather(const ScanParams P, const int32_t *__restrict__ state,
+                                                      const uint32_t *__restrict__ tags, int xy_e, int z_e,
+                                                      const double *__restrict__ base, double *sums,
+                                                      int direct_only)
 {
-    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= cap || r >= (long)row_count[0]) return;
-    double *m = sums + r * 10;
-    const double nn = m[9];
-    if (!(nn > 0.0)) { for (int k = 0; k < 9; ++k) m[k] = 0.0; return; }
-    const double mx = m[0] / nn, my = m[1] / nn, mz = m[2] / nn;
-    const double cxx = m[3] / nn - mx * mx, cxy = m[4] / nn - mx * my, cxz = m[5] / nn - mx * mz;
-    const double cyy = m[6] / nn - my * my, cyz = m[7] / nn - my * mz, czz = m[8] / nn - mz * mz;
-    m[0] = mx; m[1] = my; m[2] = mz; m[3] = cxx; m[4] = cxy; m[5] = cxz; m[6] = cyy; m[7] = cyz; m[8] = czz;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const uint32_t wid = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const uint32_t nw = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t t0 = (uint32_t)P.sy_lo * P.zs * P.nseg, t1 = (uint32_t)P.sy_hi * P.zs * P.nseg;
+    for (uint32_t tile = t0 + wid; tile < t1; tile += nw) {
+        if (tags[tile] != P.epoch) continue;                            // wave-uniform
+        const uint32_t rz = tile / P.nseg;
+        const int sx = (int)(tile % P.nseg) * 64 + lane, sy = (int)(rz / P.zs), sz = (int)(rz % P.zs);
+        if (sx >= P.xy) continue;
+        const int32_t row = state[rz * P.xy + sx];
+        if (row < 0) continue;
+        double m[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) m[k] = sums[(size_t)row * 10 + k];
+        if (!direct_only) {
+            const int x = wrap_sub(sx, P.om[0], P.xy), y = wrap_sub(sy, P.om[1], P.xy), z = wrap_sub(sz, P.om[2], P.zs);
+            for (int dx = -xy_e; dx <= xy_e; ++dx) {
+                const int xn = x + dx;
+                if (xn < 0 || xn >= P.xy) continue;
+                for (int dy = -xy_e; dy <= xy_e; ++dy) {
+                    const int yn = y + dy;
+                    if (yn < 0 || yn >= P.xy) continue;
+                    for (int dz = -z_e; dz <= z_e; ++dz) {
+                        const int zn = z + dz;
+                        if (zn < 0 || zn >= P.zs) continue;
+                        const int sxn = wrap_add(xn, P.om[0], P.xy), syn = wrap_add(yn, P.om[1], P.xy),
+                                  szn = wrap_add(zn, P.om[2], P.zs);
+                        const uint32_t rzn = (uint32_t)syn * P.zs + szn;
+                        if (tags[rzn * P.nseg + (sxn >> 6)] != P.epoch) continue;
+                        const int32_t rn = state[rzn * P.xy + sxn];
+                        if (rn < 0) continue;
+                        const double *b = base + (size_t)rn * 10;
+                        const double nn = b[9];
+                        if (!(nn > 0.0)) continue;
+                        // a point of voxel (x+dx, ...) with in-voxel position l sits at l + d relative to THIS voxel
+                        const double ddx = (double)dx, ddy = (double)dy, ddz = (double)dz;
+                        const double s0 = b[0], s1 = b[1], s2 = b[2];
+                        m[0] += s0 + nn * ddx; m[1] += s1 + nn * ddy; m[2] += s2 + nn * ddz;
+                        m[3] += b[3] + 2.0 * ddx * s0 + nn * ddx * ddx;
+                        m[4] += b[4] + ddx * s1 + ddy * s0 + nn * ddx * ddy;
+                        m[5] += b[5] + ddx * s2 + ddz * s0 + nn * ddx * ddz;
+                        m[6] += b[6] + 2.0 * ddy * s1 + nn * ddy * ddy;
+                        m[7] += b[7] + ddy * s2 + ddz * s1 + nn * ddy * ddz;
+                        m[8] += b[8] + 2.0 * ddz * s2 + nn * ddz * ddz;
+                        m[9] += nn;
+                    }
+                }
+            }
+        }
+        double *o = sums + (size_t)row * 10;
+        const double nn = m[9];
+        if (!(nn > 0.0)) { for (int k = 0; k < 9; ++k) o[k] = 0.0; o[9] = nn; continue; }
+        const double mx = m[0] / nn, my = m[1] / nn, mz = m[2] / nn;
+        o[0] = mx; o[1] = my; o[2] = mz;
+        o[3] = m[3] / nn - mx * mx; o[4] = m[4] / nn - mx * my; o[5] = m[5] / nn - mx * mz;
+        o[6] = m[6] / nn - my * my; o[7] = m[7] / nn - my * mz; o[8] = m[8] / nn - mz * mz;
+        o[9] = nn;
+    }
 }
 
 // gvom.py:858-909: pooled mean / covariance merge of one voxel; the fused metrics are float32, a ring
@@ -1450,23 +1521,24 @@ __global__ __launch_bounds__(256) void k_voxel_cloud(const Map2dParams P, double
 }
 
 hipError_t gvom_launch_stats(hipStream_t s, const ScanParams &P, int dtype, const void *world, int64_t n,
-                             const int32_t *state, const uint32_t *tags, int xy_e, int z_e, double *sums)
+                             const int32_t *state, const uint32_t *tags, int xy_e, int z_e, double *base,
+                             double *sums)
 {
+    // slab-sharded handles use the direct form only (a neighbour voxel's moments may live on another rank)
+    const int direct_only = (P.sy_hi - P.sy_lo) < P.xy ? 1 : 0;
     const unsigned blocks = (unsigned)((n + 255) / 256);
     if (dtype == 0)
         hipLaunchKernelGGL(k_stats<float>, dim3(blocks), dim3(256), 0, s, P, (const float *)world, (long)n, state,
-                           tags, xy_e, z_e, sums);
+                           tags, xy_e, z_e, base, sums, direct_only);
     else
         hipLaunchKernelGGL(k_stats<double>, dim3(blocks), dim3(256), 0, s, P, (const double *)world, (long)n, state,
-                           tags, xy_e, z_e, sums);
-    return hipGetLastError();
-}
-
-hipError_t gvom_launch_stats_finalize(hipStream_t s, double *sums, const uint32_t *row_count_dev, int64_t cap)
-{
-    if (cap <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_stats_finalize, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, s, sums, row_count_dev,
-                       (long)cap);
+                           tags, xy_e, z_e, base, sums, direct_only);
+    const uint32_t ntiles = (uint32_t)(P.sy_hi - P.sy_lo) * P.zs * P.nseg;
+    if (ntiles) {
+        unsigned gb = (ntiles + 3) / 4;
+        if (gb > 8192) gb = 8192;
+        hipLaunchKernelGGL(k_stats_gather, dim3(gb), dim3(256), 0, s, P, state, tags, xy_e, z_e, base, sums, direct_only);
+    }
     return hipGetLastError();
 }
 
@@ -1603,14 +1675,14 @@ hipError_t gvom_launch_publish_count(hipStream_t s, const uint32_t *blockcounts,
 hipError_t gvom_launch_trace(hipStream_t s, const ScanParams &P, int dtype, const void *pts,
                              int64_t stride_elems, int64_t n, void *world, uint32_t *hit,
                              uint32_t *total, int32_t *state, uint32_t *tags, uint32_t *cminh,
-                             uint32_t *counters, int variant, double *stat_sums)
+                             uint32_t *counters, int variant, double *stat_sums, double *stat_base)
 {
     const unsigned blocks = (unsigned)((n + 255) / 256);
     const unsigned nsegs = (variant == 0 || variant == 9) ? 1u : (unsigned)P.nsegs;
 #define TRACE_LAUNCH(TT, VV)                                                                     \
     hipLaunchKernelGGL((k_trace<TT, VV>), dim3(blocks, nsegs), dim3(256), 0, s, P, (const TT *)pts, \
                        (long)stride_elems, (long)n, (TT *)world, hit, total, state, tags, cminh, counters, \
-                       stat_sums)
+                       stat_sums, stat_base)
     if (dtype == 0) {
         if (variant == 0) TRACE_LAUNCH(float, 0);
         else if (variant == 9) TRACE_LAUNCH(float, 9);
