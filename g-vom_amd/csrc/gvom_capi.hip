@@ -36,7 +36,7 @@ struct Slot {                                  // one scan in sparse form
     uint32_t *tags = nullptr;                  // [ntiles] tile epochs (live iff == epoch)
     uint32_t epoch = 0;
     Buf chit, ctotal, cminh;                   // compact rows
-    Buf metrics, base;                         // optional statistics: double[rows][10] each (metrics; own-voxel moments)
+    Buf metrics, base, rowvox;                 // optional statistics: double[rows][10] x2 (metrics; own-voxel moments), row -> voxel
     int64_t origin[3] = {0, 0, 0};
     int64_t count = 0;
     bool filled = false;
@@ -311,14 +311,16 @@ int scan_launch(gvom_handle *h, const void *dev_pts, int64_t n, int64_t stride_e
     if ((rc = ensure(h, st.chit, cap * 4))) return rc;
     if ((rc = ensure(h, st.ctotal, cap * 4))) return rc;
     if ((rc = ensure(h, st.cminh, cap * 4))) return rc;
-    if (h->stats && ((rc = ensure(h, st.metrics, cap * 80)) || (rc = ensure(h, st.base, cap * 80)))) return rc;
+    if (h->stats && ((rc = ensure(h, st.metrics, cap * 80)) || (rc = ensure(h, st.base, cap * 80)) ||
+                     (rc = ensure(h, st.rowvox, cap * 4)))) return rc;
     double t0 = now_ns();
     const uint32_t seq = ++h->scan_seq;
     if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
     HIPCHK(h, gvom_launch_trace(h->stream, P, dtype, dev_pts, stride_elems, n, h->world_pts.p, h->hit,
                                 h->total, st.state, st.tags, (uint32_t *)st.cminh.p, h->counters,
                                 h->trace_variant, h->stats ? (double *)st.metrics.p : nullptr,
-                                h->stats ? (double *)st.base.p : nullptr));
+                                h->stats ? (double *)st.base.p : nullptr,
+                                h->stats ? (uint32_t *)st.rowvox.p : nullptr));
     if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
     HIPCHK(h, gvom_launch_encode(h->stream, P, dtype, h->world_pts.p, n, h->hit, h->total, st.state,
                                  (uint32_t *)st.chit.p, (uint32_t *)st.ctotal.p, (uint32_t *)st.cminh.p,
@@ -326,7 +328,8 @@ int scan_launch(gvom_handle *h, const void *dev_pts, int64_t n, int64_t stride_e
     if (h->profiling) { HIPCHK(h, hipEventRecord(h->ev[2], h->stream)); h->ev_scan = true; }
     if (h->stats) {                                      // optional per-voxel statistics
         HIPCHK(h, gvom_launch_stats(h->stream, P, dtype, h->world_pts.p, n, st.state, st.tags,
-                                    p.xy_eigen_dist, p.z_eigen_dist, (double *)st.base.p, (double *)st.metrics.p));
+                                    p.xy_eigen_dist, p.z_eigen_dist, (double *)st.base.p, (double *)st.metrics.p,
+                                    (const uint32_t *)st.rowvox.p, h->counters + 8, (int64_t)cap));
     }
     HT(h, 0, t0);                                        // scan: launches
     // Wait only for k_trace: k_encode's first thread publishes {seq, count} to host-mapped memory.
@@ -619,7 +622,7 @@ VIS void gvom_destroy(gvom_t *h)
     if (h->stream) hipStreamSynchronize(h->stream);
     auto fb = [](Buf &b) { if (b.p) hipFree(b.p); b.p = nullptr; b.bytes = 0; };
     hipFree(h->hit); hipFree(h->total);
-    for (auto &s : h->slots) { hipFree(s.state); hipFree(s.tags); fb(s.chit); fb(s.ctotal); fb(s.cminh); fb(s.metrics); fb(s.base); }
+    for (auto &s : h->slots) { hipFree(s.state); hipFree(s.tags); fb(s.chit); fb(s.ctotal); fb(s.cminh); fb(s.metrics); fb(s.base); fb(s.rowvox); }
     for (auto &f : h->fused) { hipFree(f.state); hipFree(f.tags); fb(f.hit); fb(f.total); fb(f.minh); fb(f.metrics); }
     fb(h->in_pts); fb(h->world_pts);
     hipFree(h->counters); if (h->counters_host) hipHostFree(h->counters_host);

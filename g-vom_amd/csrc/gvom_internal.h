@@ -102,7 +102,8 @@ struct Map2dParams {
 hipError_t gvom_launch_trace(hipStream_t s, const ScanParams &P, int dtype, const void *pts,
                              int64_t stride_elems, int64_t n, void *world, uint32_t *hit,
                              uint32_t *total, int32_t *state, uint32_t *tags, uint32_t *cminh,
-                             uint32_t *counters, int variant, double *stat_sums, double *stat_base);
+                             uint32_t *counters, int variant, double *stat_sums, double *stat_base,
+                             uint32_t *stat_rowvox);
 hipError_t gvom_launch_encode(hipStream_t s, const ScanParams &P, int dtype, const void *world,
                               int64_t n, uint32_t *hit, uint32_t *total, int32_t *state,
                               uint32_t *chit, uint32_t *ctotal, uint32_t *cminh, const uint32_t *tags,
@@ -121,7 +122,7 @@ hipError_t gvom_launch_map2d(hipStream_t s, const Map2dParams &P, const int32_t 
 // ---- optional per-voxel statistics (gvom.py:1172-1299, 858-909, 1333-1378, 454-473)
 hipError_t gvom_launch_stats(hipStream_t s, const ScanParams &P, int dtype, const void *world, int64_t n,
                              const int32_t *state, const uint32_t *tags, int xy_e, int z_e, double *base,
-                             double *sums);
+                             double *sums, const uint32_t *rowvox, const uint32_t *row_count_dev, int64_t cap);
 hipError_t gvom_launch_fuse_stats(hipStream_t s, const FuseParams &P, const FuseDescs &KD, const MapDesc *descs_dev,
                                   const int32_t *fstate, const uint32_t *ftags, float *fmetrics);
 hipError_t gvom_launch_voxel_cloud(hipStream_t s, const Map2dParams &P, double o0, double o1, double o2,

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void k_trace(const ScanParams P, const T *__re
                                                long stride, long n, T *__restrict__ world,
                                                uint32_t *hit, uint32_t *total, int32_t *state,
                                                uint32_t *tags, uint32_t *cminh, uint32_t *counters,
-                                               double *stat_sums, double *stat_base)
+                                               double *stat_sums, double *stat_base, uint32_t *stat_rowvox)
 {
     const int lane = threadIdx.x & (WAVE - 1);
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -148,7 +148,10 @@ __global__ __launch_bounds__(256) void k_trace(const ScanParams P, const T *__re
             state[L] = (int32_t)row;
             cminh[row] = 0x3f800000u;                   // min-height starts at 1.0f (gvom.py:1014-1015)
             if (stat_sums)                              // optional statistics: zeroed metrics (gvom.py:1011-1012)
+            {
                 for (int m = 0; m < 10; ++m) { stat_sums[(size_t)row * 10 + m] = 0.0; stat_base[(size_t)row * 10 + m] = 0.0; }
+                stat_rowvox[row] = L;                   // row -> voxel, for the per-row neighbour gather
+            }
         }
     }
     if (VAR == 0 && !pass) return;
@@ -1314,65 +1317,63 @@ __global__ __launch_bounds__(256) void k_stats(const ScanParams P, const T *__re
     }
 }
 
-// k_stats_gather: per occupied voxel of the scan (dirty tiles only): add the shifted moments of the
-// occupied voxels of its neighbourhood (see k_stats) to the directly accumulated ones, then turn the
-// raw moments into the reference's per-scan metrics layout: mean xyz, population covariance
-// xx xy xz yy yz zz (gvom.py:1224-1230, 1289-1299), count.
+// k_stats_gather: ONE WAVE per occupied voxel (= compact row; rowvox[row] is its voxel): the lanes
+// fetch the neighbourhood's voxels in parallel (lane <-> neighbour offset), shift their own-voxel
+// moments by the offset (see k_stats) and a butterfly reduction sums them; lane 0 adds the directly
+// accumulated part and turns the raw moments into the reference's per-scan metrics layout: mean
+// xyz, population covariance xx xy xz yy yz zz (gvom.py:1224-1230, 1289-1299), count.
 __global__ __launch_bounds__(256) void k_stats_gather(const ScanParams P, const int32_t *__restrict__ state,
                                                       const uint32_t *__restrict__ tags, int xy_e, int z_e,
                                                       const double *__restrict__ base, double *sums,
-                                                      int direct_only)
+                                                      const uint32_t *__restrict__ rowvox,
+                                                      const uint32_t *__restrict__ row_count, int direct_only)
 {
     const int lane = threadIdx.x & (WAVE - 1);
     const uint32_t wid = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const uint32_t nw = (gridDim.x * blockDim.x) >> 6;
-    const uint32_t t0 = (uint32_t)P.sy_lo * P.zs * P.nseg, t1 = (uint32_t)P.sy_hi * P.zs * P.nseg;
-    for (uint32_t tile = t0 + wid; tile < t1; tile += nw) {
-        if (tags[tile] != P.epoch) continue;                            // wave-uniform
-        const uint32_t rz = tile / P.nseg;
-        const int sx = (int)(tile % P.nseg) * 64 + lane, sy = (int)(rz / P.zs), sz = (int)(rz % P.zs);
-        if (sx >= P.xy) continue;
-        const int32_t row = state[rz * P.xy + sx];
-        if (row < 0) continue;
+    const uint32_t nrows = row_count[0];
+    const int wx = 2 * xy_e + 1, wz = 2 * z_e + 1, nb = wx * wx * wz;
+    for (uint32_t row = wid; row < nrows; row += nw) {
         double m[10];
 #pragma unroll
-        for (int k = 0; k < 10; ++k) m[k] = sums[(size_t)row * 10 + k];
+        for (int k = 0; k < 10; ++k) m[k] = 0.0;
         if (!direct_only) {
+            const uint32_t L = rowvox[row];
+            const int sx = (int)(L % P.xy), sz = (int)((L / P.xy) % P.zs), sy = (int)(L / ((uint32_t)P.xy * P.zs));
             const int x = wrap_sub(sx, P.om[0], P.xy), y = wrap_sub(sy, P.om[1], P.xy), z = wrap_sub(sz, P.om[2], P.zs);
-            for (int dx = -xy_e; dx <= xy_e; ++dx) {
-                const int xn = x + dx;
-                if (xn < 0 || xn >= P.xy) continue;
-                for (int dy = -xy_e; dy <= xy_e; ++dy) {
-                    const int yn = y + dy;
-                    if (yn < 0 || yn >= P.xy) continue;
-                    for (int dz = -z_e; dz <= z_e; ++dz) {
-                        const int zn = z + dz;
-                        if (zn < 0 || zn >= P.zs) continue;
-                        const int sxn = wrap_add(xn, P.om[0], P.xy), syn = wrap_add(yn, P.om[1], P.xy),
-                                  szn = wrap_add(zn, P.om[2], P.zs);
-                        const uint32_t rzn = (uint32_t)syn * P.zs + szn;
-                        if (tags[rzn * P.nseg + (sxn >> 6)] != P.epoch) continue;
-                        const int32_t rn = state[rzn * P.xy + sxn];
-                        if (rn < 0) continue;
-                        const double *b = base + (size_t)rn * 10;
-                        const double nn = b[9];
-                        if (!(nn > 0.0)) continue;
-                        // a point of voxel (x+dx, ...) with in-voxel position l sits at l + d relative to THIS voxel
-                        const double ddx = (double)dx, ddy = (double)dy, ddz = (double)dz;
-                        const double s0 = b[0], s1 = b[1], s2 = b[2];
-                        m[0] += s0 + nn * ddx; m[1] += s1 + nn * ddy; m[2] += s2 + nn * ddz;
-                        m[3] += b[3] + 2.0 * ddx * s0 + nn * ddx * ddx;
-                        m[4] += b[4] + ddx * s1 + ddy * s0 + nn * ddx * ddy;
-                        m[5] += b[5] + ddx * s2 + ddz * s0 + nn * ddx * ddz;
-                        m[6] += b[6] + 2.0 * ddy * s1 + nn * ddy * ddy;
-                        m[7] += b[7] + ddy * s2 + ddz * s1 + nn * ddy * ddz;
-                        m[8] += b[8] + 2.0 * ddz * s2 + nn * ddz * ddz;
-                        m[9] += nn;
-                    }
-                }
+            for (int j = lane; j < nb; j += WAVE) {
+                const int dx = j / (wx * wz) - xy_e, dy = (j / wz) % wx - xy_e, dz = j % wz - z_e;
+                const int xn = x + dx, yn = y + dy, zn = z + dz;
+                if (xn < 0 || xn >= P.xy || yn < 0 || yn >= P.xy || zn < 0 || zn >= P.zs) continue;
+                const int sxn = wrap_add(xn, P.om[0], P.xy), syn = wrap_add(yn, P.om[1], P.xy), szn = wrap_add(zn, P.om[2], P.zs);
+                const uint32_t rzn = (uint32_t)syn * P.zs + szn;
+                if (tags[rzn * P.nseg + (sxn >> 6)] != P.epoch) continue;
+                const int32_t rn = state[rzn * P.xy + sxn];
+                if (rn < 0) continue;
+                const double *b = base + (size_t)rn * 10;
+                const double nn = b[9];
+                if (!(nn > 0.0)) continue;
+                // a point of voxel (x+dx, ...) with in-voxel position l sits at l + d relative to THIS voxel
+                const double ddx = (double)dx, ddy = (double)dy, ddz = (double)dz;
+                const double s0 = b[0], s1 = b[1], s2 = b[2];
+                m[0] += s0 + nn * ddx; m[1] += s1 + nn * ddy; m[2] += s2 + nn * ddz;
+                m[3] += b[3] + 2.0 * ddx * s0 + nn * ddx * ddx;
+                m[4] += b[4] + ddx * s1 + ddy * s0 + nn * ddx * ddy;
+                m[5] += b[5] + ddx * s2 + ddz * s0 + nn * ddx * ddz;
+                m[6] += b[6] + 2.0 * ddy * s1 + nn * ddy * ddy;
+                m[7] += b[7] + ddy * s2 + ddz * s1 + nn * ddy * ddz;
+                m[8] += b[8] + 2.0 * ddz * s2 + nn * ddz * ddz;
+                m[9] += nn;
             }
+#pragma unroll
+            for (int k = 0; k < 10; ++k)
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) m[k] += __shfl_xor(m[k], o);
         }
+        if (lane != 0) continue;
         double *o = sums + (size_t)row * 10;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) m[k] += o[k];                       // directly accumulated part
         const double nn = m[9];
         if (!(nn > 0.0)) { for (int k = 0; k < 9; ++k) o[k] = 0.0; o[9] = nn; continue; }
         const double mx = m[0] / nn, my = m[1] / nn, mz = m[2] / nn;
@@ -1522,7 +1523,7 @@ __global__ __launch_bounds__(256) void k_voxel_cloud(const Map2dParams P, double
 
 hipError_t gvom_launch_stats(hipStream_t s, const ScanParams &P, int dtype, const void *world, int64_t n,
                              const int32_t *state, const uint32_t *tags, int xy_e, int z_e, double *base,
-                             double *sums)
+                             double *sums, const uint32_t *rowvox, const uint32_t *row_count_dev, int64_t cap)
 {
     // slab-sharded handles use the direct form only (a neighbour voxel's moments may live on another rank)
     const int direct_only = (P.sy_hi - P.sy_lo) < P.xy ? 1 : 0;
@@ -1533,11 +1534,11 @@ hipError_t gvom_launch_stats(hipStream_t s, const ScanParams &P, int dtype, cons
     else
         hipLaunchKernelGGL(k_stats<double>, dim3(blocks), dim3(256), 0, s, P, (const double *)world, (long)n, state,
                            tags, xy_e, z_e, base, sums, direct_only);
-    const uint32_t ntiles = (uint32_t)(P.sy_hi - P.sy_lo) * P.zs * P.nseg;
-    if (ntiles) {
-        unsigned gb = (ntiles + 3) / 4;
-        if (gb > 8192) gb = 8192;
-        hipLaunchKernelGGL(k_stats_gather, dim3(gb), dim3(256), 0, s, P, state, tags, xy_e, z_e, base, sums, direct_only);
+    if (cap > 0) {
+        unsigned gb = (unsigned)((cap + 3) / 4);
+        if (gb > 4096) gb = 4096;
+        hipLaunchKernelGGL(k_stats_gather, dim3(gb), dim3(256), 0, s, P, state, tags, xy_e, z_e, base, sums, rowvox,
+                           row_count_dev, direct_only);
     }
     return hipGetLastError();
 }
@@ -1675,14 +1676,15 @@ hipError_t gvom_launch_publish_count(hipStream_t s, const uint32_t *blockcounts,
 hipError_t gvom_launch_trace(hipStream_t s, const ScanParams &P, int dtype, const void *pts,
                              int64_t stride_elems, int64_t n, void *world, uint32_t *hit,
                              uint32_t *total, int32_t *state, uint32_t *tags, uint32_t *cminh,
-                             uint32_t *counters, int variant, double *stat_sums, double *stat_base)
+                             uint32_t *counters, int variant, double *stat_sums, double *stat_base,
+                             uint32_t *stat_rowvox)
 {
     const unsigned blocks = (unsigned)((n + 255) / 256);
     const unsigned nsegs = (variant == 0 || variant == 9) ? 1u : (unsigned)P.nsegs;
 #define TRACE_LAUNCH(TT, VV)                                                                     \
     hipLaunchKernelGGL((k_trace<TT, VV>), dim3(blocks, nsegs), dim3(256), 0, s, P, (const TT *)pts, \
                        (long)stride_elems, (long)n, (TT *)world, hit, total, state, tags, cminh, counters, \
-                       stat_sums, stat_base)
+                       stat_sums, stat_base, stat_rowvox)
     if (dtype == 0) {
         if (variant == 0) TRACE_LAUNCH(float, 0);
         else if (variant == 9) TRACE_LAUNCH(float, 9);
