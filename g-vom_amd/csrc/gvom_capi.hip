@@ -114,7 +114,7 @@ struct gvom_handle {
     long host_calls = 0;
     bool host_timing = false;
     bool stats = false;                                 // per-voxel statistics enabled (gvom_params.reserved0 bit 0)
-    int trace_variant = 1;                              // GVOM_TRACE_VARIANT (k_trace strategy)
+    int trace_variant = 6;                              // GVOM_TRACE_VARIANT (k_trace strategy)
     bool profiling = false;
     hipEvent_t ev[8] = {nullptr};
     float stage_ms[GVOM_N_STAGES] = {0, 0, 0, 0, 0};
@@ -179,6 +179,8 @@ void fill_scan_params(const gvom_handle *h, const int64_t origin[3], const doubl
     {
         int nsegs = 4;
         if (const char *v = getenv("GVOM_TRACE_SEGMENTS")) nsegs = atoi(v) > 0 ? atoi(v) : 4;
+        P.dbg = 0;
+        if (const char *v = getenv("GVOM_TRACE_DEBUG")) P.dbg = atoi(v);
         const int maxsteps = (p.xy_size > p.z_size ? p.xy_size : p.z_size) / 2 + 2;
         P.nsegs = nsegs;
         P.seg_len = (maxsteps + nsegs - 1) / nsegs;
@@ -260,11 +262,11 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, g
         CK(hipMalloc((void **)&h->fused[k].tags, h->ntiles * 4));
         CK(hipMemsetAsync(h->fused[k].tags, 0, h->ntiles * 4, h->stream));
     }
-    CK(hipMalloc((void **)&h->counters, 64));
+    CK(hipMalloc((void **)&h->counters, GVOM_CNT_WORDS * 4));
     CK(hipHostMalloc((void **)&h->counters_host, 64, hipHostMallocMapped | hipHostMallocCoherent));
     CK(hipHostGetDevicePointer((void **)&h->counters_host_dev, h->counters_host, 0));
     memset(h->counters_host, 0, 64);
-    CK(hipMemsetAsync(h->counters, 0, 64, h->stream));
+    CK(hipMemsetAsync(h->counters, 0, GVOM_CNT_WORDS * 4, h->stream));
     CK(hipMalloc((void **)&h->descs_dev, sizeof(MapDesc) * (GVOM_MAX_SLOTS + 1)));
     CK(hipHostMalloc((void **)&h->descs_host, sizeof(MapDesc) * (GVOM_MAX_SLOTS + 1)));
     h->fuse_blocks = ((xy + 63) / 64) * (h->sy_hi - h->sy_lo);
@@ -316,9 +318,15 @@ int scan_launch(gvom_handle *h, const void *dev_pts, int64_t n, int64_t stride_e
     double t0 = now_ns();
     const uint32_t seq = ++h->scan_seq;
     if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+    // variants 5/6 look voxels up with 32-bit integer arithmetic: exact while |origin| < 2^30
+    // (2e8 m at 0.2 m voxels); beyond that the f64 lookup of variant 1 is used
+    int variant = h->trace_variant;
+    if (variant == 5 || variant == 6)
+        for (int k = 0; k < 3; ++k)
+            if (origin[k] >= (1ll << 30) || origin[k] <= -(1ll << 30)) variant = 1;
     HIPCHK(h, gvom_launch_trace(h->stream, P, dtype, dev_pts, stride_elems, n, h->world_pts.p, h->hit,
                                 h->total, st.state, st.tags, (uint32_t *)st.cminh.p, h->counters,
-                                h->trace_variant, h->stats ? (double *)st.metrics.p : nullptr,
+                                variant, h->stats ? (double *)st.metrics.p : nullptr,
                                 h->stats ? (double *)st.base.p : nullptr,
                                 h->stats ? (uint32_t *)st.rowvox.p : nullptr));
     if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[1], h->stream));

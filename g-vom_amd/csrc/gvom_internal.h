@@ -31,6 +31,12 @@
 // one memory-side request, and k_trace runs at that request rate; with rows of 16 consecutive x
 // per line an x-dominant ray bundle (all lanes at the same x, spread over y) needed one request
 // per distinct y.  Patches make x- and y-dominant bundles equally cheap (about half the requests).
+// device counter block (uint32 words; 512 bytes).  The two counters k_trace adds to live on separate
+// cache lines: same-line atomics are serialised by the memory system.
+#define GVOM_CNT_ROWS 0        // compact rows claimed by the scan in flight
+#define GVOM_CNT_INGRID 64     // in-grid returns of the scan in flight (any rank's rows)
+#define GVOM_CNT_WORDS 128
+
 struct ScanParams {
     double xy_res, z_res;
     double min_d2;        // min_distance * min_distance (f64 product, gvom.py:1067)
@@ -46,6 +52,7 @@ struct ScanParams {
     int    sxq;           // accumulator layout: 4x4 (x,y) patches per row of patches = ceil(xy/4)
     uint32_t epoch;       // this scan's tile epoch
     // slab-sharded runs: the slab's rows as (up to two) intervals of WINDOW y, for ray culling
+    int    dbg;           // GVOM_TRACE_DEBUG bits (timing experiments only; results wrong when set)
     int    cull;          // 1: skip rays that cannot reach the slab, stop rays that have left it
     int    wlo[2], whi[2];
 };

@@ -51,6 +51,42 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
+// ---- wave-private accumulator-line cache (k_trace VAR 4) ---------------------------------------
+// One 64-entry open-addressed table per wave in LDS: key = accumulator line (64 B = 4x4 (x,y)
+// patch at one z), 16 counters per entry.  DDA steps add into the table with LDS atomics; when
+// the table fills up (or the wave is done) the wave flushes it cooperatively, 4 lines per
+// instruction with 16 lanes per line, so one line costs ONE memory-side atomic request however
+// many steps of however many lanes fell into it since the last flush.
+#define LC_EMPTY 0xFFFFFFFFu
+#define LC_FLUSH_AT 40
+#define LC_PERIOD 8          // VAR 6: flush every LC_PERIOD committing steps
+#define LC_LD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT)
+#define LC_ST(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT)
+// slot s keeps its key at keys[LC_KEYPOS(s)]: the flush handles entry 4*it + g in iteration it of
+// lane group g, so group g finds its 16 keys in 16 consecutive words (4 x 16-byte LDS reads)
+#define LC_KEYPOS(s) ((((s) & 3u) << 4) | ((s) >> 2))
+__device__ __forceinline__ void lc_flush(uint32_t *keys, uint32_t *cnt, uint32_t *total, int lane, int dbg = 0)
+{
+    // entry e = 4*it + (lane >> 4), counter c = lane & 15  <=>  cnt[it*64 + lane]: linear LDS reads
+    const int g = lane >> 4, c = lane & 15;
+    uint32_t v[16], k[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const v4i kk = *(const v4i *)&keys[g * 16 + q * 4];
+        k[q * 4 + 0] = (uint32_t)kk.x; k[q * 4 + 1] = (uint32_t)kk.y; k[q * 4 + 2] = (uint32_t)kk.z; k[q * 4 + 3] = (uint32_t)kk.w;
+    }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) v[it] = LC_LD(&cnt[it * 64 + lane]);
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        if (v[it] != 0u) {
+            if (!(dbg & 1)) atomicAdd(&total[(k[it] << 4) + (uint32_t)c], v[it]);
+            LC_ST(&cnt[it * 64 + lane], 0u);
+        }
+    }
+    LC_ST(&keys[lane], LC_EMPTY);
+}
+
 // ------------------------------------------------------------------------------------------
 // k_trace: one lane per lidar return.
 //   1. optional rigid transform (f64, written back in the cloud's dtype)      gvom.py:1040-1056
@@ -75,6 +111,8 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 //   1  lock-step loop; lanes of a wave that step into the SAME voxel as their left neighbour
 //      are merged (ballot + run length) so one lane adds the whole run: near the sensor all 64
 //      rays of a wave share a voxel and 64 same-address atomics collapse into one
+//   4  as 1, but the merged adds go into a wave-private LDS line cache that is flushed with one
+//      request per 64-B line (lc_flush): steps of a ray bundle that revisit a line are merged too
 //   9  diagnostic only: no DDA atomics at all (measures the arithmetic floor; results wrong)
 template <typename T, int VAR>
 __global__ __launch_bounds__(256) void k_trace(const ScanParams P, const T *__restrict__ in,
@@ -85,7 +123,7 @@ __global__ __launch_bounds__(256) void k_trace(const ScanParams P, const T *__re
 {
     const int lane = threadIdx.x & (WAVE - 1);
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    const int seg = (VAR == 1 || VAR == 2) ? (int)blockIdx.y : 0;      // step segment of this wave
+    const int seg = (VAR == 1 || VAR == 2 || (VAR >= 4 && VAR <= 6)) ? (int)blockIdx.y : 0;      // step segment of this wave
     if ((VAR == 0 || VAR == 9) && blockIdx.y != 0) return;
     const bool first = seg == 0;                                       // segment 0 also does the endpoint
     const bool live = i < n;
@@ -126,25 +164,35 @@ __global__ __launch_bounds__(256) void k_trace(const ScanParams P, const T *__re
         }
     }
     uint32_t old = 1;
-    if (ingrid) {
+    if (ingrid && !(P.dbg & 4)) {
         old = atomicAdd(&hit[A], 1u);
         atomicAdd(&total[A], 1u);
         const uint32_t tile = (L / P.xy) * P.nseg + ((L % P.xy) >> 6);  // stamp the tile (idempotent)
         tags[tile] = P.epoch;
     }
     // every rank sees every point, so each can count the GLOBAL number of in-grid returns: the
-    // reference's "no overlap" test (gvom.py:147-150) then needs no collective in sharded runs
+    // reference's "no overlap" test (gvom.py:147-150) then needs no collective in sharded runs.
+    // Both counters are aggregated per WORKGROUP (one atomic each, on separate cache lines):
+    // same-line atomics are served one at a time (~11.5 ns each, tools/atomic_calib), and the row
+    // claim returns a value, so per-wave atomics made every wave queue behind 2 x 2048 requests.
     const unsigned long long gm = __ballot(ingrid_any);
-    if (gm != 0ull && lane == (__ffsll((long long)gm) - 1)) atomicAdd(&counters[1], (uint32_t)__popcll(gm));
     const bool claim = ingrid && old == 0;
     const unsigned long long cm = __ballot(claim);
-    if (cm != 0ull) {                                   // wave-uniform
-        const int leader = __ffsll((long long)cm) - 1;
-        uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(&counters[0], (uint32_t)__popcll(cm));
-        base = __shfl(base, leader);
+    if (first) {                                        // workgroup-uniform (seg = blockIdx.y)
+        __shared__ uint32_t s_cl[4], s_in[4], s_base;
+        const int wv = threadIdx.x >> 6;
+        if (lane == 0) { s_cl[wv] = (uint32_t)__popcll(cm); s_in[wv] = (uint32_t)__popcll(gm); }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t nc = (s_cl[0] + s_cl[1]) + (s_cl[2] + s_cl[3]);
+            const uint32_t ni = (s_in[0] + s_in[1]) + (s_in[2] + s_in[3]);
+            if (ni) atomicAdd(&counters[GVOM_CNT_INGRID], ni);
+            s_base = nc ? atomicAdd(&counters[GVOM_CNT_ROWS], nc) : 0u;
+        }
+        __syncthreads();
         if (claim) {
-            const uint32_t row = base + (uint32_t)__popcll(cm & lanemask_lt());
+            const uint32_t wbase = s_base + (wv > 0 ? s_cl[0] : 0u) + (wv > 1 ? s_cl[1] : 0u) + (wv > 2 ? s_cl[2] : 0u);
+            const uint32_t row = wbase + (uint32_t)__popcll(cm & lanemask_lt());
             state[L] = (int32_t)row;
             cminh[row] = 0x3f800000u;                   // min-height starts at 1.0f (gvom.py:1014-1015)
             if (stat_sums)                              // optional statistics: zeroed metrics (gvom.py:1011-1012)
@@ -162,7 +210,7 @@ __global__ __launch_bounds__(256) void k_trace(const ScanParams P, const T *__re
     // all (conservative +-2 rows, so the committed updates are unchanged); waves without any
     // reaching ray leave before the DDA setup.
     bool reach = pass;
-    if (P.cull && (VAR == 1 || VAR == 2)) {
+    if (P.cull && (VAR == 1 || VAR == 2 || (VAR >= 4 && VAR <= 6))) {
         const float yend_f = e1 - (float)P.origin[1];
         const float ybeg_f = P.pt0[1] - (float)P.origin[1];
         const int y0i = (int)floorf(fminf(ybeg_f, yend_f)) - 2, y1i = (int)floorf(fmaxf(ybeg_f, yend_f)) + 2;
@@ -225,7 +273,133 @@ __global__ __launch_bounds__(256) void k_trace(const ScanParams P, const T *__re
             }
             length += step_len;
         }
-        if (VAR == 9 && sink == 0xdeadbeefu) counters[1] = sink;   // keep the arithmetic alive
+        if (VAR == 9 && sink == 0xdeadbeefu) counters[GVOM_CNT_INGRID] = sink;   // keep the arithmetic alive
+        return;
+    }
+
+    // ---- VAR 5 / 6: the production loop ----------------------------------------------------------
+    // Same lock-step, run-merged scheme as VAR 1 with a much shorter step body (the kernel is
+    // VALU-issue-bound once the atomics are merged):
+    //  * the ray state is kept in natural (x, y, z) order -- the same three f32 additions per step
+    //    as the reference's (dominant, other, other) triple, without the axis permutation;
+    //  * the window origin is an integer (gvom.py:124-126 floors it), so
+    //    floor((double)p - origin) == (int)floorf(p) - origin: no f64 in the voxel lookup.  The
+    //    f64 subtraction is exact except when p lies within half an f64 ulp below an integer, which
+    //    an f32 p can only do below 0 (|p| < 2^-37 for in-grid results, given |origin| < 2^30, which
+    //    the host checks before selecting this variant); such steps take the literal f64 path;
+    //  * the left neighbour's key comes from a DPP wave shift instead of an LDS permute;
+    //  * VAR 6 adds the wave-private LDS line cache (lc_flush): 0.96 M -> 0.47 M memory-side requests.
+    if (VAR == 5 || VAR == 6) {
+        const float incx = si == 0 ? dir : (si == 1 ? inc2 : inc1);
+        const float incy = si == 0 ? inc1 : (si == 1 ? dir : inc2);
+        const float incz = si == 0 ? inc2 : (si == 1 ? inc1 : dir);
+        float px = P.pt0[0], py = P.pt0[1], pz = P.pt0[2];
+        for (int j = seg * P.seg_len; j > 0; --j) {      // replay earlier segments (see SEGMENTS)
+            px += incx; py += incy; pz += incz;
+            length += step_len;
+        }
+        int left = (seg == P.nsegs - 1) ? INT_MAX : P.seg_len;
+        // non-finite increments (degenerate returns): the reference's first step lands on NaN/inf,
+        // which is outside the grid, and the ray ends without an update
+        const bool finite = fabsf(incx) < INFINITY && fabsf(incy) < INFINITY && fabsf(incz) < INFINITY;
+        bool active = reach && finite && (length < lim);
+        int ystop_lo = INT_MIN, ystop_hi = INT_MAX;
+        const uint32_t Ox = (uint32_t)(int)P.origin[0], Oy = (uint32_t)(int)P.origin[1], Oz = (uint32_t)(int)P.origin[2];
+        if (P.cull) {
+            const float ynow = py - (float)P.origin[1];
+            const float yseg = (seg == P.nsegs - 1) ? (e1 - (float)P.origin[1]) : ynow + incy * (float)(P.seg_len + 1);
+            const int a0 = (int)floorf(fminf(ynow, yseg)) - 2, a1 = (int)floorf(fmaxf(ynow, yseg)) + 2;
+            const bool h0 = a1 >= P.wlo[0] && a0 < P.whi[0];
+            const bool h1 = a1 >= P.wlo[1] && a0 < P.whi[1];
+            active = active && (h0 || h1);
+            if (!__any(active)) return;                  // wave-uniform
+            const int lo = min(P.wlo[0], P.wlo[1] < P.whi[1] ? P.wlo[1] : P.wlo[0]);
+            const int hi = max(P.whi[0], P.wlo[1] < P.whi[1] ? P.whi[1] : P.whi[0]);
+            if (incy > 0.0f) ystop_hi = hi + 1;
+            else if (incy < 0.0f) ystop_lo = lo - 2;
+        }
+        __shared__ __attribute__((aligned(16))) uint32_t s_keys[VAR == 6 ? 4 * 64 : 4];
+        __shared__ uint32_t s_cnt[VAR == 6 ? 4 * 1024 : 1];
+        uint32_t *lck = s_keys + (VAR == 6 ? (threadIdx.x >> 6) * 64 : 0);
+        uint32_t *lcc = s_cnt + (VAR == 6 ? (threadIdx.x >> 6) * 1024 : 0);
+        uint32_t lc_fill = 0, memo = LC_EMPTY; int memo_slot = 0;
+        if (VAR == 6) {
+            LC_ST(&lck[lane], LC_EMPTY);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) LC_ST(&lcc[c * 64 + lane], 0u);
+        }
+        const uint32_t uxy = (uint32_t)P.xy, uzs = (uint32_t)P.zs;
+        const uint32_t om0 = (uint32_t)P.om[0], om1 = (uint32_t)P.om[1], om2 = (uint32_t)P.om[2];
+        const uint32_t slab_lo = (uint32_t)P.sy_lo, slab_n = (uint32_t)(P.sy_hi - P.sy_lo);
+        if (P.dbg & 8) active = false;
+        while (__any(active)) {
+            bool commit = false;
+            uint32_t Ls = 0, sx = 0, sy = 0, sz = 0;
+            if (active) {
+                px += incx; py += incy; pz += incz;
+                uint32_t wx, wy, wz;                                      // window voxel (wraps when outside)
+                if (fminf(fminf(fabsf(px), fabsf(py)), fabsf(pz)) < 0x1p-21f) {
+                    // a coordinate within 2^-21 of zero: the reference's f64 subtraction rounds
+                    // (-tiny) - origin to -origin, i.e. floors it UP; follow it literally (rare)
+                    wx = (uint32_t)(int)floor((double)px - P.origin[0]);
+                    wy = (uint32_t)(int)floor((double)py - P.origin[1]);
+                    wz = (uint32_t)(int)floor((double)pz - P.origin[2]);
+                } else {
+                    wx = (uint32_t)(int)floorf(px) - Ox;
+                    wy = (uint32_t)(int)floorf(py) - Oy;
+                    wz = (uint32_t)(int)floorf(pz) - Oz;
+                }
+                if (wx < uxy && wy < uxy && wz < uzs) {
+                    sy = min(wy + om1, wy + om1 - uxy);                   // toroidal storage coordinates
+                    if (sy - slab_lo < slab_n) {
+                        sx = min(wx + om0, wx + om0 - uxy);
+                        sz = min(wz + om2, wz + om2 - uzs);
+                        Ls = acc_idx((int)sx, (int)sy, (int)sz, P.zs, P.sxq);
+                        commit = true;
+                    }
+                    length += step_len;
+                    active = length < lim && --left > 0 && (int)wy < ystop_hi && (int)wy > ystop_lo;
+                } else {
+                    active = false;                                       // ray left the grid (gvom.py:1135-1144)
+                }
+            }
+            const unsigned long long cmask = __ballot(commit);
+            if (cmask == 0ull) continue;                                  // wave-uniform
+            // merge runs of equal voxel indices among neighbouring lanes
+            const uint32_t key = commit ? Ls : (0xFFFFFF00u | (uint32_t)lane);
+            const uint32_t leftk = (uint32_t)__builtin_amdgcn_update_dpp((int)~key, (int)key, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+            const bool head = commit && leftk != key;
+            const unsigned long long nh = cmask & ~__ballot(head);       // followers
+            if (head && !(P.dbg & 16)) {
+                const unsigned long long after = (nh >> lane) >> 1;
+                const uint32_t run = (uint32_t)__ffsll((long long)~after);   // 1 + followers
+                if (VAR == 6) {
+                    // memo: the (line, row-in-line) this lane added to last; a miss looks the line up
+                    // (or inserts it) and stamps the voxel's tile tag
+                    const uint32_t line = Ls >> 4, lrow = Ls >> 2;
+                    int slot = -1;
+                    if (lrow == memo) slot = memo_slot;
+                    else {
+                        // direct-mapped: 4 x 4 patches x 4 z levels around wherever the bundle is
+                        const uint32_t hh = ((sz & 3u) << 4) | (((sy >> 2) & 3u) << 2) | ((sx >> 2) & 3u);
+                        const uint32_t was = atomicCAS(&lck[LC_KEYPOS(hh)], LC_EMPTY, line);
+                        if (was == LC_EMPTY || was == line) slot = (int)hh;
+                        if (!(P.dbg & 2)) tags[(sy * uzs + sz) * (uint32_t)P.nseg + (sx >> 6)] = P.epoch;
+                        if (slot >= 0) { memo = lrow; memo_slot = slot; }
+                    }
+                    if (slot >= 0) atomicAdd(&lcc[slot * 16 + (int)(Ls & 15u)], run);
+                    else atomicAdd(&total[Ls], run);                      // table congested: direct add
+                } else {
+                    atomicAdd(&total[Ls], run);
+                    tags[(sy * uzs + sz) * (uint32_t)P.nseg + (sx >> 6)] = P.epoch;
+                }
+            }
+            if (VAR == 6 && ++lc_fill == LC_PERIOD) {                      // wave-uniform
+                lc_flush(lck, lcc, total, lane, P.dbg);
+                lc_fill = 0; memo = LC_EMPTY;
+            }
+        }
+        if (VAR == 6 && lc_fill != 0u) lc_flush(lck, lcc, total, lane, P.dbg);
         return;
     }
 
@@ -259,6 +433,16 @@ __global__ __launch_bounds__(256) void k_trace(const ScanParams P, const T *__re
         else if (sy_dir < 0.0f) ystop_lo = lo - 2;
     }
     uint32_t n_heads = 0, n_lines = 0, n_instr = 0;      // VAR 2 only
+    __shared__ __attribute__((aligned(16))) uint32_t s_lc_keys[VAR == 4 ? 4 * 64 : 4];
+    __shared__ uint32_t s_lc_cnt[VAR == 4 ? 4 * 1024 : 1];
+    uint32_t *lck = s_lc_keys + (VAR == 4 ? (threadIdx.x >> 6) * 64 : 0);
+    uint32_t *lcc = s_lc_cnt + (VAR == 4 ? (threadIdx.x >> 6) * 1024 : 0);
+    uint32_t lc_fill = 0, memo_line = LC_EMPTY; int memo_slot = 0;
+    if (VAR == 4) {
+        LC_ST(&lck[lane], LC_EMPTY);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) LC_ST(&lcc[c * 64 + lane], 0u);
+    }
     while (__any(active)) {
         bool commit = false;
         uint32_t Ls = 0, Ts = 0;
@@ -292,11 +476,40 @@ __global__ __launch_bounds__(256) void k_trace(const ScanParams P, const T *__re
         const bool head = commit && (lane == 0 || left != key);
         const unsigned long long cmask = __ballot(commit);
         const unsigned long long nh = cmask & ~__ballot(head);               // followers
+        bool lc_new = false;
         if (head) {
             const unsigned long long after = (nh >> lane) >> 1;
             const uint32_t run = (uint32_t)__ffsll((long long)~after);       // 1 + followers
-            atomicAdd(&total[Ls], run);
-            tags[Ts] = P.epoch;                                              // stamp the tile (idempotent store)
+            if (VAR == 4) {
+                // memo: the (line, row-in-line) this lane added to last; a miss looks the line up
+                // (or inserts it) and stamps the voxel's tile tag
+                const uint32_t line = Ls >> 4, lrow = Ls >> 2;
+                int slot = -1;
+                if (lrow == memo_line) slot = memo_slot;
+                else {
+                    uint32_t hh = (line * 2654435761u) >> 26;
+                    for (int pr = 0; pr < 8; ++pr) {
+                        const uint32_t was = atomicCAS(&lck[LC_KEYPOS(hh)], LC_EMPTY, line);
+                        if (was == LC_EMPTY) { lc_new = true; slot = (int)hh; break; }
+                        if (was == line) { slot = (int)hh; break; }
+                        hh = (hh + 1u) & 63u;
+                    }
+                    tags[Ts] = P.epoch;
+                    if (slot >= 0) { memo_line = lrow; memo_slot = slot; }
+                }
+                if (slot >= 0) atomicAdd(&lcc[slot * 16 + (int)(Ls & 15u)], run);
+                else atomicAdd(&total[Ls], run);                                // table congested: direct add
+            } else {
+                atomicAdd(&total[Ls], run);
+                tags[Ts] = P.epoch;                                          // stamp the tile (idempotent store)
+            }
+        }
+        if (VAR == 4) {
+            lc_fill += (uint32_t)__popcll(__ballot(lc_new));
+            if (lc_fill >= LC_FLUSH_AT) {                                    // wave-uniform
+                lc_flush(lck, lcc, total, lane);
+                lc_fill = 0; memo_line = LC_EMPTY;
+            }
         }
         if (VAR == 2) {                                   // diagnostic: heads, distinct 64-B lines, instructions
             const unsigned long long hm = __ballot(head);
@@ -310,6 +523,7 @@ __global__ __launch_bounds__(256) void k_trace(const ScanParams P, const T *__re
             n_heads += (uint32_t)__popcll(hm); n_lines += (uint32_t)__popcll(nlm); n_instr += hm ? 1u : 0u;
         }
     }
+    if (VAR == 4 && lc_fill != 0u) lc_flush(lck, lcc, total, lane);
     if (VAR == 2 && lane == 0) { atomicAdd(&counters[4], n_heads); atomicAdd(&counters[5], n_lines); atomicAdd(&counters[6], n_instr); }
 }
 
@@ -367,9 +581,9 @@ __global__ __launch_bounds__(256) void k_encode(const ScanParams P, unsigned enc
         // k_trace has completed: the scan's row count is final.  Publish {seq, count} as ONE
         // 8-byte system-scope store to host-mapped memory (the host spins on it and returns to
         // its caller while this kernel and k_minh still run) and re-arm the counter.
-        const uint32_t c = counters[0];
-        const uint32_t any = counters[1] ? 0x80000000u : 0u;     // some return landed in the grid (any rank)
-        counters[0] = 0; counters[1] = 0;
+        const uint32_t c = counters[GVOM_CNT_ROWS];
+        const uint32_t any = counters[GVOM_CNT_INGRID] ? 0x80000000u : 0u;     // some return landed in the grid (any rank)
+        counters[GVOM_CNT_ROWS] = 0; counters[GVOM_CNT_INGRID] = 0;
         counters[8] = c; counters[9] = 0;               // device-side copy (int64) for sharded runs
         __hip_atomic_store(host_flag, ((unsigned long long)seq << 32) | any | c, __ATOMIC_RELEASE,
                            __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1689,10 +1903,16 @@ hipError_t gvom_launch_trace(hipStream_t s, const ScanParams &P, int dtype, cons
         if (variant == 0) TRACE_LAUNCH(float, 0);
         else if (variant == 9) TRACE_LAUNCH(float, 9);
         else if (variant == 2) TRACE_LAUNCH(float, 2);
+        else if (variant == 4) TRACE_LAUNCH(float, 4);
+        else if (variant == 5) TRACE_LAUNCH(float, 5);
+        else if (variant == 6) TRACE_LAUNCH(float, 6);
         else TRACE_LAUNCH(float, 1);
     } else {
         if (variant == 0) TRACE_LAUNCH(double, 0);
         else if (variant == 9) TRACE_LAUNCH(double, 9);
+        else if (variant == 4) TRACE_LAUNCH(double, 4);
+        else if (variant == 5) TRACE_LAUNCH(double, 5);
+        else if (variant == 6) TRACE_LAUNCH(double, 6);
         else TRACE_LAUNCH(double, 1);
     }
 #undef TRACE_LAUNCH

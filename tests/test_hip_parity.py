@@ -273,3 +273,56 @@ def test_concurrent_scan_and_combine_threads(gvom_mod):
         if a is not None:
             for k in range(4):
                 assert np.array_equal(a[k], b[k])
+
+
+def test_trace_exact_zero_and_tiny_negative_coordinates(gvom_mod):
+    """k_trace looks voxels up with integer arithmetic; the reference's floor((f64)p - origin) rounds
+    a coordinate just below zero UP (gvom.py:1121-1133).  Sensor exactly at the world origin with
+    rays whose off-axis slopes are 0, +-1e-17 and +-1e-30 (what sin(pi) gives a lidar driver)."""
+    params = (0.2, 0.2, 64, 32, 2) + synth.REF_TAIL
+    rng = np.random.default_rng(11)
+    base = []
+    for r in (2.0, 3.7, 5.1):
+        for t in (0.0, 1e-17, -1e-17, 1e-30, -1e-30, 1e-9, -1e-9):
+            base += [(r, t, 0.3), (-r, t, -0.2), (t, r, 0.1), (t, -r, t), (r, r * t, t), (-r, -r, t)]
+    pc = np.asarray(base, dtype=np.float64)
+    pc = np.concatenate([pc, rng.uniform(-6, 6, (3000, 3)) * np.array([1, 1, 0.3])])
+    steps = [("scan", pc, (0.0, 0.0, 0.0), None), ("combine",),
+             ("scan", pc.astype(np.float32), (-1e-12, 1e-20, -0.0), None), ("combine",)]
+    got, want = _run_both(gvom_mod, params, steps)
+    assert compare_records(got, want, float_tol=1e-5) > 20
+
+
+def test_trace_far_origin_uses_f64_lookup(gvom_mod):
+    """|origin| >= 2^30 voxels: the integer voxel lookup is not used (gvom_capi.hip selects the
+    f64 variant); results still match the oracle."""
+    params = (0.2, 0.2, 64, 32, 1) + synth.REF_TAIL
+    ego = (2.5e8, -2.5e8, 3.0)
+    rng = np.random.default_rng(5)
+    pc = rng.uniform(-5, 5, (4000, 3)) * np.array([1, 1, 0.3]) + np.asarray(ego)
+    steps = [("scan", pc, ego, None), ("combine",)]
+    got, want = _run_both(gvom_mod, params, steps)
+    assert compare_records(got, want, float_tol=1e-5) > 10
+
+
+def test_trace_variants_agree(gvom_mod, monkeypatch):
+    """GVOM_TRACE_VARIANT (read by gvom_create): the per-lane-atomic kernel (0), the f64 lock-step
+    kernel (1), the integer-lookup kernel (5) and the production LDS-line-cache kernel (6) leave
+    bit-identical scan slots."""
+    params, scans = synth.config_inputs("c2", n_scans=2)
+    ref = None
+    for variant in ("0", "1", "5", "6"):
+        monkeypatch.setenv("GVOM_TRACE_VARIANT", variant)
+        g = gvom_mod.Gvom(*params)
+        slots = []
+        for pc, ego, tf in scans:
+            g.process_pointcloud(pc, ego, tf)
+            b = g.last_buffer_index
+            slots.append(scenarios.dense_from_compact(scenarios.host(g.index_buffer[b]), scenarios.host(g.hit_count_buffer[b]),
+                                                      scenarios.host(g.total_count_buffer[b]), scenarios.host(g.min_height_buffer[b])))
+        if ref is None:
+            ref = slots
+        else:
+            for a, b_ in zip(ref, slots):
+                for x, y in zip(a, b_):
+                    assert np.array_equal(x, y), "variant %s differs" % variant
