@@ -104,6 +104,7 @@ struct gvom_handle {
     void *out_host = nullptr;                           // pinned, device-mapped staging for the 4 outputs
     char *out_host_dev = nullptr;                       // device view of out_host (zero-copy target)
     bool zero_copy = true;                              // GVOM_ZERO_COPY=0: device buffer + D2H copy
+    bool out_coherent = true;                           // GVOM_OUT_COHERENT=0: coarse-grained output buffers
     uint32_t scan_seq = 0;                              // sequence number of the {seq,count} flag
     bool ev_scan = false, ev_fuse = false, ev_map = false;   // which profiling events are recorded
     bool maps_valid = false;
@@ -285,6 +286,7 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, g
     CK(hipHostMalloc(&h->out_host, h->cells2d * 20, hipHostMallocMapped));
     CK(hipHostGetDevicePointer((void **)&h->out_host_dev, h->out_host, 0));
     if (const char *v = getenv("GVOM_ZERO_COPY")) h->zero_copy = atoi(v) != 0;
+    if (const char *v = getenv("GVOM_OUT_COHERENT")) h->out_coherent = atoi(v) != 0;
     for (auto &e : h->ev) CK(hipEventCreate(&e));
     CK(hipStreamSynchronize(h->stream));
 #undef CK
@@ -527,12 +529,13 @@ int fuse_impl(gvom_handle *h, bool publish_now)
 // 2-D maps (k_map2d) from height/inferred of the whole window (all rows must be present).
 // gathered: sharded run -- every row of the interleaved height buffer (heights + owner-computed
 // positive densities) has been all-gathered and this rank computes ALL rows of the outputs.
-int map2d_impl(gvom_handle *h, bool gathered, bool publish, char *out_dev)
+int map2d_impl(gvom_handle *h, bool gathered, bool publish, char *out_dev, bool yx)
 {
     const gvom_params &p = h->prm;
     const Fused &F = h->fused[h->cur];
     Map2dParams P;
     memset(&P, 0, sizeof P);
+    if (const char *v = getenv("GVOM_MAP2D_DEBUG")) P.dbg = atoi(v);
     P.xy = p.xy_size; P.zs = p.z_size;
     P.om[0] = (int)floor_mod(F.origin[0], p.xy_size);
     P.om[1] = (int)floor_mod(F.origin[1], p.xy_size);
@@ -542,7 +545,7 @@ int map2d_impl(gvom_handle *h, bool gathered, bool publish, char *out_dev)
     P.xy_res = p.xy_resolution; P.z_res = p.z_resolution;
     P.pos_thr = p.positive_obstacle_threshold; P.neg_thr = p.negative_obstacle_threshold;
     P.slope_thr = p.slope_obstacle_threshold; P.robot_height = p.robot_height;
-    P.out_storage_order = 0;
+    P.out_yx = yx ? 1 : 0;
     P.gathered_pos = gathered ? 1 : 0;
     P.nseg = h->nseg;
     P.hs = h->hs;
@@ -686,7 +689,7 @@ VIS int gvom_combine_maps(gvom_t *h, double origin_world[3], int32_t *positive, 
     double t0 = now_ns();
     int rc = fuse_impl(h, false);
     if (rc) return rc;
-    if ((rc = map2d_impl(h, false, true, h->zero_copy ? h->out_host_dev : (char *)h->out_pos))) return rc;
+    if ((rc = map2d_impl(h, false, true, h->zero_copy ? h->out_host_dev : (char *)h->out_pos, false))) return rc;
     const size_t n2 = h->cells2d;
     char *stage = (char *)h->out_host;
     if (!h->zero_copy && (positive || negative || visibility || roughness))
@@ -710,7 +713,8 @@ VIS int gvom_combine_maps(gvom_t *h, double origin_world[3], int32_t *positive, 
 
 // ---- zero-copy outputs ---------------------------------------------------------------------
 // gvom_output_buffer_alloc returns a pinned, device-mapped host buffer of 20*xy*xy bytes laid out
-// [positive i32 | negative i32 | visibility i32 | roughness f64] (each xy*xy, [x][y] order).
+// [positive i32 | negative i32 | visibility i32 | roughness f64] (each xy*xy, COLUMN-major:
+// cell (x, y) at m[y*xy + x]).
 // gvom_combine_maps_into makes k_map2d write the four maps straight into such a buffer: no D2H
 // copy command and no pinned->caller memcpy.  The caller owns the buffer until it frees it
 // (g-vom_amd/gvom.py recycles them through a pool when the returned numpy arrays are collected).
@@ -719,7 +723,9 @@ VIS int gvom_output_buffer_alloc(gvom_t *h, void **host_ptr)
     if (!h || !host_ptr) return GVOM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipHostMalloc(host_ptr, h->cells2d * 20, hipHostMallocMapped));
+    // GVOM_OUT_COHERENT=1: fine-grained (coherent) pinned memory -- stores leave the GPU as they are
+    // issued instead of being written back from L2 at the end of the kernel
+    HIPCHK(h, hipHostMalloc(host_ptr, h->cells2d * 20, hipHostMallocMapped | (h->out_coherent ? hipHostMallocCoherent : 0u)));
     return GVOM_OK;
 }
 
@@ -743,7 +749,7 @@ VIS int gvom_combine_maps_into(gvom_t *h, double origin_world[3], void *pinned_o
     if (rc) return rc;
     char *dev = nullptr;
     HIPCHK(h, hipHostGetDevicePointer((void **)&dev, pinned_out, 0));
-    if ((rc = map2d_impl(h, false, true, dev))) return rc;
+    if ((rc = map2d_impl(h, false, true, dev, true))) return rc;
     HT(h, 2, t0);
     if ((rc = finish_combine(h))) return rc;
     HT(h, 3, t0);
@@ -861,7 +867,7 @@ VIS int gvom_combine_map2d_into(gvom_t *h, double origin_world[3], void *pinned_
     HIPCHK(h, hipSetDevice(h->device));
     char *dev = nullptr;
     HIPCHK(h, hipHostGetDevicePointer((void **)&dev, pinned_out, 0));
-    int rc = map2d_impl(h, true, false, dev);
+    int rc = map2d_impl(h, true, false, dev, true);
     if (rc) return rc;
     if ((rc = finish_combine(h))) return rc;
     if (origin_world) {

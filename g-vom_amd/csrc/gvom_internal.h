@@ -99,7 +99,8 @@ struct Map2dParams {
     int hs;                 // row stride (elements) of the height / inferred-height maps
     int gathered_pos;       // 1: positive-obstacle densities come from the gathered height buffer (sharded)
     uint32_t epoch;         // epoch of the fused map (tile liveness of fstate)
-    int out_storage_order;  // 1: the four outputs stay [sy][sx] (sharded runs); 0: reference [x][y]
+    int dbg;                // GVOM_MAP2D_DEBUG bits (timing experiments only)
+    int out_yx;             // 1: returned maps in [y][x] memory order (column-major [x, y]); 0: row-major [x][y]
     double origin_z;        // fused origin z (voxels)
     double xy_res, z_res;
     double pos_thr, neg_thr, slope_thr, robot_height;

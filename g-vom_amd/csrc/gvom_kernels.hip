@@ -1224,6 +1224,16 @@ __global__ void k_publish_count(const uint32_t *blockcounts, int nblocks, unsign
     if (threadIdx.x == 0) *dev_counter = s_red[0];
 }
 
+// Store that leaves the GPU now (system scope: written through L2) instead of staying in the
+// write-back L2 until the end-of-kernel release.  (Measured: the 1.3 MB of returned maps cost
+// ~23 us of PCIe time either way -- the link, not the issue order, is the limit.)
+template <typename V>
+__device__ __forceinline__ void st_sys(V *p, V v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("" ::: "memory");                       // keep the compiler from sinking it to the kernel's end
+}
+
 // ------------------------------------------------------------------------------------------
 // k_map2d: every 2-D output of combine_maps from height/inferred height, one lane per cell.
 //
@@ -1237,13 +1247,15 @@ __global__ void k_publish_count(const uint32_t *blockcounts, int nblocks, unsign
 // -- straight into host-mapped memory on the single-GPU path (no D2H copy command) -- or left
 // in storage order for sharded runs.
 // ------------------------------------------------------------------------------------------
-#define M2_TX 8
-#define M2_TY 32
 #define M2_HALO 15
-#define M2_W (M2_TX + 2 * M2_HALO)   // 62
-#define M2_H (M2_TY + 2 * M2_HALO)   // 38
 
-template <bool GATHERED_POS>
+// TX x TY window cells per workgroup (256 threads).  YX = false: 8 x 32 tile, the four returned
+// maps in row-major [x][y] order (transposed through LDS, runs of 32 consecutive y).  YX = true:
+// 32 x 8 tile, the maps in [y][x] memory order -- the SAME arrays seen as column-major (numpy:
+// Fortran-ordered, indexed [x, y]); a lane's 32 neighbours in x form 128/256-byte runs without a
+// transpose, and each map is stored as soon as it is known (all global loads come first: vmcnt is
+// in-order, a load behind a host-memory store would wait for the store to drain over PCIe).
+template <bool GATHERED_POS, bool YX>
 __global__ __launch_bounds__(256) void k_map2d(const Map2dParams P, const int32_t *__restrict__ fstate,
                                                const uint32_t *__restrict__ ftags,
                                                const uint32_t *__restrict__ fhit,
@@ -1256,32 +1268,49 @@ __global__ __launch_bounds__(256) void k_map2d(const Map2dParams P, const int32_
                                                const uint32_t *blockcounts, int nblocks,
                                                unsigned long long *host_counter)
 {
+    constexpr int M2_TX = YX ? 32 : 8, M2_TY = YX ? 8 : 32;
+    constexpr int M2_W = M2_TX + 2 * M2_HALO, M2_H = M2_TY + 2 * M2_HALO;      // 62 x 38 (YX) or 38 x 62
     __shared__ double ht[M2_H][M2_W];
     __shared__ unsigned long long rowm[M2_H];
     __shared__ unsigned long long colm[M2_W];
-    __shared__ int o_pos[M2_TX][M2_TY + 1], o_neg[M2_TX][M2_TY + 1], o_vis[M2_TX][M2_TY + 1];
-    __shared__ double o_rgh[M2_TX][M2_TY + 1];
+    __shared__ int o_pos[YX ? 1 : M2_TX][M2_TY + 1], o_neg[YX ? 1 : M2_TX][M2_TY + 1], o_vis[YX ? 1 : M2_TX][M2_TY + 1];
+    __shared__ double o_rgh[YX ? 1 : M2_TX][M2_TY + 1];
 
     const int xy = P.xy;
     const int tid = threadIdx.x;
-    const int tx = tid & (M2_TX - 1), ty = tid >> 3;
+    const int tx = tid & (M2_TX - 1), ty = tid / M2_TX;
     const int lane = tid & 63, wv = tid >> 6;
     const int X0 = blockIdx.x * M2_TX, Y0 = blockIdx.y * M2_TY;
-    if (host_counter && blockIdx.x == 0 && blockIdx.y == 0) {
+    if (host_counter && blockIdx.x == 0 && blockIdx.y == 0 && !(P.dbg & 16)) {
         // k_fuse is complete: publish the fused occupied-voxel count (host-mapped memory)
-        __shared__ unsigned long long s_red[M2_TX * M2_TY];
-        publish_block_counts(blockcounts, nblocks, host_counter, s_red, tid, M2_TX * M2_TY);
+        __shared__ unsigned long long s_red[256];
+        publish_block_counts(blockcounts, nblocks, host_counter, s_red, tid, 256);
     }
 
     // ---- stage the tile (+halo) and its row masks ------------------------------------------
-    for (int r = wv; r < M2_H; r += 4) {
-        const int gy = Y0 - M2_HALO + r, gx = X0 - M2_HALO + lane;
-        double v = -1000.0;
-        if (lane < M2_W && gy >= 0 && gy < xy && gx >= 0 && gx < xy)
-            v = height[(size_t)wrap_add(gy, P.om[1], xy) * P.hs + wrap_add(gx, P.om[0], xy)];
-        if (lane < M2_W) ht[r][lane] = v;
-        const unsigned long long m = __ballot(v > -1000);
-        if (lane == 0) rowm[r] = m;
+    {   // all of a wave's rows are fetched before the first use: independent, unconditional loads
+        // (out-of-window cells read a valid dummy address and are replaced by -1000)
+        constexpr int NR = (M2_H + 3) / 4;
+        double v[NR];
+        bool inw[NR];
+        const int gx = X0 - M2_HALO + lane;
+        const int sxh = wrap_add((gx >= 0 && gx < xy) ? gx : 0, P.om[0], xy);
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int r = wv + 4 * k, gy = Y0 - M2_HALO + r;
+            inw[k] = r < M2_H && lane < M2_W && gy >= 0 && gy < xy && gx >= 0 && gx < xy;
+            v[k] = height[inw[k] ? (size_t)wrap_add(gy, P.om[1], xy) * P.hs + sxh : (size_t)0];
+        }
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int r = wv + 4 * k;
+            const double vv = inw[k] ? v[k] : -1000.0;
+            const unsigned long long m = __ballot(vv > -1000);
+            if (r < M2_H) {
+                if (lane < M2_W) ht[r][lane] = vv;
+                if (lane == 0) rowm[r] = m;
+            }
+        }
     }
     __syncthreads();
     if (tid < M2_W) {
@@ -1296,8 +1325,56 @@ __global__ __launch_bounds__(256) void k_map2d(const Map2dParams P, const int32_
     const int sx0 = wrap_add(mine ? x0 : 0, P.om[0], xy), sy0 = wrap_add(mine ? y0 : 0, P.om[1], xy);
     mine = mine && sy0 >= P.y_lo && sy0 < P.y_hi;                      // else: another rank's row
     const int lx = tx + M2_HALO, ly = ty + M2_HALO;
+    const size_t c_out = (size_t)y0 * xy + x0;                         // YX: [y][x] (column-major [x, y])
+    const bool wr = !(P.dbg & 1);
     if (mine) {
     const double h00 = ht[ly][lx];
+    // ---- global loads first.  Stores into host-mapped memory are acknowledged slowly and vmcnt is
+    // in-order: any load issued after them would stall the wave until they have drained over PCIe,
+    // so everything this cell reads from memory is fetched before its first returned map is stored.
+    const double inf00 = inferred[(size_t)sy0 * P.hs + sx0];
+    int dens_pos = 0;                                        // positive-obstacle density x100 (gvom.py:489-521)
+    if (GATHERED_POS) {
+        // sharded runs: the slab owner computed the density (k_posdens), all-gathered with the heights
+        dens_pos = (int)height[(size_t)sy0 * P.hs + 2 * (size_t)xy + sx0];
+    } else {
+        const double fmin = floor(((h00 + P.pos_thr) / P.z_res) - P.origin_z) + 1.0;
+        const double fmax = floor(((h00 + P.robot_height) / P.z_res) - P.origin_z);
+        if (fmin >= 0 && fmin < (double)P.zs && fmax >= 0 && fmax < (double)P.zs && !(P.dbg & 2)) {
+            const int zmin = (int)fmin, zmax = (int)fmax;
+            double density = 0.0, nn = 0.0;
+            // 8 levels per round: tags, then states, then counts -- three dependent round trips
+            // per round instead of three per level (unconditional loads, dummy index when dead)
+            for (int zb = zmin; zb <= zmax; zb += 8) {
+                uint32_t rz[8], tg[8], hc[8], tc[8];
+                int32_t row[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int z = (zb + k <= zmax) ? zb + k : zmin;
+                    rz[k] = (uint32_t)sy0 * P.zs + (uint32_t)wrap_add(z, P.om[2], P.zs);
+                    tg[k] = ftags[rz[k] * P.nseg + (sx0 >> 6)];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const bool live = zb + k <= zmax && tg[k] == P.epoch;       // live tile
+                    row[k] = fstate[live ? rz[k] * xy + sx0 : 0u];
+                    if (!live) row[k] = -1;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t r = row[k] >= 0 ? (uint32_t)row[k] : 0u;
+                    hc[k] = fhit[r]; tc[k] = ftotal[r];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (row[k] >= 0 && (int32_t)hc[k] > 10) { nn += (double)(int32_t)tc[k]; density += (double)(int32_t)hc[k]; }
+            }
+            if (nn > 0.0) density /= nn;
+            dens_pos = (int)(density * 100);
+        }
+    }
+    const int visv = h00 > -1000 ? 1 : 0;                    // gvom.py:414-422
+    if (YX && wr) st_sys(&out_vis[c_out], visv);
 
     // ---- slope / roughness: 3x3 least-squares plane (gvom.py:665-734) ---------------------
     // cells outside the window hold -1000 in the tile, i.e. are skipped exactly like the
@@ -1310,7 +1387,7 @@ __global__ __launch_bounds__(256) void k_map2d(const Map2dParams P, const int32_
 #pragma unroll
             for (int dy = -1; dy <= 1; ++dy)
                 if (ht[ly + dy][lx + dx] > -1000) ++n_good;
-        if (n_good >= 3) {
+        if (n_good >= 3 && !(P.dbg & 4)) {
             double mean_x = 0.0, mean_y = 0.0, mean_z = 0.0;
 #pragma unroll
             for (int dx = -1; dx <= 1; ++dx)
@@ -1368,14 +1445,16 @@ __global__ __launch_bounds__(256) void k_map2d(const Map2dParams P, const int32_
     }
     const size_t c_yx = (size_t)sy0 * xy + sx0;
     slope_x[c_yx] = sxv; slope_y[c_yx] = syv; rough[c_yx] = rv;
+    if (YX && wr) st_sys(&out_rough[c_out], rv);
+    const int pos = (sqrt(sxv * sxv + syv * syv) >= P.slope_thr) ? 100 : dens_pos;   // gvom.py:489-521
+    if (YX && wr) st_sys(&out_pos[c_out], pos);
 
     // ---- guess height (gvom.py:558-661), typos at :581 and :655 reproduced ---------------
     // ring i, direction +x: first valid cell of column x0+i for dy in [-i, i)   -> colm bit-scan
     //                   -x: column x0-i, dy in [-i+1, i];  +y: row y0+i, dx in [-i+1, i];
     //                   -y: row y0-i, dx in [-i, i)                               (gvom.py:588-638)
     double dh_out = 0.0;
-    const double inf00 = inferred[(size_t)sy0 * P.hs + sx0];
-    if (!(h00 > -1000 || inf00 == -1000.0)) {
+    if (!(h00 > -1000 || inf00 == -1000.0) && !(P.dbg & 8)) {
         bool x_p_done = false, x_n_done = false, y_p_done = false, y_n_done = false;
         double x_ph = -1000, x_nh = -1000, y_ph = -1000, y_nh = -1000;
         int i = 0;
@@ -1417,42 +1496,15 @@ __global__ __launch_bounds__(256) void k_map2d(const Map2dParams P, const int32_
     }
     guessed[c_yx] = dh_out;
     const int negv = dh_out > P.neg_thr ? 100 : 0;           // gvom.py:479-485
-    const int visv = h00 > -1000 ? 1 : 0;                    // gvom.py:414-422
+    if (YX && wr) st_sys(&out_neg[c_out], negv);
 
-    // ---- positive obstacles (gvom.py:489-521) ------------------------------------------
-    int pos = 0;
-    if (sqrt(sxv * sxv + syv * syv) >= P.slope_thr) {
-        pos = 100;
-    } else if (GATHERED_POS) {
-        // sharded runs: the slab owner computed the density (k_posdens), all-gathered with the heights
-        pos = (int)height[(size_t)sy0 * P.hs + 2 * (size_t)xy + sx0];
-    } else {
-        const double fmin = floor(((h00 + P.pos_thr) / P.z_res) - P.origin_z) + 1.0;
-        const double fmax = floor(((h00 + P.robot_height) / P.z_res) - P.origin_z);
-        if (fmin >= 0 && fmin < (double)P.zs && fmax >= 0 && fmax < (double)P.zs) {
-            const int zmin = (int)fmin, zmax = (int)fmax;
-            double density = 0.0, nn = 0.0;
-            for (int z = zmin; z <= zmax; ++z) {
-                const int sz = wrap_add(z, P.om[2], P.zs);
-                const uint32_t rz = (uint32_t)sy0 * P.zs + sz;
-                int32_t row = -1;
-                if (ftags[rz * P.nseg + (sx0 >> 6)] == P.epoch) row = fstate[rz * xy + sx0];   // live tile
-                if (row >= 0) {
-                    const uint32_t hc = fhit[row];
-                    if ((int32_t)hc > 10) { nn += (double)(int32_t)ftotal[row]; density += (double)(int32_t)hc; }
-                }
-            }
-            if (nn > 0.0) density /= nn;
-            pos = (int)(density * 100);
-        }
-    }
-    o_pos[tx][ty] = pos; o_neg[tx][ty] = negv; o_vis[tx][ty] = visv; o_rgh[tx][ty] = rv;
+    if (!YX) { o_pos[tx][ty] = pos; o_neg[tx][ty] = negv; o_vis[tx][ty] = visv; o_rgh[tx][ty] = rv; }
     }   // mine
-    {
+    if (!YX) {
         __syncthreads();
         const int ox = tid >> 5, oy = tid & 31;              // 32 consecutive lanes -> 32 consecutive y
         const int gx = X0 + ox, gy = Y0 + oy;
-        if (gx < xy && gy < xy) {
+        if (gx < xy && gy < xy && !(P.dbg & 1)) {
             const size_t c_xy = (size_t)gx * xy + gy;
             out_pos[c_xy] = o_pos[ox][oy]; out_neg[c_xy] = o_neg[ox][oy];
             out_vis[c_xy] = o_vis[ox][oy]; out_rough[c_xy] = o_rgh[ox][oy];
@@ -1970,16 +2022,16 @@ hipError_t gvom_launch_map2d(hipStream_t s, const Map2dParams &P, const int32_t 
                              double *out_rough, int32_t *out_vis, const uint32_t *blockcounts,
                              int nblocks, unsigned long long *host_counter)
 {
-    const dim3 grid((P.xy + M2_TX - 1) / M2_TX, (P.xy + M2_TY - 1) / M2_TY);
     if (P.y_hi <= P.y_lo) return hipSuccess;
-    if (P.gathered_pos)
-        hipLaunchKernelGGL(k_map2d<true>, grid, dim3(M2_TX * M2_TY), 0, s, P, fstate, ftags, fhit, ftotal, height,
-                           inferred, slope_x, slope_y, rough, guessed, out_pos, out_neg, out_rough, out_vis,
-                           blockcounts, nblocks, host_counter);
-    else
-        hipLaunchKernelGGL(k_map2d<false>, grid, dim3(M2_TX * M2_TY), 0, s, P, fstate, ftags, fhit, ftotal, height,
-                           inferred, slope_x, slope_y, rough, guessed, out_pos, out_neg, out_rough, out_vis,
-                           blockcounts, nblocks, host_counter);
+    const int tx = P.out_yx ? 32 : 8, ty = P.out_yx ? 8 : 32;
+    const dim3 grid((P.xy + tx - 1) / tx, (P.xy + ty - 1) / ty);
+#define MAP2D_LAUNCH(G, Y)                                                                              \
+    hipLaunchKernelGGL((k_map2d<G, Y>), grid, dim3(256), 0, s, P, fstate, ftags, fhit, ftotal, height, \
+                       inferred, slope_x, slope_y, rough, guessed, out_pos, out_neg, out_rough, out_vis, \
+                       blockcounts, nblocks, host_counter)
+    if (P.gathered_pos) { if (P.out_yx) MAP2D_LAUNCH(true, true); else MAP2D_LAUNCH(true, false); }
+    else { if (P.out_yx) MAP2D_LAUNCH(false, true); else MAP2D_LAUNCH(false, false); }
+#undef MAP2D_LAUNCH
     return hipGetLastError();
 }
 

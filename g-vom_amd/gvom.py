@@ -322,10 +322,13 @@ class Gvom(object):
         if rc != GVOM_OK:
             return rc, None
         raw = np.asarray(holder)
-        positive = raw[0:4 * n2].view(np.int32).reshape(xy, xy)
-        negative = raw[4 * n2:8 * n2].view(np.int32).reshape(xy, xy)
-        visibility = raw[8 * n2:12 * n2].view(np.int32).reshape(xy, xy)
-        roughness = raw[12 * n2:20 * n2].view(np.float64).reshape(xy, xy)
+        # the library writes the maps in [y][x] memory order: seen through .T they are the reference's
+        # [x, y]-indexed arrays in Fortran order (what gvom_ros.py's reshape(..., order='F') reads
+        # without a copy), and the GPU writes them as contiguous runs without a transpose
+        positive = raw[0:4 * n2].view(np.int32).reshape(xy, xy).T
+        negative = raw[4 * n2:8 * n2].view(np.int32).reshape(xy, xy).T
+        visibility = raw[8 * n2:12 * n2].view(np.int32).reshape(xy, xy).T
+        roughness = raw[12 * n2:20 * n2].view(np.float64).reshape(xy, xy).T
         return GVOM_OK, (origin, positive, negative, roughness, visibility)
 
     # ---- accessors / debug API (reference gvom.py:356-410) ------------------------------

@@ -115,8 +115,11 @@ int gvom_combine_maps(gvom_t *h, double origin_world[3], int32_t *positive, int3
 
 /* Zero-copy variant of combine_maps: the four maps are written by the GPU straight into a
  * pinned, device-mapped host buffer obtained from gvom_output_buffer_alloc (20*xy*xy bytes:
- * [positive i32 | negative i32 | visibility i32 | roughness f64], each xy*xy in [x][y] order).
- * The caller owns the buffer (and may keep several alive) until gvom_output_buffer_free. */
+ * [positive i32 | negative i32 | visibility i32 | roughness f64]).  Unlike gvom_combine_maps,
+ * each map is stored COLUMN-MAJOR: cell (x, y) at m[y*xy_size + x] -- the Fortran-ordered form of
+ * the reference's [x, y]-indexed arrays, which is what gvom_ros.py:141-162 reads
+ * (np.reshape(map, -1, order='F')); the GPU writes it as contiguous runs without a transpose and
+ * streams each map out as soon as it is known.  The caller owns the buffer (and may keep several alive) until gvom_output_buffer_free. */
 int gvom_output_buffer_alloc(gvom_t *h, void **host_ptr);
 int gvom_output_buffer_free(gvom_t *h, void *host_ptr);
 int gvom_combine_maps_into(gvom_t *h, double origin_world[3], void *pinned_out);

@@ -8,6 +8,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
+[ -x $REPO/tools/pmc_calib ] || hipcc -O3 --offload-arch=gfx950 -Wno-unused-value $REPO/tools/pmc_calib.hip -o $REPO/tools/pmc_calib
 cd /tmp
 BENCH="python3 $REPO/bench.py --no-cpu --steps 30 --warmup 5 $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/bench_trace.json 2> $OUT/trace.err
