@@ -178,9 +178,11 @@ void fill_scan_params(const gvom_handle *h, const int64_t origin[3], const doubl
     P.sxq = (p.xy_size + 3) / 4;
     // DDA segments: the ego sits at the window centre, so a ray takes at most size/2 + 2 steps
     {
-        int nsegs = 4;
-        if (const char *v = getenv("GVOM_TRACE_SEGMENTS")) nsegs = atoi(v) > 0 ? atoi(v) : 4;
+        int nsegs = 6;
+        if (const char *v = getenv("GVOM_TRACE_SEGMENTS")) nsegs = atoi(v) > 0 ? atoi(v) : 6;
         P.dbg = 0;
+        P.lc_period = 12;
+        if (const char *v = getenv("GVOM_TRACE_PERIOD")) P.lc_period = atoi(v) > 0 ? atoi(v) : 12;
         if (const char *v = getenv("GVOM_TRACE_DEBUG")) P.dbg = atoi(v);
         const int maxsteps = (p.xy_size > p.z_size ? p.xy_size : p.z_size) / 2 + 2;
         P.nsegs = nsegs;

@@ -52,6 +52,7 @@ struct ScanParams {
     int    sxq;           // accumulator layout: 4x4 (x,y) patches per row of patches = ceil(xy/4)
     uint32_t epoch;       // this scan's tile epoch
     // slab-sharded runs: the slab's rows as (up to two) intervals of WINDOW y, for ray culling
+    int    lc_period;     // k_trace line cache: flush every lc_period committing steps (GVOM_TRACE_PERIOD)
     int    dbg;           // GVOM_TRACE_DEBUG bits (timing experiments only; results wrong when set)
     int    cull;          // 1: skip rays that cannot reach the slab, stop rays that have left it
     int    wlo[2], whi[2];

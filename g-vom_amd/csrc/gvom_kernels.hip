@@ -115,7 +115,7 @@ __device__ __forceinline__ void lc_flush(uint32_t *keys, uint32_t *cnt, uint32_t
 //      request per 64-B line (lc_flush): steps of a ray bundle that revisit a line are merged too
 //   9  diagnostic only: no DDA atomics at all (measures the arithmetic floor; results wrong)
 template <typename T, int VAR>
-__global__ __launch_bounds__(256) void k_trace(const ScanParams P, const T *__restrict__ in,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_trace(const ScanParams P, const T *__restrict__ in,
                                                long stride, long n, T *__restrict__ world,
                                                uint32_t *hit, uint32_t *total, int32_t *state,
                                                uint32_t *tags, uint32_t *cminh, uint32_t *counters,
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256) void k_trace(const ScanParams P, const T *__re
                     tags[(sy * uzs + sz) * (uint32_t)P.nseg + (sx >> 6)] = P.epoch;
                 }
             }
-            if (VAR == 6 && ++lc_fill == LC_PERIOD) {                      // wave-uniform
+            if (VAR == 6 && ++lc_fill == (uint32_t)P.lc_period) {                      // wave-uniform
                 lc_flush(lck, lcc, total, lane, P.dbg);
                 lc_fill = 0; memo = LC_EMPTY;
             }
