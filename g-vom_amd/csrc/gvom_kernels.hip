@@ -985,9 +985,9 @@ __global__ __launch_bounds__(1024) void k_fuse4(const FuseParams P, const FuseDe
 {
     __shared__ uint32_t s_cnt[16];
     __shared__ unsigned long long s_live[16][GVOM_MAX_SLOTS + 1];
-    __shared__ int s_zocc[16][WAVE];
-    __shared__ uint32_t s_hocc[16][WAVE];
-    __shared__ int s_zfree[16][WAVE];
+    __shared__ unsigned long long s_zh[16][WAVE];          // per wave and column: min of (z << 32 | min-height bits) over occupied voxels
+    __shared__ uint32_t s_zf[16][WAVE];                    // per wave and column: lowest observed-free z
+    __shared__ uint32_t s_list[16][4 * WAVE];              // per wave: the occupied voxels of one 4-level group, compacted
 
     const MapDesc *__restrict__ descs = descs_mem ? descs_mem : KD.d;
     const int lane = threadIdx.x & (WAVE - 1);
@@ -1016,14 +1016,15 @@ __global__ __launch_bounds__(1024) void k_fuse4(const FuseParams P, const FuseDe
     const uint32_t colbase = (uint32_t)sy * P.zs * P.xy + (col_ok ? sxb : 0);
     const uint32_t tbase = (uint32_t)sy * P.zs * P.nseg + blockIdx.x;
     uint32_t running = 0;
-    int zocc[4] = {INT_MAX, INT_MAX, INT_MAX, INT_MAX}, zfree[4] = {INT_MAX, INT_MAX, INT_MAX, INT_MAX};
-    uint32_t hocc[4] = {0x3f800000u, 0x3f800000u, 0x3f800000u, 0x3f800000u};
+    int zfree[4] = {INT_MAX, INT_MAX, INT_MAX, INT_MAX};
+    s_zh[w][lane] = ((unsigned long long)INT_MAX << 32) | 0x3f800000ull;      // wave-private until the tail
+    s_zf[w][lane] = (uint32_t)INT_MAX;
     const uint32_t rbase = ((blockIdx.y * gridDim.x + blockIdx.x) * (uint32_t)P.nz + w) *
                            (uint32_t)(WAVE * P.zc * P.cpw);
 
     {   // phase 0: live-tile masks of every source for the (<= 64) tiles of this wave
         const int cc_l = lane >> 4, k_l = lane & 15;
-        const int zl = (w * P.cpw + cc_l) * P.zc + k_l;
+        const int zl = (cc_l * P.nz + w) * P.zc + k_l;      // chunks are dealt round-robin to the waves (see below)
         const bool valid_l = cc_l < P.cpw && k_l < P.zc && zl < P.zs;
         const uint32_t tl = tbase + (uint32_t)wrap_add(valid_l ? zl : 0, P.om[2], P.zs) * P.nseg;
         for (int s0 = 0; s0 < nsrc; s0 += 4) {
@@ -1032,14 +1033,16 @@ __global__ __launch_bounds__(1024) void k_fuse4(const FuseParams P, const FuseDe
             for (int j = 0; j < 4; ++j) tv[j] = ((gptr_u32)descs[min(s0 + j, nsrc - 1)].tags)[tl];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const unsigned long long m = __ballot(valid_l && tv[j] == descs[min(s0 + j, nsrc - 1)].epoch);
+                const unsigned long long m = (P.debug & 4) ? 0ull : __ballot(valid_l && tv[j] == descs[min(s0 + j, nsrc - 1)].epoch);
                 if (lane == 0 && s0 + j < nsrc) s_live[w][s0 + j] = m;
             }
         }
     }
 
     for (int cc = 0; cc < P.cpw; ++cc) {
-        const int z0 = (w * P.cpw + cc) * P.zc;
+        // chunk cc of wave w is chunk cc*nz + w of the column: the observed band (ground +- a few
+        // metres) is a run of neighbouring chunks, and this spreads it over all waves of the workgroup
+        const int z0 = (cc * P.nz + w) * P.zc;
         if (z0 >= P.zs) break;
         const int z1 = min(z0 + P.zc, P.zs);
         uint32_t anylive = 0;
@@ -1104,74 +1107,86 @@ __global__ __launch_bounds__(1024) void k_fuse4(const FuseParams P, const FuseDe
 #pragma unroll
             for (int i = 0; i < 4; ++i) nonempty = nonempty || ((occbits >> (4 * j + i)) & 1u) || c[4 * j + i] != -1;
             const unsigned long long nb = __ballot(inside && nonempty);
-            if ((nb >> (16 * q)) & 0xffffull) {           // some lane of MY tile (same q) has content
+            if (((nb >> (16 * q)) & 0xffffull) && !(P.debug & 1)) {           // some lane of MY tile (same q) has content
                 if (g == 0 && zq[j] < z1)
                     ftags[tbase + (uint32_t)wrap_add(zq[j], P.om[2], P.zs) * P.nseg] = P.epoch;
                 if (inside) {
                     *reinterpret_cast<int4 *>(fstate + roff[j]) = make_int4(c[4 * j], c[4 * j + 1], c[4 * j + 2], c[4 * j + 3]);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        if ((occbits >> (4 * j + i)) & 1u) { if (zocc[i] == INT_MAX) zocc[i] = zq[j]; }
-                        else if (c[4 * j + i] < -1 && zfree[i] == INT_MAX) zfree[i] = zq[j];   // gvom.py:551
+                        if (!((occbits >> (4 * j + i)) & 1u) && c[4 * j + i] < -1 && zfree[i] == INT_MAX) zfree[i] = zq[j];   // gvom.py:551
                     }
                 }
             }
         }
 
-        // occupied voxels (sparse): per j (4 levels x 64 columns of the wave), batched gathers
+        // occupied voxels (sparse): the (<= 256) occupied voxels of a 4-level group are compacted
+        // across the wave and handled ONE LANE PER VOXEL: every source's state at that voxel is
+        // fetched in one round trip and the rows' counts in a second one, whatever the number of
+        // levels and sources (the per-level, per-source form was a chain of up to 16 round trips).
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const uint32_t gbits = (occbits >> (4 * j)) & 0xfu;
+            const uint32_t gbits = (P.debug & 2) ? 0u : (occbits >> (4 * j)) & 0xfu;
             if (!__any(gbits != 0)) continue;               // wave-uniform
-            uint32_t hh[4] = {0, 0, 0, 0}, tt[4] = {0, 0, 0, 0}, mm[4] = {0x3f800000u, 0x3f800000u, 0x3f800000u, 0x3f800000u};
-            for (int s = 0; s < nsrc; ++s) {
-                const gptr_i32 sp = (gptr_i32)descs[s].state;
-                const gptr_u32 hp = (gptr_u32)descs[s].hit, tp = (gptr_u32)descs[s].total, mp = (gptr_u32)descs[s].minh;
-                const uint32_t live = (uint32_t)(s_live[w][s] >> (16 * cc)) & 0xffffu;
-                const int dz = descs[s].d[2];
-                const bool zin = gbits && ((live >> (4 * j + q)) & 1u) && zq[j] + dz >= 0 && zq[j] + dz < P.zs;
-                const v4i v = *(gptr_v4i)(sp + (zin ? roff[j] : (uint32_t)(4 * lane)));
-                const int vv[4] = {v.x, v.y, v.z, v.w};
-                int st[4];
-                uint32_t gh[4], gt[4], gm[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    st[i] = (zin && ((gbits >> i) & 1u) && ((okm[i] >> s) & 1ull) && vv[i] >= 0) ? vv[i] : -1;
-                    const uint32_t r = st[i] >= 0 ? (uint32_t)st[i] : 0u;
-                    gh[i] = hp[r]; gt[i] = tp[r]; gm[i] = mp[r];
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (st[i] >= 0) { hh[i] += gh[i]; tt[i] += gt[i]; mm[i] = min(mm[i], gm[i]); }   // gvom.py:910-912
-            }
+            uint32_t n = 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const bool occ = (gbits >> i) & 1u;
                 const unsigned long long b = __ballot(occ);
-                if (occ) {
-                    const uint32_t row = rbase + running + (uint32_t)__popcll(b & lanemask_lt());
-                    fstate[roff[j] + i] = (int32_t)row;
-                    fhit[row] = hh[i]; ftotal[row] = tt[i]; fminh[row] = mm[i];
-                    if (zq[j] == zocc[i]) hocc[i] = mm[i];
-                }
-                running += (uint32_t)__popcll(b);
+                if (occ) s_list[w][n + (uint32_t)__popcll(b & lanemask_lt())] = ((uint32_t)lane << 2) | (uint32_t)i;
+                n += (uint32_t)__popcll(b);
             }
+            for (uint32_t base = 0; base < n; base += WAVE) {
+                const uint32_t t = base + (uint32_t)lane;
+                const bool on = t < n;
+                const uint32_t e = s_list[w][on ? t : 0u];
+                const int ci = (int)(e & 3u), go = (int)((e >> 2) & 15u), qo = (int)(e >> 6);
+                const int zv = z0 + 4 * j + qo;                                  // window level of my voxel
+                const int col = 4 * go + ci;                                     // column within the workgroup
+                const int sxc = blockIdx.x * WAVE + col;
+                const int xwc = wrap_sub(sxc, P.om[0], P.xy);
+                const uint32_t off = (uint32_t)sy * P.zs * P.xy + (uint32_t)wrap_add(zv, P.om[2], P.zs) * P.xy + (uint32_t)sxc;
+                const int lbit = 16 * cc + 4 * j + qo;                            // my tile in s_live
+                uint32_t hh = 0, tt = 0, mm = 0x3f800000u;
+                for (int s0 = 0; s0 < nsrc; s0 += 4) {
+                    int st[4];
+                    bool ok[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int sI = min(s0 + u, nsrc - 1);
+                        const int xs = xwc + descs[sI].d[0], ys = y + descs[sI].d[1], zs2 = zv + descs[sI].d[2];
+                        ok[u] = on && s0 + u < nsrc && ((s_live[w][sI] >> lbit) & 1ull) &&
+                                xs >= 0 && xs < P.xy && ys >= 0 && ys < P.xy && zs2 >= 0 && zs2 < P.zs;
+                        st[u] = ((gptr_i32)descs[sI].state)[ok[u] ? off : (uint32_t)lane];
+                    }
+                    uint32_t gh[4], gt[4], gm[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int sI = min(s0 + u, nsrc - 1);
+                        if (!ok[u]) st[u] = -1;
+                        const uint32_t r = st[u] >= 0 ? (uint32_t)st[u] : 0u;
+                        gh[u] = ((gptr_u32)descs[sI].hit)[r]; gt[u] = ((gptr_u32)descs[sI].total)[r]; gm[u] = ((gptr_u32)descs[sI].minh)[r];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (st[u] >= 0) { hh += gh[u]; tt += gt[u]; mm = min(mm, gm[u]); }          // gvom.py:910-912
+                }
+                if (on) {
+                    const uint32_t row = rbase + running + t;
+                    fstate[off] = (int32_t)row;
+                    fhit[row] = hh; ftotal[row] = tt; fminh[row] = mm;
+                    atomicMin(&s_zh[w][col], ((unsigned long long)(uint32_t)zv << 32) | mm);   // lowest occupied level wins
+                }
+            }
+            running += n;
         }
     }   // chunks
 
-    // ---- column tail: lowest occupied z (+ its min-height) / lowest free z per column.  A column's
-    // levels are spread over the 4 lanes {g, g+16, g+32, g+48}: reduce them first, then across waves.
+    // ---- column tail: lowest occupied z (+ its min-height) / lowest free z per column: LDS minima
+    // per wave (a column's levels are spread over 4 lanes and over the waves), merged below.
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int o = 16; o <= 32; o <<= 1) {
-            const int oz = __shfl_xor(zocc[i], o);
-            const uint32_t oh = (uint32_t)__shfl_xor((int)hocc[i], o);
-            if (oz < zocc[i]) { zocc[i] = oz; hocc[i] = oh; }
-            zfree[i] = min(zfree[i], __shfl_xor(zfree[i], o));
-        }
-        if (q == 0) { s_zocc[w][4 * g + i] = zocc[i]; s_hocc[w][4 * g + i] = hocc[i]; s_zfree[w][4 * g + i] = zfree[i]; }
-    }
+    for (int i = 0; i < 4; ++i)
+        if (zfree[i] != INT_MAX) atomicMin(&s_zf[w][4 * g + i], (uint32_t)zfree[i]);
     if (lane == 0) s_cnt[w] = running;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1180,14 +1195,13 @@ __global__ __launch_bounds__(1024) void k_fuse4(const FuseParams P, const FuseDe
         blockcounts[blockIdx.y * gridDim.x + blockIdx.x] = tot;
     }
     const int sx = blockIdx.x * WAVE + lane;
-    if (w == 0 && sx < P.xy) {
+    if (w == 0 && sx < P.xy && !(P.debug & 16)) {
         const int x = wrap_sub(sx, P.om[0], P.xy);
-        int zo = INT_MAX, zf = INT_MAX;
-        uint32_t hb = 0x3f800000u;
-        for (int k = 0; k < P.nz; ++k) {
-            if (zo == INT_MAX && s_zocc[k][lane] != INT_MAX) { zo = s_zocc[k][lane]; hb = s_hocc[k][lane]; }
-            if (zf == INT_MAX && s_zfree[k][lane] != INT_MAX) zf = s_zfree[k][lane];
-        }
+        unsigned long long zh = ((unsigned long long)INT_MAX << 32) | 0x3f800000ull;
+        uint32_t zfu = (uint32_t)INT_MAX;
+        for (int k = 0; k < P.nz; ++k) { zh = min(zh, s_zh[k][lane]); zfu = min(zfu, s_zf[k][lane]); }
+        const int zo = (int)(zh >> 32), zf = (int)zfu;
+        const uint32_t hb = (uint32_t)zh;
         double hval = -1000.0;
         const double xp = ((P.origin[0] + (double)x) * P.xy_res) - P.ego[0];
         const double yp = ((P.origin[1] + (double)y) * P.xy_res) - P.ego[1];
