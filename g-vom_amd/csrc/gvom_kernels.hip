@@ -165,10 +165,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     }
     uint32_t old = 1;
     if (ingrid && !(P.dbg & 4)) {
-        old = atomicAdd(&hit[A], 1u);
-        atomicAdd(&total[A], 1u);
+        if (P.dbg & 1024) atomicAdd(&hit[A], 1u); else old = atomicAdd(&hit[A], 1u);
+        if (!(P.dbg & 256)) atomicAdd(&total[A], 1u);
         const uint32_t tile = (L / P.xy) * P.nseg + ((L % P.xy) >> 6);  // stamp the tile (idempotent)
-        tags[tile] = P.epoch;
+        if (!(P.dbg & 512)) tags[tile] = P.epoch;
     }
     // every rank sees every point, so each can count the GLOBAL number of in-grid returns: the
     // reference's "no overlap" test (gvom.py:147-150) then needs no collective in sharded runs.
@@ -186,8 +186,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         if (threadIdx.x == 0) {
             const uint32_t nc = (s_cl[0] + s_cl[1]) + (s_cl[2] + s_cl[3]);
             const uint32_t ni = (s_in[0] + s_in[1]) + (s_in[2] + s_in[3]);
-            if (ni) atomicAdd(&counters[GVOM_CNT_INGRID], ni);
-            s_base = nc ? atomicAdd(&counters[GVOM_CNT_ROWS], nc) : 0u;
+            if (ni && !(P.dbg & 4096)) atomicAdd(&counters[GVOM_CNT_INGRID], ni);
+            s_base = (nc && !(P.dbg & 2048)) ? atomicAdd(&counters[GVOM_CNT_ROWS], nc) : 0u;
         }
         __syncthreads();
         if (claim) {
@@ -556,6 +556,7 @@ __global__ __launch_bounds__(256) void k_encode(const ScanParams P, unsigned enc
 {
     const int xy = P.xy, nseg = P.nseg;
     if (blockIdx.x >= enc_blocks) {                      // ---- min-height blocks ----
+        if (P.dbg & 128) return;
         const long i = (long)(blockIdx.x - enc_blocks) * 256 + threadIdx.x;
         if (i >= n) return;
         const T x = world[3 * i + 0], y = world[3 * i + 1], z = world[3 * i + 2];
@@ -606,7 +607,7 @@ __global__ __launch_bounds__(256) void k_encode(const ScanParams P, unsigned enc
             const uint32_t syl = q * 4 + (lane & 3);
             const bool ok = lane < 8 && u < t_end && syl < (uint32_t)xy && (int)syl >= P.sy_lo && (int)syl < P.sy_hi;
             const uint32_t tagv = tags[ok ? (syl * P.zs + sz) * nseg + seg : 0];
-            dmask = (uint32_t)__ballot(ok && tagv == epoch);
+            dmask = (P.dbg & 64) ? 0u : (uint32_t)__ballot(ok && tagv == epoch);
         }
         if (dmask == 0) continue;                                    // wave-uniform
 #pragma unroll
@@ -627,12 +628,14 @@ __global__ __launch_bounds__(256) void k_encode(const ScanParams P, unsigned enc
 #pragma unroll
             for (int i = 0; i < 4; ++i) st[i] = -(int32_t)t[i] - 1;
             if (any_h) {                                 // rare: an occupied voxel; its row was claimed in k_trace
+                int32_t rows[4];                         // all four fetched before the first use (one round trip)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rows[i] = state[L0 + ((h[i] > 0 && sx0 + i < (uint32_t)xy) ? (uint32_t)i : 0u)];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     if (h[i] > 0 && sx0 + i < (uint32_t)xy) {
-                        const int32_t row = state[L0 + i];
-                        chit[row] = h[i]; ctotal[row] = t[i];
-                        st[i] = row;
+                        chit[rows[i]] = h[i]; ctotal[rows[i]] = t[i];
+                        st[i] = rows[i];
                     }
                 }
                 *reinterpret_cast<uint4 *>(hit + A0) = make_uint4(0, 0, 0, 0);
