@@ -1473,36 +1473,42 @@ __global__ __launch_bounds__(256) void k_map2d(const Map2dParams P, const int32_
     double dh_out = 0.0;
     if (!(h00 > -1000 || inf00 == -1000.0) && !(P.dbg & 8)) {
         bool x_p_done = false, x_n_done = false, y_p_done = false, y_n_done = false;
-        double x_ph = -1000, x_nh = -1000, y_ph = -1000, y_nh = -1000;
+        // position of each direction's first valid cell in the tile (row, col); -1: none.  The four
+        // masks of a ring are read together and the heights only after the search: one LDS round
+        // trip per ring instead of eight dependent ones.
+        int rxp = -1, cxp = 0, rxn = -1, cxn = 0, ryp = -1, cyp = 0, ryn = -1, cyn = 0;
         int i = 0;
         while (i < 15 && !(x_n_done && x_n_done && y_p_done && y_n_done)) {
             i += 1;
             const unsigned long long span = (1ull << (2 * i)) - 1ull;
+            const unsigned long long mxp = (colm[lx + i] >> (ly - i)) & span;
+            const unsigned long long mxn = (colm[lx - i] >> (ly - i + 1)) & span;
+            const unsigned long long myp = (rowm[ly + i] >> (lx - i + 1)) & span;
+            const unsigned long long myn = (rowm[ly - i] >> (lx - i)) & span;
             if (!x_p_done) {
                 if (x0 + i < xy) {
-                    const unsigned long long m = (colm[lx + i] >> (ly - i)) & span;
-                    if (m) { x_ph = ht[ly - i + __ffsll((long long)m) - 1][lx + i]; x_p_done = true; }
+                    if (mxp) { rxp = ly - i + __ffsll((long long)mxp) - 1; cxp = lx + i; x_p_done = true; }
                 } else x_p_done = true;
             }
             if (!x_n_done) {
                 if (x0 - i >= 0) {
-                    const unsigned long long m = (colm[lx - i] >> (ly - i + 1)) & span;
-                    if (m) { x_nh = ht[ly - i + 1 + __ffsll((long long)m) - 1][lx - i]; x_n_done = true; }
+                    if (mxn) { rxn = ly - i + 1 + __ffsll((long long)mxn) - 1; cxn = lx - i; x_n_done = true; }
                 } else x_n_done = true;
             }
             if (!y_p_done) {
                 if (y0 + i < xy) {
-                    const unsigned long long m = (rowm[ly + i] >> (lx - i + 1)) & span;
-                    if (m) { y_ph = ht[ly + i][lx - i + 1 + __ffsll((long long)m) - 1]; y_p_done = true; }
+                    if (myp) { ryp = ly + i; cyp = lx - i + 1 + __ffsll((long long)myp) - 1; y_p_done = true; }
                 } else y_p_done = true;
             }
             if (!y_n_done) {
                 if (y0 - i >= 0) {
-                    const unsigned long long m = (rowm[ly - i] >> (lx - i)) & span;
-                    if (m) { y_nh = ht[ly - i][lx - i + __ffsll((long long)m) - 1]; y_n_done = true; }
+                    if (myn) { ryn = ly - i; cyn = lx - i + __ffsll((long long)myn) - 1; y_n_done = true; }
                 } else y_n_done = true;
             }
         }
+        const double hxp = ht[max(rxp, 0)][cxp], hxn = ht[max(rxn, 0)][cxn], hyp = ht[max(ryp, 0)][cyp], hyn = ht[max(ryn, 0)][cyn];
+        const double x_ph = rxp >= 0 ? hxp : -1000.0, x_nh = rxn >= 0 ? hxn : -1000.0;
+        const double y_ph = ryp >= 0 ? hyp : -1000.0, y_nh = ryn >= 0 ? hyn : -1000.0;
         double min_h = 1000.0, max_h = inf00;
         if (x_ph > -1000) { min_h = py_mind(x_ph, min_h); max_h = py_maxd(x_ph, max_h); }
         if (x_nh > -1000) { min_h = py_mind(x_nh, min_h); max_h = py_maxd(x_nh, max_h); }
