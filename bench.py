@@ -164,6 +164,15 @@ def run_single(args):
         g.process_pointcloud(pc, ego, tf)
         g.combine_maps()
     pcie_elapsed = time.perf_counter() - t1
+    # the same steps through combine_maps_occupancy (combine + the ROS node's post-processing on the
+    # GPU, 5 B/cell over PCIe instead of 20): reported beside the headline, never `value`
+    n_occ = max(10, args.steps // 4)
+    t2 = time.perf_counter()
+    for k in range(n_occ):
+        d, n, dt, ego, tf = dev[k % len(dev)]
+        g.process_pointcloud_device(d.value, n, dt, ego, tf)
+        g.combine_maps_occupancy()
+    occ_elapsed = time.perf_counter() - t2
 
     V = params[2] * params[2] * params[3]
     P = 12 if scans[0][0].dtype == np.float32 else 24
@@ -194,6 +203,7 @@ def run_single(args):
                    "step": "1 scan + 1 combine incl. D2H of the 4 maps"},
         "map_hz": args.steps / elapsed,
         "value_pcie_inclusive": n_pts * n_pcie / pcie_elapsed / 1e6,
+        "value_occupancy_api": n_pts * n_occ / occ_elapsed / 1e6,
         "stage_ms": stage_ms,
         "host_us": g.host_timing(),
         "sum_hit": stats["sum_hit"], "sum_total": stats["sum_total"], "cells": stats["cells"],

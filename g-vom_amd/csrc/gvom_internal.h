@@ -105,6 +105,8 @@ struct Map2dParams {
     double origin_z;        // fused origin z (voxels)
     double xy_res, z_res;
     double pos_thr, neg_thr, slope_thr, robot_height;
+    int occ;                // 1: write the five int8 occupancy grids of gvom_ros.py:141-165 instead of the four maps
+    double occ_density_thr, occ_min_rough, occ_max_rough;
 };
 
 // ---- launchers (gvom_kernels.hip) --------------------------------------------------------

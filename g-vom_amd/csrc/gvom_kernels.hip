@@ -1391,7 +1391,11 @@ __global__ __launch_bounds__(256) void k_map2d(const Map2dParams P, const int32_
         }
     }
     const int visv = h00 > -1000 ? 1 : 0;                    // gvom.py:414-422
-    if (YX && wr) st_sys(&out_vis[c_out], visv);
+    // OCC: instead of the four maps, the five int8 nav_msgs/OccupancyGrid.data arrays the ROS node
+    // derives from them (gvom_ros.py:141-165), planes [hard | soft | certainty | negative | roughness]
+    int8_t *const occ = reinterpret_cast<int8_t *>(out_pos);
+    const size_t n2 = (size_t)xy * xy;
+    if (YX && wr) { if (P.occ) st_sys(&occ[2 * n2 + c_out], (int8_t)(visv * 100)); else st_sys(&out_vis[c_out], visv); }
 
     // ---- slope / roughness: 3x3 least-squares plane (gvom.py:665-734) ---------------------
     // cells outside the window hold -1000 in the tile, i.e. are skipped exactly like the
@@ -1462,9 +1466,20 @@ __global__ __launch_bounds__(256) void k_map2d(const Map2dParams P, const int32_
     }
     const size_t c_yx = (size_t)sy0 * xy + sx0;
     slope_x[c_yx] = sxv; slope_y[c_yx] = syv; rough[c_yx] = rv;
-    if (YX && wr) st_sys(&out_rough[c_out], rv);
+    if (YX && wr) {
+        if (P.occ) {
+            // ((clip(r, min, max) + min) / (max - min)) * 100 in f64 as written (it ADDS min), then numpy's
+            // float64 -> int8 cast: truncate to a 32-bit integer, keep the low byte (gvom_ros.py:162-163)
+            const double rr = ((py_maxd(py_mind(rv, P.occ_max_rough), P.occ_min_rough) + P.occ_min_rough) / (P.occ_max_rough - P.occ_min_rough)) * 100.0;
+            const int32_t ri = (fabs(rr) < 2147483648.0) ? (int32_t)rr : INT_MIN;       // x86 cvttsd2si: out of range / NaN -> INT_MIN
+            st_sys(&occ[4 * n2 + c_out], (int8_t)(uint8_t)(uint32_t)ri);
+        } else st_sys(&out_rough[c_out], rv);
+    }
     const int pos = (sqrt(sxv * sxv + syv * syv) >= P.slope_thr) ? 100 : dens_pos;   // gvom.py:489-521
-    if (YX && wr) st_sys(&out_pos[c_out], pos);
+    if (YX && wr) {
+        if (P.occ) st_sys(&occ[1 * n2 + c_out], (int8_t)(((double)pos <= P.occ_density_thr && pos > 0) ? 100 : 0));   // soft, :146
+        else st_sys(&out_pos[c_out], pos);
+    }
 
     // ---- guess height (gvom.py:558-661), typos at :581 and :655 reproduced ---------------
     // ring i, direction +x: first valid cell of column x0+i for dy in [-i, i)   -> colm bit-scan
@@ -1519,7 +1534,12 @@ __global__ __launch_bounds__(256) void k_map2d(const Map2dParams P, const int32_
     }
     guessed[c_yx] = dh_out;
     const int negv = dh_out > P.neg_thr ? 100 : 0;           // gvom.py:479-485
-    if (YX && wr) st_sys(&out_neg[c_out], negv);
+    if (YX && wr) {
+        if (P.occ) {
+            st_sys(&occ[3 * n2 + c_out], (int8_t)negv);                                                    // negative, :157
+            st_sys(&occ[0 * n2 + c_out], (int8_t)max((double)pos > P.occ_density_thr ? 100 : 0, negv));   // hard, :141
+        } else st_sys(&out_neg[c_out], negv);
+    }
 
     if (!YX) { o_pos[tx][ty] = pos; o_neg[tx][ty] = negv; o_vis[tx][ty] = visv; o_rgh[tx][ty] = rv; }
     }   // mine

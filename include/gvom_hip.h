@@ -124,6 +124,19 @@ int gvom_output_buffer_alloc(gvom_t *h, void **host_ptr);
 int gvom_output_buffer_free(gvom_t *h, void *host_ptr);
 int gvom_combine_maps_into(gvom_t *h, double origin_world[3], void *pinned_out);
 
+/* combine_maps fused with the ROS node's post-processing (gvom_ros.py:141-165):
+ * advances the fusion exactly like gvom_combine_maps, but the GPU writes the five int8
+ * nav_msgs/OccupancyGrid.data arrays the node publishes into the pinned buffer (from
+ * gvom_output_buffer_alloc), as planes of xy*xy bytes, cell (x, y) at [y*xy_size + x]:
+ *   0 hard obstacles   max(100*(positive > density_threshold), negative)          :141
+ *   1 soft obstacles   100*(positive <= density_threshold)*(positive > 0)         :146
+ *   2 ground certainty visibility*100                                             :151
+ *   3 negative         negative                                                   :157
+ *   4 roughness        ((clip(r, min, max) + min)/(max - min))*100, cast to int8 as numpy does  :162-163
+ * (reproduced as written, including the "+ min" and the wrapping cast). */
+int gvom_combine_occupancy_into(gvom_t *h, double origin_world[3], void *pinned_out,
+                                double density_threshold, double min_roughness, double max_roughness);
+
 /* --- split entry points for slab-sharded (multi-GPU) runs ---------------------------------
  * Used by g-vom_amd/gvom_sharded.py; each rank holds a gvom_create_sharded() handle and
  * drives these between its torch.distributed (RCCL) collectives.  Single-GPU callers never

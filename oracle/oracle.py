@@ -442,3 +442,21 @@ def dense_from_compact(index_map, hit, total, min_height):
     hd[occ] = np.asarray(hit)[rows]; td[occ] = np.asarray(total)[rows]
     md[occ] = np.asarray(min_height)[rows]
     return state, hd, td, md
+
+
+def ros_occupancy_grids(map_data, density_threshold=50, min_roughness=-10, max_roughness=0):
+    """The post-processing the ROS node applies to combine_maps()'s result before publishing
+    (reference gvom_ros.py:141-165), restated with the same numpy operations:
+    returns the five int8 nav_msgs/OccupancyGrid.data arrays (hard, soft, certainty, negative,
+    roughness).  Parameter defaults = the node's ROS parameter defaults (gvom_ros.py:32-35).
+    As written, the roughness rescale ADDS min_roughness and the int8 cast wraps."""
+    obs_map, neg_map, rough_map, cert_map = map_data[1], map_data[2], map_data[3], map_data[4]
+    with np.errstate(invalid="ignore"):
+        hard = np.reshape(np.maximum(100 * (obs_map > density_threshold), neg_map), -1, order='F').astype(np.int8)   # :141
+        soft = np.reshape(100 * (obs_map <= density_threshold) * (obs_map > 0), -1, order='F').astype(np.int8)       # :146
+        cert = np.reshape(cert_map * 100, -1, order='F').astype(np.int8)                                               # :151
+        neg = np.reshape(neg_map, -1, order='F').astype(np.int8)                                                       # :157
+        r = ((np.maximum(np.minimum(rough_map, max_roughness), min_roughness) + min_roughness)
+             / (max_roughness - min_roughness)) * 100                                                                  # :162
+        rough = np.reshape(r, -1, order='F').astype(np.int8)                                                           # :163
+    return hard, soft, cert, neg, rough

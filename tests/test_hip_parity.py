@@ -326,3 +326,36 @@ def test_trace_variants_agree(gvom_mod, monkeypatch):
             for a, b_ in zip(ref, slots):
                 for x, y in zip(a, b_):
                     assert np.array_equal(x, y), "variant %s differs" % variant
+
+
+@pytest.mark.parametrize("occ_params", [(50, -10, 0), (12.5, -6.0, 1.5)])
+def test_combine_maps_occupancy_matches_node_postprocessing(gvom_mod, occ_params):
+    """combine_maps_occupancy() == the ROS node's numpy post-processing
+    (gvom_ros.py:141-165, restated in oracle.ros_occupancy_grids) of combine_maps()'s result, bit for
+    bit, while the map state advances identically (previous-map carry over three combines)."""
+    params, scans = synth.config_inputs("c2", n_scans=3)
+    params = params[:4] + (2,) + params[5:]
+    a, b = gvom_mod.Gvom(*params), gvom_mod.Gvom(*params)
+    assert b.combine_maps_occupancy(*occ_params) is None
+    for pc, ego, tf in scans:
+        a.process_pointcloud(pc, ego, tf)
+        b.process_pointcloud(pc, ego, tf)
+        maps = a.combine_maps()
+        got = b.combine_maps_occupancy(*occ_params)
+        want = oracle.ros_occupancy_grids(maps, *occ_params)
+        assert np.array_equal(got[0], maps[0])
+        for name, g, w in zip(("hard", "soft", "certainty", "negative", "roughness"), got[1:], want):
+            assert g.dtype == np.int8 and g.shape == w.shape
+            assert np.array_equal(g, w), "%s grid differs in %d cells" % (name, int(np.sum(g != w)))
+    assert a.combined_cell_count_cpu == b.combined_cell_count_cpu
+    # a small odd-sized grid with a transform as well
+    params2 = (0.4, 0.2, 50, 13, 2, 0.8, 0.5, 0.5, 0.3, 2.0, 2.0, 1.0, 1, 1)
+    a, b = gvom_mod.Gvom(*params2), gvom_mod.Gvom(*params2)
+    for st in _random_steps(3, 3, 6000, 50 * 0.4 * 0.55, 13 * 0.2 * 0.5, np.float64, True):
+        if st[0] == "scan":
+            a.process_pointcloud(*st[1:]); b.process_pointcloud(*st[1:])
+        else:
+            maps = a.combine_maps()
+            got = b.combine_maps_occupancy(*occ_params)
+            for g, w in zip(got[1:], oracle.ros_occupancy_grids(maps, *occ_params)):
+                assert np.array_equal(g, w)

@@ -105,3 +105,23 @@ def test_combine_old_indices_transition_table():
     want_free = [0, 0, 0, -12, -50, 0, -5, -6, -15, -16, 0]
     assert list(np.where(after >= 0, 0, after)[:11]) == want_free
     assert list((after >= 0)[:11]) == [True, True, True, False, False, True, False, False, False, False, True]
+
+
+def test_ros_occupancy_grids_known_answers():
+    """gvom_ros.py:141-165 restated (oracle.ros_occupancy_grids): thresholds, the '+ min' roughness
+    rescale and numpy's wrapping float64 -> int8 cast, on a hand-computed 2x2 example."""
+    from oracle import oracle
+    obs = np.array([[0, 30], [50, 51]], np.int32)          # [x, y]
+    neg = np.array([[100, 0], [0, 0]], np.int32)
+    cert = np.array([[1, 0], [1, 1]], np.int32)
+    rough = np.array([[-1.0, -3.2], [-25.0, 0.5]], np.float64)
+    hard, soft, c, n, r = oracle.ros_occupancy_grids((None, obs, neg, rough, cert))
+    # order='F': index = x + 2*y
+    assert hard.tolist() == [100, 0, 0, 100]               # neg at (0,0); 51 > 50 at (1,1)
+    assert soft.tolist() == [0, 100, 100, 0]               # 0 < obs <= 50
+    assert c.tolist() == [100, 100, 0, 100]
+    assert n.tolist() == [100, 0, 0, 0]
+    # (clip(r,-10,0) + -10)/10*100 : -1 -> -110 ; -25 -> -200 -> wraps to 56 ;
+    # -3.2 -> -131.99999999999997 in f64 -> truncates to -131 -> wraps to 125 ; 0.5 -> -100
+    assert r.tolist() == [-110, 56, 125, -100]
+    assert all(a.dtype == np.int8 for a in (hard, soft, c, n, r))
