@@ -110,6 +110,8 @@ struct gvom_handle {
     bool maps_valid = false;
 
     double ego[3] = {0, 0, 0};
+    int in_off[3] = {0, 1, 2};                          // element offsets of x, y, z in the cloud being scanned
+    bool in_f32 = false;                                // float32 records widened to a float64 computation (PointCloud2 ingest)
 
     double host_ns[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // host-side phase timing (GVOM_HOST_TIMING)
     long host_calls = 0;
@@ -174,6 +176,8 @@ void fill_scan_params(const gvom_handle *h, const int64_t origin[3], const doubl
     P.om[1] = (int)floor_mod(origin[1], p.xy_size);
     P.om[2] = (int)floor_mod(origin[2], p.z_size);
     P.sy_lo = h->sy_lo; P.sy_hi = h->sy_hi;
+    P.off[0] = h->in_off[0]; P.off[1] = h->in_off[1]; P.off[2] = h->in_off[2];
+    P.in_f32 = h->in_f32 ? 1 : 0;
     P.nseg = h->nseg;
     P.sxq = (p.xy_size + 3) / 4;
     // DDA segments: the ego sits at the window centre, so a ray takes at most size/2 + 2 steps
@@ -390,16 +394,30 @@ void scan_commit(gvom_handle *h, bool accept)
 }
 
 int process_impl(gvom_handle *h, const void *xyz, bool on_device, int64_t n, int64_t row_stride_bytes,
-                 int dtype, const double ego[3], const double *tf, bool defer)
+                 int dtype, const double ego[3], const double *tf, bool defer, const int64_t *off_bytes = nullptr,
+                 bool widen_f32 = false)
 {
     if (!h || !ego || n < 0 || (dtype != GVOM_DTYPE_F32 && dtype != GVOM_DTYPE_F64))
         return GVOM_ERR_INVALID;
-    const size_t esz = dtype == GVOM_DTYPE_F32 ? 4 : 8;
+    // widen_f32: float32 records (esz = 4 for addressing) scanned by the float64 kernels
+    const size_t esz = (dtype == GVOM_DTYPE_F32 || widen_f32) ? 4 : 8;
+    if (widen_f32 && dtype != GVOM_DTYPE_F64) return GVOM_ERR_INVALID;
     if (n > 0 && (!xyz || row_stride_bytes < (int64_t)(3 * esz) || row_stride_bytes % esz != 0))
         return GVOM_ERR_INVALID;
     if (n >= 2147483647LL) return GVOM_ERR_CAPACITY;
+    int64_t last_field = 2 * (int64_t)esz;                               // byte offset of the last field read
+    if (off_bytes) {
+        last_field = 0;
+        for (int k = 0; k < 3; ++k) {
+            if (off_bytes[k] < 0 || off_bytes[k] % (int64_t)esz != 0 || off_bytes[k] + (int64_t)esz > row_stride_bytes)
+                return GVOM_ERR_INVALID;
+            if (off_bytes[k] > last_field) last_field = off_bytes[k];
+        }
+    }
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->device));
+    for (int k = 0; k < 3; ++k) h->in_off[k] = off_bytes ? (int)(off_bytes[k] / (int64_t)esz) : k;
+    h->in_f32 = widen_f32;
     h->ego[0] = ego[0]; h->ego[1] = ego[1]; h->ego[2] = ego[2];       // gvom.py:102-104
     h->pending = false;
     if (n == 0) return GVOM_EMPTY_CLOUD;                               // gvom.py:107-109
@@ -407,7 +425,7 @@ int process_impl(gvom_handle *h, const void *xyz, bool on_device, int64_t n, int
     if (!on_device) {
         int rc = ensure(h, h->in_pts, (size_t)n * row_stride_bytes);
         if (rc) return rc;
-        HIPCHK(h, hipMemcpyAsync(h->in_pts.p, xyz, (size_t)(n - 1) * row_stride_bytes + 3 * esz,
+        HIPCHK(h, hipMemcpyAsync(h->in_pts.p, xyz, (size_t)(n - 1) * row_stride_bytes + (size_t)last_field + esz,
                                  hipMemcpyHostToDevice, h->stream));
         dev = h->in_pts.p;
     }
@@ -662,6 +680,22 @@ VIS int gvom_process_pointcloud_device(gvom_t *h, const void *xyz_dev, int64_t n
                                        const double *transform_4x4)
 {
     return process_impl(h, xyz_dev, true, n, row_stride_bytes, dtype, ego, transform_4x4, false);
+}
+
+// Ingest side of the ROS node (gvom_ros.py:93-109): the packed bytes of a
+// sensor_msgs/PointCloud2 (`data`, width*height records of point_step bytes, little-endian FLOAT32
+// or FLOAT64 fields x, y, z at the given byte offsets) are scanned directly; the host-side
+// ros_numpy expansion to an xyz array disappears.  ros_numpy drops records with a non-finite
+// coordinate; here such records take part and have no effect (no in-grid endpoint, no ray step).
+VIS int gvom_process_pointcloud2(gvom_t *h, const void *data, int64_t n_points, int64_t point_step,
+                                 int64_t off_x, int64_t off_y, int64_t off_z, int dtype,
+                                 const double ego[3], const double *transform_4x4)
+{
+    const int64_t off[3] = {off_x, off_y, off_z};
+    // ros_numpy returns a float64 array whatever the field type (get_xyz_points, dtype=np.float), so
+    // the reference computes a FLOAT32 cloud in f64 as well: widen on load, run the f64 kernels
+    return process_impl(h, data, false, n_points, point_step, GVOM_DTYPE_F64, ego, transform_4x4, false, off,
+                        dtype == GVOM_DTYPE_F32);
 }
 
 // Sharded runs: run the scan kernels but leave the ring untouched until every rank's cell

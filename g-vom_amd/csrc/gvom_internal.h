@@ -52,6 +52,9 @@ struct ScanParams {
     int    sxq;           // accumulator layout: 4x4 (x,y) patches per row of patches = ceil(xy/4)
     uint32_t epoch;       // this scan's tile epoch
     // slab-sharded runs: the slab's rows as (up to two) intervals of WINDOW y, for ray culling
+    int    off[3];        // element offsets of x, y, z inside a point record (0, 1, 2 unless PointCloud2 ingest)
+    int    in_f32;        // 1: the records hold float32 fields that are widened to the (float64) compute type,
+                          //    as ros_numpy hands the reference a float64 array (stride and offsets in 4-byte units)
     int    lc_period;     // k_trace line cache: flush every lc_period committing steps (GVOM_TRACE_PERIOD)
     int    dbg;           // GVOM_TRACE_DEBUG bits (timing experiments only; results wrong when set)
     int    cull;          // 1: skip rays that cannot reach the slab, stop rays that have left it

@@ -129,8 +129,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const bool live = i < n;
     T x = 0, y = 0, z = 0;
     if (live) {
-        const T *p = in + i * stride;
-        x = p[0]; y = p[1]; z = p[2];
+        if (sizeof(T) == 8 && P.in_f32) {                // PointCloud2 FLOAT32 fields, computed in f64
+            const float *p = reinterpret_cast<const float *>(in) + i * stride;
+            x = (T)p[P.off[0]]; y = (T)p[P.off[1]]; z = (T)p[P.off[2]];
+        } else {
+            const T *p = in + i * stride;
+            x = p[P.off[0]]; y = p[P.off[1]]; z = p[P.off[2]];
+        }
         if (P.has_tf) {
             const double dx = (double)x, dy = (double)y, dz = (double)z;
             const double o0 = ((dx * P.tf[0] + dy * P.tf[1]) + dz * P.tf[2]) + P.tf[3];

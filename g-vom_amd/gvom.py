@@ -79,6 +79,8 @@ ABI = [
     ("gvom_create_sharded", _I, [ctypes.POINTER(GvomParams), _I, _I, _I, ctypes.POINTER(_P)]),
     ("gvom_destroy", None, [_P]),
     ("gvom_process_pointcloud", _I, [_P, _P, _I64, _I64, _I, _DP, _P]),
+    ("gvom_process_pointcloud2", _I, [_P, _P, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                       ctypes.c_int64, ctypes.c_int, _P, _P]),
     ("gvom_process_pointcloud_device", _I, [_P, _P, _I64, _I64, _I, _DP, _P]),
     ("gvom_combine_maps", _I, [_P, _P, _P, _P, _P, _P]),
     ("gvom_output_buffer_alloc", _I, [_P, ctypes.POINTER(_P)]),
@@ -175,6 +177,27 @@ class _PinnedOutput(object):
         pool = self._pool
         if pool is not None:
             pool.append(self.ptr)           # recycled by the next combine_maps (or freed on close)
+
+
+def transform_from_translation_rotation(translation, rotation):
+    """4x4 matrix of a translation (x, y, z) and a quaternion (x, y, z, w): what the node builds with
+    tf.TransformerROS.fromTranslationRotation (gvom_ros.py:105).  Restates tf.transformations
+    (ROS geometry 1.13, not part of the reference checkout): translation_matrix @ quaternion_matrix,
+    with quaternion_matrix's normalisation q *= sqrt(2 / q.q) and its near-zero quaternion -> identity."""
+    q = np.array(rotation[:4], dtype=np.float64, copy=True)
+    nq = np.dot(q, q)
+    if nq < np.finfo(float).eps * 4.0:
+        r = np.identity(4)
+    else:
+        q *= np.sqrt(2.0 / nq)
+        q = np.outer(q, q)
+        r = np.array(((1.0 - q[1, 1] - q[2, 2], q[0, 1] - q[2, 3], q[0, 2] + q[1, 3], 0.0),
+                      (q[0, 1] + q[2, 3], 1.0 - q[0, 0] - q[2, 2], q[1, 2] - q[0, 3], 0.0),
+                      (q[0, 2] - q[1, 3], q[1, 2] + q[0, 3], 1.0 - q[0, 0] - q[1, 1], 0.0),
+                      (0.0, 0.0, 0.0, 1.0)), dtype=np.float64)
+    t = np.identity(4)
+    t[:3, 3] = translation[:3]
+    return np.dot(t, r)
 
 
 class Gvom(object):
@@ -293,6 +316,47 @@ class Gvom(object):
             tf = np.ascontiguousarray(np.asarray(transform, dtype=np.float64))
         return self._check(self._lib.gvom_process_pointcloud_device(
             self._h, ctypes.c_void_p(int(dev_ptr)), int(n), int(stride), code, ego, _ptr(tf)))
+
+    # ---- ingest side of the ROS node (reference gvom_ros.py:93-109) ----------
+    def process_pointcloud2(self, data, n_points, point_step, offsets, ego_position, transform=None,
+                            field_dtype=np.float32):
+        """Scans the packed bytes of a sensor_msgs/PointCloud2 directly: `data` (bytes / buffer) holds
+        n_points records of point_step bytes with little-endian x, y, z fields of `field_dtype`
+        (float32 = PointField.FLOAT32, float64 = FLOAT64) at byte `offsets` (x, y, z).  Equivalent to
+            pc = ros_numpy.point_cloud2.pointcloud2_to_xyz_array(msg)     # gvom_ros.py:108
+            self.process_pointcloud(pc, ego_position, transform)          # gvom_ros.py:109
+        (ros_numpy hands over a float64 array with the non-finite records removed; here FLOAT32
+        fields are widened on the GPU and non-finite records have no effect on the map)."""
+        buf = np.frombuffer(data, dtype=np.uint8)
+        if buf.size < int(n_points) * int(point_step):
+            raise ValueError("PointCloud2 data shorter than n_points * point_step")
+        code = 0 if np.dtype(field_dtype) == np.float32 else 1
+        ego = (ctypes.c_double * 3)(float(ego_position[0]), float(ego_position[1]), float(ego_position[2]))
+        self.ego_position = ego_position
+        tf = None
+        if transform is not None:
+            tf = np.ascontiguousarray(np.asarray(transform, dtype=np.float64))
+        rc = self._check(self._lib.gvom_process_pointcloud2(
+            self._h, ctypes.c_void_p(buf.ctypes.data), int(n_points), int(point_step),
+            int(offsets[0]), int(offsets[1]), int(offsets[2]), code, ego, _ptr(tf)))
+        if rc == GVOM_EMPTY_CLOUD:
+            print("[WARNING] Processing an empty pointcloud, nothing will happen!")
+        elif rc == GVOM_NO_OVERLAP:
+            print("[WARNING] The pointcloud points don't overlap with any voxels, nothing will happen!")
+        return None
+
+    def process_pointcloud2_msg(self, msg, ego_position, transform=None):
+        """process_pointcloud2 for a sensor_msgs/PointCloud2-like object (fields[].name/offset/datatype,
+        point_step, row_step, width, height, data, is_bigendian)."""
+        f = {fd.name: fd for fd in msg.fields}
+        kinds = {f[k].datatype for k in "xyz"}
+        if getattr(msg, "is_bigendian", False) or len(kinds) != 1 or not kinds <= {7, 8}:
+            raise ValueError("x, y, z must be little-endian FLOAT32 (7) or FLOAT64 (8) fields of one type")
+        if msg.height > 1 and msg.row_step != msg.width * msg.point_step:
+            raise ValueError("row padding is not supported")
+        return self.process_pointcloud2(msg.data, msg.width * msg.height, msg.point_step,
+                                        (f["x"].offset, f["y"].offset, f["z"].offset), ego_position,
+                                        transform, np.float32 if kinds == {7} else np.float64)
 
     def combine_maps(self):
         """Combines all maps in the buffer and processes the resultant map into 2D maps

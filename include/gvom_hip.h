@@ -107,6 +107,17 @@ int gvom_process_pointcloud_device(gvom_t *h, const void *xyz_dev, int64_t n,
                                    int64_t row_stride_bytes, int dtype, const double ego[3],
                                    const double *transform_4x4);
 
+/* Ingest side of the ROS node (gvom_ros.py:93-109): scans the packed bytes of a
+ * sensor_msgs/PointCloud2 directly -- `data` holds n_points (= width*height, no row padding)
+ * records of point_step bytes with little-endian fields x, y, z of type `dtype` (GVOM_DTYPE_F32 =
+ * PointField.FLOAT32, GVOM_DTYPE_F64 = FLOAT64) at byte offsets off_x/off_y/off_z (multiples of
+ * the field size).  Replaces ros_numpy.point_cloud2.pointcloud2_to_xyz_array + process_pointcloud;
+ * records with a non-finite coordinate (which ros_numpy removes) have no effect on the map.
+ * Same return codes as gvom_process_pointcloud. */
+int gvom_process_pointcloud2(gvom_t *h, const void *data, int64_t n_points, int64_t point_step,
+                             int64_t off_x, int64_t off_y, int64_t off_z, int dtype,
+                             const double ego[3], const double *transform_4x4);
+
 /* --- Gvom.combine_maps (gvom.py:177-354) --------------------------------------------------
  * Caller-allocated xy_size*xy_size outputs (any of them may be NULL to skip its copy).
  * Returns GVOM_OK or GVOM_EMPTY_BUFFER. */

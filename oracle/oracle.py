@@ -460,3 +460,20 @@ def ros_occupancy_grids(map_data, density_threshold=50, min_roughness=-10, max_r
              / (max_roughness - min_roughness)) * 100                                                                  # :162
         rough = np.reshape(r, -1, order='F').astype(np.int8)                                                           # :163
     return hard, soft, cert, neg, rough
+
+
+def pointcloud2_to_xyz_array(data, n_points, point_step, offsets, field_dtype=np.float32, remove_nans=True):
+    """What the node feeds process_pointcloud (reference gvom_ros.py:108): ros_numpy 0.0.x
+    point_cloud2.pointcloud2_to_xyz_array = get_xyz_points(pointcloud2_to_array(msg)) -- a float64
+    (dtype=np.float) [N', 3] array of the x, y, z fields with the records that have a non-finite
+    coordinate removed.  ros_numpy is not part of the reference checkout; restated from its
+    published source."""
+    rec = np.dtype({"names": ["x", "y", "z"], "formats": [np.dtype(field_dtype)] * 3,
+                    "offsets": [int(o) for o in offsets], "itemsize": int(point_step)})
+    arr = np.frombuffer(data, dtype=rec, count=int(n_points))
+    if remove_nans:
+        mask = np.isfinite(arr["x"]) & np.isfinite(arr["y"]) & np.isfinite(arr["z"])
+        arr = arr[mask]
+    pts = np.zeros(arr.shape + (3,), dtype=np.float64)
+    pts[..., 0] = arr["x"]; pts[..., 1] = arr["y"]; pts[..., 2] = arr["z"]
+    return pts

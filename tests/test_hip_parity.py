@@ -359,3 +359,50 @@ def test_combine_maps_occupancy_matches_node_postprocessing(gvom_mod, occ_params
             got = b.combine_maps_occupancy(*occ_params)
             for g, w in zip(got[1:], oracle.ros_occupancy_grids(maps, *occ_params)):
                 assert np.array_equal(g, w)
+
+
+def _pointcloud2_bytes(xyz32, point_step, offsets, seed):
+    """Packed PointCloud2 data: x, y, z float32 at `offsets`, the other bytes random (intensity, ring,
+    timestamps ...), a few records with NaN / inf coordinates as real drivers emit."""
+    rng = np.random.default_rng(seed)
+    n = xyz32.shape[0]
+    raw = rng.integers(0, 256, (n, point_step), dtype=np.uint8)
+    pts = xyz32.copy()
+    bad = rng.choice(n, size=max(3, n // 200), replace=False)
+    pts[bad[0::3], 0] = np.nan; pts[bad[1::3], 1] = np.inf; pts[bad[2::3], 2] = -np.inf
+    for k, off in enumerate(offsets):
+        raw[:, off:off + 4] = pts[:, k:k + 1].copy().view(np.uint8)
+    return raw.tobytes()
+
+
+@pytest.mark.parametrize("layout", [(16, (0, 4, 8)), (48, (0, 4, 8)), (32, (12, 4, 20))])
+def test_pointcloud2_ingest_matches_ros_numpy_path(gvom_mod, layout):
+    """process_pointcloud2(raw PointCloud2 bytes) == process_pointcloud(
+    ros_numpy.pointcloud2_to_xyz_array(msg)) -- the float64 array without the non-finite records,
+    restated in oracle.pointcloud2_to_xyz_array -- on the HIP path AND against the CPU oracle;
+    with the node's tf matrix (quaternion + translation, gvom_ros.py:93-105)."""
+    point_step, offs = layout
+    params = (0.4, 0.2, 64, 32, 2) + synth.REF_TAIL
+    tf = gvom_mod.transform_from_translation_rotation((0.3, -0.2, 0.1), (0.01, -0.02, 0.38, 0.92))
+    assert np.allclose(tf[:3, :3] @ tf[:3, :3].T, np.eye(3), atol=1e-12) and tf[3].tolist() == [0, 0, 0, 1]
+    g2, g1, want = gvom_mod.Gvom(*params), gvom_mod.Gvom(*params), oracle.OracleGvom(*params)
+    rng = np.random.default_rng(17)
+    for k in range(3):
+        ego = (0.5 * k, -0.3 * k, 0.05 * k)
+        xyz = (rng.uniform(-12, 12, (20000, 3)) * np.array([1, 1, 0.25])).astype(np.float32)
+        data = _pointcloud2_bytes(xyz, point_step, offs, 100 + k)
+        pc = oracle.pointcloud2_to_xyz_array(data, xyz.shape[0], point_step, offs)
+        assert pc.dtype == np.float64 and pc.shape[0] < xyz.shape[0]
+        g2.process_pointcloud2(data, xyz.shape[0], point_step, offs, ego, tf)
+        g1.process_pointcloud(pc, ego, tf)
+        want.process_pointcloud(pc, ego, tf)
+        b = g2.last_buffer_index
+        slot = lambda g: scenarios.dense_from_compact(*[scenarios.host(x) for x in (
+            g.index_buffer[b], g.hit_count_buffer[b], g.total_count_buffer[b], g.min_height_buffer[b])])
+        for u, v in zip(slot(g2), slot(g1)):
+            assert np.array_equal(u, v)
+        m2, m1, mo = g2.combine_maps(), g1.combine_maps(), want.combine_maps()
+        for u, v, w in zip(m2, m1, mo):
+            assert np.array_equal(u, v)
+            assert np.allclose(u, w, rtol=0, atol=1e-5)
+        assert np.array_equal(m2[1], mo[1]) and np.array_equal(m2[2], mo[2]) and np.array_equal(m2[4], mo[4])
