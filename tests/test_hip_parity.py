@@ -406,3 +406,42 @@ def test_pointcloud2_ingest_matches_ros_numpy_path(gvom_mod, layout):
             assert np.array_equal(u, v)
             assert np.allclose(u, w, rtol=0, atol=1e-5)
         assert np.array_equal(m2[1], mo[1]) and np.array_equal(m2[2], mo[2]) and np.array_equal(m2[4], mo[4])
+
+
+def test_c5_full_size_properties(gvom_mod):
+    """BASELINE c5's grid and cloud on one GPU (1024x1024x128 = 134 M voxels, 4,194,304 points from
+    16 interleaved OS1-128-shaped sensors): too large for the CPU oracle, so size-independent
+    properties -- point-order invariance of every per-voxel count and every returned map, count
+    conservation, and agreement of the PointCloud2 ingest (f64 computation) with the same cloud
+    passed as float64."""
+    params = (0.2, 0.2, 1024, 128, 1) + synth.REF_TAIL
+    scene = synth.make_scene(2, extent=90.0)
+    ego = (0.4, -0.2, 0.0)
+    pc = np.concatenate([synth.lidar_scan(scene, beams=128, sensor=ego, yaw=2 * np.pi / 2048 * r / 16, noise_seed=r)
+                         for r in range(16)], axis=0)
+    assert pc.shape[0] == 4194304 and pc.dtype == np.float32
+    a, b = gvom_mod.Gvom(*params), gvom_mod.Gvom(*params)
+    a.process_pointcloud(pc, ego)
+    b.process_pointcloud(np.ascontiguousarray(pc[np.random.default_rng(1).permutation(pc.shape[0])]), ego)
+    da, db = a.read_dense(0), b.read_dense(0)
+    for k in range(4):
+        assert np.array_equal(da[k], db[k])
+    state, hit, total, minh, origin, cells = da
+    del db
+    st = a.scan_stats()
+    assert cells == int((state >= 0).sum()) == int((hit > 0).sum()) == st["cells"]
+    assert st["sum_hit"] == int(hit.sum())
+    free_total = int((-state[state < -1].astype(np.int64) - 1).sum())
+    assert st["sum_total"] == int(total.sum()) + free_total >= st["sum_hit"] > 1000000
+    oa, ob = a.combine_maps(), b.combine_maps()
+    for x, y in zip(oa, ob):
+        assert np.array_equal(x, y)
+    assert set(np.unique(oa[4])) <= {0, 1} and oa[4].sum() > 10000
+    del a, b, da, state, hit, total, minh
+    # PointCloud2 ingest at full size == the float64 cloud (what ros_numpy would hand over)
+    c, d = gvom_mod.Gvom(*params), gvom_mod.Gvom(*params)
+    c.process_pointcloud2(pc.tobytes(), pc.shape[0], 12, (0, 4, 8), ego)
+    d.process_pointcloud(pc.astype(np.float64), ego)
+    for x, y in zip(c.combine_maps(), d.combine_maps()):
+        assert np.array_equal(x, y)
+    assert c.scan_stats() == d.scan_stats()
