@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GVOM_ABI_VERSION 1
+#define GVOM_ABI_VERSION 2   /* 2: *_into outputs column-major; occupancy and PointCloud2 entry points */
 
 /* return codes (>= 0: the reference's documented outcomes; < 0: failures) */
 #define GVOM_OK                0
