@@ -543,14 +543,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 // them as "never observed" (-1), which is what the reference's -1 fill + __assign_indices yield.
 //
 // The same launch also carries the min-height pass (gvom.py:1303-1329) in its trailing blocks
-// [enc_blocks, gridDim.x): one lane per return, f32 atomic-min of the fractional z inside its
+// [0, mh_blocks): one lane per return, f32 atomic-min of the fractional z inside its
 // voxel, keyed by the voxel's compact row.  The value is a - floor(a) >= 0, so the float order
 // equals the order of its bit pattern and an unsigned atomicMin is exact.  It only needs what
 // k_trace left behind (row ids of occupied voxels, rows initialised to 1.0f), and the encode
 // blocks never write those words, so both parts run concurrently.
 // ------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void k_encode(const ScanParams P, unsigned enc_blocks,
+__global__ __launch_bounds__(256) void k_encode(const ScanParams P, unsigned enc_blocks, unsigned mh_blocks,
                                                 uint32_t t_begin, uint32_t t_end,
                                                 uint32_t *hit, uint32_t *total, int32_t *state,
                                                 uint32_t *chit, uint32_t *ctotal, uint32_t *cminh,
@@ -560,9 +560,23 @@ __global__ __launch_bounds__(256) void k_encode(const ScanParams P, unsigned enc
                                                 uint32_t seq)
 {
     const int xy = P.xy, nseg = P.nseg;
-    if (blockIdx.x >= enc_blocks) {                      // ---- min-height blocks ----
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // k_trace has completed: the scan's row count is final.  Publish {seq, count} as ONE
+        // 8-byte system-scope store to host-mapped memory (the host spins on it and returns to
+        // its caller while this kernel and k_minh still run) and re-arm the counter.
+        const uint32_t c = counters[GVOM_CNT_ROWS];
+        const uint32_t any = counters[GVOM_CNT_INGRID] ? 0x80000000u : 0u;     // some return landed in the grid (any rank)
+        counters[GVOM_CNT_ROWS] = 0; counters[GVOM_CNT_INGRID] = 0;
+        counters[8] = c; counters[9] = 0;               // device-side copy (int64) for sharded runs
+        __hip_atomic_store(host_flag, ((unsigned long long)seq << 32) | any | c, __ATOMIC_RELEASE,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    // The min-height blocks come FIRST in the grid: their dependent chain (point -> state -> atomicMin)
+    // then hides under the encode blocks instead of forming the kernel's tail.  They only read rows
+    // that k_trace claimed; the encode blocks rewrite those state words with the same value.
+    if (blockIdx.x < mh_blocks) {                        // ---- min-height blocks ----
         if (P.dbg & 128) return;
-        const long i = (long)(blockIdx.x - enc_blocks) * 256 + threadIdx.x;
+        const long i = (long)blockIdx.x * 256 + threadIdx.x;
         if (i >= n) return;
         const T x = world[3 * i + 0], y = world[3 * i + 1], z = world[3 * i + 2];
         const T d2 = (x * x + y * y) + z * z;
@@ -583,23 +597,12 @@ __global__ __launch_bounds__(256) void k_encode(const ScanParams P, unsigned enc
         if (row >= 0) atomicMin(&cminh[row], __float_as_uint(v));
         return;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        // k_trace has completed: the scan's row count is final.  Publish {seq, count} as ONE
-        // 8-byte system-scope store to host-mapped memory (the host spins on it and returns to
-        // its caller while this kernel and k_minh still run) and re-arm the counter.
-        const uint32_t c = counters[GVOM_CNT_ROWS];
-        const uint32_t any = counters[GVOM_CNT_INGRID] ? 0x80000000u : 0u;     // some return landed in the grid (any rank)
-        counters[GVOM_CNT_ROWS] = 0; counters[GVOM_CNT_INGRID] = 0;
-        counters[8] = c; counters[9] = 0;               // device-side copy (int64) for sharded runs
-        __hip_atomic_store(host_flag, ((unsigned long long)seq << 32) | any | c, __ATOMIC_RELEASE,
-                           __HIP_MEMORY_SCOPE_SYSTEM);
-    }
     // ---- encode blocks: one wave per QUAD = 4 storage rows (sy = 4q .. 4q+3) x 64 sx at one sz,
     // i.e. 4 tiles = 16 accumulator lines.  Lane (p = lane >> 2, r = lane & 3) owns the 4 voxels
     // sx = 64*seg + 4p .. +3 of row sy = 4q + r: one 16-byte load of hit and of total (its quarter of
     // a 4x4 patch line) and one 16-byte store of state.
     const int lane = threadIdx.x & (WAVE - 1);
-    const uint32_t wid = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const uint32_t wid = __builtin_amdgcn_readfirstlane(((blockIdx.x - mh_blocks) * blockDim.x + threadIdx.x) >> 6);
     const uint32_t nw = (enc_blocks * blockDim.x) >> 6;
     const int p4 = lane >> 2, r = lane & 3;
     const bool vec_state = (xy & 3) == 0;                // 16-byte aligned state rows
@@ -2034,11 +2037,11 @@ hipError_t gvom_launch_encode(hipStream_t s, const ScanParams &P, int dtype, con
     if (enc_blocks < 1) enc_blocks = 1;
     const unsigned mh_blocks = (unsigned)((n + 255) / 256);          // min-height part
     if (dtype == 0)
-        hipLaunchKernelGGL(k_encode<float>, dim3(enc_blocks + mh_blocks), dim3(256), 0, s, P, enc_blocks,
+        hipLaunchKernelGGL(k_encode<float>, dim3(enc_blocks + mh_blocks), dim3(256), 0, s, P, enc_blocks, mh_blocks,
                            t_begin, t_end, hit, total, state, chit, ctotal, cminh, tags, P.epoch,
                            (const float *)world, (long)n, counters, host_flag, seq);
     else
-        hipLaunchKernelGGL(k_encode<double>, dim3(enc_blocks + mh_blocks), dim3(256), 0, s, P, enc_blocks,
+        hipLaunchKernelGGL(k_encode<double>, dim3(enc_blocks + mh_blocks), dim3(256), 0, s, P, enc_blocks, mh_blocks,
                            t_begin, t_end, hit, total, state, chit, ctotal, cminh, tags, P.epoch,
                            (const double *)world, (long)n, counters, host_flag, seq);
     return hipGetLastError();
