@@ -445,3 +445,35 @@ def test_c5_full_size_properties(gvom_mod):
     for x, y in zip(c.combine_maps(), d.combine_maps()):
         assert np.array_equal(x, y)
     assert c.scan_stats() == d.scan_stats()
+
+
+def test_long_run_moving_window_matches_oracle(gvom_mod):
+    """600 scan+combine steps with a random-walking sensor (the robot-centred window shifts ~170
+    voxels in x and y and wraps the toroidal storage several times; ring slots and tile epochs are
+    reused hundreds of times): every 25th step, and the last, must match the oracle bit for bit
+    (ints) / 1e-5 (floats)."""
+    params = (0.4, 0.2, 48, 24, 3, 0.8, 0.5, 0.5, 0.3, 2.0, 2.0, 1.0, 1, 1)
+    g, want = gvom_mod.Gvom(*params), oracle.OracleGvom(*params)
+    rng = np.random.default_rng(2024)
+    ego = np.zeros(3)
+    heading = 0.0
+    checked = 0
+    for k in range(600):
+        heading += rng.normal(0, 0.15)
+        ego = ego + np.array([0.32 * np.cos(heading) + 0.1, 0.32 * np.sin(heading) + 0.12, rng.normal(0, 0.02)])
+        n = int(rng.integers(1500, 4000))
+        pc = np.stack([rng.uniform(-9, 9, n) + ego[0], rng.uniform(-9, 9, n) + ego[1],
+                       rng.normal(-0.9, 0.6, n) + ego[2]], axis=1).astype(np.float32 if k % 2 else np.float64)
+        tf = scenarios.rot_z(0.01 * (k % 7), (0.0, 0.0, 0.0)) if k % 3 == 0 else None
+        e = tuple(float(v) for v in ego)
+        g.process_pointcloud(pc, e, tf)
+        want.process_pointcloud(pc, e, tf)
+        a, b = g.combine_maps(), want.combine_maps()
+        if k % 25 == 24 or k == 599:
+            assert np.array_equal(a[0], b[0])
+            for i in (1, 2, 4):
+                assert np.array_equal(a[i], b[i]), "step %d map %d differs" % (k, i)
+            assert np.allclose(a[3], b[3], rtol=0, atol=1e-5)
+            assert g.combined_cell_count_cpu == want.combined_cell_count_cpu
+            checked += 1
+    assert checked == 24 and abs(ego[0]) + abs(ego[1]) > 40.0
