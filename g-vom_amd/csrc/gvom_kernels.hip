@@ -114,7 +114,8 @@ __device__ __forceinline__ void lc_flush(uint32_t *keys, uint32_t *cnt, uint32_t
 //   4  as 1, but the merged adds go into a wave-private LDS line cache that is flushed with one
 //      request per 64-B line (lc_flush): steps of a ray bundle that revisit a line are merged too
 //   9  diagnostic only: no DDA atomics at all (measures the arithmetic floor; results wrong)
-template <typename T, int VAR>
+// CULL = false: the handle owns every row (no slab tests / ray culling compiled into the step body)
+template <typename T, int VAR, bool CULL = true>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_trace(const ScanParams P, const T *__restrict__ in,
                                                long stride, long n, T *__restrict__ world,
                                                uint32_t *hit, uint32_t *total, int32_t *state,
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         bool active = reach && finite && (length < lim);
         int ystop_lo = INT_MIN, ystop_hi = INT_MAX;
         const uint32_t Ox = (uint32_t)(int)P.origin[0], Oy = (uint32_t)(int)P.origin[1], Oz = (uint32_t)(int)P.origin[2];
-        if (P.cull) {
+        if (CULL && P.cull) {
             const float ynow = py - (float)P.origin[1];
             const float yseg = (seg == P.nsegs - 1) ? (e1 - (float)P.origin[1]) : ynow + incy * (float)(P.seg_len + 1);
             const int a0 = (int)floorf(fminf(ynow, yseg)) - 2, a1 = (int)floorf(fmaxf(ynow, yseg)) + 2;
@@ -356,14 +357,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 }
                 if (wx < uxy && wy < uxy && wz < uzs) {
                     sy = min(wy + om1, wy + om1 - uxy);                   // toroidal storage coordinates
-                    if (sy - slab_lo < slab_n) {
+                    if (!CULL || sy - slab_lo < slab_n) {
                         sx = min(wx + om0, wx + om0 - uxy);
                         sz = min(wz + om2, wz + om2 - uzs);
                         Ls = acc_idx((int)sx, (int)sy, (int)sz, P.zs, P.sxq);
                         commit = true;
                     }
                     length += step_len;
-                    active = length < lim && --left > 0 && (int)wy < ystop_hi && (int)wy > ystop_lo;
+                    active = length < lim && --left > 0;
+                    if (CULL) active = active && (int)wy < ystop_hi && (int)wy > ystop_lo;
                 } else {
                     active = false;                                       // ray left the grid (gvom.py:1135-1144)
                 }
@@ -2002,23 +2004,28 @@ hipError_t gvom_launch_trace(hipStream_t s, const ScanParams &P, int dtype, cons
     hipLaunchKernelGGL((k_trace<TT, VV>), dim3(blocks, nsegs), dim3(256), 0, s, P, (const TT *)pts, \
                        (long)stride_elems, (long)n, (TT *)world, hit, total, state, tags, cminh, counters, \
                        stat_sums, stat_base, stat_rowvox)
+#define TRACE_LAUNCH_NC(TT, VV)                                                                  \
+    hipLaunchKernelGGL((k_trace<TT, VV, false>), dim3(blocks, nsegs), dim3(256), 0, s, P, (const TT *)pts, \
+                       (long)stride_elems, (long)n, (TT *)world, hit, total, state, tags, cminh, counters, \
+                       stat_sums, stat_base, stat_rowvox)
     if (dtype == 0) {
         if (variant == 0) TRACE_LAUNCH(float, 0);
         else if (variant == 9) TRACE_LAUNCH(float, 9);
         else if (variant == 2) TRACE_LAUNCH(float, 2);
         else if (variant == 4) TRACE_LAUNCH(float, 4);
         else if (variant == 5) TRACE_LAUNCH(float, 5);
-        else if (variant == 6) TRACE_LAUNCH(float, 6);
+        else if (variant == 6) { if (P.cull) TRACE_LAUNCH(float, 6); else TRACE_LAUNCH_NC(float, 6); }
         else TRACE_LAUNCH(float, 1);
     } else {
         if (variant == 0) TRACE_LAUNCH(double, 0);
         else if (variant == 9) TRACE_LAUNCH(double, 9);
         else if (variant == 4) TRACE_LAUNCH(double, 4);
         else if (variant == 5) TRACE_LAUNCH(double, 5);
-        else if (variant == 6) TRACE_LAUNCH(double, 6);
+        else if (variant == 6) { if (P.cull) TRACE_LAUNCH(double, 6); else TRACE_LAUNCH_NC(double, 6); }
         else TRACE_LAUNCH(double, 1);
     }
 #undef TRACE_LAUNCH
+#undef TRACE_LAUNCH_NC
     return hipGetLastError();
 }
 
