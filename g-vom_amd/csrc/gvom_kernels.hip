@@ -304,6 +304,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             px += incx; py += incy; pz += incz;
             length += step_len;
         }
+        // steps this wave may still take: every active lane has taken the same number, so the
+        // counter is wave-uniform (scalar)
         int left = (seg == P.nsegs - 1) ? INT_MAX : P.seg_len;
         // non-finite increments (degenerate returns): the reference's first step lands on NaN/inf,
         // which is outside the grid, and the ray ends without an update
@@ -339,6 +341,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         const uint32_t slab_lo = (uint32_t)P.sy_lo, slab_n = (uint32_t)(P.sy_hi - P.sy_lo);
         if (P.dbg & 8) active = false;
         while (__any(active)) {
+            --left;
             bool commit = false;
             uint32_t Ls = 0, sx = 0, sy = 0, sz = 0;
             if (active) {
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                         commit = true;
                     }
                     length += step_len;
-                    active = length < lim && --left > 0;
+                    active = length < lim && left > 0;
                     if (CULL) active = active && (int)wy < ystop_hi && (int)wy > ystop_lo;
                 } else {
                     active = false;                                       // ray left the grid (gvom.py:1135-1144)
