@@ -100,7 +100,8 @@ __device__ __forceinline__ void lc_flush(uint32_t *keys, uint32_t *cnt, uint32_t
 // chain (f32 add -> f64 floor/compare -> index -> shuffle/ballot -> atomic), so the kernel would
 // be latency-bound.  Each coordinate advances by a constant-sign f32 increment, i.e. monotonically,
 // and so does `length`; therefore "the ray has already ended before step k" is decided by the
-// state AT step k alone, and a ray's steps can be split into nsegs segments handled by different
+// state AT step k alone -- given that step 1 lies inside the grid, which every later segment
+// checks -- and a ray's steps can be split into nsegs segments handled by different
 // waves (blockIdx.y): a lane first replays the skipped steps with the reference's exact f32/f64
 // accumulation (3 f32 adds + 1 f64 add per step, no floor, no memory traffic), then runs the full
 // step body for its own seg_len steps.  Results are bit-identical; there are nsegs x more waves.
@@ -300,6 +301,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         const float incy = si == 0 ? inc1 : (si == 1 ? dir : inc2);
         const float incz = si == 0 ? inc2 : (si == 1 ? inc1 : dir);
         float px = P.pt0[0], py = P.pt0[1], pz = P.pt0[2];
+        if (seg > 0) {
+            // The reference stops at the FIRST step outside the grid (gvom.py:1135-1144).  The steps
+            // inside the grid form one interval (monotone coordinates, convex box), so a later
+            // segment may only run if step 1 is inside -- otherwise the ray (sensor outside the
+            // window, possible when a grid dimension is 1) would be picked up where it ENTERS.
+            const double g0 = floor((double)(px + incx) - P.origin[0]);
+            const double g1 = floor((double)(py + incy) - P.origin[1]);
+            const double g2 = floor((double)(pz + incz) - P.origin[2]);
+            if (!(g0 >= 0.0 && g0 < dxy && g1 >= 0.0 && g1 < dxy && g2 >= 0.0 && g2 < dzs)) reach = false;
+        }
         for (int j = seg * P.seg_len; j > 0; --j) {      // replay earlier segments (see SEGMENTS)
             px += incx; py += incy; pz += incz;
             length += step_len;
@@ -414,6 +425,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     }
 
     // ---- VAR 1: lock-step, run-merged (VAR 2: same + diagnostic counters) -------------------
+    if (seg > 0) {
+        // later segments only run if step 1 lies inside the grid (the reference stops at the first
+        // step outside; the inside steps form one interval -- see the VAR 5/6 loop)
+        const float q0 = pd + dir, q1 = p1 + inc1, q2 = p2 + inc2;
+        const double g0 = floor((double)(si == 0 ? q0 : (si == 1 ? q2 : q1)) - P.origin[0]);
+        const double g1 = floor((double)(si == 0 ? q1 : (si == 1 ? q0 : q2)) - P.origin[1]);
+        const double g2 = floor((double)(si == 0 ? q2 : (si == 1 ? q1 : q0)) - P.origin[2]);
+        if (!(g0 >= 0.0 && g0 < dxy && g1 >= 0.0 && g1 < dxy && g2 >= 0.0 && g2 < dzs)) reach = false;
+    }
     // replay the steps of earlier segments (exact accumulation; see SEGMENTS above)
     for (int j = seg * P.seg_len; j > 0; --j) {
         pd = pd + dir; p1 = p1 + inc1; p2 = p2 + inc2;

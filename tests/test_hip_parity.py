@@ -477,3 +477,45 @@ def test_long_run_moving_window_matches_oracle(gvom_mod):
             assert g.combined_cell_count_cpu == want.combined_cell_count_cpu
             checked += 1
     assert checked == 24 and abs(ego[0]) + abs(ego[1]) > 40.0
+
+
+def _fuzz_case(seed):
+    """A random small configuration and call sequence with the inputs that sit on the edges of the
+    algorithm: returns on voxel faces and grid corners, axis-parallel rays, returns at the sensor
+    (zero-length rays), duplicates, far outliers, empty clouds, exact-integer and negative egos."""
+    rng = np.random.default_rng(seed)
+    xy_res = float(rng.choice([0.1, 0.25, 0.4, 1.0])); z_res = float(rng.choice([0.1, 0.2, 0.5]))
+    xy = int(rng.integers(4, 71)); zs = int(rng.integers(1, 41)); buf = int(rng.integers(1, 5))
+    params = (xy_res, z_res, xy, zs, buf, float(rng.choice([0.0, 0.5, 2.0])),
+              float(rng.uniform(0.1, 1.0)), float(rng.uniform(0.1, 1.0)), float(rng.uniform(0.1, 0.6)),
+              float(rng.uniform(0.5, 3.0)), float(rng.uniform(0.0, 5.0)), float(rng.uniform(0.0, 2.0)), 1, 1)
+    half = np.array([xy * xy_res, xy * xy_res, zs * z_res]) * 0.5
+    steps = []
+    ego = np.round(rng.uniform(-3, 3, 3), int(rng.integers(0, 3)))          # often exact integers
+    for k in range(int(rng.integers(1, 7))):
+        ego = ego + np.round(rng.uniform(-1.5, 1.5, 3) * np.array([1, 1, 0.1]), int(rng.integers(0, 3)))
+        n = int(rng.choice([0, 1, 7, 300, 3000]))
+        parts = [rng.uniform(-1.2, 1.2, (n, 3)) * half + ego]
+        if n:
+            m = max(1, n // 6)
+            grid = np.round(rng.uniform(-1, 1, (m, 3)) * half / np.array([xy_res, xy_res, z_res])) * np.array([xy_res, xy_res, z_res])
+            parts.append(grid + np.floor(ego / np.array([xy_res, xy_res, z_res])) * np.array([xy_res, xy_res, z_res]))   # on voxel faces
+            ax = np.zeros((m, 3)); ax[np.arange(m), rng.integers(0, 3, m)] = rng.uniform(-1, 1, m) * half.min()
+            parts.append(ax + ego)                                            # axis-parallel rays
+            parts.append(np.repeat(ego[None], 3, 0))                          # zero-length rays
+            parts.append(parts[0][:m])                                        # duplicates
+            parts.append(rng.uniform(-40, 40, (3, 3)) * half + ego)           # far outside the grid
+        pc = np.concatenate(parts, 0).astype(rng.choice([np.float32, np.float64]))
+        tf = scenarios.rot_z(float(rng.uniform(-0.2, 0.2)), tuple(rng.uniform(-0.1, 0.1, 3))) if rng.random() < 0.4 else None
+        steps.append(("scan", pc, tuple(float(v) for v in ego), tf))
+        if rng.random() < 0.7:
+            steps.append(("combine",))
+    steps.append(("combine",))
+    return params, steps
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_fuzz_small_configurations_match_oracle(gvom_mod, seed):
+    params, steps = _fuzz_case(1000 + seed)
+    got, want = _run_both(gvom_mod, params, steps)
+    assert compare_records(got, want, float_tol=1e-5) > 3
