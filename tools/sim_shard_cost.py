@@ -11,13 +11,17 @@ import numpy as np
 import gvom, synth
 
 name = sys.argv[1] if len(sys.argv) > 1 else "m256"
+worlds = tuple(int(w) for w in sys.argv[2].split(",")) if len(sys.argv) > 2 else (1, 2, 4, 8)
+only = tuple(int(r) for r in sys.argv[3].split(",")) if len(sys.argv) > 3 else None
 params, beams, _ = synth.CONFIGS[name]
 scene = synth.make_scene(2)
-for world in (1, 2, 4, 8):
+for world in worlds:
     clouds = [synth.lidar_scan(scene, beams=beams, yaw=2 * np.pi / 2048 * r / world, noise_seed=r) for r in range(world)]
     full = np.concatenate(clouds, 0)
     worst = {}
     for r in range(world):
+        if only is not None and r not in only:
+            continue
         g = gvom.Gvom(*params, device=0, _shard=(r, world))
         L = g._lib
         for it in range(6):
