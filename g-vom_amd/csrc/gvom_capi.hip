@@ -117,6 +117,7 @@ struct gvom_handle {
     long host_calls = 0;
     bool host_timing = false;
     bool stats = false;                                 // per-voxel statistics enabled (gvom_params.reserved0 bit 0)
+    int acc_pad = 7, sxq = 0;                           // accumulator row pitch (lines) = ceil(xy/4) + acc_pad
     int trace_variant = 6;                              // GVOM_TRACE_VARIANT (k_trace strategy)
     bool profiling = false;
     hipEvent_t ev[8] = {nullptr};
@@ -171,7 +172,6 @@ void fill_scan_params(const gvom_handle *h, const int64_t origin[3], const doubl
     P.pt0[0] = (float)(h->ego[0] / p.xy_resolution);
     P.pt0[1] = (float)(h->ego[1] / p.xy_resolution);
     P.pt0[2] = (float)(h->ego[2] / p.z_resolution);
-    P.rinv[0] = (float)(1.0 / p.xy_resolution); P.rinv[1] = (float)(1.0 / p.z_resolution);
     P.xy = p.xy_size; P.zs = p.z_size;
     P.om[0] = (int)floor_mod(origin[0], p.xy_size);
     P.om[1] = (int)floor_mod(origin[1], p.xy_size);
@@ -180,7 +180,7 @@ void fill_scan_params(const gvom_handle *h, const int64_t origin[3], const doubl
     P.off[0] = h->in_off[0]; P.off[1] = h->in_off[1]; P.off[2] = h->in_off[2];
     P.in_f32 = h->in_f32 ? 1 : 0;
     P.nseg = h->nseg;
-    P.sxq = (p.xy_size + 3) / 4;
+    P.sxq = h->sxq;
     // DDA segments: the ego sits at the window centre, so a ray takes at most size/2 + 2 steps
     {
         int nsegs = 6;
@@ -227,6 +227,7 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, g
     h->device = device_id;
     h->rank = rank; h->world = world;
     if (const char *v = getenv("GVOM_TRACE_VARIANT")) h->trace_variant = atoi(v);
+    if (const char *v = getenv("GVOM_ACC_PAD")) h->acc_pad = atoi(v) >= 0 ? atoi(v) : 0;
     h->stats = (params->reserved0 & GVOM_FLAG_VOXEL_STATISTICS) != 0;
     if (const char *v = getenv("GVOM_VOXEL_STATISTICS")) h->stats = atoi(v) != 0;
     if (const char *v = getenv("GVOM_HOST_TIMING")) h->host_timing = atoi(v) != 0;
@@ -251,7 +252,11 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, g
     CK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     h->own_stream = h->stream;
     // accumulators are micro-tiled in 4x4 (x,y) patches (gvom_internal.h "ACCUMULATOR LAYOUT")
-    const size_t acc_elems = (size_t)((xy + 3) / 4) * ((xy + 3) / 4) * zs * 16 + 256;
+    // row pitch of the patch rows, padded (GVOM_ACC_PAD lines of 64 B) so that the z levels of one
+    // (x, y) patch -- xy*16 bytes apart, a multiple of 4 KiB for xy = 256 -- do not all map to the
+    // same memory channel
+    h->sxq = (xy + 3) / 4 + h->acc_pad;
+    const size_t acc_elems = (size_t)h->sxq * ((xy + 3) / 4) * zs * 16 + 256;
     CK(hipMalloc((void **)&h->hit, acc_elems * 4));
     CK(hipMalloc((void **)&h->total, acc_elems * 4));
     CK(hipMemsetAsync(h->hit, 0, acc_elems * 4, h->stream));

@@ -151,43 +151,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const bool pass = live && !((double)d2 < P.min_d2);
     const double dxy = (double)P.xy, dzs = (double)P.zs;
 
-    // ---- later segments: leave before the f64 setup when no ray of the wave can still be running ----
-    // After J = seg * seg_len replayed steps `length` is >= J * (1 - 2^-22) (every step adds
-    // |1 / sd| with |sd| <= 1 + 2^-23), and a ray stops once length >= ray_length - 1
-    // (gvom.py:1127): a ray with ray_length <= J + 0.9 takes no step in this segment.  Likewise a ray
-    // whose position after J steps lies more than a voxel outside the window has left the grid for
-    // good (coordinates are monotone; a ray whose step 1 is outside is not picked up by later segments
-    // at all).  Both are decided conservatively in f32 from the raw return, with margins far above the
-    // rounding of this estimate and of the reference's accumulation; NaN/inf compare false and take
-    // the full path.  39 % of the later-segment waves of the headline scan leave here.
-    if ((VAR == 5 || VAR == 6) && seg > 0) {
-        const float J = (float)(seg * P.seg_len);
-        const float ax = (float)x * P.rinv[0], ay = (float)y * P.rinv[0], az = (float)z * P.rinv[1];
-        const float ux = ax - P.pt0[0], uy = ay - P.pt0[1], uz = az - P.pt0[2];
-        const float r = sqrtf((ux * ux + uy * uy) + uz * uz);
-        const float mag = ((fabsf(ax) + fabsf(ay)) + fabsf(az)) + ((fabsf(P.pt0[0]) + fabsf(P.pt0[1])) + fabsf(P.pt0[2]));
-        const float slack = r * 1e-5f + mag * 2e-6f;                     // >> error of r
-        bool dead = !pass || (r + slack <= J + 0.9f);
-        const float um = fmaxf(fmaxf(fabsf(ux), fabsf(uy)), fabsf(uz));
-        const float t = J / um;                                          // steps -> ray parameter (inf/NaN: not dead)
-        const float qx = (P.pt0[0] + t * ux) - (float)P.origin[0];
-        const float qy = (P.pt0[1] + t * uy) - (float)P.origin[1];
-        const float qz = (P.pt0[2] + t * uz) - (float)P.origin[2];
-        const float m2 = 2.0f + (J + mag) * 1e-3f;                       // >> f32 drift of J accumulated steps (J * 2^-24 * |p|)
-        dead = dead || qx < -m2 || qx > (float)P.xy + m2 || qy < -m2 || qy > (float)P.xy + m2 || qz < -m2 || qz > (float)P.zs + m2;
-        if (CULL && P.cull) {
-            // slab-sharded runs: the same estimate bounds the window rows this segment can cross (the exact
-            // test below repeats this with +-2 rows after the setup); segments that stay clear of the
-            // slab's rows by the extra margin m2 leave here
-            const float yend = (seg == P.nsegs - 1) ? ay - (float)P.origin[1] : qy + ((float)(P.seg_len + 1) / um) * uy;
-            const float ylo = fminf(qy, yend) - (m2 + 2.0f), yhi = fmaxf(qy, yend) + (m2 + 2.0f);
-            const bool h0 = yhi >= (float)P.wlo[0] && ylo < (float)P.whi[0];
-            const bool h1 = yhi >= (float)P.wlo[1] && ylo < (float)P.whi[1];
-            dead = dead || (!(h0 || h1) && fabsf(qy) < INFINITY && fabsf(yend) < INFINITY);   // NaN/inf: full path
-        }
-        if (__all(dead)) return;                                         // wave-uniform
-    }
-
     // ---- endpoint ------------------------------------------------------------------------
     bool ingrid = false, ingrid_any = false;
     uint32_t L = 0, A = 0;
