@@ -59,6 +59,36 @@ class Hip(object):
         return p
 
 
+def pin_to_gpu_numa(device):
+    """Benchmark hygiene (what `numactl --cpunodebind` does): run this process on the CPUs of the
+    NUMA node the GPU hangs off, so kernel launches (doorbell writes) and completion flags (GPU
+    writes to host memory the host spins on) do not cross the socket interconnect.  On the 2-socket
+    test hosts an unpinned process lands on either socket and a step costs 150 or 165 us.
+    Best effort: returns the CPU list used, or None (GVOM_BENCH_NO_PIN=1 disables it)."""
+    if os.environ.get("GVOM_BENCH_NO_PIN") or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        rt = ctypes.CDLL("libamdhip64.so")
+        buf = ctypes.create_string_buffer(64)
+        if rt.hipDeviceGetPCIBusId(buf, 64, int(device)) != 0:
+            return None
+        bdf = buf.value.decode().lower()
+        with open("/sys/bus/pci/devices/%s/local_cpulist" % bdf) as f:
+            spec = f.read().strip()
+        cpus = set()
+        for part in spec.split(","):
+            if part:
+                a, _, b = part.partition("-")
+                cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return spec
+    except Exception:
+        return None
+
+
 def cpu_baseline(params, scans, budget_s=20.0):
     """Times the CPU oracle (single thread, C restatement of the reference's algorithm) on a
     bounded sample of the same workload: whole steps (one scan + one combine) until the
@@ -120,6 +150,7 @@ def atomic_ceiling(kernel, ms):
 def run_single(args):
     import gvom
     import synth
+    affinity = pin_to_gpu_numa(0)
     hip = Hip()
     hip.set_device(0)
     name = args.config
@@ -200,7 +231,8 @@ def run_single(args):
         "config": {"workload": synth.CONFIGS[name][2], "name": name, "points_per_scan": n_pts,
                    "grid": [params[2], params[2], params[3]], "buffer_size": params[4],
                    "poses": len(scans), "input": "device-resident f32 xyz",
-                   "step": "1 scan + 1 combine incl. D2H of the 4 maps"},
+                   "step": "1 scan + 1 combine incl. D2H of the 4 maps",
+                   "host_affinity": affinity},
         "map_hz": args.steps / elapsed,
         "value_pcie_inclusive": n_pts * n_pcie / pcie_elapsed / 1e6,
         "value_occupancy_api": n_pts * n_occ / occ_elapsed / 1e6,

@@ -24,6 +24,8 @@ def run(args):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import bench
+    affinity = bench.pin_to_gpu_numa(local_rank)      # each rank next to its own GPU
     torch.cuda.set_device(local_rank)
     dist.init_process_group("nccl", init_method="env://", device_id=torch.device("cuda", local_rank))
     name = args.config
@@ -80,7 +82,7 @@ def run(args):
             "config": {"workload": desc + "; %d sensors, one shared map, grid sharded into %d y-slabs"
                        % (world, world), "name": name, "points_per_step": n_total,
                        "points_per_gpu": n_local, "grid": [params[2], params[2], params[3]],
-                       "buffer_size": params[4],
+                       "buffer_size": params[4], "host_affinity_rank0": affinity,
                        "collectives": "per step: all_gather(cloud, 12 B/pt) + in-place all_gather(height|inferred|"
                        "density rows, 24 B/cell) over RCCL; none on per-voxel data"},
             "map_hz": args.steps / elapsed,
