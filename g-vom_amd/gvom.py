@@ -307,8 +307,8 @@ class Gvom(object):
                                   row_stride_bytes=None):
         """Same as process_pointcloud for a cloud already resident in HBM (raw device pointer)."""
         self.ego_position = ego_position
-        code = 0 if np.dtype(dtype) == np.float32 else 1
-        stride = row_stride_bytes or 3 * np.dtype(dtype).itemsize
+        code = 0 if (dtype is np.float32 or np.dtype(dtype) == np.float32) else 1
+        stride = row_stride_bytes or (12 if code == 0 else 24)
         ego = (ctypes.c_double * 3)(float(ego_position[0]), float(ego_position[1]),
                                     float(ego_position[2]))
         tf = None
@@ -418,10 +418,11 @@ class Gvom(object):
         # the library writes the maps in [y][x] memory order: seen through .T they are the reference's
         # [x, y]-indexed arrays in Fortran order (what gvom_ros.py's reshape(..., order='F') reads
         # without a copy), and the GPU writes them as contiguous runs without a transpose
-        positive = raw[0:4 * n2].view(np.int32).reshape(xy, xy).T
-        negative = raw[4 * n2:8 * n2].view(np.int32).reshape(xy, xy).T
-        visibility = raw[8 * n2:12 * n2].view(np.int32).reshape(xy, xy).T
-        roughness = raw[12 * n2:20 * n2].view(np.float64).reshape(xy, xy).T
+        # (one constructor call per map: this runs after the GPU has finished, on the step's critical path)
+        positive = np.ndarray((xy, xy), np.int32, raw, 0, (4, 4 * xy))
+        negative = np.ndarray((xy, xy), np.int32, raw, 4 * n2, (4, 4 * xy))
+        visibility = np.ndarray((xy, xy), np.int32, raw, 8 * n2, (4, 4 * xy))
+        roughness = np.ndarray((xy, xy), np.float64, raw, 12 * n2, (8, 8 * xy))
         return GVOM_OK, (origin, positive, negative, roughness, visibility)
 
     # ---- accessors / debug API (reference gvom.py:356-410) ------------------------------
