@@ -45,6 +45,7 @@ def run(args):
 
     for _ in range(args.warmup):
         step()
+    stats = sh.b.g.scan_stats()             # exact accumulator sums of THIS rank's slab (roofline accounting)
     acc = dict.fromkeys(gvom.STAGE_NAMES, 0.0)
     sample, n_sampled = max(1, getattr(args, "sample", 8)), 0
     torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
@@ -72,6 +73,13 @@ def run(args):
         n_total = n_local * world
         V = params[2] * params[2] * params[3]
         dom = max(stage_ms, key=lambda s: stage_ms[s])
+        # algorithmic bytes of rank 0's launches (on its slab of V / world voxels; k_trace
+        # reads the whole gathered cloud and adds the slab's share of the accumulator updates)
+        alg = {"trace": n_total * 12 + 4 * (stats["sum_hit"] + stats["sum_total"]),
+               "encode": 20 * V // world + n_total * 12 + 4 * stats["sum_hit"],
+               "fuse": (4 * (min(1, params[4]) + 1) + 8) * V // world,
+               "map2d": 68 * params[2] * params[2]}
+        achieved = alg[dom] / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else None
         out = {
             "metric": "M points/sec (process_pointcloud + combine_maps, 256^3 voxel grid); map Hz beside it",
             "value": n_total * args.steps / elapsed / 1e6, "unit": "M points/s",
@@ -87,10 +95,11 @@ def run(args):
                        "density rows, 24 B/cell) over RCCL; none on per-voxel data"},
             "map_hz": args.steps / elapsed,
             "stage_ms_rank0": stage_ms,
-            "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": None, "peak": 8000.0,
-                         "unit": "GB/s", "frac": None, "traffic": None,
-                         "note": "per-kernel roofline is reported by the N=1 run; slab kernels here "
-                                 "process V/%d voxels each (V=%d)" % (world, V)},
+            "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": 8000.0,
+                         "unit": "GB/s", "frac": achieved / 8000.0 if achieved else None, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": stage_ms[dom],
+                         "note": "rank 0's launches on its slab of V/%d voxels (V=%d); PMC traffic is "
+                                 "profiled on the N=1 run" % (world, V)},
         }
     dist.barrier()
     dist.destroy_process_group()

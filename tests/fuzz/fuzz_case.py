@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Debug helper: prints / dumps one case of tests/test_hip_parity.py::_fuzz_case and (on a GPU box)
-the voxels where the HIP path and the oracle disagree.  Usage: tools/fuzz_case.py <seed> [hip]"""
+the voxels where the HIP path and the oracle disagree.  Usage: tests/fuzz/fuzz_case.py <seed> [hip]"""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in ("tests", "tests/golden", "g-vom_amd", ""):
     sys.path.insert(0, os.path.join(ROOT, p))
 import importlib

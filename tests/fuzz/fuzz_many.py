@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Runs tests/test_hip_parity.py::_fuzz_case for a range of seeds on the GPU box and reports the
-seeds whose HIP records differ from the oracle.  Usage: tools/fuzz_many.py <first> <count> [stats]"""
+seeds whose HIP records differ from the oracle.  Usage: tests/fuzz/fuzz_many.py <first> <count> [stats]"""
 import os, sys, io, contextlib
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in ("tests", "tests/golden", "g-vom_amd", ""):
     sys.path.insert(0, os.path.join(ROOT, p))
 import importlib

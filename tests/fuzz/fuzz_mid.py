@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Mid-size randomized parity run (not in the test-suite: ~0.5 s of CPU oracle per case): grids of
 64..160 x 8..64 voxels, lidar-shaped scans of a random box scene with random sensor poses, random
-thresholds, buffer 1..8, 2..8 scans with interleaved combines.  Usage: tools/fuzz_mid.py <first> <count>"""
+thresholds, buffer 1..8, 2..8 scans with interleaved combines.  Usage: tests/fuzz/fuzz_mid.py <first> <count>"""
 import os, sys, io, contextlib
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in ("tests", "tests/golden", "g-vom_amd", ""):
     sys.path.insert(0, os.path.join(ROOT, p))
 import scenarios, gvom, synth

@@ -3,10 +3,10 @@
 tests/test_hip_parity.py::_fuzz_case (grid size rounded to a multiple of the world size), W sharded
 handles are fed the whole cloud and the rows each owns must equal the unsharded handle's, for every
 ring slot after every scan and for the fused map after every combine (the 2-D stage needs the
-collective and is covered by tests/test_hip_sharded.py).  Usage: tools/fuzz_shard.py <first> <count>"""
+collective and is covered by tests/test_hip_sharded.py).  Usage: tests/fuzz/fuzz_shard.py <first> <count>"""
 import os, sys, io, contextlib, ctypes
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in ("tests", "tests/golden", "g-vom_amd", ""):
     sys.path.insert(0, os.path.join(ROOT, p))
 import importlib

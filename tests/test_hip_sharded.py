@@ -39,12 +39,12 @@ def test_sharded_hip_equals_single_handle(world):
 
 @pytest.mark.gpu
 def test_sharded_kernels_fuzz_against_unsharded_handle():
-    """tools/fuzz_shard.py on 90 edge-case seeds: 2/4/8 sharded handles on one GPU, every rank's rows of
+    """tests/fuzz/fuzz_shard.py on 90 edge-case seeds: 2/4/8 sharded handles on one GPU, every rank's rows of
     every ring slot and of the fused map equal the unsharded handle's (scan culling, per-segment
     culling, slab encode and slab fusion)."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_shard.py"), "70000", "90"],
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz", "fuzz_shard.py"), "70000", "90"],
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "checked 90 seeds, 0 failures" in out.stdout, out.stdout[-2000:]
