@@ -171,11 +171,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         }
     }
     uint32_t old = 1;
-    if (ingrid && !(P.dbg & 4)) {
-        if (P.dbg & 1024) atomicAdd(&hit[A], 1u); else old = atomicAdd(&hit[A], 1u);
-        if (!(P.dbg & 256)) atomicAdd(&total[A], 1u);
-        const uint32_t tile = (L / P.xy) * P.nseg + ((L % P.xy) >> 6);  // stamp the tile (idempotent)
-        if (!(P.dbg & 512)) tags[tile] = P.epoch;
+    if (first) {                                         // workgroup-uniform
+        // neighbouring returns of a beam end in the same voxel (33 consecutive azimuths at 2 m range):
+        // the first lane of each run of equal voxels adds the whole run, so a voxel costs one
+        // same-address atomic per run instead of one per return (they are served one at a time)
+        const uint32_t key = ingrid ? A : (0xFFFFFF00u | (uint32_t)lane);
+        const uint32_t leftk = (uint32_t)__builtin_amdgcn_update_dpp((int)~key, (int)key, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+        const bool ehead = ingrid && leftk != key;
+        const unsigned long long followers = __ballot(ingrid) & ~__ballot(ehead);
+        if (ehead && !(P.dbg & 4)) {
+            const uint32_t run = (uint32_t)__ffsll((long long)~((followers >> lane) >> 1));   // 1 + followers
+            old = atomicAdd(&hit[A], run);
+            atomicAdd(&total[A], run);
+            tags[(L / P.xy) * P.nseg + ((L % P.xy) >> 6)] = P.epoch;   // stamp the tile (idempotent)
+        }
+        ingrid = ehead;                                  // only a run's first lane can claim the voxel's row
     }
     // every rank sees every point, so each can count the GLOBAL number of in-grid returns: the
     // reference's "no overlap" test (gvom.py:147-150) then needs no collective in sharded runs.
@@ -601,25 +611,40 @@ __global__ __launch_bounds__(256) void k_encode(const ScanParams P, unsigned enc
     // that k_trace claimed; the encode blocks rewrite those state words with the same value.
     if (blockIdx.x < mh_blocks) {                        // ---- min-height blocks ----
         if (P.dbg & 128) return;
+        const int lane = threadIdx.x & (WAVE - 1);
         const long i = (long)blockIdx.x * 256 + threadIdx.x;
-        if (i >= n) return;
-        const T x = world[3 * i + 0], y = world[3 * i + 1], z = world[3 * i + 2];
-        const T d2 = (x * x + y * y) + z * z;
-        if ((double)d2 < P.min_d2) return;
-        const double fx = floor((double)x / P.xy_res - P.origin[0]);
-        if (!(fx >= 0.0 && fx < (double)P.xy)) return;
-        const double fy = floor((double)y / P.xy_res - P.origin[1]);
-        if (!(fy >= 0.0 && fy < (double)P.xy)) return;
-        const double az = (double)z / P.z_res - P.origin[2];
-        const double fz = floor(az);
-        if (!(fz >= 0.0 && fz < (double)P.zs)) return;
-        const int sy = wrap_add((int)fy, P.om[1], P.xy);
-        if (sy < P.sy_lo || sy >= P.sy_hi) return;
-        const int sx = wrap_add((int)fx, P.om[0], P.xy);
-        const int sz = wrap_add((int)fz, P.om[2], P.zs);
-        const int32_t row = state[((uint32_t)sy * P.zs + sz) * P.xy + sx];
-        const float v = (float)(az - fz);               // local_point[2], f64 -> f32 (gvom.py:1326,1329)
-        if (row >= 0) atomicMin(&cminh[row], __float_as_uint(v));
+        int32_t row = -1;
+        uint32_t vbits = 0xFFFFFFFFu;
+        if (i < n) {
+            const T x = world[3 * i + 0], y = world[3 * i + 1], z = world[3 * i + 2];
+            const T d2 = (x * x + y * y) + z * z;
+            const double fx = floor((double)x / P.xy_res - P.origin[0]);
+            const double fy = floor((double)y / P.xy_res - P.origin[1]);
+            const double az = (double)z / P.z_res - P.origin[2];
+            const double fz = floor(az);
+            if (!((double)d2 < P.min_d2) && fx >= 0.0 && fx < (double)P.xy && fy >= 0.0 && fy < (double)P.xy &&
+                fz >= 0.0 && fz < (double)P.zs) {
+                const int sy = wrap_add((int)fy, P.om[1], P.xy);
+                if (sy >= P.sy_lo && sy < P.sy_hi) {
+                    const int sx = wrap_add((int)fx, P.om[0], P.xy);
+                    const int sz = wrap_add((int)fz, P.om[2], P.zs);
+                    row = state[((uint32_t)sy * P.zs + sz) * P.xy + sx];
+                    vbits = __float_as_uint((float)(az - fz));   // local_point[2], f64 -> f32 (gvom.py:1326,1329)
+                }
+            }
+        }
+        // Neighbouring returns of a beam land in the same voxel (33 consecutive azimuths at 2 m range):
+        // fold each run of equal rows with a segmented min scan and let its LAST lane issue one atomic
+        // (same-address atomics are served one at a time; with N sensors in one map the near field gets
+        // N times the returns).  min is idempotent, so folding in a same-row lane twice is harmless.
+        const uint32_t key = row >= 0 ? (uint32_t)row : (0xFFFFFF00u | (uint32_t)lane);
+#pragma unroll
+        for (int o = 1; o < WAVE; o <<= 1) {
+            const uint32_t k2 = (uint32_t)__shfl_up((int)key, o), v2 = (uint32_t)__shfl_up((int)vbits, o);
+            if (lane >= o && k2 == key) vbits = min(vbits, v2);
+        }
+        const uint32_t knext = (uint32_t)__shfl_down((int)key, 1);
+        if (row >= 0 && (lane == WAVE - 1 || knext != key)) atomicMin(&cminh[row], vbits);
         return;
     }
     // ---- encode blocks: one wave per QUAD = 4 storage rows (sy = 4q .. 4q+3) x 64 sx at one sz,
