@@ -49,6 +49,7 @@ struct ScanParams {
     int    sy_lo, sy_hi;  // storage rows owned by this rank: [sy_lo, sy_hi)
     int    nseg;          // tiles per (sy, sz) row
     int    nsegs, seg_len; // DDA steps are split into nsegs segments of seg_len steps (last: open-ended)
+    unsigned long long seg_order; // nibble k = the segment handled by the workgroups with blockIdx.y == k
     int    sxq;           // accumulator layout: 4x4 (x,y) patches per row of patches = ceil(xy/4)
     uint32_t epoch;       // this scan's tile epoch
     // slab-sharded runs: the slab's rows as (up to two) intervals of WINDOW y, for ray culling

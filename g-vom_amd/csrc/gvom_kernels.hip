@@ -125,7 +125,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 {
     const int lane = threadIdx.x & (WAVE - 1);
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    const int seg = (VAR == 1 || VAR == 2 || (VAR >= 4 && VAR <= 6)) ? (int)blockIdx.y : 0;      // step segment of this wave
+    // step segment of this wave: workgroups are dispatched in blockIdx.y order, P.seg_order maps that
+    // order to segments (4 bits each)
+    const int seg = (VAR == 1 || VAR == 2 || (VAR >= 4 && VAR <= 6)) ? (int)((P.seg_order >> (4 * blockIdx.y)) & 15u) : 0;
     if ((VAR == 0 || VAR == 9) && blockIdx.y != 0) return;
     const bool first = seg == 0;                                       // segment 0 also does the endpoint
     const bool live = i < n;
