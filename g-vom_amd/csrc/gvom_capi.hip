@@ -192,6 +192,29 @@ void fill_scan_params(const gvom_handle *h, const int64_t origin[3], const doubl
         if (const char *v = getenv("GVOM_TRACE_DEBUG")) P.dbg = atoi(v);
         const int maxsteps = (p.xy_size > p.z_size ? p.xy_size : p.z_size) / 2 + 2;
         P.nsegs = nsegs;
+        P.seg_len = (maxsteps + nsegs - 1) / nsegs;
+        if (P.seg_len < 8) { P.seg_len = 8; }
+        for (int k = 0; k < 10; ++k) P.seg_start[k] = (k < nsegs ? k : nsegs) * P.seg_len;
+        if (nsegs >= 3 && nsegs <= 9 && P.seg_len >= 12 && !getenv("GVOM_TRACE_UNIFORM")) {
+            // The workgroups of the last segments are dispatched last and form the kernel's tail, and
+            // only the longest rays reach them: the last two segments are shortened (0.85 and 0.6 of
+            // the others).  Measured on the 131 k-point scans: 48.9 -> 46.5 us against equal lengths
+            // (boundaries 0,24,48,72,96,116 of 130 steps; the optimum is flat within +-2 steps
+            // except for the last boundary).
+            const double unit = (double)maxsteps / ((nsegs - 2) + 0.85 + 0.6);
+            double acc = 0.0;
+            for (int k = 0; k < 10; ++k) {
+                P.seg_start[k] = (int)(acc + 0.5);
+                acc += k < nsegs - 2 ? unit : (k == nsegs - 2 ? 0.85 * unit : (k == nsegs - 1 ? 0.6 * unit : unit));
+            }
+        }
+        if (const char *v = getenv("GVOM_TRACE_STARTS")) {          // e.g. "0,20,42,66,90,112": first step - 1 of every segment
+            int vals[10], cnt = 0;
+            for (const char *q = v; *q && cnt < 10;) { vals[cnt++] = atoi(q); while (*q && *q != ',') ++q; if (*q) ++q; }
+            bool ok = cnt == nsegs && vals[0] == 0;
+            for (int k = 1; k < cnt; ++k) ok = ok && vals[k] > vals[k - 1];
+            if (ok) { for (int k = 0; k < 10; ++k) P.seg_start[k] = k < cnt ? vals[k] : vals[cnt - 1] + P.seg_len; }
+        }
         P.seg_order = 0;
         for (int k = 0; k < nsegs && k < 16; ++k) P.seg_order |= (unsigned long long)k << (4 * k);
         if (const char *v = getenv("GVOM_TRACE_ORDER")) {            // e.g. "450123": dispatch order of the segments
@@ -199,8 +222,6 @@ void fill_scan_params(const gvom_handle *h, const int64_t origin[3], const doubl
             for (; v[k] && k < 16; ++k) o |= (unsigned long long)((v[k] - '0') & 15) << (4 * k);
             if (k == nsegs) P.seg_order = o;
         }
-        P.seg_len = (maxsteps + nsegs - 1) / nsegs;
-        if (P.seg_len < 8) { P.seg_len = 8; }
     }
     P.epoch = 0;
     // slab rows as intervals of window y (storage row sy <-> window row (sy - om1) mod xy)

@@ -49,6 +49,7 @@ struct ScanParams {
     int    sy_lo, sy_hi;  // storage rows owned by this rank: [sy_lo, sy_hi)
     int    nseg;          // tiles per (sy, sz) row
     int    nsegs, seg_len; // DDA steps are split into nsegs segments of seg_len steps (last: open-ended)
+    int    seg_start[10];  // VAR 5/6: segment s covers steps (seg_start[s], seg_start[s+1]]; uniform = s * seg_len
     unsigned long long seg_order; // nibble k = the segment handled by the workgroups with blockIdx.y == k
     int    sxq;           // accumulator layout: 4x4 (x,y) patches per row of patches = ceil(xy/4)
     uint32_t epoch;       // this scan's tile epoch

@@ -323,13 +323,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             const double g2 = floor((double)(pz + incz) - P.origin[2]);
             if (!(g0 >= 0.0 && g0 < dxy && g1 >= 0.0 && g1 < dxy && g2 >= 0.0 && g2 < dzs)) reach = false;
         }
-        for (int j = seg * P.seg_len; j > 0; --j) {      // replay earlier segments (see SEGMENTS)
+        const int seg_first = P.seg_start[seg], seg_steps = P.seg_start[seg + 1] - seg_first;   // this wave's steps: (seg_first, seg_first + seg_steps]
+        for (int j = seg_first; j > 0; --j) {            // replay earlier segments (see SEGMENTS)
             px += incx; py += incy; pz += incz;
             length += step_len;
         }
         // steps this wave may still take: every active lane has taken the same number, so the
         // counter is wave-uniform (scalar)
-        int left = (seg == P.nsegs - 1) ? INT_MAX : P.seg_len;
+        int left = (seg == P.nsegs - 1) ? INT_MAX : seg_steps;
         // non-finite increments (degenerate returns): the reference's first step lands on NaN/inf,
         // which is outside the grid, and the ray ends without an update
         const bool finite = fabsf(incx) < INFINITY && fabsf(incy) < INFINITY && fabsf(incz) < INFINITY;
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         const uint32_t Ox = (uint32_t)(int)P.origin[0], Oy = (uint32_t)(int)P.origin[1], Oz = (uint32_t)(int)P.origin[2];
         if (CULL && P.cull) {
             const float ynow = py - (float)P.origin[1];
-            const float yseg = (seg == P.nsegs - 1) ? (e1 - (float)P.origin[1]) : ynow + incy * (float)(P.seg_len + 1);
+            const float yseg = (seg == P.nsegs - 1) ? (e1 - (float)P.origin[1]) : ynow + incy * (float)(seg_steps + 1);
             const int a0 = (int)floorf(fminf(ynow, yseg)) - 2, a1 = (int)floorf(fmaxf(ynow, yseg)) + 2;
             const bool h0 = a1 >= P.wlo[0] && a0 < P.whi[0];
             const bool h1 = a1 >= P.wlo[1] && a0 < P.whi[1];
