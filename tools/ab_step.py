@@ -30,11 +30,12 @@ for _ in range(30):
     g.process_pointcloud_device(d.value, pc.shape[0], pc.dtype, ego, tf); g.combine_maps()
 g.set_profiling(True)
 acc = [[] for _ in settings]
+stage = os.environ.get("AB_STAGE", "trace")
 for k in range(steps):
     i = k % len(settings)
     apply(settings[i])
     g.process_pointcloud_device(d.value, pc.shape[0], pc.dtype, ego, tf); g.combine_maps()
-    acc[i].append(g.last_stage_ms()["trace"] * 1e3)
+    acc[i].append(g.last_stage_ms()[stage] * 1e3)
 for a, v in zip(args, acc):
     v = np.array(v)
-    print("%-50s trace us: median %.2f mean %.2f p10 %.2f p90 %.2f (n=%d)" % (a, np.median(v), v.mean(), np.percentile(v, 10), np.percentile(v, 90), len(v)))
+    print("%-50s %s us: median %.2f mean %.2f p10 %.2f p90 %.2f (n=%d)" % (a, stage, np.median(v), v.mean(), np.percentile(v, 10), np.percentile(v, 90), len(v)))
