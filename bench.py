@@ -169,7 +169,8 @@ def run_single(args):
     # exact integer accounting for the roofline (algorithmic bytes)
     stats = g.scan_stats()
     # HIP-event timing of the kernels happens INSIDE the timed region, on the library's own
-    # stream, on every `sample`-th step (event records add ~4 us of gap per kernel boundary)
+    # stream, on every `sample`-th step (a sampled step is ~80 us longer: event records between the
+    # kernels and a stream sync to read them)
     acc = dict.fromkeys(gvom.STAGE_NAMES, 0.0)
     sample, n_sampled = max(1, args.sample), 0
     t0 = time.perf_counter()
@@ -260,7 +261,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--config", default="m256", choices=["c2", "c3", "m256", "m256b8"])
     ap.add_argument("--poses", type=int, default=1, help="distinct sensor poses cycled through")
-    ap.add_argument("--sample", type=int, default=8, help="HIP-event-time the kernels on every n-th timed step")
+    ap.add_argument("--sample", type=int, default=50,
+                    help="HIP-event-time the kernels on every n-th timed step (a sampled step costs ~80 us more: "
+                         "event records + a stream sync; every 8th step inflated the step average by 10 us)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()

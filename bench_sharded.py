@@ -47,7 +47,7 @@ def run(args):
         step()
     stats = sh.b.g.scan_stats()             # exact accumulator sums of THIS rank's slab (roofline accounting)
     acc = dict.fromkeys(gvom.STAGE_NAMES, 0.0)
-    sample, n_sampled = max(1, getattr(args, "sample", 8)), 0
+    sample, n_sampled = max(1, getattr(args, "sample", 50)), 0
     torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
