@@ -1333,8 +1333,16 @@ __device__ __forceinline__ void st_sys(V *p, V v)
 // Fortran-ordered, indexed [x, y]); a lane's 32 neighbours in x form 128/256-byte runs without a
 // transpose, and each map is stored as soon as it is known (all global loads come first: vmcnt is
 // in-order, a load behind a host-memory store would wait for the store to drain over PCIe).
+//
+// TWO WAVE ROLES (512 threads = the tile's 256 cells twice).  The kernel is a latency chain (tile
+// staging, then three dependent global round trips for the positive-obstacle density) followed by
+// 1.31 MB of stores into host memory (23 us of PCIe at 57 GB/s): when every wave walks the whole
+// chain, all stores are issued in the kernel's last microseconds and the link idles until then.
+// Waves 0-3 therefore compute ONLY slope / roughness -- LDS data, no global load -- and store the
+// f64 roughness map (40 % of the bytes) while waves 4-7 are still waiting for their density loads;
+// those then store visibility / positive / negative.  The slope-obstacle flag crosses through LDS.
 template <bool GATHERED_POS, bool YX>
-__global__ __launch_bounds__(256) void k_map2d(const Map2dParams P, const int32_t *__restrict__ fstate,
+__global__ __launch_bounds__(512) void k_map2d(const Map2dParams P, const int32_t *__restrict__ fstate,
                                                const uint32_t *__restrict__ ftags,
                                                const uint32_t *__restrict__ fhit,
                                                const uint32_t *__restrict__ ftotal,
@@ -1354,34 +1362,37 @@ __global__ __launch_bounds__(256) void k_map2d(const Map2dParams P, const int32_
     __shared__ int o_pos[YX ? 1 : M2_TX][M2_TY + 1], o_neg[YX ? 1 : M2_TX][M2_TY + 1], o_vis[YX ? 1 : M2_TX][M2_TY + 1];
     __shared__ double o_rgh[YX ? 1 : M2_TX][M2_TY + 1];
 
+    __shared__ unsigned char s_steep[256];                   // slope >= threshold (role A -> role B)
     const int xy = P.xy;
     const int tid = threadIdx.x;
-    const int tx = tid & (M2_TX - 1), ty = tid / M2_TX;
+    const int cell = tid & 255;                              // the tile's cell this thread works on
+    const bool role_b = tid >= 256;                          // waves 4-7: density, guess height, i32 maps
+    const int tx = cell & (M2_TX - 1), ty = cell / M2_TX;
     const int lane = tid & 63, wv = tid >> 6;
     const int X0 = blockIdx.x * M2_TX, Y0 = blockIdx.y * M2_TY;
     if (host_counter && blockIdx.x == 0 && blockIdx.y == 0 && !(P.dbg & 16)) {
         // k_fuse is complete: publish the fused occupied-voxel count (host-mapped memory)
-        __shared__ unsigned long long s_red[256];
-        publish_block_counts(blockcounts, nblocks, host_counter, s_red, tid, 256);
+        __shared__ unsigned long long s_red[512];
+        publish_block_counts(blockcounts, nblocks, host_counter, s_red, tid, 512);
     }
 
     // ---- stage the tile (+halo) and its row masks ------------------------------------------
     {   // all of a wave's rows are fetched before the first use: independent, unconditional loads
         // (out-of-window cells read a valid dummy address and are replaced by -1000)
-        constexpr int NR = (M2_H + 3) / 4;
+        constexpr int NR = (M2_H + 7) / 8;
         double v[NR];
         bool inw[NR];
         const int gx = X0 - M2_HALO + lane;
         const int sxh = wrap_add((gx >= 0 && gx < xy) ? gx : 0, P.om[0], xy);
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
-            const int r = wv + 4 * k, gy = Y0 - M2_HALO + r;
+            const int r = wv + 8 * k, gy = Y0 - M2_HALO + r;
             inw[k] = r < M2_H && lane < M2_W && gy >= 0 && gy < xy && gx >= 0 && gx < xy;
             v[k] = height[inw[k] ? (size_t)wrap_add(gy, P.om[1], xy) * P.hs + sxh : (size_t)0];
         }
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
-            const int r = wv + 4 * k;
+            const int r = wv + 8 * k;
             const double vv = inw[k] ? v[k] : -1000.0;
             const unsigned long long m = __ballot(vv > -1000);
             if (r < M2_H) {
@@ -1405,63 +1416,24 @@ __global__ __launch_bounds__(256) void k_map2d(const Map2dParams P, const int32_
     const int lx = tx + M2_HALO, ly = ty + M2_HALO;
     const size_t c_out = (size_t)y0 * xy + x0;                         // YX: [y][x] (column-major [x, y])
     const bool wr = !(P.dbg & 1);
-    if (mine) {
-    const double h00 = ht[ly][lx];
-    // ---- global loads first.  Stores into host-mapped memory are acknowledged slowly and vmcnt is
-    // in-order: any load issued after them would stall the wave until they have drained over PCIe,
-    // so everything this cell reads from memory is fetched before its first returned map is stored.
-    const double inf00 = inferred[(size_t)sy0 * P.hs + sx0];
-    int dens_pos = 0;                                        // positive-obstacle density x100 (gvom.py:489-521)
-    if (GATHERED_POS) {
-        // sharded runs: the slab owner computed the density (k_posdens), all-gathered with the heights
-        dens_pos = (int)height[(size_t)sy0 * P.hs + 2 * (size_t)xy + sx0];
-    } else {
-        const double fmin = floor(((h00 + P.pos_thr) / P.z_res) - P.origin_z) + 1.0;
-        const double fmax = floor(((h00 + P.robot_height) / P.z_res) - P.origin_z);
-        if (fmin >= 0 && fmin < (double)P.zs && fmax >= 0 && fmax < (double)P.zs && !(P.dbg & 2)) {
-            const int zmin = (int)fmin, zmax = (int)fmax;
-            double density = 0.0, nn = 0.0;
-            // 8 levels per round: tags, then states, then counts -- three dependent round trips
-            // per round instead of three per level (unconditional loads, dummy index when dead)
-            for (int zb = zmin; zb <= zmax; zb += 8) {
-                uint32_t rz[8], tg[8], hc[8], tc[8];
-                int32_t row[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int z = (zb + k <= zmax) ? zb + k : zmin;
-                    rz[k] = (uint32_t)sy0 * P.zs + (uint32_t)wrap_add(z, P.om[2], P.zs);
-                    tg[k] = ftags[rz[k] * P.nseg + (sx0 >> 6)];
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const bool live = zb + k <= zmax && tg[k] == P.epoch;       // live tile
-                    row[k] = fstate[live ? rz[k] * xy + sx0 : 0u];
-                    if (!live) row[k] = -1;
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const uint32_t r = row[k] >= 0 ? (uint32_t)row[k] : 0u;
-                    hc[k] = fhit[r]; tc[k] = ftotal[r];
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if (row[k] >= 0 && (int32_t)hc[k] > 10) { nn += (double)(int32_t)tc[k]; density += (double)(int32_t)hc[k]; }
-            }
-            if (nn > 0.0) density /= nn;
-            dens_pos = (int)(density * 100);
-        }
-    }
-    const int visv = h00 > -1000 ? 1 : 0;                    // gvom.py:414-422
-    // OCC: instead of the four maps, the five int8 nav_msgs/OccupancyGrid.data arrays the ROS node
-    // derives from them (gvom_ros.py:141-165), planes [hard | soft | certainty | negative | roughness]
+    double h00 = -1000.0, inf00 = 0.0, rv = -1.0;
+    int dens_pos = 0, pos = 0, negv = 0, visv = 0;           // dens_pos: positive-obstacle density x100 (gvom.py:489-521)
     int8_t *const occ = reinterpret_cast<int8_t *>(out_pos);
     const size_t n2 = (size_t)xy * xy;
+    const size_t c_yx = (size_t)sy0 * xy + sx0;
+    if (mine) h00 = ht[ly][lx];
+    if (!role_b) {
+    if (mine) {
+    // visibility needs only the staged height: it leaves with the first stores (gvom.py:414-422)
+    // OCC: instead of the four maps, the five int8 nav_msgs/OccupancyGrid.data arrays the ROS node
+    // derives from them (gvom_ros.py:141-165), planes [hard | soft | certainty | negative | roughness]
+    visv = h00 > -1000 ? 1 : 0;
     if (YX && wr) { if (P.occ) st_sys(&occ[2 * n2 + c_out], (int8_t)(visv * 100)); else st_sys(&out_vis[c_out], visv); }
-
-    // ---- slope / roughness: 3x3 least-squares plane (gvom.py:665-734) ---------------------
+    if (!YX) o_vis[tx][ty] = visv;
+    // ---- role A: slope / roughness: 3x3 least-squares plane (gvom.py:665-734) ---------------------
     // cells outside the window hold -1000 in the tile, i.e. are skipped exactly like the
     // reference's clipped ranges; iteration order is x outer / y inner as in the reference.
-    double sxv = 0.0, syv = 0.0, rv = -1.0;
+    double sxv = 0.0, syv = 0.0;
     {
         int n_good = 0;
 #pragma unroll
@@ -1525,7 +1497,6 @@ __global__ __launch_bounds__(256) void k_map2d(const Map2dParams P, const int32_
             }
         }
     }
-    const size_t c_yx = (size_t)sy0 * xy + sx0;
     slope_x[c_yx] = sxv; slope_y[c_yx] = syv; rough[c_yx] = rv;
     if (YX && wr) {
         if (P.occ) {
@@ -1536,7 +1507,60 @@ __global__ __launch_bounds__(256) void k_map2d(const Map2dParams P, const int32_
             st_sys(&occ[4 * n2 + c_out], (int8_t)(uint8_t)(uint32_t)ri);
         } else st_sys(&out_rough[c_out], rv);
     }
-    const int pos = (sqrt(sxv * sxv + syv * syv) >= P.slope_thr) ? 100 : dens_pos;   // gvom.py:489-521
+    s_steep[cell] = (sqrt(sxv * sxv + syv * syv) >= P.slope_thr) ? 1 : 0;   // gvom.py:489-521, used by role B
+    if (!YX) o_rgh[tx][ty] = rv;
+    }   // mine
+    } else {
+    if (mine) {
+    // ---- role B, before the barrier: every global load of the cell.  Stores into host-mapped memory
+    // are acknowledged slowly and vmcnt is in-order: a load issued after one would stall the wave
+    // until the store has drained over PCIe, so this role stores nothing before its loads are back.
+    inf00 = inferred[(size_t)sy0 * P.hs + sx0];
+    if (GATHERED_POS) {
+        // sharded runs: the slab owner computed the density (k_posdens), all-gathered with the heights
+        dens_pos = (int)height[(size_t)sy0 * P.hs + 2 * (size_t)xy + sx0];
+    } else {
+        const double fmin = floor(((h00 + P.pos_thr) / P.z_res) - P.origin_z) + 1.0;
+        const double fmax = floor(((h00 + P.robot_height) / P.z_res) - P.origin_z);
+        if (fmin >= 0 && fmin < (double)P.zs && fmax >= 0 && fmax < (double)P.zs && !(P.dbg & 2)) {
+            const int zmin = (int)fmin, zmax = (int)fmax;
+            double density = 0.0, nn = 0.0;
+            // 8 levels per round: tags, then states, then counts -- three dependent round trips
+            // per round instead of three per level (unconditional loads, dummy index when dead)
+            for (int zb = zmin; zb <= zmax; zb += 8) {
+                uint32_t rz[8], tg[8], hc[8], tc[8];
+                int32_t row[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int z = (zb + k <= zmax) ? zb + k : zmin;
+                    rz[k] = (uint32_t)sy0 * P.zs + (uint32_t)wrap_add(z, P.om[2], P.zs);
+                    tg[k] = ftags[rz[k] * P.nseg + (sx0 >> 6)];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const bool live = zb + k <= zmax && tg[k] == P.epoch;       // live tile
+                    row[k] = fstate[live ? rz[k] * xy + sx0 : 0u];
+                    if (!live) row[k] = -1;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t r = row[k] >= 0 ? (uint32_t)row[k] : 0u;
+                    hc[k] = fhit[r]; tc[k] = ftotal[r];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (row[k] >= 0 && (int32_t)hc[k] > 10) { nn += (double)(int32_t)tc[k]; density += (double)(int32_t)hc[k]; }
+            }
+            if (nn > 0.0) density /= nn;
+            dens_pos = (int)(density * 100);
+        }
+    }
+    }   // mine
+    }
+    __syncthreads();
+    if (role_b && mine) {
+    visv = h00 > -1000 ? 1 : 0;                    // gvom.py:414-422 (stored by role A)
+    pos = s_steep[cell] ? 100 : dens_pos;                    // gvom.py:489-521 (slope test done by role A)
     if (YX && wr) {
         if (P.occ) st_sys(&occ[1 * n2 + c_out], (int8_t)(((double)pos <= P.occ_density_thr && pos > 0) ? 100 : 0));   // soft, :146
         else st_sys(&out_pos[c_out], pos);
@@ -1594,7 +1618,7 @@ __global__ __launch_bounds__(256) void k_map2d(const Map2dParams P, const int32_
         if (dh > 0) dh_out = dh;
     }
     guessed[c_yx] = dh_out;
-    const int negv = dh_out > P.neg_thr ? 100 : 0;           // gvom.py:479-485
+    negv = dh_out > P.neg_thr ? 100 : 0;           // gvom.py:479-485
     if (YX && wr) {
         if (P.occ) {
             st_sys(&occ[3 * n2 + c_out], (int8_t)negv);                                                    // negative, :157
@@ -1602,13 +1626,13 @@ __global__ __launch_bounds__(256) void k_map2d(const Map2dParams P, const int32_
         } else st_sys(&out_neg[c_out], negv);
     }
 
-    if (!YX) { o_pos[tx][ty] = pos; o_neg[tx][ty] = negv; o_vis[tx][ty] = visv; o_rgh[tx][ty] = rv; }
-    }   // mine
+    if (!YX) { o_pos[tx][ty] = pos; o_neg[tx][ty] = negv; }
+    }   // role B, mine
     if (!YX) {
         __syncthreads();
         const int ox = tid >> 5, oy = tid & 31;              // 32 consecutive lanes -> 32 consecutive y
         const int gx = X0 + ox, gy = Y0 + oy;
-        if (gx < xy && gy < xy && !(P.dbg & 1)) {
+        if (tid < 256 && gx < xy && gy < xy && !(P.dbg & 1)) {
             const size_t c_xy = (size_t)gx * xy + gy;
             out_pos[c_xy] = o_pos[ox][oy]; out_neg[c_xy] = o_neg[ox][oy];
             out_vis[c_xy] = o_vis[ox][oy]; out_rough[c_xy] = o_rgh[ox][oy];
@@ -2137,7 +2161,7 @@ hipError_t gvom_launch_map2d(hipStream_t s, const Map2dParams &P, const int32_t 
     const int tx = P.out_yx ? 32 : 8, ty = P.out_yx ? 8 : 32;
     const dim3 grid((P.xy + tx - 1) / tx, (P.xy + ty - 1) / ty);
 #define MAP2D_LAUNCH(G, Y)                                                                              \
-    hipLaunchKernelGGL((k_map2d<G, Y>), grid, dim3(256), 0, s, P, fstate, ftags, fhit, ftotal, height, \
+    hipLaunchKernelGGL((k_map2d<G, Y>), grid, dim3(512), 0, s, P, fstate, ftags, fhit, ftotal, height, \
                        inferred, slope_x, slope_y, rough, guessed, out_pos, out_neg, out_rough, out_vis, \
                        blockcounts, nblocks, host_counter)
     if (P.gathered_pos) { if (P.out_yx) MAP2D_LAUNCH(true, true); else MAP2D_LAUNCH(true, false); }

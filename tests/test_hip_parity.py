@@ -361,6 +361,36 @@ def test_combine_maps_occupancy_matches_node_postprocessing(gvom_mod, occ_params
                 assert np.array_equal(g, w)
 
 
+def test_c_entry_combine_maps_fills_caller_buffers_row_major(gvom_mod):
+    """include/gvom_hip.h gvom_combine_maps(): the plain C entry a non-Python host binds (caller-owned
+    buffers, maps in row-major [x][y] order -- k_map2d's transposing variant) returns the same maps as
+    Gvom.combine_maps() (pinned zero-copy buffers, column-major variant), which the tests above hold
+    to the golden vectors and the oracle; a grid whose size is no multiple of the 32 x 8 tile as well."""
+    import ctypes
+    for params, n_pts in (((0.2, 0.2, 128, 32, 2, 1.0, 0.5, 0.5, 0.3, 2.0, 4.0, 1.0, 1, 1), 40000),
+                          ((0.4, 0.2, 50, 13, 2, 0.8, 0.5, 0.5, 0.3, 2.0, 2.0, 1.0, 1, 1), 6000)):
+        xy = params[2]
+        a, b = gvom_mod.Gvom(*params), gvom_mod.Gvom(*params)
+        L = b._lib
+        for st in _random_steps(5, 3, n_pts, xy * params[0] * 0.55, params[3] * params[1] * 0.5, np.float32, True):
+            if st[0] == "scan":
+                a.process_pointcloud(*st[1:]); b.process_pointcloud(*st[1:])
+                continue
+            want = a.combine_maps()
+            origin = np.full(3, np.nan)
+            pos = np.full((xy, xy), -7, np.int32); neg = np.full((xy, xy), -7, np.int32)
+            vis = np.full((xy, xy), -7, np.int32); rough = np.full((xy, xy), np.nan)
+            rc = L.gvom_combine_maps(b._h, origin.ctypes.data_as(ctypes.c_void_p), pos.ctypes.data_as(ctypes.c_void_p),
+                                     neg.ctypes.data_as(ctypes.c_void_p), rough.ctypes.data_as(ctypes.c_void_p),
+                                     vis.ctypes.data_as(ctypes.c_void_p))
+            assert rc == gvom_mod.GVOM_OK
+            assert np.array_equal(origin, want[0])
+            for name, g, w in (("positive", pos, want[1]), ("negative", neg, want[2]), ("visibility", vis, want[4])):
+                assert np.array_equal(g, w), "%s differs in %d cells" % (name, int(np.sum(g != w)))
+            assert np.array_equal(rough, want[3]), "roughness differs"
+        assert a.combined_cell_count_cpu == b.combined_cell_count_cpu
+
+
 def _pointcloud2_bytes(xyz32, point_step, offsets, seed):
     """Packed PointCloud2 data: x, y, z float32 at `offsets`, the other bytes random (intensity, ring,
     timestamps ...), a few records with NaN / inf coordinates as real drivers emit."""
