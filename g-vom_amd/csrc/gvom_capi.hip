@@ -652,8 +652,11 @@ int posdens_impl(gvom_handle *h)
     P.z_res = p.z_resolution;
     P.pos_thr = p.positive_obstacle_threshold; P.robot_height = p.robot_height;
     P.nseg = h->nseg; P.hs = h->hs; P.epoch = F.epoch;
+    // its first workgroup also publishes the fused cell count (k_fuse has completed by then)
     HIPCHK(h, gvom_launch_posdens(h->stream, P, F.state, F.tags, (const uint32_t *)F.hit.p,
-                                  (const uint32_t *)F.total.p, h->hmaps));
+                                  (const uint32_t *)F.total.p, h->hmaps, h->blockcounts, h->fuse_blocks,
+                                  (unsigned long long *)(h->counters_host_dev + 2),
+                                  (unsigned long long *)(h->counters + 10)));
     return GVOM_OK;
 }
 
@@ -894,9 +897,9 @@ VIS int gvom_combine_fuse(gvom_t *h, int64_t *local_cells)
     if (!h) return GVOM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->device));
-    int rc = fuse_impl(h, true);
+    int rc = fuse_impl(h, false);
     if (rc) return rc;
-    if ((rc = posdens_impl(h))) return rc;                // third row of the height buffer
+    if ((rc = posdens_impl(h))) return rc;                // third row of the height buffer + the cell count
     if (!h->blocking) {                                   // count stays on the device (GVOM_BUF_FUSED_CELLS)
         if (local_cells) *local_cells = -1;
         return GVOM_OK;

@@ -154,7 +154,8 @@ hipError_t gvom_launch_read_dense(hipStream_t s, int xy, int zs, const int om[3]
 hipError_t gvom_launch_unwrap_f64(hipStream_t s, int xy, int om0, int om1, const double *in, int in_stride, double *out_xy);
 hipError_t gvom_launch_posdens(hipStream_t s, const Map2dParams &P, const int32_t *fstate,
                                const uint32_t *ftags, const uint32_t *fhit, const uint32_t *ftotal,
-                               double *hmaps);
+                               double *hmaps, const uint32_t *blockcounts, int nblocks,
+                               unsigned long long *host_counter, unsigned long long *dev_counter);
 hipError_t gvom_launch_debug_height(hipStream_t s, int xy, int om0, int om1, const double origin[3], double xy_res,
                                     double z_res, const double *height, int hs, const double *rough,
                                     const double *sx, const double *sy, float *out7,

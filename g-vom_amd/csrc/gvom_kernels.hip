@@ -2004,9 +2004,19 @@ __global__ void k_unwrap(int xy, int om0, int om1, const E *__restrict__ in, int
 __global__ __launch_bounds__(256) void k_posdens(const Map2dParams P, const int32_t *__restrict__ fstate,
                                                  const uint32_t *__restrict__ ftags,
                                                  const uint32_t *__restrict__ fhit,
-                                                 const uint32_t *__restrict__ ftotal, double *hmaps)
+                                                 const uint32_t *__restrict__ ftotal, double *hmaps,
+                                                 const uint32_t *blockcounts, int nblocks,
+                                                 unsigned long long *host_counter, unsigned long long *dev_counter)
 {
     const int xy = P.xy;
+    if (host_counter && blockIdx.x == 0 && blockIdx.y == 0) {
+        // k_fuse is complete: publish this rank's fused occupied-voxel count (host-mapped memory and
+        // the device word the sharded layer all-reduces on demand)
+        __shared__ unsigned long long s_red[256];
+        const int tid = threadIdx.y * 64 + threadIdx.x;
+        publish_block_counts(blockcounts, nblocks, host_counter, s_red, tid, 256);
+        if (tid == 0) *dev_counter = s_red[0];
+    }
     const int sx0 = blockIdx.x * 64 + threadIdx.x, sy0 = P.y_lo + blockIdx.y * 4 + threadIdx.y;
     if (sx0 >= xy || sy0 >= P.y_hi) return;
     const double h00 = hmaps[(size_t)sy0 * P.hs + sx0];
@@ -2016,15 +2026,32 @@ __global__ __launch_bounds__(256) void k_posdens(const Map2dParams P, const int3
     if (fmin >= 0 && fmin < (double)P.zs && fmax >= 0 && fmax < (double)P.zs) {
         const int zmin = (int)fmin, zmax = (int)fmax;
         double density = 0.0, nn = 0.0;
-        for (int z = zmin; z <= zmax; ++z) {
-            const int sz = wrap_add(z, P.om[2], P.zs);
-            const uint32_t rz = (uint32_t)sy0 * P.zs + sz;
-            int32_t row = -1;
-            if (ftags[rz * P.nseg + (sx0 >> 6)] == P.epoch) row = fstate[rz * xy + sx0];
-            if (row >= 0) {
-                const uint32_t hc = fhit[row];
-                if ((int32_t)hc > 10) { nn += (double)(int32_t)ftotal[row]; density += (double)(int32_t)hc; }
+        // 8 levels per round: tags, then states, then counts -- three dependent round trips per round
+        // instead of three per level (unconditional loads, dummy index when dead); same sums in the
+        // same (ascending z) order as k_map2d's unsharded path
+        for (int zb = zmin; zb <= zmax; zb += 8) {
+            uint32_t rz[8], tg[8], hc[8], tc[8];
+            int32_t row[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int z = (zb + k <= zmax) ? zb + k : zmin;
+                rz[k] = (uint32_t)sy0 * P.zs + (uint32_t)wrap_add(z, P.om[2], P.zs);
+                tg[k] = ftags[rz[k] * P.nseg + (sx0 >> 6)];
             }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const bool live = zb + k <= zmax && tg[k] == P.epoch;       // live tile
+                row[k] = fstate[live ? rz[k] * xy + sx0 : 0u];
+                if (!live) row[k] = -1;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t r = row[k] >= 0 ? (uint32_t)row[k] : 0u;
+                hc[k] = fhit[r]; tc[k] = ftotal[r];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (row[k] >= 0 && (int32_t)hc[k] > 10) { nn += (double)(int32_t)tc[k]; density += (double)(int32_t)hc[k]; }
         }
         if (nn > 0.0) density /= nn;
         pos = (int)(density * 100);
@@ -2190,11 +2217,15 @@ hipError_t gvom_launch_unwrap_f64(hipStream_t s, int xy, int om0, int om1, const
 
 hipError_t gvom_launch_posdens(hipStream_t s, const Map2dParams &P, const int32_t *fstate,
                                const uint32_t *ftags, const uint32_t *fhit, const uint32_t *ftotal,
-                               double *hmaps)
+                               double *hmaps, const uint32_t *blockcounts, int nblocks,
+                               unsigned long long *host_counter, unsigned long long *dev_counter)
 {
-    if (P.y_hi <= P.y_lo) return hipSuccess;
+    if (P.y_hi <= P.y_lo) {                               // a rank without rows still publishes its (zero) count
+        hipLaunchKernelGGL(k_publish_count, dim3(1), dim3(256), 0, s, blockcounts, nblocks, host_counter, dev_counter);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_posdens, dim3((P.xy + 63) / 64, (P.y_hi - P.y_lo + 3) / 4), dim3(64, 4), 0, s, P,
-                       fstate, ftags, fhit, ftotal, hmaps);
+                       fstate, ftags, fhit, ftotal, hmaps, blockcounts, nblocks, host_counter, dev_counter);
     return hipGetLastError();
 }
 

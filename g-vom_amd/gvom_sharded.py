@@ -123,6 +123,7 @@ class ShardedGvom(object):
         self._cells_dirty = False
         self._cell_count = None
         self._staged = self.dist.get_backend(self.group) == "gloo"
+        self._gather_buf, self._gather_key = None, None
 
     # -- collectives ------------------------------------------------------------------------
     def _all_gather_cloud(self, local):
@@ -130,10 +131,15 @@ class ShardedGvom(object):
         dev = local.device
         if local.is_cuda and self._staged:
             local = local.cpu()          # gloo has no GPU all_gather: stage through the host (tests only)
-        out = torch.empty((self.world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype,
-                          device=local.device)
-        self.dist.all_gather_into_tensor(out, local.contiguous(), group=self.group)
-        return out.to(dev)
+        key = (local.shape, local.dtype, local.device)
+        out = self._gather_buf if self._gather_key == key else None
+        if out is None:                  # reused from scan to scan (the trace of the previous scan has
+            out = torch.empty((self.world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype,
+                              device=local.device)       # finished: the caller saw its return code)
+            self._gather_buf, self._gather_key = out, key
+        self.dist.all_gather_into_tensor(out, local if local.is_contiguous() else local.contiguous(),
+                                         group=self.group)
+        return out if out.device == dev else out.to(dev)
 
     def _all_gather_rows_inplace(self, full):
         """full: [xy, width] tensor whose rows [rank*rows, (rank+1)*rows) are valid on this rank."""
