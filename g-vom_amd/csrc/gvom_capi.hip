@@ -118,6 +118,7 @@ struct gvom_handle {
     long host_calls = 0;
     bool host_timing = false;
     bool stats = false;                                 // per-voxel statistics enabled (gvom_params.reserved0 bit 0)
+    int trace_reverse = 0;                              // k_trace walks the cloud backwards (learnt from the previous scan)
     int acc_pad = 7, sxq = 0;                           // accumulator row pitch (lines) = ceil(xy/4) + acc_pad
     int trace_variant = 6;                              // GVOM_TRACE_VARIANT (k_trace strategy)
     bool profiling = false;
@@ -346,6 +347,9 @@ int scan_launch(gvom_handle *h, const void *dev_pts, int64_t n, int64_t stride_e
     origin[2] = (int64_t)floor((h->ego[2] / p.z_resolution) - p.z_size / 2.0);
     ScanParams P;
     fill_scan_params(h, origin, tf, P);
+    P.nblk = (int)((n + 255) / 256);
+    P.blk_reverse = h->trace_reverse;
+    if (const char *v = getenv("GVOM_TRACE_REVERSE")) P.blk_reverse = atoi(v) != 0;
     if (!getenv("GVOM_TRACE_ORDER")) {
         // Dispatch order of k_trace's segments.  About 2048 workgroups are resident at a time, i.e. the
         // first R = 2048 / (workgroups per segment) segments start together and the rest follow as
@@ -421,6 +425,8 @@ int scan_launch(gvom_handle *h, const void *dev_pts, int64_t n, int64_t stride_e
     {
         const unsigned long long fl = *(volatile unsigned long long *)h->counters_host;
         st.count = (int64_t)(fl & 0x7fffffffull);          // occupied voxels of THIS rank's slab
+        const unsigned long long vote = *((volatile unsigned long long *)h->counters_host + 2);   // stored before `fl`
+        if ((uint32_t)(vote >> 32) == seq && (vote & 3ull) < 2ull) h->trace_reverse = (int)(vote & 1ull);   // else: keep
         h->pending_any = (fl & 0x80000000ull) != 0;        // some return landed in the grid on ANY rank
     }
     st.origin[0] = origin[0]; st.origin[1] = origin[1]; st.origin[2] = origin[2];

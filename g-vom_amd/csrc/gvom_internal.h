@@ -35,7 +35,8 @@
 // cache lines: same-line atomics are serialised by the memory system.
 #define GVOM_CNT_ROWS 0        // compact rows claimed by the scan in flight
 #define GVOM_CNT_INGRID 64     // in-grid returns of the scan in flight (any rank's rows)
-#define GVOM_CNT_WORDS 128
+#define GVOM_CNT_VOTE 128     // order vote (k_encode): long rays of the first / second (+16) cloud half, two pairs (+32) by scan parity
+#define GVOM_CNT_WORDS 192
 
 struct ScanParams {
     double xy_res, z_res;
@@ -50,6 +51,7 @@ struct ScanParams {
     int    nseg;          // tiles per (sy, sz) row
     int    nsegs, seg_len; // DDA steps are split into nsegs segments of seg_len steps (last: open-ended)
     int    seg_start[10];  // VAR 5/6: segment s covers steps (seg_start[s], seg_start[s+1]]; uniform = s * seg_len
+    int    blk_reverse, nblk; // workgroup b of a segment handles returns [256 * (blk_reverse ? nblk-1-b : b), +256)
     unsigned long long seg_order; // nibble k = the segment handled by the workgroups with blockIdx.y == k
     int    sxq;           // accumulator layout: 4x4 (x,y) patches per row of patches = ceil(xy/4)
     uint32_t epoch;       // this scan's tile epoch

@@ -124,7 +124,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                                                double *stat_sums, double *stat_base, uint32_t *stat_rowvox)
 {
     const int lane = threadIdx.x & (WAVE - 1);
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    // ADAPTIVE CLOUD ORDER.  The workgroups of a segment are dispatched in blockIdx.x order; when the
+    // heavy ones (long rays) come first the kernel's tail is shorter (measured: -2.5 us when a
+    // beam-major scan that stores its short, downward beams first is walked backwards).  Which end of
+    // the cloud is heavy is learnt from earlier scans: k_encode's min-height blocks count the long rays
+    // per cloud half, the next launch's first thread compares the halves and the host passes the
+    // decision on (two scans later).  The mapping is a bijection, so results do not depend on it.
+    const unsigned blk = P.blk_reverse ? (unsigned)P.nblk - 1u - blockIdx.x : blockIdx.x;
+    const long i = (long)blk * 256 + threadIdx.x;
     // step segment of this wave: workgroups are dispatched in blockIdx.y order, P.seg_order maps that
     // order to segments (4 bits each)
     const int seg = (VAR == 1 || VAR == 2 || (VAR >= 4 && VAR <= 6)) ? (int)((P.seg_order >> (4 * blockIdx.y)) & 15u) : 0;
@@ -605,6 +612,15 @@ __global__ __launch_bounds__(256) void k_encode(const ScanParams P, unsigned enc
         const uint32_t c = counters[GVOM_CNT_ROWS];
         const uint32_t any = counters[GVOM_CNT_INGRID] ? 0x80000000u : 0u;     // some return landed in the grid (any rank)
         counters[GVOM_CNT_ROWS] = 0; counters[GVOM_CNT_INGRID] = 0;
+        // order vote for k_trace (see there): long rays per cloud half -> 64-bit word 2 of the host block (1: second half is
+        // heavier, walk the cloud backwards; 0: forwards; 2: no clear difference, keep the order)
+        // (counted by the min-height blocks of the PREVIOUS scan's launch -- this launch's are adding to
+        // the other pair of counters right now)
+        const uint32_t vb = GVOM_CNT_VOTE + ((seq & 1u) ? 0u : 32u);
+        const uint32_t v0 = counters[vb], v1 = counters[vb + 16];
+        counters[vb] = 0; counters[vb + 16] = 0;
+        const unsigned long long verdict = (unsigned long long)v1 * 8 > (unsigned long long)v0 * 9 ? 1ull : ((unsigned long long)v0 * 8 > (unsigned long long)v1 * 9 ? 0ull : 2ull);
+        __hip_atomic_store(host_flag + 2, ((unsigned long long)seq << 32) | verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         counters[8] = c; counters[9] = 0;               // device-side copy (int64) for sharded runs
         __hip_atomic_store(host_flag, ((unsigned long long)seq << 32) | any | c, __ATOMIC_RELEASE,
                            __HIP_MEMORY_SCOPE_SYSTEM);
@@ -618,13 +634,18 @@ __global__ __launch_bounds__(256) void k_encode(const ScanParams P, unsigned enc
         const long i = (long)blockIdx.x * 256 + threadIdx.x;
         int32_t row = -1;
         uint32_t vbits = 0xFFFFFFFFu;
+        bool longray = false;
         if (i < n) {
             const T x = world[3 * i + 0], y = world[3 * i + 1], z = world[3 * i + 2];
             const T d2 = (x * x + y * y) + z * z;
-            const double fx = floor((double)x / P.xy_res - P.origin[0]);
-            const double fy = floor((double)y / P.xy_res - P.origin[1]);
-            const double az = (double)z / P.z_res - P.origin[2];
+            const double qx = (double)x / P.xy_res, qy = (double)y / P.xy_res, qz = (double)z / P.z_res;
+            const double fx = floor(qx - P.origin[0]);
+            const double fy = floor(qy - P.origin[1]);
+            const double az = qz - P.origin[2];
             const double fz = floor(az);
+            // a ray of about as many dominant-axis steps as k_trace's last segment starts at is "long"
+            const float reach = fmaxf(fmaxf(fabsf((float)qx - P.pt0[0]), fabsf((float)qy - P.pt0[1])), fabsf((float)qz - P.pt0[2]));
+            longray = reach > (float)P.seg_start[P.nsegs - 1];
             if (!((double)d2 < P.min_d2) && fx >= 0.0 && fx < (double)P.xy && fy >= 0.0 && fy < (double)P.xy &&
                 fz >= 0.0 && fz < (double)P.zs) {
                 const int sy = wrap_add((int)fy, P.om[1], P.xy);
@@ -648,6 +669,13 @@ __global__ __launch_bounds__(256) void k_encode(const ScanParams P, unsigned enc
         }
         const uint32_t knext = (uint32_t)__shfl_down((int)key, 1);
         if (row >= 0 && (lane == WAVE - 1 || knext != key)) atomicMin(&cminh[row], vbits);
+        // order vote for the scan after the next one (k_trace "ADAPTIVE CLOUD ORDER"): long rays per
+        // cloud half; counters alternate with the scan's parity so the publishing thread above reads a
+        // finished pair
+        // (every 8th block votes: same-address atomics are served one at a time, 2048 of them cost 10 us)
+        const unsigned long long lm = (blockIdx.x & 7u) == 0u ? __ballot(longray) : 0ull;
+        if (lane == 0 && lm)
+            atomicAdd(&counters[GVOM_CNT_VOTE + ((seq & 1u) ? 32u : 0u) + (2 * i >= n ? 16u : 0u)], (uint32_t)__popcll(lm));
         return;
     }
     // ---- encode blocks: one wave per QUAD = 4 storage rows (sy = 4q .. 4q+3) x 64 sx at one sz,
