@@ -173,6 +173,8 @@ def run_single(args):
     # kernels and a stream sync to read them)
     acc = dict.fromkeys(gvom.STAGE_NAMES, 0.0)
     sample, n_sampled = max(1, args.sample), 0
+    import gc
+    gc.collect(); gc.disable()            # no cyclic-GC pauses inside the timed region (buffers recycle by refcount)
     t0 = time.perf_counter()
     for k in range(args.steps):
         prof = (k % sample) == 0
@@ -186,6 +188,7 @@ def run_single(args):
             for s in acc:
                 acc[s] += ms[s]
     elapsed = time.perf_counter() - t0
+    gc.enable()
     stage_ms = {s: acc[s] / n_sampled for s in acc}
     # PCIe-inclusive rate (never `value`): the same steps with the cloud handed over as a HOST
     # buffer, the reference's own calling convention (gvom.py:110 cuda.to_device)

@@ -48,6 +48,8 @@ def run(args):
     stats = sh.b.g.scan_stats()             # exact accumulator sums of THIS rank's slab (roofline accounting)
     acc = dict.fromkeys(gvom.STAGE_NAMES, 0.0)
     sample, n_sampled = max(1, getattr(args, "sample", 50)), 0
+    import gc
+    gc.collect(); gc.disable()            # no cyclic-GC pauses inside the timed region
     torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -63,6 +65,7 @@ def run(args):
                 acc[s] += ms[s]
     torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
