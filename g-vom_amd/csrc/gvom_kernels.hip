@@ -51,15 +51,13 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
-// ---- wave-private accumulator-line cache (k_trace VAR 4) ---------------------------------------
+// ---- wave-private accumulator-line cache (k_trace VAR 6) ---------------------------------------
 // One 64-entry open-addressed table per wave in LDS: key = accumulator line (64 B = 4x4 (x,y)
 // patch at one z), 16 counters per entry.  DDA steps add into the table with LDS atomics; when
 // the table fills up (or the wave is done) the wave flushes it cooperatively, 4 lines per
 // instruction with 16 lanes per line, so one line costs ONE memory-side atomic request however
 // many steps of however many lanes fell into it since the last flush.
 #define LC_EMPTY 0xFFFFFFFFu
-#define LC_FLUSH_AT 40
-#define LC_PERIOD 8          // VAR 6: flush every LC_PERIOD committing steps
 #define LC_LD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT)
 #define LC_ST(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT)
 // slot s keeps its key at keys[LC_KEYPOS(s)]: the flush handles entry 4*it + g in iteration it of
@@ -112,8 +110,9 @@ __device__ __forceinline__ void lc_flush(uint32_t *keys, uint32_t *cnt, uint32_t
 //   1  lock-step loop; lanes of a wave that step into the SAME voxel as their left neighbour
 //      are merged (ballot + run length) so one lane adds the whole run: near the sensor all 64
 //      rays of a wave share a voxel and 64 same-address atomics collapse into one
-//   4  as 1, but the merged adds go into a wave-private LDS line cache that is flushed with one
-//      request per 64-B line (lc_flush): steps of a ray bundle that revisit a line are merged too
+//   5  as 1 with the short step body of the production loop (integer voxel lookup, DPP neighbour key)
+//   6  production: 5 + a wave-private LDS line cache flushed with one request per 64-B line (lc_flush):
+//      steps of a ray bundle that revisit a line are merged too
 //   9  diagnostic only: no DDA atomics at all (measures the arithmetic floor; results wrong)
 // CULL = false: the handle owns every row (no slab tests / ray culling compiled into the step body)
 template <typename T, int VAR, bool CULL = true>
@@ -134,7 +133,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const long i = (long)blk * 256 + threadIdx.x;
     // step segment of this wave: workgroups are dispatched in blockIdx.y order, P.seg_order maps that
     // order to segments (4 bits each)
-    const int seg = (VAR == 1 || VAR == 2 || (VAR >= 4 && VAR <= 6)) ? (int)((P.seg_order >> (4 * blockIdx.y)) & 15u) : 0;
+    const int seg = (VAR == 1 || VAR == 2 || VAR == 5 || VAR == 6) ? (int)((P.seg_order >> (4 * blockIdx.y)) & 15u) : 0;
     if ((VAR == 0 || VAR == 9) && blockIdx.y != 0) return;
     const bool first = seg == 0;                                       // segment 0 also does the endpoint
     const bool live = i < n;
@@ -236,7 +235,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     // all (conservative +-2 rows, so the committed updates are unchanged); waves without any
     // reaching ray leave before the DDA setup.
     bool reach = pass;
-    if (P.cull && (VAR == 1 || VAR == 2 || (VAR >= 4 && VAR <= 6))) {
+    if (P.cull && (VAR == 1 || VAR == 2 || VAR == 5 || VAR == 6)) {
         const float yend_f = e1 - (float)P.origin[1];
         const float ybeg_f = P.pt0[1] - (float)P.origin[1];
         const int y0i = (int)floorf(fminf(ybeg_f, yend_f)) - 2, y1i = (int)floorf(fmaxf(ybeg_f, yend_f)) + 2;
@@ -483,16 +482,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         else if (sy_dir < 0.0f) ystop_lo = lo - 2;
     }
     uint32_t n_heads = 0, n_lines = 0, n_instr = 0;      // VAR 2 only
-    __shared__ __attribute__((aligned(16))) uint32_t s_lc_keys[VAR == 4 ? 4 * 64 : 4];
-    __shared__ uint32_t s_lc_cnt[VAR == 4 ? 4 * 1024 : 1];
-    uint32_t *lck = s_lc_keys + (VAR == 4 ? (threadIdx.x >> 6) * 64 : 0);
-    uint32_t *lcc = s_lc_cnt + (VAR == 4 ? (threadIdx.x >> 6) * 1024 : 0);
-    uint32_t lc_fill = 0, memo_line = LC_EMPTY; int memo_slot = 0;
-    if (VAR == 4) {
-        LC_ST(&lck[lane], LC_EMPTY);
-#pragma unroll
-        for (int c = 0; c < 16; ++c) LC_ST(&lcc[c * 64 + lane], 0u);
-    }
     while (__any(active)) {
         bool commit = false;
         uint32_t Ls = 0, Ts = 0;
@@ -526,40 +515,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         const bool head = commit && (lane == 0 || left != key);
         const unsigned long long cmask = __ballot(commit);
         const unsigned long long nh = cmask & ~__ballot(head);               // followers
-        bool lc_new = false;
         if (head) {
             const unsigned long long after = (nh >> lane) >> 1;
             const uint32_t run = (uint32_t)__ffsll((long long)~after);       // 1 + followers
-            if (VAR == 4) {
-                // memo: the (line, row-in-line) this lane added to last; a miss looks the line up
-                // (or inserts it) and stamps the voxel's tile tag
-                const uint32_t line = Ls >> 4, lrow = Ls >> 2;
-                int slot = -1;
-                if (lrow == memo_line) slot = memo_slot;
-                else {
-                    uint32_t hh = (line * 2654435761u) >> 26;
-                    for (int pr = 0; pr < 8; ++pr) {
-                        const uint32_t was = atomicCAS(&lck[LC_KEYPOS(hh)], LC_EMPTY, line);
-                        if (was == LC_EMPTY) { lc_new = true; slot = (int)hh; break; }
-                        if (was == line) { slot = (int)hh; break; }
-                        hh = (hh + 1u) & 63u;
-                    }
-                    tags[Ts] = P.epoch;
-                    if (slot >= 0) { memo_line = lrow; memo_slot = slot; }
-                }
-                if (slot >= 0) atomicAdd(&lcc[slot * 16 + (int)(Ls & 15u)], run);
-                else atomicAdd(&total[Ls], run);                                // table congested: direct add
-            } else {
-                atomicAdd(&total[Ls], run);
-                tags[Ts] = P.epoch;                                          // stamp the tile (idempotent store)
-            }
-        }
-        if (VAR == 4) {
-            lc_fill += (uint32_t)__popcll(__ballot(lc_new));
-            if (lc_fill >= LC_FLUSH_AT) {                                    // wave-uniform
-                lc_flush(lck, lcc, total, lane);
-                lc_fill = 0; memo_line = LC_EMPTY;
-            }
+            atomicAdd(&total[Ls], run);
+            tags[Ts] = P.epoch;                                              // stamp the tile (idempotent store)
         }
         if (VAR == 2) {                                   // diagnostic: heads, distinct 64-B lines, instructions
             const unsigned long long hm = __ballot(head);
@@ -573,7 +533,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             n_heads += (uint32_t)__popcll(hm); n_lines += (uint32_t)__popcll(nlm); n_instr += hm ? 1u : 0u;
         }
     }
-    if (VAR == 4 && lc_fill != 0u) lc_flush(lck, lcc, total, lane);
     if (VAR == 2 && lane == 0) { atomicAdd(&counters[4], n_heads); atomicAdd(&counters[5], n_lines); atomicAdd(&counters[6], n_instr); }
 }
 
@@ -2142,14 +2101,12 @@ hipError_t gvom_launch_trace(hipStream_t s, const ScanParams &P, int dtype, cons
         if (variant == 0) TRACE_LAUNCH(float, 0);
         else if (variant == 9) TRACE_LAUNCH(float, 9);
         else if (variant == 2) TRACE_LAUNCH(float, 2);
-        else if (variant == 4) TRACE_LAUNCH(float, 4);
         else if (variant == 5) TRACE_LAUNCH(float, 5);
         else if (variant == 6) { if (P.cull) TRACE_LAUNCH(float, 6); else TRACE_LAUNCH_NC(float, 6); }
         else TRACE_LAUNCH(float, 1);
     } else {
         if (variant == 0) TRACE_LAUNCH(double, 0);
         else if (variant == 9) TRACE_LAUNCH(double, 9);
-        else if (variant == 4) TRACE_LAUNCH(double, 4);
         else if (variant == 5) TRACE_LAUNCH(double, 5);
         else if (variant == 6) { if (P.cull) TRACE_LAUNCH(double, 6); else TRACE_LAUNCH_NC(double, 6); }
         else TRACE_LAUNCH(double, 1);
