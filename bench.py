@@ -166,8 +166,6 @@ def run_single(args):
 
     for k in range(args.warmup):
         step(k)
-    # exact integer accounting for the roofline (algorithmic bytes)
-    stats = g.scan_stats()
     # HIP-event timing of the kernels happens INSIDE the timed region, on the library's own
     # stream, on every `sample`-th step (a sampled step is ~80 us longer: event records between the
     # kernels and a stream sync to read them)
@@ -208,6 +206,10 @@ def run_single(args):
         g.process_pointcloud_device(d.value, n, dt, ego, tf)
         g.combine_maps_occupancy()
     occ_elapsed = time.perf_counter() - t2
+    # exact integer accounting for the roofline (algorithmic bytes).  AFTER the timed regions:
+    # the dense read-back allocates and frees 16*V bytes, and that free shows up as one 7-15 ms step
+    # shortly afterwards (tools/step_hist.py), i.e. +4-8 us on the average of 1000 steps
+    stats = g.scan_stats()
 
     V = params[2] * params[2] * params[3]
     P = 12 if scans[0][0].dtype == np.float32 else 24

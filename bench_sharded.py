@@ -45,7 +45,6 @@ def run(args):
 
     for _ in range(args.warmup):
         step()
-    stats = sh.b.g.scan_stats()             # exact accumulator sums of THIS rank's slab (roofline accounting)
     acc = dict.fromkeys(gvom.STAGE_NAMES, 0.0)
     sample, n_sampled = max(1, getattr(args, "sample", 50)), 0
     import gc
@@ -66,6 +65,8 @@ def run(args):
     torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     gc.enable()
+    stats = sh.b.g.scan_stats()             # exact accumulator sums of THIS rank's slab (roofline accounting;
+                                            # after the timed region: its 16*V-byte temporary costs a hiccup)
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
