@@ -62,8 +62,8 @@ class Hip(object):
 def pin_to_gpu_numa(device):
     """Benchmark hygiene (what `numactl --cpunodebind` does): run this process on the CPUs of the
     NUMA node the GPU hangs off, so kernel launches (doorbell writes) and completion flags (GPU
-    writes to host memory the host spins on) do not cross the socket interconnect.  On the 2-socket
-    test hosts an unpinned process lands on either socket and a step costs 150 or 165 us.
+    writes to host memory the host spins on) do not cross the socket interconnect (2-socket test
+    hosts: 130.0-131.2 us/step pinned, 130.9-131.5 unpinned).
     Best effort: returns the CPU list used, or None (GVOM_BENCH_NO_PIN=1 disables it)."""
     if os.environ.get("GVOM_BENCH_NO_PIN") or not hasattr(os, "sched_setaffinity"):
         return None
