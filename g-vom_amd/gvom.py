@@ -411,19 +411,21 @@ class Gvom(object):
             self._check(self._lib.gvom_output_buffer_alloc(self._h, ctypes.byref(p)))
             ptr = p.value
         holder = _PinnedOutput(self._out_pool, ptr, n2 * 20)
-        rc = self._check(entry_point(self._h, _ptr(origin), ctypes.c_void_p(ptr)))
-        if rc != GVOM_OK:
-            return rc, None
+        # The views are built BEFORE the (blocking) call: k_encode is still running on the GPU when
+        # combine_maps is entered, so this host work is hidden; after the call only the return is left.
         raw = np.asarray(holder)
         # the library writes the maps in [y][x] memory order: seen through .T they are the reference's
         # [x, y]-indexed arrays in Fortran order (what gvom_ros.py's reshape(..., order='F') reads
         # without a copy), and the GPU writes them as contiguous runs without a transpose
-        # (one constructor call per map: this runs after the GPU has finished, on the step's critical path)
         positive = np.ndarray((xy, xy), np.int32, raw, 0, (4, 4 * xy))
         negative = np.ndarray((xy, xy), np.int32, raw, 4 * n2, (4, 4 * xy))
         visibility = np.ndarray((xy, xy), np.int32, raw, 8 * n2, (4, 4 * xy))
         roughness = np.ndarray((xy, xy), np.float64, raw, 12 * n2, (8, 8 * xy))
-        return GVOM_OK, (origin, positive, negative, roughness, visibility)
+        out = (origin, positive, negative, roughness, visibility)
+        rc = self._check(entry_point(self._h, _ptr(origin), ctypes.c_void_p(ptr)))
+        if rc != GVOM_OK:
+            return rc, None
+        return GVOM_OK, out
 
     # ---- accessors / debug API (reference gvom.py:356-410) ------------------------------
     def get_map_as_occupancy_grid(self):
