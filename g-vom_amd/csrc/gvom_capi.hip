@@ -174,6 +174,7 @@ void fill_scan_params(const gvom_handle *h, const int64_t origin[3], const doubl
     P.pt0[0] = (float)(h->ego[0] / p.xy_resolution);
     P.pt0[1] = (float)(h->ego[1] / p.xy_resolution);
     P.pt0[2] = (float)(h->ego[2] / p.z_resolution);
+    P.rinv[0] = (float)(1.0 / p.xy_resolution); P.rinv[1] = (float)(1.0 / p.z_resolution);
     P.xy = p.xy_size; P.zs = p.z_size;
     P.om[0] = (int)floor_mod(origin[0], p.xy_size);
     P.om[1] = (int)floor_mod(origin[1], p.xy_size);

@@ -44,6 +44,7 @@ struct ScanParams {
     double origin[3];     // window origin in voxels, integer valued (gvom.py:123-126)
     double tf[12];        // rows 0..2 of the 4x4 (gvom.py:1044-1052)
     float  pt0[3];        // (float)(ego / res)  (gvom.py:1097-1099)
+    float  rinv[2];       // (float)(1 / xy_res), (float)(1 / z_res): k_trace's conservative early-exit estimate only
     int    has_tf;
     int    xy, zs;
     int    om[3];         // origin mod size (storage offset)

@@ -159,6 +159,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const bool pass = live && !((double)d2 < P.min_d2);
     const double dxy = (double)P.xy, dzs = (double)P.zs;
 
+    // ---- later segments: leave before the f64 setup when no ray of the wave can still be running ----
+    // After J = seg_start[seg] replayed steps `length` is >= J * (1 - 2^-22) (every step adds |1 / sd|
+    // with |sd| <= 1 + 2^-23), and a ray stops once length >= ray_length - 1 (gvom.py:1127): a ray
+    // with ray_length <= J + 0.9 takes no step in this segment.  Decided conservatively in f32 from
+    // the raw return, with a margin far above the rounding of this estimate; NaN/inf compare false
+    // and take the full path.
+    if ((VAR == 5 || VAR == 6) && seg > 0) {
+        const float ax = (float)x * P.rinv[0], ay = (float)y * P.rinv[0], az = (float)z * P.rinv[1];
+        const float ux = ax - P.pt0[0], uy = ay - P.pt0[1], uz = az - P.pt0[2];
+        const float r = sqrtf((ux * ux + uy * uy) + uz * uz);
+        const float mag = ((fabsf(ax) + fabsf(ay)) + fabsf(az)) + ((fabsf(ux) + fabsf(uy)) + fabsf(uz));
+        const bool dead = !pass || (r + (r * 1e-5f + mag * 4e-6f) <= (float)P.seg_start[seg] + 0.9f);
+        if (__all(dead)) return;                                         // wave-uniform
+    }
+
     // ---- endpoint ------------------------------------------------------------------------
     bool ingrid = false, ingrid_any = false;
     uint32_t L = 0, A = 0;
