@@ -187,17 +187,17 @@ void fill_scan_params(const gvom_handle *h, const int64_t origin[3], const doubl
     // DDA segments: the ego sits at the window centre, so a ray takes at most size/2 + 2 steps
     {
         int nsegs = 6;
-        if (const char *v = getenv("GVOM_TRACE_SEGMENTS")) nsegs = atoi(v) > 0 ? atoi(v) : 6;
+        if (const char *v = gvom_tune_env("GVOM_TRACE_SEGMENTS")) nsegs = atoi(v) > 0 ? atoi(v) : 6;
         P.dbg = 0;
         P.lc_period = 12;
-        if (const char *v = getenv("GVOM_TRACE_PERIOD")) P.lc_period = atoi(v) > 0 ? atoi(v) : 12;
-        if (const char *v = getenv("GVOM_TRACE_DEBUG")) P.dbg = atoi(v);
+        if (const char *v = gvom_tune_env("GVOM_TRACE_PERIOD")) P.lc_period = atoi(v) > 0 ? atoi(v) : 12;
+        if (const char *v = gvom_tune_env("GVOM_TRACE_DEBUG")) P.dbg = atoi(v);
         const int maxsteps = (p.xy_size > p.z_size ? p.xy_size : p.z_size) / 2 + 2;
         P.nsegs = nsegs;
         P.seg_len = (maxsteps + nsegs - 1) / nsegs;
         if (P.seg_len < 8) { P.seg_len = 8; }
         for (int k = 0; k < 10; ++k) P.seg_start[k] = (k < nsegs ? k : nsegs) * P.seg_len;
-        if (nsegs >= 3 && nsegs <= 9 && P.seg_len >= 12 && !getenv("GVOM_TRACE_UNIFORM")) {
+        if (nsegs >= 3 && nsegs <= 9 && P.seg_len >= 12 && !gvom_tune_env("GVOM_TRACE_UNIFORM")) {
             // The workgroups of the last segments are dispatched last and form the kernel's tail, and
             // only the longest rays reach them: the last two segments are shortened (0.85 and 0.6 of
             // the others).  Measured on the 131 k-point scans: 48.9 -> 46.5 us against equal lengths
@@ -210,7 +210,7 @@ void fill_scan_params(const gvom_handle *h, const int64_t origin[3], const doubl
                 acc += k < nsegs - 2 ? unit : (k == nsegs - 2 ? 0.85 * unit : (k == nsegs - 1 ? 0.6 * unit : unit));
             }
         }
-        if (const char *v = getenv("GVOM_TRACE_STARTS")) {          // e.g. "0,20,42,66,90,112": first step - 1 of every segment
+        if (const char *v = gvom_tune_env("GVOM_TRACE_STARTS")) {          // e.g. "0,20,42,66,90,112": first step - 1 of every segment
             int vals[10], cnt = 0;
             for (const char *q = v; *q && cnt < 10;) { vals[cnt++] = atoi(q); while (*q && *q != ',') ++q; if (*q) ++q; }
             bool ok = cnt == nsegs && vals[0] == 0;
@@ -219,7 +219,7 @@ void fill_scan_params(const gvom_handle *h, const int64_t origin[3], const doubl
         }
         P.seg_order = 0;
         for (int k = 0; k < nsegs && k < 16; ++k) P.seg_order |= (unsigned long long)k << (4 * k);
-        if (const char *v = getenv("GVOM_TRACE_ORDER")) {            // e.g. "450123": dispatch order of the segments
+        if (const char *v = gvom_tune_env("GVOM_TRACE_ORDER")) {            // e.g. "450123": dispatch order of the segments
             unsigned long long o = 0; int k = 0;
             for (; v[k] && k < 16; ++k) o |= (unsigned long long)((v[k] - '0') & 15) << (4 * k);
             if (k == nsegs) P.seg_order = o;
@@ -350,8 +350,8 @@ int scan_launch(gvom_handle *h, const void *dev_pts, int64_t n, int64_t stride_e
     fill_scan_params(h, origin, tf, P);
     P.nblk = (int)((n + 255) / 256);
     P.blk_reverse = h->trace_reverse;
-    if (const char *v = getenv("GVOM_TRACE_REVERSE")) P.blk_reverse = atoi(v) != 0;
-    if (!getenv("GVOM_TRACE_ORDER")) {
+    if (const char *v = gvom_tune_env("GVOM_TRACE_REVERSE")) P.blk_reverse = atoi(v) != 0;
+    if (!gvom_tune_env("GVOM_TRACE_ORDER")) {
         // Dispatch order of k_trace's segments.  About 2048 workgroups are resident at a time, i.e. the
         // first R = 2048 / (workgroups per segment) segments start together and the rest follow as
         // slots free up.  Segment 0's workgroups also carry the endpoint atomics and the row claim
@@ -508,7 +508,7 @@ int choose_nz(int zs, int *zc, int *cpw)
     *zc = (zs + nchunks - 1) / nchunks;
     nchunks = (zs + *zc - 1) / *zc;
     int want_waves = 4;
-    if (const char *v = getenv("GVOM_FUSE_WAVES")) want_waves = atoi(v) > 0 ? atoi(v) : 4;
+    if (const char *v = gvom_tune_env("GVOM_FUSE_WAVES")) want_waves = atoi(v) > 0 ? atoi(v) : 4;
     *cpw = (nchunks + want_waves - 1) / want_waves;
     if (*cpw < 1) *cpw = 1;
     if (*cpw > 4) *cpw = 4;                               // a wave's tiles (16 per chunk) fit one 64-bit mask
@@ -560,7 +560,7 @@ int fuse_impl(gvom_handle *h, bool publish_now)
     (void)bound;
     P.sy_lo = h->sy_lo; P.sy_hi = h->sy_hi;
     P.nz = choose_nz(p.z_size, &P.zc, &P.cpw);
-    if (const char *v = getenv("GVOM_FUSE_DEBUG")) P.debug = atoi(v);
+    if (const char *v = gvom_tune_env("GVOM_FUSE_DEBUG")) P.debug = atoi(v);
     P.nseg = h->nseg;
     P.hs = h->hs;
     F.epoch = ++h->epoch;
@@ -615,7 +615,7 @@ int map2d_impl(gvom_handle *h, bool gathered, bool publish, char *out_dev, bool 
     const Fused &F = h->fused[h->cur];
     Map2dParams P;
     memset(&P, 0, sizeof P);
-    if (const char *v = getenv("GVOM_MAP2D_DEBUG")) P.dbg = atoi(v);
+    if (const char *v = gvom_tune_env("GVOM_MAP2D_DEBUG")) P.dbg = atoi(v);
     P.xy = p.xy_size; P.zs = p.z_size;
     P.om[0] = (int)floor_mod(F.origin[0], p.xy_size);
     P.om[1] = (int)floor_mod(F.origin[1], p.xy_size);

@@ -19,6 +19,26 @@
 
 #define GVOM_MAX_SLOTS 64
 
+// Tuning / diagnostic switches read on the hot path (every scan and combine).
+// A dozen getenv() misses per step cost ~1.5 us of host time in front of the k_trace launch, so they
+// are only looked up when the process environment held some GVOM_ switch the first time one was
+// asked for (tools/ab_step.py, which changes them while running, sets GVOM_ENV_DYNAMIC=1 first).
+#include <stdlib.h>
+#include <string.h>
+extern char **environ;
+static inline const char *gvom_tune_env(const char *name)
+{
+    static int mode = 0;                                   // 1: nothing to look up; 2: getenv every time
+    if (mode == 0) {
+        int m = 1;
+        for (char **e = environ; e && *e; ++e)
+            if (!strncmp(*e, "GVOM_", 5) && strncmp(*e, "GVOM_HIP_LIBRARY=", 17) && strncmp(*e, "GVOM_BENCH_", 11) &&
+                strncmp(*e, "GVOM_AMD_HOME=", 14)) { m = 2; break; }
+        mode = m;
+    }
+    return mode == 2 ? getenv(name) : nullptr;
+}
+
 // TILES: 64 consecutive sx of one (sy, sz) row = 256 bytes of every per-voxel array.  Tile index
 // T = (sy*zs + sz)*nseg + (sx >> 6), nseg = ceil(xy/64).  Every scan / fused map carries one
 // uint32 tag per tile; a tile holds valid data iff tag == the map's epoch, otherwise all its

@@ -2143,7 +2143,7 @@ hipError_t gvom_launch_encode(hipStream_t s, const ScanParams &P, int dtype, con
     const uint32_t ntiles = t_end - t_begin;
     unsigned enc_blocks = (ntiles + 7) / 8;
     unsigned enc_cap = 8192;                              // measured on 256^3: 4096 -> 20.0 us, 8192 (one pass per wave) -> 18.8 us
-    if (const char *v = getenv("GVOM_ENCODE_BLOCKS")) enc_cap = atoi(v) > 0 ? (unsigned)atoi(v) : 8192u;
+    if (const char *v = gvom_tune_env("GVOM_ENCODE_BLOCKS")) enc_cap = atoi(v) > 0 ? (unsigned)atoi(v) : 8192u;
     if (enc_blocks > enc_cap) enc_blocks = enc_cap;
     if (enc_blocks < 1) enc_blocks = 1;
     const unsigned mh_blocks = (unsigned)((n + 255) / 256);          // min-height part

@@ -4,6 +4,7 @@
 clock/box drift hits all settings alike.
 Usage: tools/ab_step.py [--config m256] [--steps 400] "GVOM_TRACE_DEBUG=0" "GVOM_TRACE_DEBUG=16384" ..."""
 import os, sys, ctypes
+os.environ.setdefault("GVOM_ENV_DYNAMIC", "1")     # the library re-reads its switches at every call only if some GVOM_ variable exists
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "g-vom_amd")); sys.path.insert(0, ROOT)
