@@ -516,7 +516,7 @@ int choose_nz(int zs, int *zc, int *cpw)
 }
 
 // fusion + column reductions (k_fuse) into fused[1 - cur]
-int fuse_impl(gvom_handle *h, bool publish_now)
+int fuse_impl(gvom_handle *h)
 {
     const gvom_params &p = h->prm;
     const Slot &last = h->slots[h->ring[h->last_buffer_index]];
@@ -594,10 +594,6 @@ int fuse_impl(gvom_handle *h, bool publish_now)
     if (h->profiling) { HIPCHK(h, hipEventRecord(h->ev[5], h->stream)); h->ev_fuse = true; }
     if (h->stats)
         HIPCHK(h, gvom_launch_fuse_stats(h->stream, P, KD, descs_mem, F.state, F.tags, (float *)F.metrics.p));
-    if (publish_now)
-        HIPCHK(h, gvom_launch_publish_count(h->stream, h->blockcounts, h->fuse_blocks,
-                                            (unsigned long long *)(h->counters_host_dev + 2),
-                                            (unsigned long long *)(h->counters + 10)));
     F.valid = true;
     h->cur = nxt;
     h->has_combined = true;
@@ -787,7 +783,7 @@ VIS int gvom_combine_maps(gvom_t *h, double origin_world[3], int32_t *positive, 
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->device));
     double t0 = now_ns();
-    int rc = fuse_impl(h, false);
+    int rc = fuse_impl(h);
     if (rc) return rc;
     if ((rc = map2d_impl(h, false, true, h->zero_copy ? h->out_host_dev : (char *)h->out_pos, false))) return rc;
     const size_t n2 = h->cells2d;
@@ -845,7 +841,7 @@ VIS int gvom_combine_maps_into(gvom_t *h, double origin_world[3], void *pinned_o
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->device));
     double t0 = now_ns();
-    int rc = fuse_impl(h, false);
+    int rc = fuse_impl(h);
     if (rc) return rc;
     char *dev = nullptr;
     HIPCHK(h, hipHostGetDevicePointer((void **)&dev, pinned_out, 0));
@@ -874,7 +870,7 @@ VIS int gvom_combine_occupancy_into(gvom_t *h, double origin_world[3], void *pin
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->device));
     double t0 = now_ns();
-    int rc = fuse_impl(h, false);
+    int rc = fuse_impl(h);
     if (rc) return rc;
     char *dev = nullptr;
     HIPCHK(h, hipHostGetDevicePointer((void **)&dev, pinned_out, 0));
@@ -904,7 +900,7 @@ VIS int gvom_combine_fuse(gvom_t *h, int64_t *local_cells)
     if (!h) return GVOM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->device));
-    int rc = fuse_impl(h, false);
+    int rc = fuse_impl(h);
     if (rc) return rc;
     if ((rc = posdens_impl(h))) return rc;                // third row of the height buffer + the cell count
     if (!h->blocking) {                                   // count stays on the device (GVOM_BUF_FUSED_CELLS)

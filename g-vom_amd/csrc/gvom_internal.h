@@ -147,8 +147,6 @@ hipError_t gvom_launch_encode(hipStream_t s, const ScanParams &P, int dtype, con
                               int64_t n, uint32_t *hit, uint32_t *total, int32_t *state,
                               uint32_t *chit, uint32_t *ctotal, uint32_t *cminh, const uint32_t *tags,
                               uint32_t *counters, unsigned long long *host_flag, uint32_t seq);
-hipError_t gvom_launch_publish_count(hipStream_t s, const uint32_t *blockcounts, int nblocks,
-                                     unsigned long long *host_counter, unsigned long long *dev_counter);
 hipError_t gvom_launch_fuse(hipStream_t s, const FuseParams &P, const FuseDescs &KD,
                             const MapDesc *descs_dev, int32_t *fstate, uint32_t *fhit, uint32_t *ftotal, uint32_t *fminh,
                             uint32_t *ftags, uint32_t *blockcounts, double *height, double *inferred);

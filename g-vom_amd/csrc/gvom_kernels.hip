@@ -2086,13 +2086,6 @@ __global__ void k_debug_height(int xy, int om0, int om1, double o0, double o1, d
     }
 }
 
-hipError_t gvom_launch_publish_count(hipStream_t s, const uint32_t *blockcounts, int nblocks,
-                                     unsigned long long *host_counter, unsigned long long *dev_counter)
-{
-    hipLaunchKernelGGL(k_publish_count, dim3(1), dim3(256), 0, s, blockcounts, nblocks, host_counter, dev_counter);
-    return hipGetLastError();
-}
-
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
