@@ -24,12 +24,17 @@ for world in worlds:
             continue
         g = gvom.Gvom(*params, device=0, _shard=(r, world))
         L = g._lib
-        for it in range(6):
-            g.set_profiling(it >= 2)
+        acc, cnt = {}, 0
+        for it in range(26):
+            g.set_profiling(it >= 6)
             g.process_pointcloud(full, (0.0, 0.0, 0.0))
             L.gvom_combine_fuse(g._h, None)
             L.gvom_sync(g._h)
-        ms = g.last_stage_ms()
+            if it >= 6:
+                for k, v in g.last_stage_ms().items():
+                    acc[k] = acc.get(k, 0.0) + v
+                cnt += 1
+        ms = {k: v / cnt for k, v in acc.items()}
         print("world %d rank %d: trace %.1f encode %.1f fuse %.1f us" % (world, r, ms["trace"] * 1e3, ms["encode"] * 1e3, ms["fuse"] * 1e3))
         for k in ("trace", "encode", "fuse"):
             worst[k] = max(worst.get(k, 0), ms[k] * 1e3)
