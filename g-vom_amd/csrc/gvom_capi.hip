@@ -207,11 +207,13 @@ void fill_scan_params(const gvom_handle *h, const int64_t origin[3], const doubl
             // the others).  Measured on the 131 k-point scans: 48.9 -> 46.5 us against equal lengths
             // (boundaries 0,24,48,72,96,116 of 130 steps; the optimum is flat within +-2 steps
             // except for the last boundary).
-            const double unit = (double)maxsteps / ((nsegs - 2) + 0.85 + 0.6);
+            // (3 segments, sharded handles: boundaries 0,60,110 measured 2-3 % faster than 0,53,98)
+            const double w_last = nsegs <= 3 ? 0.35 : 0.6;
+            const double unit = (double)maxsteps / ((nsegs - 2) + 0.85 + w_last);
             double acc = 0.0;
             for (int k = 0; k < 10; ++k) {
                 P.seg_start[k] = (int)(acc + 0.5);
-                acc += k < nsegs - 2 ? unit : (k == nsegs - 2 ? 0.85 * unit : (k == nsegs - 1 ? 0.6 * unit : unit));
+                acc += k < nsegs - 2 ? unit : (k == nsegs - 2 ? 0.85 * unit : (k == nsegs - 1 ? w_last * unit : unit));
             }
         }
         if (const char *v = gvom_tune_env("GVOM_TRACE_STARTS")) {          // e.g. "0,20,42,66,90,112": first step - 1 of every segment
