@@ -48,3 +48,16 @@ def test_sharded_kernels_fuzz_against_unsharded_handle():
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "checked 90 seeds, 0 failures" in out.stdout, out.stdout[-2000:]
+
+
+@pytest.mark.gpu
+def test_sharded_kernels_on_weak_scaling_clouds():
+    """tests/fuzz/shard_big.py: 4 and 8 sharded handles on one GPU fed the bench's weak-scaling clouds
+    (524 k / 1 M returns: the 3-segment trace path of sharded handles); every rank's rows of the slot
+    and of the fused map equal the unsharded handle's over three moving scans."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz", "shard_big.py"), "4,8"],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-2000:]
+    assert "shard_big: 0 mismatches" in out.stdout
