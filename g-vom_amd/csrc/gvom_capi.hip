@@ -187,10 +187,11 @@ void fill_scan_params(const gvom_handle *h, const int64_t origin[3], const doubl
     // DDA segments: the ego sits at the window centre, so a ray takes at most size/2 + 2 steps
     {
         int nsegs = 6;
-        // slab-sharded handles see the whole weak-scaling cloud (world x the returns of one scan) but trace
-        // only what crosses their rows: from 4 ranks on, 3 segments (half the waves and setups) measured
-        // faster on the critical, ego-adjacent ranks (4 ranks: 138 -> 132 us, 8 ranks: 227 -> 209 us)
-        if (h->sy_hi - h->sy_lo < h->prm.xy_size && n_points > 3 * 131072) nsegs = 3;
+        // segments exist to fill the chip with waves when a scan has few returns; above three 131 k-point
+        // scans' worth there are plenty, and 3 segments (half the waves and setups) measured faster: sharded
+        // handles, which see the whole weak-scaling cloud, 138 -> 132 us (4 ranks) and 227 -> 209 us (8 ranks)
+        // on the ego-adjacent ranks; unsharded 1 M / 4 M-return clouds (c4 / c5) 609 -> 591 / 2578 -> 2465 us
+        if (n_points > 3 * 131072) nsegs = 3;
         if (const char *v = gvom_tune_env("GVOM_TRACE_SEGMENTS")) nsegs = atoi(v) > 0 ? atoi(v) : nsegs;
         P.dbg = 0;
         P.lc_period = 12;
