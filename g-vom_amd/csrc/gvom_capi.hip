@@ -70,7 +70,11 @@ struct gvom_handle {
     std::mutex mu;
     std::string err;
 
-    uint32_t *hit = nullptr, *total = nullptr;          // dense accumulators, zero between scans
+    uint32_t *hit = nullptr, *total = nullptr, *mh = nullptr;   // dense accumulators (hit, ray passes, min-height), zero between scans
+    size_t acc_elems = 0;
+    int tune_segs = 0, tune_ep_row = -1, tune_period = 0; // gvom_set_tuning (0 / -1: automatic)
+    unsigned resident_blocks = 2048;                    // 256-thread workgroups resident on the device (queried)
+    bool f32_sqrt = false;                              // GVOM_FLAG_CUDA_F32_SQRT
     std::vector<Slot> slots;                            // buffer_size + 1 (one is staging)
     std::vector<int> ring;                              // ring position -> slots index
     int staging = 0;
@@ -100,12 +104,8 @@ struct gvom_handle {
     double *slope_x = nullptr, *slope_y = nullptr, *rough = nullptr, *guessed = nullptr;   // [sy][sx]
     hipStream_t own_stream = nullptr;                   // created by the library (stream may be attached)
     bool blocking = true;                               // split entry points synchronize before returning
-    int32_t *out_pos = nullptr, *out_neg = nullptr, *out_vis = nullptr;
-    double *out_rough = nullptr;
     void *out_host = nullptr;                           // pinned, device-mapped staging for the 4 outputs
     char *out_host_dev = nullptr;                       // device view of out_host (zero-copy target)
-    bool zero_copy = true;                              // GVOM_ZERO_COPY=0: device buffer + D2H copy
-    bool out_coherent = true;                           // GVOM_OUT_COHERENT=0: coarse-grained output buffers
     uint32_t scan_seq = 0;                              // sequence number of the {seq,count} flag
     bool ev_scan = false, ev_fuse = false, ev_map = false;   // which profiling events are recorded
     bool maps_valid = false;
@@ -118,9 +118,7 @@ struct gvom_handle {
     long host_calls = 0;
     bool host_timing = false;
     bool stats = false;                                 // per-voxel statistics enabled (gvom_params.reserved0 bit 0)
-    int trace_reverse = 0;                              // k_trace walks the cloud backwards (learnt from the previous scan)
     int acc_pad = 7, sxq = 0;                           // accumulator row pitch (lines) = ceil(xy/4) + acc_pad
-    int trace_variant = 6;                              // GVOM_TRACE_VARIANT (k_trace strategy)
     bool profiling = false;
     hipEvent_t ev[8] = {nullptr};
     float stage_ms[GVOM_N_STAGES] = {0, 0, 0, 0, 0};
@@ -184,66 +182,34 @@ void fill_scan_params(const gvom_handle *h, const int64_t origin[3], const doubl
     P.in_f32 = h->in_f32 ? 1 : 0;
     P.nseg = h->nseg;
     P.sxq = h->sxq;
-    // DDA segments: the ego sits at the window centre, so a ray takes at most size/2 + 2 steps
+    // DDA step segments: the ego sits at the window centre, so a ray takes at most size/2 + 2 steps.
+    // Segments exist to fill the chip with waves when a scan has few returns (a 131 k-point scan is 2
+    // waves per SIMD); every segment wave repeats the ray set-up and replays the earlier steps, so
+    // clouds with plenty of returns use fewer segments.  The last two segments are shortened: their
+    // workgroups are dispatched last and only the longest rays reach them.  (Measured, 256^3 / 131 k
+    // points: 5 segments 43.6 us, 6: 44.1, 7: 43.8, 4: 46.4; flush period 16: -0.4 us against 12.)
     {
-        int nsegs = 6;
-        // segments exist to fill the chip with waves when a scan has few returns; above three 131 k-point
-        // scans' worth there are plenty, and 3 segments (half the waves and setups) measured faster: sharded
-        // handles, which see the whole weak-scaling cloud, 138 -> 132 us (4 ranks) and 227 -> 209 us (8 ranks)
-        // on the ego-adjacent ranks; unsharded 1 M / 4 M-return clouds (c4 / c5) 609 -> 591 / 2578 -> 2465 us
-        if (n_points > 3 * 131072) nsegs = 3;
-        if (const char *v = gvom_tune_env("GVOM_TRACE_SEGMENTS")) nsegs = atoi(v) > 0 ? atoi(v) : nsegs;
-        P.dbg = 0;
-        P.lc_period = 12;
-        if (const char *v = gvom_tune_env("GVOM_TRACE_PERIOD")) P.lc_period = atoi(v) > 0 ? atoi(v) : 12;
-        if (const char *v = gvom_tune_env("GVOM_TRACE_DEBUG")) P.dbg = atoi(v);
         const int maxsteps = (p.xy_size > p.z_size ? p.xy_size : p.z_size) / 2 + 2;
+        int nsegs = n_points > 3 * 131072 ? 3 : 5;
+        if (h->tune_segs > 0) nsegs = h->tune_segs;
+        if (nsegs > 9) nsegs = 9;
+        if (nsegs > maxsteps / 8) nsegs = maxsteps / 8 > 0 ? maxsteps / 8 : 1;
         P.nsegs = nsegs;
-        P.seg_len = (maxsteps + nsegs - 1) / nsegs;
-        if (P.seg_len < 8) { P.seg_len = 8; }
-        for (int k = 0; k < 10; ++k) P.seg_start[k] = (k < nsegs ? k : nsegs) * P.seg_len;
-        if (nsegs >= 3 && nsegs <= 9 && P.seg_len >= 12 && !gvom_tune_env("GVOM_TRACE_UNIFORM")) {
-            // The workgroups of the last segments are dispatched last and form the kernel's tail, and
-            // only the longest rays reach them: the last two segments are shortened (0.85 and 0.6 of
-            // the others).  Measured on the 131 k-point scans: 48.9 -> 46.5 us against equal lengths
-            // (boundaries 0,24,48,72,96,116 of 130 steps; the optimum is flat within +-2 steps
-            // except for the last boundary).
-            // (3 segments, sharded handles: boundaries 0,60,110 measured 2-3 % faster than 0,53,98)
-            const double w_last = nsegs <= 3 ? 0.35 : 0.6;
-            const double unit = (double)maxsteps / ((nsegs - 2) + 0.85 + w_last);
-            double acc = 0.0;
-            for (int k = 0; k < 10; ++k) {
-                P.seg_start[k] = (int)(acc + 0.5);
-                acc += k < nsegs - 2 ? unit : (k == nsegs - 2 ? 0.85 * unit : (k == nsegs - 1 ? w_last * unit : unit));
-            }
-        }
-        if (const char *v = gvom_tune_env("GVOM_TRACE_STARTS")) {          // e.g. "0,20,42,66,90,112": first step - 1 of every segment
-            int vals[10], cnt = 0;
-            for (const char *q = v; *q && cnt < 10;) { vals[cnt++] = atoi(q); while (*q && *q != ',') ++q; if (*q) ++q; }
-            bool ok = cnt == nsegs && vals[0] == 0;
-            for (int k = 1; k < cnt; ++k) ok = ok && vals[k] > vals[k - 1];
-            if (ok) { for (int k = 0; k < 10; ++k) P.seg_start[k] = k < cnt ? vals[k] : vals[cnt - 1] + P.seg_len; }
-        }
-        P.seg_order = 0;
-        for (int k = 0; k < nsegs && k < 16; ++k) P.seg_order |= (unsigned long long)k << (4 * k);
-        if (const char *v = gvom_tune_env("GVOM_TRACE_ORDER")) {            // e.g. "450123": dispatch order of the segments
-            unsigned long long o = 0; int k = 0;
-            for (; v[k] && k < 16; ++k) o |= (unsigned long long)((v[k] - '0') & 15) << (4 * k);
-            if (k == nsegs) P.seg_order = o;
+        P.lc_period = h->tune_period > 0 ? h->tune_period : 16;
+        if (P.lc_period > 32) P.lc_period = 32;          // the line cache is direct-mapped with 64 entries
+        P.ep_row = h->tune_ep_row >= 0 ? h->tune_ep_row : 0;   // endpoint blocks first: their atomics retire under the walk
+        if (P.ep_row > P.nsegs) P.ep_row = P.nsegs;
+        P.f32_sqrt = h->f32_sqrt ? 1 : 0;
+        P.dbg = gvom_diag_env("GVOM_TRACE_DEBUG");
+        const double w_last = nsegs <= 3 ? 0.35 : 0.6;
+        const double unit = nsegs >= 3 ? (double)maxsteps / ((nsegs - 2) + 0.85 + w_last) : (double)maxsteps / nsegs;
+        double acc = 0.0;
+        for (int k = 0; k < 10; ++k) {
+            P.seg_start[k] = (int)(acc + 0.5);
+            acc += (nsegs < 3 || k < nsegs - 2) ? unit : (k == nsegs - 2 ? 0.85 * unit : (k == nsegs - 1 ? w_last * unit : unit));
         }
     }
     P.epoch = 0;
-    // slab rows as intervals of window y (storage row sy <-> window row (sy - om1) mod xy)
-    P.cull = 0;
-    P.wlo[0] = 0; P.whi[0] = p.xy_size; P.wlo[1] = 1 << 30; P.whi[1] = -(1 << 30);
-    const int len = h->sy_hi - h->sy_lo;
-    if (len < p.xy_size) {
-        P.cull = 1;
-        const int a = (int)floor_mod((int64_t)h->sy_lo - P.om[1], p.xy_size);
-        if (a + len <= p.xy_size) { P.wlo[0] = a; P.whi[0] = a + len; }
-        else { P.wlo[0] = a; P.whi[0] = p.xy_size; P.wlo[1] = 0; P.whi[1] = a + len - p.xy_size; }
-        if (len == 0) { P.wlo[0] = 1 << 30; P.whi[0] = -(1 << 30); }
-    }
 }
 
 int create_impl(const gvom_params *params, int device_id, int rank, int world, gvom_t **out)
@@ -264,9 +230,8 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, g
     h->prm = *params;
     h->device = device_id;
     h->rank = rank; h->world = world;
-    if (const char *v = getenv("GVOM_TRACE_VARIANT")) h->trace_variant = atoi(v);
-    if (const char *v = getenv("GVOM_ACC_PAD")) h->acc_pad = atoi(v) >= 0 ? atoi(v) : 0;
     h->stats = (params->reserved0 & GVOM_FLAG_VOXEL_STATISTICS) != 0;
+    h->f32_sqrt = (params->reserved0 & GVOM_FLAG_CUDA_F32_SQRT) != 0;
     if (const char *v = getenv("GVOM_VOXEL_STATISTICS")) h->stats = atoi(v) != 0;
     if (const char *v = getenv("GVOM_HOST_TIMING")) h->host_timing = atoi(v) != 0;
     const int xy = params->xy_size, zs = params->z_size;
@@ -295,10 +260,18 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, g
     // same memory channel
     h->sxq = (xy + 3) / 4 + h->acc_pad;
     const size_t acc_elems = (size_t)h->sxq * ((xy + 3) / 4) * zs * 16 + 256;
+    h->acc_elems = acc_elems;
     CK(hipMalloc((void **)&h->hit, acc_elems * 4));
     CK(hipMalloc((void **)&h->total, acc_elems * 4));
+    CK(hipMalloc((void **)&h->mh, acc_elems * 4));
     CK(hipMemsetAsync(h->hit, 0, acc_elems * 4, h->stream));
     CK(hipMemsetAsync(h->total, 0, acc_elems * 4, h->stream));
+    CK(hipMemsetAsync(h->mh, 0, acc_elems * 4, h->stream));
+    {   // 256-thread workgroups the device keeps resident (8 per CU at <= 64 VGPRs / <= 80 SGPRs)
+        hipDeviceProp_t pr;
+        CK(hipGetDeviceProperties(&pr, device_id));
+        h->resident_blocks = (unsigned)pr.multiProcessorCount * 8u;
+    }
     h->slots.resize(params->buffer_size + 1);
     for (auto &s : h->slots) {
         CK(hipMalloc((void **)&s.state, h->V * 4));
@@ -329,20 +302,32 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, g
     double **maps[4] = {&h->slope_x, &h->slope_y, &h->rough, &h->guessed};
     for (auto m : maps) CK(hipMalloc((void **)m, h->cells2d * 8));
 
-    CK(hipMalloc((void **)&h->out_pos, h->cells2d * 20));              // [pos | neg | vis | rough] packed:
-    h->out_neg = h->out_pos + h->cells2d;                              // one D2H copy per combine
-    h->out_vis = h->out_neg + h->cells2d;
-    h->out_rough = (double *)(h->out_vis + h->cells2d);
     CK(hipHostMalloc(&h->out_host, h->cells2d * 20, hipHostMallocMapped));
     CK(hipHostGetDevicePointer((void **)&h->out_host_dev, h->out_host, 0));
-    if (const char *v = getenv("GVOM_ZERO_COPY")) h->zero_copy = atoi(v) != 0;
-    if (const char *v = getenv("GVOM_OUT_COHERENT")) h->out_coherent = atoi(v) != 0;
     for (auto &e : h->ev) CK(hipEventCreate(&e));
     CK(hipStreamSynchronize(h->stream));
 #undef CK
     *out = h;
     return GVOM_OK;
 }
+
+// A failed scan must not leak into the next one: k_trace may already have added to the dense
+// accumulators and raised the in-grid flag.  Clears them (stream-ordered, best effort).
+void scan_abort(gvom_handle *h)
+{
+    (void)hipMemsetAsync(h->hit, 0, h->acc_elems * 4, h->stream);
+    (void)hipMemsetAsync(h->total, 0, h->acc_elems * 4, h->stream);
+    (void)hipMemsetAsync(h->mh, 0, h->acc_elems * 4, h->stream);
+    (void)hipMemsetAsync(h->counters, 0, GVOM_CNT_WORDS * 4, h->stream);
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipGetLastError();
+    h->pending = false;
+}
+
+// Tile epochs are 32-bit and only grow (two per step).  Before the counter can wrap, every live map
+// is re-tagged with a small epoch and every other tag is zeroed, so a stale tile can never collide
+// with a future epoch.  (2^32 epochs = ~3 days at 7.7 kHz.)
+int renumber_epochs(gvom_handle *h);
 
 // Scan kernels up to (not including) the commit.  `dev_pts` is device memory.
 int scan_launch(gvom_handle *h, const void *dev_pts, int64_t n, int64_t stride_elems, int dtype,
@@ -353,69 +338,51 @@ int scan_launch(gvom_handle *h, const void *dev_pts, int64_t n, int64_t stride_e
     origin[0] = (int64_t)floor((h->ego[0] / p.xy_resolution) - p.xy_size / 2.0);     // gvom.py:124
     origin[1] = (int64_t)floor((h->ego[1] / p.xy_resolution) - p.xy_size / 2.0);
     origin[2] = (int64_t)floor((h->ego[2] / p.z_resolution) - p.z_size / 2.0);
+    int rc;
+    if (h->epoch >= 0xFFFFFF00u && (rc = renumber_epochs(h))) return rc;
     ScanParams P;
     fill_scan_params(h, origin, tf, P, n);
-    P.nblk = (int)((n + 255) / 256);
-    P.blk_reverse = h->trace_reverse;
-    if (const char *v = gvom_tune_env("GVOM_TRACE_REVERSE")) P.blk_reverse = atoi(v) != 0;
-    if (!gvom_tune_env("GVOM_TRACE_ORDER")) {
-        // Dispatch order of k_trace's segments.  About 2048 workgroups are resident at a time, i.e. the
-        // first R = 2048 / (workgroups per segment) segments start together and the rest follow as
-        // slots free up.  Segment 0's workgroups also carry the endpoint atomics and the row claim
-        // (two barriers); dispatching them LAST within the first round measured 2.6-2.9 us faster on
-        // the 131 k-point scans (R = 4), slower when only two segments fit (262 k points), so the
-        // natural order is kept for R < 3.
-        const int64_t nblk = (n + 255) / 256;
-        const int R = nblk > 0 ? (int)std::min<int64_t>(2048 / nblk, P.nsegs) : 0;
-        if (R >= 3) {
-            unsigned long long o = 0;
-            for (int k = 0; k < P.nsegs; ++k) {
-                const int seg = k < R - 1 ? k + 1 : (k == R - 1 ? 0 : k);
-                o |= (unsigned long long)seg << (4 * k);
-            }
-            P.seg_order = o;
-        }
-    }
     Slot &st = h->slots[h->staging];
     st.epoch = ++h->epoch;                                 // tiles stamped by this scan
     P.epoch = st.epoch;
     const size_t esz = dtype == GVOM_DTYPE_F32 ? 4 : 8;
-    int rc;
-    if ((rc = ensure(h, h->world_pts, (size_t)n * 3 * esz))) return rc;
-    const size_t cap = (size_t)n < h->slabV ? (size_t)n : h->slabV;      // C <= min(N, slab voxels)
+    // compact rows are indexed by return (the row of an occupied voxel = the index of one of its returns)
+    const size_t cap = (size_t)n;
     if ((rc = ensure(h, st.chit, cap * 4))) return rc;
     if ((rc = ensure(h, st.ctotal, cap * 4))) return rc;
     if ((rc = ensure(h, st.cminh, cap * 4))) return rc;
-    if (h->stats && ((rc = ensure(h, st.metrics, cap * 80)) || (rc = ensure(h, st.base, cap * 80)) ||
-                     (rc = ensure(h, st.rowvox, cap * 4)))) return rc;
+    if (h->stats && ((rc = ensure(h, h->world_pts, (size_t)n * 3 * esz)) || (rc = ensure(h, st.metrics, cap * 80)) ||
+                     (rc = ensure(h, st.base, cap * 80)) || (rc = ensure(h, st.rowvox, cap * 4)))) return rc;
     double t0 = now_ns();
     const uint32_t seq = ++h->scan_seq;
     if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
-    // variants 5/6 look voxels up with 32-bit integer arithmetic: exact while |origin| < 2^30
-    // (2e8 m at 0.2 m voxels); beyond that the f64 lookup of variant 1 is used
-    int variant = h->trace_variant;
-    if (variant == 5 || variant == 6)
-        for (int k = 0; k < 3; ++k)
-            if (origin[k] >= (1ll << 30) || origin[k] <= -(1ll << 30)) variant = 1;
-    HIPCHK(h, gvom_launch_trace(h->stream, P, dtype, dev_pts, stride_elems, n, h->world_pts.p, h->hit,
-                                h->total, st.state, st.tags, (uint32_t *)st.cminh.p, h->counters,
-                                variant, h->stats ? (double *)st.metrics.p : nullptr,
-                                h->stats ? (double *)st.base.p : nullptr,
-                                h->stats ? (uint32_t *)st.rowvox.p : nullptr));
+    // voxels are looked up with 32-bit integer arithmetic: exact while |origin| < 2^30 (2e8 m at
+    // 0.2 m voxels); beyond that the kernels take the reference's literal f64 form
+    bool big = false;
+    for (int k = 0; k < 3; ++k)
+        if (origin[k] >= (1ll << 30) || origin[k] <= -(1ll << 30)) big = true;
+    if (h->stats) HIPCHK(h, hipMemsetAsync(st.rowvox.p, 0xFF, cap * 4, h->stream));   // no row claimed yet
+    hipError_t le = gvom_launch_trace(h->stream, P, dtype, big, dev_pts, stride_elems, n,
+                                      h->stats ? h->world_pts.p : nullptr, h->hit, h->total, h->mh, st.state,
+                                      st.tags, h->counters, h->stats ? (double *)st.metrics.p : nullptr,
+                                      h->stats ? (double *)st.base.p : nullptr,
+                                      h->stats ? (uint32_t *)st.rowvox.p : nullptr);
+    if (le != hipSuccess) { scan_abort(h); HIPCHK(h, le); }
     if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
-    HIPCHK(h, gvom_launch_encode(h->stream, P, dtype, h->world_pts.p, n, h->hit, h->total, st.state,
-                                 (uint32_t *)st.chit.p, (uint32_t *)st.ctotal.p, (uint32_t *)st.cminh.p,
-                                 st.tags, h->counters, (unsigned long long *)h->counters_host_dev, seq));
+    le = gvom_launch_encode(h->stream, P, h->hit, h->total, h->mh, st.state, (uint32_t *)st.chit.p,
+                            (uint32_t *)st.ctotal.p, (uint32_t *)st.cminh.p, st.tags, h->counters,
+                            (unsigned long long *)h->counters_host_dev, seq, h->resident_blocks);
+    if (le != hipSuccess) { scan_abort(h); HIPCHK(h, le); }
     if (h->profiling) { HIPCHK(h, hipEventRecord(h->ev[2], h->stream)); h->ev_scan = true; }
     if (h->stats) {                                      // optional per-voxel statistics
         HIPCHK(h, gvom_launch_stats(h->stream, P, dtype, h->world_pts.p, n, st.state, st.tags,
                                     p.xy_eigen_dist, p.z_eigen_dist, (double *)st.base.p, (double *)st.metrics.p,
-                                    (const uint32_t *)st.rowvox.p, h->counters + 8, (int64_t)cap));
+                                    (const uint32_t *)st.rowvox.p));
     }
     HT(h, 0, t0);                                        // scan: launches
-    // Wait only for k_trace: k_encode's first thread publishes {seq, count} to host-mapped memory.
-    // The caller gets control back while k_encode / k_minh still run; everything it can do next
-    // with this handle is stream-ordered behind them.
+    // Wait only for k_trace: k_encode's first thread publishes {seq, any-in-grid} to host-mapped
+    // memory.  The caller gets control back while k_encode still runs; everything it can do next
+    // with this handle is stream-ordered behind it.
     {
         volatile unsigned long long *flag = (volatile unsigned long long *)h->counters_host;
         const double deadline = now_ns() + 2.0e9;
@@ -423,8 +390,13 @@ int scan_launch(gvom_handle *h, const void *dev_pts, int64_t n, int64_t stride_e
         while ((uint32_t)(*flag >> 32) != seq) {
             _mm_pause();
             if ((++spins & 0x3ff) == 0 && now_ns() > deadline) {      // device trouble: fall back
-                HIPCHK(h, hipStreamSynchronize(h->stream));
-                if ((uint32_t)(*flag >> 32) != seq) { h->err = "scan row count was never published"; return GVOM_ERR_HIP; }
+                hipError_t se = hipStreamSynchronize(h->stream);
+                if (se != hipSuccess || (uint32_t)(*flag >> 32) != seq) {
+                    scan_abort(h);
+                    h->err = se != hipSuccess ? std::string("scan failed: ") + hipGetErrorString(se)
+                                              : "scan completion was never published";
+                    return GVOM_ERR_HIP;
+                }
             }
         }
     }
@@ -432,11 +404,9 @@ int scan_launch(gvom_handle *h, const void *dev_pts, int64_t n, int64_t stride_e
     if (h->host_timing) h->host_calls++;
     {
         const unsigned long long fl = *(volatile unsigned long long *)h->counters_host;
-        st.count = (int64_t)(fl & 0x7fffffffull);          // occupied voxels of THIS rank's slab
-        const unsigned long long vote = *((volatile unsigned long long *)h->counters_host + 2);   // stored before `fl`
-        if ((uint32_t)(vote >> 32) == seq && (vote & 3ull) < 2ull) h->trace_reverse = (int)(vote & 1ull);   // else: keep
-        h->pending_any = (fl & 0x80000000ull) != 0;        // some return landed in the grid on ANY rank
+        h->pending_any = (fl & 0x80000000ull) != 0;        // some return landed in the grid
     }
+    st.count = -1;                                         // occupied voxels: counted on demand (test hooks)
     st.origin[0] = origin[0]; st.origin[1] = origin[1]; st.origin[2] = origin[2];
     st.stats_valid = false;
     st.stats.points = n;
@@ -458,6 +428,27 @@ void scan_commit(gvom_handle *h, bool accept)
     h->slots[old].filled = false;
     h->last_buffer_index = b;
     h->buffer_index = (b + 1 >= h->prm.buffer_size) ? 0 : b + 1;
+}
+
+int renumber_epochs(gvom_handle *h)
+{
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    uint32_t next = 0;
+    for (size_t k = 0; k < h->slots.size(); ++k) {
+        Slot &sl = h->slots[k];
+        const uint32_t fresh = sl.filled ? ++next : 0u;  // the staging slot's tiles are dead
+        HIPCHK(h, gvom_launch_retag(h->stream, sl.tags, h->ntiles, sl.epoch, fresh));
+        sl.epoch = fresh;
+    }
+    for (int k = 0; k < 2; ++k) {
+        Fused &f = h->fused[k];
+        const uint32_t fresh = f.valid ? ++next : 0u;
+        HIPCHK(h, gvom_launch_retag(h->stream, f.tags, h->ntiles, f.epoch, fresh));
+        f.epoch = fresh;
+    }
+    h->epoch = next;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return GVOM_OK;
 }
 
 int process_impl(gvom_handle *h, const void *xyz, bool on_device, int64_t n, int64_t row_stride_bytes,
@@ -515,7 +506,6 @@ int choose_nz(int zs, int *zc, int *cpw)
     *zc = (zs + nchunks - 1) / nchunks;
     nchunks = (zs + *zc - 1) / *zc;
     int want_waves = 4;
-    if (const char *v = gvom_tune_env("GVOM_FUSE_WAVES")) want_waves = atoi(v) > 0 ? atoi(v) : 4;
     *cpw = (nchunks + want_waves - 1) / want_waves;
     if (*cpw < 1) *cpw = 1;
     if (*cpw > 4) *cpw = 4;                               // a wave's tiles (16 per chunk) fit one 64-bit mask
@@ -539,7 +529,6 @@ int fuse_impl(gvom_handle *h)
     P.om[1] = (int)floor_mod(F.origin[1], p.xy_size);
     P.om[2] = (int)floor_mod(F.origin[2], p.z_size);
     int ns = 0;
-    int64_t bound = 0;
     for (int i = 0; i < p.buffer_size; ++i) {                          // slot order, gvom.py:198
         const Slot &s = h->slots[h->ring[i]];
         if (!s.filled) continue;
@@ -550,7 +539,6 @@ int fuse_impl(gvom_handle *h)
         d.d[1] = clamp_delta(F.origin[1] - s.origin[1], p.xy_size);
         d.d[2] = clamp_delta(F.origin[2] - s.origin[2], p.z_size);
         d.epoch = s.epoch; d.tags = s.tags; d.metrics = h->stats ? s.metrics.p : nullptr;
-        bound += s.count;
     }
     P.nslots = ns;
     P.has_prev = prev ? 1 : 0;
@@ -562,14 +550,13 @@ int fuse_impl(gvom_handle *h)
         d.d[1] = clamp_delta(F.origin[1] - prev->origin[1], p.xy_size);
         d.d[2] = clamp_delta(F.origin[2] - prev->origin[2], p.z_size);
         d.epoch = prev->epoch; d.tags = prev->tags; d.metrics = h->stats ? prev->metrics.p : nullptr;
-        bound += prev->count;
     }
-    (void)bound;
     P.sy_lo = h->sy_lo; P.sy_hi = h->sy_hi;
     P.nz = choose_nz(p.z_size, &P.zc, &P.cpw);
-    if (const char *v = gvom_tune_env("GVOM_FUSE_DEBUG")) P.debug = atoi(v);
+    P.dbg = gvom_diag_env("GVOM_FUSE_DEBUG");
     P.nseg = h->nseg;
     P.hs = h->hs;
+    if (h->epoch >= 0xFFFFFF00u) { int rc0 = renumber_epochs(h); if (rc0) return rc0; }
     F.epoch = ++h->epoch;
     P.epoch = F.epoch;
     // every wave of k_fuse owns a static range of 64*zc compact rows (no global reservation)
@@ -618,7 +605,7 @@ int map2d_impl(gvom_handle *h, bool gathered, bool publish, char *out_dev, bool 
     const Fused &F = h->fused[h->cur];
     Map2dParams P;
     memset(&P, 0, sizeof P);
-    if (const char *v = gvom_tune_env("GVOM_MAP2D_DEBUG")) P.dbg = atoi(v);
+    P.dbg = gvom_diag_env("GVOM_MAP2D_DEBUG");
     P.xy = p.xy_size; P.zs = p.z_size;
     P.om[0] = (int)floor_mod(F.origin[0], p.xy_size);
     P.om[1] = (int)floor_mod(F.origin[1], p.xy_size);
@@ -719,7 +706,7 @@ VIS void gvom_destroy(gvom_t *h)
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
     auto fb = [](Buf &b) { if (b.p) hipFree(b.p); b.p = nullptr; b.bytes = 0; };
-    hipFree(h->hit); hipFree(h->total);
+    hipFree(h->hit); hipFree(h->total); hipFree(h->mh);
     for (auto &s : h->slots) { hipFree(s.state); hipFree(s.tags); fb(s.chit); fb(s.ctotal); fb(s.cminh); fb(s.metrics); fb(s.base); fb(s.rowvox); }
     for (auto &f : h->fused) { hipFree(f.state); hipFree(f.tags); fb(f.hit); fb(f.total); fb(f.minh); fb(f.metrics); }
     fb(h->in_pts); fb(h->world_pts);
@@ -728,7 +715,6 @@ VIS void gvom_destroy(gvom_t *h)
     hipFree(h->blockcounts);
     hipFree(h->hmaps); hipFree(h->slope_x); hipFree(h->slope_y);
     hipFree(h->rough); hipFree(h->guessed);
-    hipFree(h->out_pos);
     if (h->out_host) hipHostFree(h->out_host);
     for (auto &e : h->ev) if (e) hipEventDestroy(e);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
@@ -771,7 +757,7 @@ VIS int gvom_scan_begin(gvom_t *h, const void *xyz, int on_device, int64_t n, in
                         int64_t *local_cells)
 {
     int rc = process_impl(h, xyz, on_device != 0, n, row_stride_bytes, dtype, ego, transform_4x4, true);
-    if (local_cells) *local_cells = (rc == GVOM_OK) ? h->slots[h->staging].count : 0;
+    if (local_cells) *local_cells = (rc == GVOM_OK && h->pending_any) ? 1 : 0;   // != 0: some return landed in the grid
     return rc;
 }
 
@@ -792,11 +778,9 @@ VIS int gvom_combine_maps(gvom_t *h, double origin_world[3], int32_t *positive, 
     double t0 = now_ns();
     int rc = fuse_impl(h);
     if (rc) return rc;
-    if ((rc = map2d_impl(h, false, true, h->zero_copy ? h->out_host_dev : (char *)h->out_pos, false))) return rc;
+    if ((rc = map2d_impl(h, false, true, h->out_host_dev, false))) return rc;
     const size_t n2 = h->cells2d;
     char *stage = (char *)h->out_host;
-    if (!h->zero_copy && (positive || negative || visibility || roughness))
-        HIPCHK(h, hipMemcpyAsync(stage, h->out_pos, n2 * 20, hipMemcpyDeviceToHost, h->stream));
     HT(h, 2, t0);                                        // combine: launches
     if ((rc = finish_combine(h))) return rc;
     HT(h, 3, t0);                                        // combine: wait
@@ -828,7 +812,7 @@ VIS int gvom_output_buffer_alloc(gvom_t *h, void **host_ptr)
     HIPCHK(h, hipSetDevice(h->device));
     // GVOM_OUT_COHERENT=1: fine-grained (coherent) pinned memory -- stores leave the GPU as they are
     // issued instead of being written back from L2 at the end of the kernel
-    HIPCHK(h, hipHostMalloc(host_ptr, h->cells2d * 20, hipHostMallocMapped | (h->out_coherent ? hipHostMallocCoherent : 0u)));
+    HIPCHK(h, hipHostMalloc(host_ptr, h->cells2d * 20, hipHostMallocMapped | hipHostMallocCoherent));
     return GVOM_OK;
 }
 
@@ -1066,6 +1050,12 @@ VIS int gvom_read_dense(gvom_t *h, int which, int32_t *state, int32_t *hit, int3
     if (e == hipSuccess && hit) e = hipMemcpy(hit, tmp + V, V * 4, hipMemcpyDeviceToHost);
     if (e == hipSuccess && total) e = hipMemcpy(total, tmp + 2 * V, V * 4, hipMemcpyDeviceToHost);
     if (e == hipSuccess && min_h) e = hipMemcpy(min_h, tmp + 3 * V, V * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && cell_count && cnt < 0) {       // a scan's occupied voxels are counted on demand
+        std::vector<int32_t> stv(V);
+        e = hipMemcpy(stv.data(), tmp, V * 4, hipMemcpyDeviceToHost);
+        cnt = 0;
+        for (size_t i = 0; i < V; ++i) cnt += stv[i] >= 0;
+    }
     hipFree(tmp);
     HIPCHK(h, e);
     if (origin) for (int k = 0; k < 3; ++k) origin[k] = (double)org[k];
@@ -1228,15 +1218,17 @@ VIS int gvom_host_timing(gvom_t *h, double us[8])
     return GVOM_OK;
 }
 
-// diagnostic (GVOM_TRACE_VARIANT=2): cumulative {run heads, distinct-64B-line heads, atomic wave
-// instructions} of k_trace since creation
-VIS int gvom_debug_trace_counters(gvom_t *h, uint32_t out[3])
+// Performance knobs that never change a result: "segs" = step segments per ray in k_trace, "period" =
+// committing steps between two flushes of a wave's line cache, "ep_row" = dispatch row of the endpoint
+// blocks (0 / 0 / -1: automatic).
+VIS int gvom_set_tuning(gvom_t *h, const char *name, int value)
 {
-    if (!h || !out) return GVOM_ERR_INVALID;
+    if (!h || !name) return GVOM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
-    HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipMemcpy(out, h->counters + 4, 12, hipMemcpyDeviceToHost));
+    if (!strcmp(name, "segs")) h->tune_segs = value;
+    else if (!strcmp(name, "ep_row")) h->tune_ep_row = value;
+    else if (!strcmp(name, "period")) h->tune_period = value;
+    else return GVOM_ERR_INVALID;
     return GVOM_OK;
 }
 

@@ -19,25 +19,19 @@
 
 #define GVOM_MAX_SLOTS 64
 
-// Tuning / diagnostic switches read on the hot path (every scan and combine).
-// A dozen getenv() misses per step cost ~1.5 us of host time in front of the k_trace launch, so they
-// are only looked up when the process environment held some GVOM_ switch the first time one was
-// asked for (tools/ab_step.py, which changes them while running, sets GVOM_ENV_DYNAMIC=1 first).
+// Timing experiments (parts of a kernel switched off; results are WRONG when set) exist only in the
+// diagnostic build (make diag -> lib/libgvom_hip_diag.so, -DGVOM_DIAG): there the GVOM_*_DEBUG
+// environment variables are read per call.  The production library compiles every such test away and
+// reads no environment variable that can change a result.
 #include <stdlib.h>
 #include <string.h>
-extern char **environ;
-static inline const char *gvom_tune_env(const char *name)
-{
-    static int mode = 0;                                   // 1: nothing to look up; 2: getenv every time
-    if (mode == 0) {
-        int m = 1;
-        for (char **e = environ; e && *e; ++e)
-            if (!strncmp(*e, "GVOM_", 5) && strncmp(*e, "GVOM_HIP_LIBRARY=", 17) && strncmp(*e, "GVOM_BENCH_", 11) &&
-                strncmp(*e, "GVOM_AMD_HOME=", 14)) { m = 2; break; }
-        mode = m;
-    }
-    return mode == 2 ? getenv(name) : nullptr;
-}
+#ifdef GVOM_DIAG
+#define GVOM_DBG(P, bits) ((P).dbg & (bits))
+static inline int gvom_diag_env(const char *name) { const char *v = getenv(name); return v ? atoi(v) : 0; }
+#else
+#define GVOM_DBG(P, bits) 0
+static inline int gvom_diag_env(const char *) { return 0; }
+#endif
 
 // TILES: 64 consecutive sx of one (sy, sz) row = 256 bytes of every per-voxel array.  Tile index
 // T = (sy*zs + sz)*nseg + (sx >> 6), nseg = ceil(xy/64).  Every scan / fused map carries one
@@ -53,9 +47,7 @@ static inline const char *gvom_tune_env(const char *name)
 // per distinct y.  Patches make x- and y-dominant bundles equally cheap (about half the requests).
 // device counter block (uint32 words; 512 bytes).  The two counters k_trace adds to live on separate
 // cache lines: same-line atomics are serialised by the memory system.
-#define GVOM_CNT_ROWS 0        // compact rows claimed by the scan in flight
-#define GVOM_CNT_INGRID 64     // in-grid returns of the scan in flight (any rank's rows)
-#define GVOM_CNT_VOTE 128     // order vote (k_encode): long rays of the first / second (+16) cloud half, two pairs (+32) by scan parity
+#define GVOM_CNT_INGRID 64     // != 0: some return of the scan in flight landed in the grid
 #define GVOM_CNT_WORDS 192
 
 struct ScanParams {
@@ -68,22 +60,19 @@ struct ScanParams {
     int    has_tf;
     int    xy, zs;
     int    om[3];         // origin mod size (storage offset)
-    int    sy_lo, sy_hi;  // storage rows owned by this rank: [sy_lo, sy_hi)
+    int    sy_lo, sy_hi;  // storage rows ENCODED by this handle: [sy_lo, sy_hi) (a rank's slab; all rows otherwise)
     int    nseg;          // tiles per (sy, sz) row
-    int    nsegs, seg_len; // DDA steps are split into nsegs segments of seg_len steps (last: open-ended)
-    int    seg_start[10];  // VAR 5/6: segment s covers steps (seg_start[s], seg_start[s+1]]; uniform = s * seg_len
-    int    blk_reverse, nblk; // workgroup b of a segment handles returns [256 * (blk_reverse ? nblk-1-b : b), +256)
-    unsigned long long seg_order; // nibble k = the segment handled by the workgroups with blockIdx.y == k
-    int    sxq;           // accumulator layout: 4x4 (x,y) patches per row of patches = ceil(xy/4)
+    int    nsegs;         // k_trace: step segments s = (seg_start[s], seg_start[s+1]], the last one open-ended
+    int    seg_start[10];
+    int    ep_row;        // k_trace: blockIdx.y of the endpoint blocks (the other rows are the segments, ascending)
+    int    lc_period;     // k_trace: flush the wave's line cache every lc_period committing steps
+    int    f32_sqrt;      // GVOM_FLAG_CUDA_F32_SQRT: ray_length = sqrtf(f32 sum) (real Numba-CUDA typing, gvom.py:1109)
+    int    sxq;           // accumulator layout: 4x4 (x,y) patches per row of patches = ceil(xy/4) + padding
     uint32_t epoch;       // this scan's tile epoch
-    // slab-sharded runs: the slab's rows as (up to two) intervals of WINDOW y, for ray culling
     int    off[3];        // element offsets of x, y, z inside a point record (0, 1, 2 unless PointCloud2 ingest)
     int    in_f32;        // 1: the records hold float32 fields that are widened to the (float64) compute type,
                           //    as ros_numpy hands the reference a float64 array (stride and offsets in 4-byte units)
-    int    lc_period;     // k_trace line cache: flush every lc_period committing steps (GVOM_TRACE_PERIOD)
-    int    dbg;           // GVOM_TRACE_DEBUG bits (timing experiments only; results wrong when set)
-    int    cull;          // 1: skip rays that cannot reach the slab, stop rays that have left it
-    int    wlo[2], whi[2];
+    int    dbg;           // diagnostic build only
 };
 
 struct MapDesc {          // one source map of the fusion (ring slot or previous fused map)
@@ -112,7 +101,7 @@ struct FuseParams {
     int nz;                 // z-chunks per workgroup (block = 64 * nz threads)
     int zc;                 // window-z cells per chunk (<= 64)
     int cpw;                // chunks per wave (a wave walks them in ascending z)
-    int debug;              // GVOM_FUSE_DEBUG bits (timing experiments only): 1 no code stores, 2 no emit, 4 all tiles dead
+    int dbg;                // diagnostic build only (GVOM_FUSE_DEBUG): 1 no code stores, 2 no emit, 4 all tiles dead
     double origin[3];       // fused origin (voxels)
     double ego[3];          // latest ego (gvom.py:294-295)
     double xy_res, z_res;
@@ -128,7 +117,7 @@ struct Map2dParams {
     int hs;                 // row stride (elements) of the height / inferred-height maps
     int gathered_pos;       // 1: positive-obstacle densities come from the gathered height buffer (sharded)
     uint32_t epoch;         // epoch of the fused map (tile liveness of fstate)
-    int dbg;                // GVOM_MAP2D_DEBUG bits (timing experiments only)
+    int dbg;                // diagnostic build only (GVOM_MAP2D_DEBUG)
     int out_yx;             // 1: returned maps in [y][x] memory order (column-major [x, y]); 0: row-major [x][y]
     double origin_z;        // fused origin z (voxels)
     double xy_res, z_res;
@@ -138,15 +127,14 @@ struct Map2dParams {
 };
 
 // ---- launchers (gvom_kernels.hip) --------------------------------------------------------
-hipError_t gvom_launch_trace(hipStream_t s, const ScanParams &P, int dtype, const void *pts,
+hipError_t gvom_launch_trace(hipStream_t s, const ScanParams &P, int dtype, bool big_origin, const void *pts,
                              int64_t stride_elems, int64_t n, void *world, uint32_t *hit,
-                             uint32_t *total, int32_t *state, uint32_t *tags, uint32_t *cminh,
-                             uint32_t *counters, int variant, double *stat_sums, double *stat_base,
+                             uint32_t *total, uint32_t *mh, int32_t *state, uint32_t *tags,
+                             uint32_t *counters, double *stat_sums, double *stat_base,
                              uint32_t *stat_rowvox);
-hipError_t gvom_launch_encode(hipStream_t s, const ScanParams &P, int dtype, const void *world,
-                              int64_t n, uint32_t *hit, uint32_t *total, int32_t *state,
-                              uint32_t *chit, uint32_t *ctotal, uint32_t *cminh, const uint32_t *tags,
-                              uint32_t *counters, unsigned long long *host_flag, uint32_t seq);
+hipError_t gvom_launch_encode(hipStream_t s, const ScanParams &P, uint32_t *hit, uint32_t *total, uint32_t *mh,
+                              int32_t *state, uint32_t *chit, uint32_t *ctotal, uint32_t *cminh, const uint32_t *tags,
+                              uint32_t *counters, unsigned long long *host_flag, uint32_t seq, unsigned resident_blocks);
 hipError_t gvom_launch_fuse(hipStream_t s, const FuseParams &P, const FuseDescs &KD,
                             const MapDesc *descs_dev, int32_t *fstate, uint32_t *fhit, uint32_t *ftotal, uint32_t *fminh,
                             uint32_t *ftags, uint32_t *blockcounts, double *height, double *inferred);
@@ -159,13 +147,14 @@ hipError_t gvom_launch_map2d(hipStream_t s, const Map2dParams &P, const int32_t 
 // ---- optional per-voxel statistics (gvom.py:1172-1299, 858-909, 1333-1378, 454-473)
 hipError_t gvom_launch_stats(hipStream_t s, const ScanParams &P, int dtype, const void *world, int64_t n,
                              const int32_t *state, const uint32_t *tags, int xy_e, int z_e, double *base,
-                             double *sums, const uint32_t *rowvox, const uint32_t *row_count_dev, int64_t cap);
+                             double *sums, const uint32_t *rowvox);
 hipError_t gvom_launch_fuse_stats(hipStream_t s, const FuseParams &P, const FuseDescs &KD, const MapDesc *descs_dev,
                                   const int32_t *fstate, const uint32_t *ftags, float *fmetrics);
 hipError_t gvom_launch_voxel_cloud(hipStream_t s, const Map2dParams &P, double o0, double o1, double o2,
                                    const int32_t *fstate, const uint32_t *ftags, const uint32_t *fhit,
                                    const uint32_t *ftotal, const float *fmetrics, float *out, int64_t max_rows,
                                    unsigned long long *row_counter);
+hipError_t gvom_launch_retag(hipStream_t s, uint32_t *tags, size_t n, uint32_t old_epoch, uint32_t new_epoch);
 // test hooks / debug accessors
 hipError_t gvom_launch_read_dense(hipStream_t s, int xy, int zs, const int om[3], int sy_lo, int sy_hi,
                                   const uint32_t *tags, uint32_t epoch, const int32_t *state, const uint32_t *chit,

@@ -51,219 +51,222 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
-// ---- wave-private accumulator-line cache (k_trace VAR 6) ---------------------------------------
-// One 64-entry open-addressed table per wave in LDS: key = accumulator line (64 B = 4x4 (x,y)
-// patch at one z), 16 counters per entry.  DDA steps add into the table with LDS atomics; when
-// the table fills up (or the wave is done) the wave flushes it cooperatively, 4 lines per
-// instruction with 16 lanes per line, so one line costs ONE memory-side atomic request however
-// many steps of however many lanes fell into it since the last flush.
+// ---- wave-private accumulator-line cache (k_trace) -----------------------------------------------
+// One 64-entry direct-mapped table per wave in LDS: key = accumulator line (64 B = 4x4 (x,y)
+// patch at one z), 16 counters per entry.  DDA steps add into the table with LDS atomics; at the
+// end of the wave's item the wave flushes it cooperatively, 4 lines per instruction with 16 lanes
+// per line, so one line costs ONE memory-side atomic request however many steps of however many
+// lanes fell into it.
 #define LC_EMPTY 0xFFFFFFFFu
 #define LC_LD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT)
 #define LC_ST(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT)
 // slot s keeps its key at keys[LC_KEYPOS(s)]: the flush handles entry 4*it + g in iteration it of
 // lane group g, so group g finds its 16 keys in 16 consecutive words (4 x 16-byte LDS reads)
 #define LC_KEYPOS(s) ((((s) & 3u) << 4) | ((s) >> 2))
-__device__ __forceinline__ void lc_flush(uint32_t *keys, uint32_t *cnt, uint32_t *total, int lane, int dbg = 0)
+__device__ __forceinline__ void lc_flush(const ScanParams &P, uint32_t *keys, uint32_t *cnt, uint32_t *total, int lane)
 {
-    // entry e = 4*it + (lane >> 4), counter c = lane & 15  <=>  cnt[it*64 + lane]: linear LDS reads
+    // entry e = 4*it + (lane >> 4), counter c = lane & 15  <=>  cnt[it*64 + lane]: linear LDS reads.
+    // Two batches of 8 entries: 16 registers in flight instead of 32 (the step loop's own state has
+    // to stay in registers across an in-loop flush).
     const int g = lane >> 4, c = lane & 15;
-    uint32_t v[16], k[16];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const v4i kk = *(const v4i *)&keys[g * 16 + q * 4];
-        k[q * 4 + 0] = (uint32_t)kk.x; k[q * 4 + 1] = (uint32_t)kk.y; k[q * 4 + 2] = (uint32_t)kk.z; k[q * 4 + 3] = (uint32_t)kk.w;
-    }
+    for (int half = 0; half < 2; ++half) {
+        uint32_t v[8], k[8];
 #pragma unroll
-    for (int it = 0; it < 16; ++it) v[it] = LC_LD(&cnt[it * 64 + lane]);
+        for (int q = 0; q < 2; ++q) {
+            const v4i kk = *(const v4i *)&keys[g * 16 + half * 8 + q * 4];
+            k[q * 4 + 0] = (uint32_t)kk.x; k[q * 4 + 1] = (uint32_t)kk.y; k[q * 4 + 2] = (uint32_t)kk.z; k[q * 4 + 3] = (uint32_t)kk.w;
+        }
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
-        if (v[it] != 0u) {
-            if (!(dbg & 1)) atomicAdd(&total[(k[it] << 4) + (uint32_t)c], v[it]);
-            LC_ST(&cnt[it * 64 + lane], 0u);
+        for (int it = 0; it < 8; ++it) v[it] = LC_LD(&cnt[(half * 8 + it) * 64 + lane]);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            if (v[it] != 0u) {
+                if (!GVOM_DBG(P, 1)) atomicAdd(&total[(k[it] << 4) + (uint32_t)c], v[it]);
+                LC_ST(&cnt[(half * 8 + it) * 64 + lane], 0u);
+            }
         }
     }
     LC_ST(&keys[lane], LC_EMPTY);
 }
 
-// ------------------------------------------------------------------------------------------
-// k_trace: one lane per lidar return.
-//   1. optional rigid transform (f64, written back in the cloud's dtype)      gvom.py:1040-1056
-//   2. min-distance reject measured from the WORLD origin                       gvom.py:1064-1068
-//   3. endpoint voxel: hit += 1, total += 1; the lane that sees hit go 0 -> 1 claims the
-//      voxel's compact row with ONE wave-aggregated atomic (ballot + popcount)  gvom.py:1070-1090,1158
-//   4. dominant-axis DDA from the ego position, total += 1 per step             gvom.py:1093-1150
-// Only voxels whose storage row sy lies in [sy_lo, sy_hi) are committed (multi-GPU slabs).
-//
-// SEGMENTS.  A 131k-point scan is only 2 waves per SIMD and the step body is a long dependent
-// chain (f32 add -> f64 floor/compare -> index -> shuffle/ballot -> atomic), so the kernel would
-// be latency-bound.  Each coordinate advances by a constant-sign f32 increment, i.e. monotonically,
-// and so does `length`; therefore "the ray has already ended before step k" is decided by the
-// state AT step k alone -- given that step 1 lies inside the grid, which every later segment
-// checks -- and a ray's steps can be split into nsegs segments handled by different
-// waves (blockIdx.y): a lane first replays the skipped steps with the reference's exact f32/f64
-// accumulation (3 f32 adds + 1 f64 add per step, no floor, no memory traffic), then runs the full
-// step body for its own seg_len steps.  Results are bit-identical; there are nsegs x more waves.
-// ------------------------------------------------------------------------------------------
-// VAR selects the accumulation strategy of the DDA loop (A/B-able at run time through the
-// GVOM_TRACE_VARIANT environment variable, read by gvom_create):
-//   0  one global atomic per lane and step (divergent per-lane loop)
-//   1  lock-step loop; lanes of a wave that step into the SAME voxel as their left neighbour
-//      are merged (ballot + run length) so one lane adds the whole run: near the sensor all 64
-//      rays of a wave share a voxel and 64 same-address atomics collapse into one
-//   5  as 1 with the short step body of the production loop (integer voxel lookup, DPP neighbour key)
-//   6  production: 5 + a wave-private LDS line cache flushed with one request per 64-B line (lc_flush):
-//      steps of a ray bundle that revisit a line are merged too
-//   9  diagnostic only: no DDA atomics at all (measures the arithmetic floor; results wrong)
-// CULL = false: the handle owns every row (no slab tests / ray culling compiled into the step body)
-template <typename T, int VAR, bool CULL = true>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_trace(const ScanParams P, const T *__restrict__ in,
-                                               long stride, long n, T *__restrict__ world,
-                                               uint32_t *hit, uint32_t *total, int32_t *state,
-                                               uint32_t *tags, uint32_t *cminh, uint32_t *counters,
-                                               double *stat_sums, double *stat_base, uint32_t *stat_rowvox)
+// One lidar return: load (any record layout, gvom_ros.py:93-109) + optional rigid transform in f64,
+// source order, rounded to the cloud's dtype (gvom.py:1040-1056).
+template <typename T>
+__device__ __forceinline__ void load_return(const ScanParams &P, const T *__restrict__ in, long stride, long i,
+                                            T &x, T &y, T &z)
 {
-    const int lane = threadIdx.x & (WAVE - 1);
-    // ADAPTIVE CLOUD ORDER.  The workgroups of a segment are dispatched in blockIdx.x order; when the
-    // heavy ones (long rays) come first the kernel's tail is shorter (measured: -2.5 us when a
-    // beam-major scan that stores its short, downward beams first is walked backwards).  Which end of
-    // the cloud is heavy is learnt from earlier scans: k_encode's min-height blocks count the long rays
-    // per cloud half, the next launch's first thread compares the halves and the host passes the
-    // decision on (two scans later).  The mapping is a bijection, so results do not depend on it.
-    const unsigned blk = P.blk_reverse ? (unsigned)P.nblk - 1u - blockIdx.x : blockIdx.x;
-    const long i = (long)blk * 256 + threadIdx.x;
-    // step segment of this wave: workgroups are dispatched in blockIdx.y order, P.seg_order maps that
-    // order to segments (4 bits each)
-    const int seg = (VAR == 1 || VAR == 2 || VAR == 5 || VAR == 6) ? (int)((P.seg_order >> (4 * blockIdx.y)) & 15u) : 0;
-    if ((VAR == 0 || VAR == 9) && blockIdx.y != 0) return;
-    const bool first = seg == 0;                                       // segment 0 also does the endpoint
-    const bool live = i < n;
-    T x = 0, y = 0, z = 0;
-    if (live) {
-        if (sizeof(T) == 8 && P.in_f32) {                // PointCloud2 FLOAT32 fields, computed in f64
-            const float *p = reinterpret_cast<const float *>(in) + i * stride;
-            x = (T)p[P.off[0]]; y = (T)p[P.off[1]]; z = (T)p[P.off[2]];
-        } else {
-            const T *p = in + i * stride;
-            x = p[P.off[0]]; y = p[P.off[1]]; z = p[P.off[2]];
-        }
-        if (P.has_tf) {
-            const double dx = (double)x, dy = (double)y, dz = (double)z;
-            const double o0 = ((dx * P.tf[0] + dy * P.tf[1]) + dz * P.tf[2]) + P.tf[3];
-            const double o1 = ((dx * P.tf[4] + dy * P.tf[5]) + dz * P.tf[6]) + P.tf[7];
-            const double o2 = ((dx * P.tf[8] + dy * P.tf[9]) + dz * P.tf[10]) + P.tf[11];
-            x = (T)o0; y = (T)o1; z = (T)o2;
-        }
-        if (first) { world[3 * i + 0] = x; world[3 * i + 1] = y; world[3 * i + 2] = z; }
+    if (sizeof(T) == 8 && P.in_f32) {                    // PointCloud2 FLOAT32 fields, computed in f64
+        const float *p = reinterpret_cast<const float *>(in) + i * stride;
+        x = (T)p[P.off[0]]; y = (T)p[P.off[1]]; z = (T)p[P.off[2]];
+    } else {
+        const T *p = in + i * stride;
+        x = p[P.off[0]]; y = p[P.off[1]]; z = p[P.off[2]];
     }
-    const T d2 = (x * x + y * y) + z * z;
-    const bool pass = live && !((double)d2 < P.min_d2);
-    const double dxy = (double)P.xy, dzs = (double)P.zs;
-
-    // ---- later segments: leave before the f64 setup when no ray of the wave can still be running ----
-    // After J = seg_start[seg] replayed steps `length` is >= J * (1 - 2^-22) (every step adds |1 / sd|
-    // with |sd| <= 1 + 2^-23), and a ray stops once length >= ray_length - 1 (gvom.py:1127): a ray
-    // with ray_length <= J + 0.9 takes no step in this segment.  Decided conservatively in f32 from
-    // the raw return, with a margin far above the rounding of this estimate; NaN/inf compare false
-    // and take the full path.
-    if ((VAR == 5 || VAR == 6) && seg > 0) {
-        const float ax = (float)x * P.rinv[0], ay = (float)y * P.rinv[0], az = (float)z * P.rinv[1];
-        const float ux = ax - P.pt0[0], uy = ay - P.pt0[1], uz = az - P.pt0[2];
-        const float r = sqrtf((ux * ux + uy * uy) + uz * uz);
-        const float mag = ((fabsf(ax) + fabsf(ay)) + fabsf(az)) + ((fabsf(ux) + fabsf(uy)) + fabsf(uz));
-        const bool dead = !pass || (r + (r * 1e-5f + mag * 4e-6f) <= (float)P.seg_start[seg] + 0.9f);
-        if (__all(dead)) return;                                         // wave-uniform
+    if (P.has_tf) {
+        const double dx = (double)x, dy = (double)y, dz = (double)z;
+        const double o0 = ((dx * P.tf[0] + dy * P.tf[1]) + dz * P.tf[2]) + P.tf[3];
+        const double o1 = ((dx * P.tf[4] + dy * P.tf[5]) + dz * P.tf[6]) + P.tf[7];
+        const double o2 = ((dx * P.tf[8] + dy * P.tf[9]) + dz * P.tf[10]) + P.tf[11];
+        x = (T)o0; y = (T)o1; z = (T)o2;
     }
+}
 
-    // ---- endpoint ------------------------------------------------------------------------
-    bool ingrid = false, ingrid_any = false;
-    uint32_t L = 0, A = 0;
-    if (pass && first) {
+// floor(x) as int32 in ONE instruction (v_cvt_flr_i32_f32: round toward -inf, saturating, NaN -> 0):
+// identical to (int)floorf(x) wherever that is defined
+__device__ __forceinline__ int cvt_floor_i32(float x)
+{
+    int r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+// a * b + c for a, b < 2^24 (full-rate v_mad_u32_u24; the 32-bit multiply is quarter rate)
+__device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// the same with a wave-uniform multiplier (kept in an SGPR: no v_mov per use)
+__device__ __forceinline__ uint32_t mad24s(uint32_t a, uint32_t sb, uint32_t c)
+{
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(sb), "v"(c));
+    return r;
+}
+// lane mask of a predicate without the bool -> int -> compare round trip of __ballot / __any
+__device__ __forceinline__ unsigned long long lanes(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(1))) uint32_t glb_u32;
+// accumulator index as acc_idx(), with 24-bit multiplies (zs <= 1024, sxq < 2^12, sy >> 2 < 2^12)
+__device__ __forceinline__ uint32_t acc_idx24(uint32_t sx, uint32_t sy, uint32_t sz, uint32_t zs, uint32_t sxq)
+{
+    const uint32_t t = mad24s(sy >> 2, zs, sz);
+    return (mad24s(t, sxq, sx >> 2) << 4) | ((sy & 3u) << 2) | (sx & 3u);
+}
+
+// Window voxel of a ray position (gvom.py:1121-1144: floor((f64)p - origin), inside test).
+// LIT = false: the window origin is an integer (gvom.py:124-126 floors it), so
+// floor((double)p - origin) == (int)floorf(p) - origin -- no f64 in the lookup.  The f64 subtraction
+// rounds across an integer only when p lies within half an f64 ulp BELOW an integer, which an f32 p
+// can only do just below 0 (|p| < 2^-23, given |origin| < 2^30, which the host checks before selecting
+// the integer form); callers use LIT = true (the reference's literal f64 expression) wherever a
+// coordinate may come that close to zero, and always when |origin| >= 2^30.
+// Returns "inside the window"; wx/wy/wz are only meaningful then.
+template <bool LIT>
+__device__ __forceinline__ bool window_voxel(const ScanParams &P, float px, float py, float pz,
+                                             uint32_t &wx, uint32_t &wy, uint32_t &wz)
+{
+    if (LIT) {
+        const double fx = floor((double)px - P.origin[0]);
+        const double fy = floor((double)py - P.origin[1]);
+        const double fz = floor((double)pz - P.origin[2]);
+        const bool in = fx >= 0.0 && fx < (double)P.xy && fy >= 0.0 && fy < (double)P.xy && fz >= 0.0 && fz < (double)P.zs;
+        wx = in ? (uint32_t)(int)fx : 0u; wy = in ? (uint32_t)(int)fy : 0u; wz = in ? (uint32_t)(int)fz : 0u;
+        return in;
+    }
+    wx = (uint32_t)cvt_floor_i32(px) - (uint32_t)(int)P.origin[0];
+    wy = (uint32_t)cvt_floor_i32(py) - (uint32_t)(int)P.origin[1];
+    wz = (uint32_t)cvt_floor_i32(pz) - (uint32_t)(int)P.origin[2];
+    return max(wx, wy) < (uint32_t)P.xy && wz < (uint32_t)P.zs;
+}
+// one position, either form: literal when a coordinate is within 2^-21 of zero
+template <bool BIG>
+__device__ __forceinline__ bool window_voxel_auto(const ScanParams &P, float px, float py, float pz,
+                                                  uint32_t &wx, uint32_t &wy, uint32_t &wz)
+{
+    if (BIG || fminf(fminf(fabsf(px), fabsf(py)), fabsf(pz)) < 0x1p-21f) return window_voxel<true>(P, px, py, pz, wx, wy, wz);
+    return window_voxel<false>(P, px, py, pz, wx, wy, wz);
+}
+
+// Number of DDA steps the reference's length test lets a ray take (gvom.py:1127,1149):
+//   length_0 = 0, length_j = fl(length_{j-1} + step_len) in f64; step j runs iff length_{j-1} < lim,
+// i.e. n = the smallest j with length_j >= lim (0 if lim <= 0), capped at `cap` + 1 (callers only need
+// to know "more than cap").  The accumulated sum differs from j * step_len by at most j^2 * step_len *
+// 2^-53, so n = ceil(lim / step_len) unless lim lies within that band of a multiple of step_len; only
+// then (probability ~1e-12 per ray) the sum is accumulated literally.
+__device__ __forceinline__ uint32_t ray_steps(double lim, double step_len, double inv_step, uint32_t cap)
+{
+    if (!(0.0 < lim)) return 0u;
+    const double q = lim * inv_step;                      // ~ lim / step_len (inv_step ~ 1 / step_len: any error is caught by the band test)
+    if (!(q < (double)cap + 2.0)) return cap + 1u;                        // also inf / NaN quotients: literal path below never needed
+    const double jc = ceil(q);
+    const double e = (jc * jc) * step_len * 0x1p-51 + step_len * 0x1p-50;
+    const double lo = (jc - 1.0) * step_len, hi = jc * step_len;
+    if (lo + e < lim && hi - e >= lim) return (uint32_t)jc;
+    uint32_t n = 0;
+    double length = 0.0;
+    while (length < lim && n <= cap) { length += step_len; ++n; }
+    return n;
+}
+
+// Endpoint voxel of one return: hit += 1, total += 1, min-height (gvom.py:1070-1090, 1303-1329); the
+// voxel's compact row is the index of (one of) its returns -- no row counter, no barrier.  All atomics
+// are fire-and-forget.
+template <typename T>
+__device__ __forceinline__ void endpoint_update(const ScanParams &P, int lane, long i, bool pass, T x, T y, T z,
+                                                uint32_t *hit, uint32_t *total, uint32_t *mh, int32_t *state,
+                                                uint32_t *tags, uint32_t *counters, double *stat_sums,
+                                                double *stat_base, uint32_t *stat_rowvox)
+{
+    bool ingrid = false;
+    uint32_t L = 0, A = 0, mbits = 0;
+    if (pass) {
         const double fx = floor((double)x / P.xy_res - P.origin[0]);
         const double fy = floor((double)y / P.xy_res - P.origin[1]);
-        const double fz = floor((double)z / P.z_res - P.origin[2]);
-        if (fx >= 0.0 && fx < dxy && fy >= 0.0 && fy < dxy && fz >= 0.0 && fz < dzs) {
-            ingrid_any = true;                           // in the grid, whichever rank owns the row
+        const double az = (double)z / P.z_res - P.origin[2];
+        const double fz = floor(az);
+        if (fx >= 0.0 && fx < (double)P.xy && fy >= 0.0 && fy < (double)P.xy && fz >= 0.0 && fz < (double)P.zs) {
+            ingrid = true;
             const int sx = wrap_add((int)fx, P.om[0], P.xy);
             const int sy = wrap_add((int)fy, P.om[1], P.xy);
             const int sz = wrap_add((int)fz, P.om[2], P.zs);
-            if (sy >= P.sy_lo && sy < P.sy_hi) {
-                ingrid = true;
-                L = ((uint32_t)sy * P.zs + sz) * P.xy + sx;
-                A = acc_idx(sx, sy, sz, P.zs, P.sxq);
-            }
+            L = ((uint32_t)sy * P.zs + sz) * P.xy + sx;
+            A = acc_idx(sx, sy, sz, P.zs, P.sxq);
+            // local_point[2], f64 -> f32 (gvom.py:1326,1329): in [0, 1], so the float order equals the
+            // order of its bit pattern; kept as 1.0f's bits MINUS the value's (0 = the 1.0f the reference
+            // initialises with, gvom.py:1014-1015) so that the accumulator is zero between scans
+            mbits = 0x3f800000u - __float_as_uint((float)(az - fz));
         }
     }
-    uint32_t old = 1;
-    if (first) {                                         // workgroup-uniform
-        // neighbouring returns of a beam end in the same voxel (33 consecutive azimuths at 2 m range):
-        // the first lane of each run of equal voxels adds the whole run, so a voxel costs one
-        // same-address atomic per run instead of one per return (they are served one at a time)
-        const uint32_t key = ingrid ? A : (0xFFFFFF00u | (uint32_t)lane);
-        const uint32_t leftk = (uint32_t)__builtin_amdgcn_update_dpp((int)~key, (int)key, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-        const bool ehead = ingrid && leftk != key;
-        const unsigned long long followers = __ballot(ingrid) & ~__ballot(ehead);
-        if (ehead && !(P.dbg & 4)) {
-            const uint32_t run = (uint32_t)__ffsll((long long)~((followers >> lane) >> 1));   // 1 + followers
-            old = atomicAdd(&hit[A], run);
-            atomicAdd(&total[A], run);
-            tags[(L / P.xy) * P.nseg + ((L % P.xy) >> 6)] = P.epoch;   // stamp the tile (idempotent)
-        }
-        ingrid = ehead;                                  // only a run's first lane can claim the voxel's row
-    }
-    // every rank sees every point, so each can count the GLOBAL number of in-grid returns: the
-    // reference's "no overlap" test (gvom.py:147-150) then needs no collective in sharded runs.
-    // Both counters are aggregated per WORKGROUP (one atomic each, on separate cache lines):
-    // same-line atomics are served one at a time (~11.5 ns each, tools/atomic_calib), and the row
-    // claim returns a value, so per-wave atomics made every wave queue behind 2 x 2048 requests.
-    const unsigned long long gm = __ballot(ingrid_any);
-    const bool claim = ingrid && old == 0;
-    const unsigned long long cm = __ballot(claim);
-    if (first) {                                        // workgroup-uniform (seg = blockIdx.y)
-        __shared__ uint32_t s_cl[4], s_in[4], s_base;
-        const int wv = threadIdx.x >> 6;
-        if (lane == 0) { s_cl[wv] = (uint32_t)__popcll(cm); s_in[wv] = (uint32_t)__popcll(gm); }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const uint32_t nc = (s_cl[0] + s_cl[1]) + (s_cl[2] + s_cl[3]);
-            const uint32_t ni = (s_in[0] + s_in[1]) + (s_in[2] + s_in[3]);
-            if (ni && !(P.dbg & 4096)) atomicAdd(&counters[GVOM_CNT_INGRID], ni);
-            s_base = (nc && !(P.dbg & 2048)) ? atomicAdd(&counters[GVOM_CNT_ROWS], nc) : 0u;
-        }
-        __syncthreads();
-        if (claim) {
-            const uint32_t wbase = s_base + (wv > 0 ? s_cl[0] : 0u) + (wv > 1 ? s_cl[1] : 0u) + (wv > 2 ? s_cl[2] : 0u);
-            const uint32_t row = wbase + (uint32_t)__popcll(cm & lanemask_lt());
-            state[L] = (int32_t)row;
-            cminh[row] = 0x3f800000u;                   // min-height starts at 1.0f (gvom.py:1014-1015)
-            if (stat_sums)                              // optional statistics: zeroed metrics (gvom.py:1011-1012)
-            {
-                for (int m = 0; m < 10; ++m) { stat_sums[(size_t)row * 10 + m] = 0.0; stat_base[(size_t)row * 10 + m] = 0.0; }
-                stat_rowvox[row] = L;                   // row -> voxel, for the per-row neighbour gather
-            }
+    // some return landed in the grid: the scan will be committed (gvom.py:147-150)
+    if (lanes(ingrid) != 0ull && lane == 0) counters[GVOM_CNT_INGRID] = 1u;
+    // neighbouring returns of a beam end in the same voxel (33 consecutive azimuths at 2 m range):
+    // the first lane of each run of equal voxels adds the whole run
+    const uint32_t key = ingrid ? A : (0xFFFFFF00u | (uint32_t)lane);
+    const uint32_t leftk = (uint32_t)__builtin_amdgcn_update_dpp((int)~key, (int)key, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    const bool ehead = ingrid && leftk != key;
+    const unsigned long long followers = lanes(ingrid) & ~lanes(ehead);
+    if (ingrid && mbits && !GVOM_DBG(P, 4)) atomicMax(&mh[A], mbits);
+    if (ehead && !GVOM_DBG(P, 4)) {
+        const uint32_t run = (uint32_t)__ffsll((long long)~((followers >> lane) >> 1));   // 1 + followers
+        atomicAdd(&hit[A], run);
+        atomicAdd(&total[A], run);
+        tags[(L / P.xy) * P.nseg + ((L % P.xy) >> 6)] = P.epoch;   // stamp the tile (idempotent)
+        // the voxel's compact row = this return's index.  Several runs (other waves) may end in the
+        // same voxel: the last store wins, every candidate is a valid, unique row.
+        state[L] = (int32_t)i;
+        if (stat_sums) {                            // optional statistics: zeroed metrics (gvom.py:1011-1012)
+            for (int m = 0; m < 10; ++m) { stat_sums[(size_t)i * 10 + m] = 0.0; stat_base[(size_t)i * 10 + m] = 0.0; }
+            stat_rowvox[i] = L;                     // row -> voxel, for the per-row neighbour gather
         }
     }
-    if (VAR == 0 && !pass) return;
+}
 
-    // ---- ray ------------------------------------------------------------------------------
-    const float e1 = (float)((double)y / P.xy_res);
-    // slab-sharded runs: a ray whose window-y range cannot touch this rank's rows is not traced at
-    // all (conservative +-2 rows, so the committed updates are unchanged); waves without any
-    // reaching ray leave before the DDA setup.
-    bool reach = pass;
-    if (P.cull && (VAR == 1 || VAR == 2 || VAR == 5 || VAR == 6)) {
-        const float yend_f = e1 - (float)P.origin[1];
-        const float ybeg_f = P.pt0[1] - (float)P.origin[1];
-        const int y0i = (int)floorf(fminf(ybeg_f, yend_f)) - 2, y1i = (int)floorf(fmaxf(ybeg_f, yend_f)) + 2;
-        const bool hit0 = y1i >= P.wlo[0] && y0i < P.whi[0];
-        const bool hit1 = y1i >= P.wlo[1] && y0i < P.whi[1];
-        reach = pass && (hit0 || hit1);
-        if (!__any(reach)) return;                       // wave-uniform
-    }
+// Ray set-up of one return (gvom.py:1093-1118): per-step increments in natural (x, y, z) order, the
+// f64 step length and the length limit of the reference's loop test.
+struct RaySetup { float incx, incy, incz; double step_len, inv_step, lim; bool finite; };
+template <typename T>
+__device__ __forceinline__ RaySetup ray_setup(const ScanParams &P, T x, T y, T z)
+{
     const float e0 = (float)((double)x / P.xy_res);
+    const float e1 = (float)((double)y / P.xy_res);
     const float e2 = (float)((double)z / P.z_res);
     float s0 = e0 - P.pt0[0], s1 = e1 - P.pt0[1], s2 = e2 - P.pt0[2];
     const float ss = (s0 * s0 + s1 * s1) + s2 * s2;
-    const double ray_length = sqrt((double)ss);          // math.sqrt -> f64
+    // math.sqrt -> f64; GVOM_FLAG_CUDA_F32_SQRT: sqrt of the f32 sum in f32, as real
+    // Numba-CUDA types it (gvom.py:1109-1114)
+    const double ray_length = P.f32_sqrt ? (double)sqrtf(ss) : sqrt((double)ss);
     s0 = (float)((double)s0 / ray_length);
     s1 = (float)((double)s1 / ray_length);
     s2 = (float)((double)s2 / ray_length);
@@ -272,7 +275,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     int si = 0;
     if (smax == a1) si = 1;
     if (smax == a2) si = 2;                              // ties: z over y over x
-    // axis permutation kept in registers: (d, o1, o2) = (si, si+1, si+2) mod 3
     const float sd  = si == 0 ? s0 : (si == 1 ? s1 : s2);
     const float so1 = si == 0 ? s1 : (si == 1 ? s2 : s0);
     const float so2 = si == 0 ? s2 : (si == 1 ? s0 : s1);
@@ -281,384 +283,223 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const float inc1 = so1 / adom;
     const float inc2 = so2 / adom;
     const double step_len = fabs(1.0 / (double)sd);
-    float pd = si == 0 ? P.pt0[0] : (si == 1 ? P.pt0[1] : P.pt0[2]);
-    float p1 = si == 0 ? P.pt0[1] : (si == 1 ? P.pt0[2] : P.pt0[0]);
-    float p2 = si == 0 ? P.pt0[2] : (si == 1 ? P.pt0[0] : P.pt0[1]);
-    double length = 0.0;
     const double lim = ray_length - 1.0;
-
-    if (VAR == 0 || VAR == 9) {
-        uint32_t sink = 0;
-        while (length < lim) {
-            pd = pd + dir; p1 = p1 + inc1; p2 = p2 + inc2;
-            const float px = si == 0 ? pd : (si == 1 ? p2 : p1);
-            const float py = si == 0 ? p1 : (si == 1 ? pd : p2);
-            const float pz = si == 0 ? p2 : (si == 1 ? p1 : pd);
-            const double fx = floor((double)px - P.origin[0]);
-            if (!(fx >= 0.0 && fx < dxy)) break;
-            const double fy = floor((double)py - P.origin[1]);
-            if (!(fy >= 0.0 && fy < dxy)) break;
-            const double fz = floor((double)pz - P.origin[2]);
-            if (!(fz >= 0.0 && fz < dzs)) break;
-            const int sy = wrap_add((int)fy, P.om[1], P.xy);
-            if (sy >= P.sy_lo && sy < P.sy_hi) {
-                const int sx = wrap_add((int)fx, P.om[0], P.xy);
-                const int sz = wrap_add((int)fz, P.om[2], P.zs);
-                const uint32_t Ls = acc_idx(sx, sy, sz, P.zs, P.sxq);
-                if (VAR == 0) {
-                    atomicAdd(&total[Ls], 1u);
-                    const uint32_t tile = ((uint32_t)sy * P.zs + sz) * P.nseg + (sx >> 6);
-                    tags[tile] = P.epoch;
-                } else sink += Ls;
-            }
-            length += step_len;
-        }
-        if (VAR == 9 && sink == 0xdeadbeefu) counters[GVOM_CNT_INGRID] = sink;   // keep the arithmetic alive
-        return;
-    }
-
-    // ---- VAR 5 / 6: the production loop ----------------------------------------------------------
-    // Same lock-step, run-merged scheme as VAR 1 with a much shorter step body (the kernel is
-    // VALU-issue-bound once the atomics are merged):
-    //  * the ray state is kept in natural (x, y, z) order -- the same three f32 additions per step
-    //    as the reference's (dominant, other, other) triple, without the axis permutation;
-    //  * the window origin is an integer (gvom.py:124-126 floors it), so
-    //    floor((double)p - origin) == (int)floorf(p) - origin: no f64 in the voxel lookup.  The
-    //    f64 subtraction is exact except when p lies within half an f64 ulp below an integer, which
-    //    an f32 p can only do below 0 (|p| < 2^-37 for in-grid results, given |origin| < 2^30, which
-    //    the host checks before selecting this variant); such steps take the literal f64 path;
-    //  * the left neighbour's key comes from a DPP wave shift instead of an LDS permute;
-    //  * VAR 6 adds the wave-private LDS line cache (lc_flush): 0.96 M -> 0.47 M memory-side requests.
-    if (VAR == 5 || VAR == 6) {
-        const float incx = si == 0 ? dir : (si == 1 ? inc2 : inc1);
-        const float incy = si == 0 ? inc1 : (si == 1 ? dir : inc2);
-        const float incz = si == 0 ? inc2 : (si == 1 ? inc1 : dir);
-        float px = P.pt0[0], py = P.pt0[1], pz = P.pt0[2];
-        if (seg > 0) {
-            // The reference stops at the FIRST step outside the grid (gvom.py:1135-1144).  The steps
-            // inside the grid form one interval (monotone coordinates, convex box), so a later
-            // segment may only run if step 1 is inside -- otherwise the ray (sensor outside the
-            // window, possible when a grid dimension is 1) would be picked up where it ENTERS.
-            const double g0 = floor((double)(px + incx) - P.origin[0]);
-            const double g1 = floor((double)(py + incy) - P.origin[1]);
-            const double g2 = floor((double)(pz + incz) - P.origin[2]);
-            if (!(g0 >= 0.0 && g0 < dxy && g1 >= 0.0 && g1 < dxy && g2 >= 0.0 && g2 < dzs)) reach = false;
-        }
-        const int seg_first = P.seg_start[seg], seg_steps = P.seg_start[seg + 1] - seg_first;   // this wave's steps: (seg_first, seg_first + seg_steps]
-        for (int j = seg_first; j > 0; --j) {            // replay earlier segments (see SEGMENTS)
-            px += incx; py += incy; pz += incz;
-            length += step_len;
-        }
-        // steps this wave may still take: every active lane has taken the same number, so the
-        // counter is wave-uniform (scalar)
-        int left = (seg == P.nsegs - 1) ? INT_MAX : seg_steps;
-        // non-finite increments (degenerate returns): the reference's first step lands on NaN/inf,
-        // which is outside the grid, and the ray ends without an update
-        const bool finite = fabsf(incx) < INFINITY && fabsf(incy) < INFINITY && fabsf(incz) < INFINITY;
-        bool active = reach && finite && (length < lim);
-        int ystop_lo = INT_MIN, ystop_hi = INT_MAX;
-        const uint32_t Ox = (uint32_t)(int)P.origin[0], Oy = (uint32_t)(int)P.origin[1], Oz = (uint32_t)(int)P.origin[2];
-        if (CULL && P.cull) {
-            const float ynow = py - (float)P.origin[1];
-            const float yseg = (seg == P.nsegs - 1) ? (e1 - (float)P.origin[1]) : ynow + incy * (float)(seg_steps + 1);
-            const int a0 = (int)floorf(fminf(ynow, yseg)) - 2, a1 = (int)floorf(fmaxf(ynow, yseg)) + 2;
-            const bool h0 = a1 >= P.wlo[0] && a0 < P.whi[0];
-            const bool h1 = a1 >= P.wlo[1] && a0 < P.whi[1];
-            active = active && (h0 || h1);
-            if (!__any(active)) return;                  // wave-uniform
-            const int lo = min(P.wlo[0], P.wlo[1] < P.whi[1] ? P.wlo[1] : P.wlo[0]);
-            const int hi = max(P.whi[0], P.wlo[1] < P.whi[1] ? P.whi[1] : P.whi[0]);
-            if (incy > 0.0f) ystop_hi = hi + 1;
-            else if (incy < 0.0f) ystop_lo = lo - 2;
-        }
-        __shared__ __attribute__((aligned(16))) uint32_t s_keys[VAR == 6 ? 4 * 64 : 4];
-        __shared__ uint32_t s_cnt[VAR == 6 ? 4 * 1024 : 1];
-        uint32_t *lck = s_keys + (VAR == 6 ? (threadIdx.x >> 6) * 64 : 0);
-        uint32_t *lcc = s_cnt + (VAR == 6 ? (threadIdx.x >> 6) * 1024 : 0);
-        uint32_t lc_fill = 0, memo = LC_EMPTY; int memo_slot = 0;
-        if (VAR == 6) {
-            LC_ST(&lck[lane], LC_EMPTY);
-#pragma unroll
-            for (int c = 0; c < 16; ++c) LC_ST(&lcc[c * 64 + lane], 0u);
-        }
-        const uint32_t uxy = (uint32_t)P.xy, uzs = (uint32_t)P.zs;
-        const uint32_t om0 = (uint32_t)P.om[0], om1 = (uint32_t)P.om[1], om2 = (uint32_t)P.om[2];
-        const uint32_t slab_lo = (uint32_t)P.sy_lo, slab_n = (uint32_t)(P.sy_hi - P.sy_lo);
-        if (P.dbg & 8) active = false;
-        while (__any(active)) {
-            --left;
-            bool commit = false;
-            uint32_t Ls = 0, sx = 0, sy = 0, sz = 0;
-            if (active) {
-                px += incx; py += incy; pz += incz;
-                uint32_t wx, wy, wz;                                      // window voxel (wraps when outside)
-                if (fminf(fminf(fabsf(px), fabsf(py)), fabsf(pz)) < 0x1p-21f) {
-                    // a coordinate within 2^-21 of zero: the reference's f64 subtraction rounds
-                    // (-tiny) - origin to -origin, i.e. floors it UP; follow it literally (rare)
-                    wx = (uint32_t)(int)floor((double)px - P.origin[0]);
-                    wy = (uint32_t)(int)floor((double)py - P.origin[1]);
-                    wz = (uint32_t)(int)floor((double)pz - P.origin[2]);
-                } else {
-                    wx = (uint32_t)(int)floorf(px) - Ox;
-                    wy = (uint32_t)(int)floorf(py) - Oy;
-                    wz = (uint32_t)(int)floorf(pz) - Oz;
-                }
-                if (wx < uxy && wy < uxy && wz < uzs) {
-                    sy = min(wy + om1, wy + om1 - uxy);                   // toroidal storage coordinates
-                    if (!CULL || sy - slab_lo < slab_n) {
-                        sx = min(wx + om0, wx + om0 - uxy);
-                        sz = min(wz + om2, wz + om2 - uzs);
-                        Ls = acc_idx((int)sx, (int)sy, (int)sz, P.zs, P.sxq);
-                        commit = true;
-                    }
-                    length += step_len;
-                    active = length < lim && left > 0;
-                    if (CULL) active = active && (int)wy < ystop_hi && (int)wy > ystop_lo;
-                } else {
-                    active = false;                                       // ray left the grid (gvom.py:1135-1144)
-                }
-            }
-            const unsigned long long cmask = __ballot(commit);
-            if (cmask == 0ull) continue;                                  // wave-uniform
-            // merge runs of equal voxel indices among neighbouring lanes
-            const uint32_t key = commit ? Ls : (0xFFFFFF00u | (uint32_t)lane);
-            const uint32_t leftk = (uint32_t)__builtin_amdgcn_update_dpp((int)~key, (int)key, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-            const bool head = commit && leftk != key;
-            const unsigned long long nh = cmask & ~__ballot(head);       // followers
-            if (head && !(P.dbg & 16)) {
-                const unsigned long long after = (nh >> lane) >> 1;
-                const uint32_t run = (uint32_t)__ffsll((long long)~after);   // 1 + followers
-                if (VAR == 6) {
-                    // memo: the (line, row-in-line) this lane added to last; a miss looks the line up
-                    // (or inserts it) and stamps the voxel's tile tag
-                    const uint32_t line = Ls >> 4, lrow = Ls >> 2;
-                    int slot = -1;
-                    if (lrow == memo) slot = memo_slot;
-                    else {
-                        // direct-mapped: 4 x 4 patches x 4 z levels around wherever the bundle is
-                        const uint32_t hh = ((sz & 3u) << 4) | (((sy >> 2) & 3u) << 2) | ((sx >> 2) & 3u);
-                        const uint32_t was = atomicCAS(&lck[LC_KEYPOS(hh)], LC_EMPTY, line);
-                        if (was == LC_EMPTY || was == line) slot = (int)hh;
-                        if (!(P.dbg & 2)) tags[(sy * uzs + sz) * (uint32_t)P.nseg + (sx >> 6)] = P.epoch;
-                        if (slot >= 0) { memo = lrow; memo_slot = slot; }
-                    }
-                    if (slot >= 0) atomicAdd(&lcc[slot * 16 + (int)(Ls & 15u)], run);
-                    else atomicAdd(&total[Ls], run);                      // table congested: direct add
-                } else {
-                    atomicAdd(&total[Ls], run);
-                    tags[(sy * uzs + sz) * (uint32_t)P.nseg + (sx >> 6)] = P.epoch;
-                }
-            }
-            if (VAR == 6 && ++lc_fill == (uint32_t)P.lc_period) {                      // wave-uniform
-                lc_flush(lck, lcc, total, lane, P.dbg);
-                lc_fill = 0; memo = LC_EMPTY;
-            }
-        }
-        if (VAR == 6 && lc_fill != 0u) lc_flush(lck, lcc, total, lane, P.dbg);
-        return;
-    }
-
-    // ---- VAR 1: lock-step, run-merged (VAR 2: same + diagnostic counters) -------------------
-    if (seg > 0) {
-        // later segments only run if step 1 lies inside the grid (the reference stops at the first
-        // step outside; the inside steps form one interval -- see the VAR 5/6 loop)
-        const float q0 = pd + dir, q1 = p1 + inc1, q2 = p2 + inc2;
-        const double g0 = floor((double)(si == 0 ? q0 : (si == 1 ? q2 : q1)) - P.origin[0]);
-        const double g1 = floor((double)(si == 0 ? q1 : (si == 1 ? q0 : q2)) - P.origin[1]);
-        const double g2 = floor((double)(si == 0 ? q2 : (si == 1 ? q1 : q0)) - P.origin[2]);
-        if (!(g0 >= 0.0 && g0 < dxy && g1 >= 0.0 && g1 < dxy && g2 >= 0.0 && g2 < dzs)) reach = false;
-    }
-    // replay the steps of earlier segments (exact accumulation; see SEGMENTS above)
-    for (int j = seg * P.seg_len; j > 0; --j) {
-        pd = pd + dir; p1 = p1 + inc1; p2 = p2 + inc2;
-        length += step_len;
-    }
-    int left = (seg == P.nsegs - 1) ? INT_MAX : P.seg_len;             // steps this wave may take
-    bool active = reach && (length < lim);
-    // ... and a ray is dropped once it has moved past the slab's rows (y is monotone along a ray)
-    const float sy_dir = si == 1 ? sd : (si == 0 ? so1 : so2);           // slope of the y axis
-    int ystop_lo = INT_MIN, ystop_hi = INT_MAX;
-    if (P.cull) {
-        // this SEGMENT's window-y range (conservative +-2 rows): segments that only cross other
-        // ranks' rows are dropped, so a rank steps (almost) only through its own slab
-        const float ynow = (si == 1 ? pd : (si == 0 ? p1 : p2)) - (float)P.origin[1];
-        const float yinc = si == 1 ? dir : (si == 0 ? inc1 : inc2);
-        const float yseg = (seg == P.nsegs - 1) ? (e1 - (float)P.origin[1]) : ynow + yinc * (float)(P.seg_len + 1);
-        const int a0 = (int)floorf(fminf(ynow, yseg)) - 2, a1 = (int)floorf(fmaxf(ynow, yseg)) + 2;
-        const bool h0 = a1 >= P.wlo[0] && a0 < P.whi[0];
-        const bool h1 = a1 >= P.wlo[1] && a0 < P.whi[1];
-        active = active && (h0 || h1);
-        if (!__any(active)) return;                      // wave-uniform
-    }
-    if (P.cull && active) {
-        const int lo = min(P.wlo[0], P.wlo[1] < P.whi[1] ? P.wlo[1] : P.wlo[0]);
-        const int hi = max(P.whi[0], P.wlo[1] < P.whi[1] ? P.whi[1] : P.whi[0]);
-        if (sy_dir > 0.0f) ystop_hi = hi + 1;            // moving towards +y: done beyond the last owned row
-        else if (sy_dir < 0.0f) ystop_lo = lo - 2;
-    }
-    uint32_t n_heads = 0, n_lines = 0, n_instr = 0;      // VAR 2 only
-    while (__any(active)) {
-        bool commit = false;
-        uint32_t Ls = 0, Ts = 0;
-        if (active) {
-            pd = pd + dir; p1 = p1 + inc1; p2 = p2 + inc2;
-            const float px = si == 0 ? pd : (si == 1 ? p2 : p1);
-            const float py = si == 0 ? p1 : (si == 1 ? pd : p2);
-            const float pz = si == 0 ? p2 : (si == 1 ? p1 : pd);
-            const double fx = floor((double)px - P.origin[0]);
-            const double fy = floor((double)py - P.origin[1]);
-            const double fz = floor((double)pz - P.origin[2]);
-            if (fx >= 0.0 && fx < dxy && fy >= 0.0 && fy < dxy && fz >= 0.0 && fz < dzs) {
-                const int sy = wrap_add((int)fy, P.om[1], P.xy);
-                if (sy >= P.sy_lo && sy < P.sy_hi) {
-                    const int sx = wrap_add((int)fx, P.om[0], P.xy);
-                    const int sz = wrap_add((int)fz, P.om[2], P.zs);
-                    Ls = acc_idx(sx, sy, sz, P.zs, P.sxq);   // accumulator index: the merge key and the atomic's target
-                    Ts = ((uint32_t)sy * P.zs + sz) * P.nseg + (sx >> 6);
-                    commit = true;
-                }
-                length += step_len;
-                active = length < lim && --left > 0 && (int)fy < ystop_hi && (int)fy > ystop_lo;
-            } else {
-                active = false;                           // ray left the grid (gvom.py:1135-1144)
-            }
-        }
-        if (!__any(commit)) continue;                     // nothing to add in this step (wave-uniform)
-        // merge runs of equal voxel indices among neighbouring lanes
-        const uint32_t key = commit ? Ls : (0xFFFFFF00u | (uint32_t)lane);   // > any voxel index
-        const uint32_t left = (uint32_t)__shfl_up((int)key, 1);
-        const bool head = commit && (lane == 0 || left != key);
-        const unsigned long long cmask = __ballot(commit);
-        const unsigned long long nh = cmask & ~__ballot(head);               // followers
-        if (head) {
-            const unsigned long long after = (nh >> lane) >> 1;
-            const uint32_t run = (uint32_t)__ffsll((long long)~after);       // 1 + followers
-            atomicAdd(&total[Ls], run);
-            tags[Ts] = P.epoch;                                              // stamp the tile (idempotent store)
-        }
-        if (VAR == 2) {                                   // diagnostic: heads, distinct 64-B lines, instructions
-            const unsigned long long hm = __ballot(head);
-            const uint32_t lkey = head ? (Ls >> 4) : (0xFFFFFF00u | (uint32_t)lane);
-            // previous head's line: scan left for the nearest head lane
-            const unsigned long long below = hm & lanemask_lt();
-            const int prev = below ? 63 - __clzll((long long)below) : lane;
-            const uint32_t pl = (uint32_t)__shfl((int)lkey, prev);
-            const bool newline = head && (below == 0ull || pl != lkey);
-            const unsigned long long nlm = __ballot(newline);
-            n_heads += (uint32_t)__popcll(hm); n_lines += (uint32_t)__popcll(nlm); n_instr += hm ? 1u : 0u;
-        }
-    }
-    if (VAR == 2 && lane == 0) { atomicAdd(&counters[4], n_heads); atomicAdd(&counters[5], n_lines); atomicAdd(&counters[6], n_instr); }
+    // natural (x, y, z) order: the same three f32 additions per step as the reference's
+    // (dominant, other, other) triple, without the axis permutation
+    const float incx = si == 0 ? dir : (si == 1 ? inc2 : inc1);
+    const float incy = si == 0 ? inc1 : (si == 1 ? dir : inc2);
+    const float incz = si == 0 ? inc2 : (si == 1 ? inc1 : dir);
+    // non-finite increments (degenerate returns): the reference's first step lands on NaN/inf,
+    // which is outside the grid, and the ray ends without an update
+    const bool finite = fabsf(incx) < INFINITY && fabsf(incy) < INFINITY && fabsf(incz) < INFINITY;
+    RaySetup R;
+    R.incx = incx; R.incy = incy; R.incz = incz; R.step_len = step_len; R.inv_step = fabs((double)sd); R.lim = lim; R.finite = finite;
+    return R;
 }
 
 // ------------------------------------------------------------------------------------------
-// k_encode: visits only the tiles k_trace stamped with this scan's epoch (one wave per tile, four
-// tiles in flight per wave).  Per voxel of a dirty tile:
-//   occupied (hit > 0): row was claimed in k_trace -> move hit/total to the compact arrays,
-//                       initialise min-height to 1.0f                  gvom.py:1164-1168,1014
+// walk_steps: at most `steps` lock-step DDA steps of a 64-ray bundle, total += 1 per step
+// (gvom.py:1119-1150).  The step body is straight-line: ray state in natural (x,y,z) order, voxel
+// lookup in 32-bit integers (window_voxel), left neighbour's key by a DPP wave shift; lanes stepping
+// into the same voxel as their left neighbour are merged (2 ballots + run length) and the merged adds
+// go into the wave-private LDS line cache (lc_flush), flushed every `period` committing steps with
+// one memory-side request per line; tile tags stamped on cache misses only.
+// ------------------------------------------------------------------------------------------
+template <bool LIT, bool P2>
+__device__ __forceinline__ void walk_steps(const ScanParams &P, int lane, uint32_t j, uint32_t cnt, float px, float py, float pz,
+                                           float incx, float incy, float incz, bool active, int steps, int period,
+                                           uint32_t *lck, uint32_t *lcc, uint32_t *total, uint32_t *tags)
+{
+    const uint32_t uxy = (uint32_t)P.xy, uzs = (uint32_t)P.zs, usxq = (uint32_t)P.sxq, unseg = (uint32_t)P.nseg;
+    const uint32_t om0 = (uint32_t)P.om[0], om1 = (uint32_t)P.om[1], om2 = (uint32_t)P.om[2];
+    lds_u32 *const keys3 = (lds_u32 *)lck;
+    lds_u32 *const cnt3 = (lds_u32 *)lcc;
+    glb_u32 *const total1 = (glb_u32 *)total;
+    uint32_t memo = LC_EMPTY; int memo_slot = 0;
+    int dirty = 0;                                        // committing steps since the last flush
+    for (int left = steps; left > 0 && lanes(active) != 0ull; --left) {
+        ++j;
+        // every lane computes (a finished ray's lanes produce values nobody uses): no divergent
+        // region around the arithmetic
+        px += incx; py += incy; pz += incz;
+        uint32_t wx, wy, wz;                                              // window voxel
+        const bool inw = window_voxel<LIT>(P, px, py, pz, wx, wy, wz);
+        const bool commit = active & inw;
+        active = commit & (j < cnt);                                      // gvom.py:1127 (length test), 1135-1144 (left the grid)
+        const unsigned long long cmask = lanes(commit);
+        if (cmask == 0ull) break;                                         // wave-uniform: no lane is active any more
+        if (dirty == period) { lc_flush(P, lck, lcc, total, lane); dirty = 0; memo = LC_EMPTY; }
+        ++dirty;
+        uint32_t sx, sy, sz;                                              // toroidal storage coordinates
+        if (P2) { sx = (wx + om0) & (uxy - 1u); sy = (wy + om1) & (uxy - 1u); sz = (wz + om2) & (uzs - 1u); }
+        else { sx = min(wx + om0, wx + om0 - uxy); sy = min(wy + om1, wy + om1 - uxy); sz = min(wz + om2, wz + om2 - uzs); }
+        const uint32_t Ls = acc_idx24(sx, sy, sz, uzs, usxq);
+        // merge runs of equal voxel indices among neighbouring lanes
+        const uint32_t key = commit ? Ls : (0xFFFFFF00u | (uint32_t)lane);
+        const uint32_t leftk = (uint32_t)__builtin_amdgcn_update_dpp((int)~key, (int)key, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+        const bool head = commit & (leftk != key);
+        const unsigned long long hm = lanes(head);
+        // a run ends in front of the next head or of the next lane without a step
+        const unsigned long long ends = (hm | ~cmask) >> 1;
+        if (head && !GVOM_DBG(P, 16)) {
+            // memo: the (line, row-in-line) this lane added to last; a miss looks the line up
+            // (or inserts it) and stamps the voxel's tile tag
+            const uint32_t line = Ls >> 4, lrow = Ls >> 2;
+            const bool miss = lrow != memo;
+            // direct-mapped: 4 x 4 patches x 4 z levels around wherever the bundle is
+            const uint32_t hh = ((sz & 3u) << 4) | (((sy >> 2) & 3u) << 2) | ((sx >> 2) & 3u);
+            uint32_t was = LC_EMPTY;
+            if (miss) {
+                __hip_atomic_compare_exchange_strong(&keys3[LC_KEYPOS(hh)], &was, line, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (!GVOM_DBG(P, 2)) tags[mad24s(mad24s(sy, uzs, sz), unseg, sx >> 6)] = P.epoch;
+            }
+            // (independent of the look-up: issued while the LDS compare-and-swap is in flight)
+            const unsigned long long after = ends >> lane;
+            const uint32_t run = after ? (uint32_t)__ffsll((long long)after) : (uint32_t)(64 - lane);   // lanes in my run
+            int slot = memo_slot;
+            if (miss) {
+                slot = (was == LC_EMPTY || was == line) ? (int)hh : -1;
+                if (slot >= 0) { memo = lrow; memo_slot = slot; }
+            }
+            if (slot >= 0) __hip_atomic_fetch_add(&cnt3[slot * 16 + (int)(Ls & 15u)], run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else __hip_atomic_fetch_add(&total1[Ls], run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // table congested: direct add
+        }
+    }
+    if (dirty) lc_flush(P, lck, lcc, total, lane);
+}
+
+// Dispatch of the four step-loop forms: literal f64 lookup iff a coordinate of some active ray may come
+// within 2^-21 of zero during these `steps` steps (or the origin is beyond 2^30); power-of-two grids
+// wrap by masking.
+template <bool BIG>
+__device__ __forceinline__ void walk_item(const ScanParams &P, int lane, uint32_t j, uint32_t cnt, float px, float py, float pz,
+                                          float incx, float incy, float incz, bool active, int steps, int period,
+                                          uint32_t *lck, uint32_t *lcc, uint32_t *total, uint32_t *tags)
+{
+    // (the positions visited run monotonically from p + inc -- the first one, an exact f32 add as in
+    // the loop -- to about p + steps * inc; the margin is far above the rounding of that estimate, which
+    // is below steps * ulp(steps) wherever the hull is near zero; NaN estimates compare false: such a
+    // lane is inactive or leaves the grid at once)
+    bool lit = BIG;
+    if (!BIG) {
+        const float fs = (float)min((uint32_t)steps, cnt - j);            // steps this ray can still take here (active lanes: cnt > j)
+        const float ax = px + incx, ay = py + incy, az = pz + incz;
+        const float qx = px + fs * incx, qy = py + fs * incy, qz = pz + fs * incz;
+        const bool nz = (fminf(ax, qx) <= 1e-4f && fmaxf(ax, qx) >= -1e-4f) || (fminf(ay, qy) <= 1e-4f && fmaxf(ay, qy) >= -1e-4f) ||
+                        (fminf(az, qz) <= 1e-4f && fmaxf(az, qz) >= -1e-4f);
+        lit = lanes(active & nz) != 0ull;
+    }
+    const bool p2 = ((P.xy & (P.xy - 1)) | (P.zs & (P.zs - 1))) == 0;
+    if (lit) {
+        if (p2) walk_steps<true, true>(P, lane, j, cnt, px, py, pz, incx, incy, incz, active, steps, period, lck, lcc, total, tags);
+        else walk_steps<true, false>(P, lane, j, cnt, px, py, pz, incx, incy, incz, active, steps, period, lck, lcc, total, tags);
+    } else {
+        if (p2) walk_steps<false, true>(P, lane, j, cnt, px, py, pz, incx, incy, incz, active, steps, period, lck, lcc, total, tags);
+        else walk_steps<false, false>(P, lane, j, cnt, px, py, pz, incx, incy, incz, active, steps, period, lck, lcc, total, tags);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_trace.  Grid (ceil(N/256), nsegs + 1): row P.ep_row holds the endpoint
+// blocks (endpoint_update), every other row one STEP SEGMENT of the rays: a wave sets its 64 rays up
+// (ray_setup, ray_steps), replays the steps of the earlier segments -- three f32 additions per step,
+// the reference's exact accumulation, no lookup, no memory traffic -- and runs the step body for its
+// own steps (seg_start[s], seg_start[s+1]]; the last segment is open-ended.  Coordinates are monotone,
+// so "the ray has already ended before step k" is decided by the state AT step k alone, given that
+// step 1 lies inside the grid, which every wave checks.
+// ------------------------------------------------------------------------------------------
+template <typename T, bool BIG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_trace(
+    const ScanParams P, const T *__restrict__ in, long stride, long n, T *__restrict__ world, uint32_t *hit,
+    uint32_t *total, uint32_t *mh, int32_t *state, uint32_t *tags, uint32_t *counters, double *stat_sums,
+    double *stat_base, uint32_t *stat_rowvox)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < n;
+    T x = 0, y = 0, z = 0;
+    if (live) load_return(P, in, stride, i, x, y, z);
+    const T d2 = (x * x + y * y) + z * z;
+    const bool pass = live && !((double)d2 < P.min_d2);
+    if ((int)blockIdx.y == P.ep_row) {
+        if (live && world) { world[3 * i + 0] = x; world[3 * i + 1] = y; world[3 * i + 2] = z; }   // statistics only
+        endpoint_update<T>(P, lane, i, pass, x, y, z, hit, total, mh, state, tags, counters, stat_sums, stat_base, stat_rowvox);
+        return;
+    }
+    const int seg = (int)blockIdx.y - ((int)blockIdx.y > P.ep_row ? 1 : 0);
+    const uint32_t j0 = (uint32_t)P.seg_start[seg];
+    // ---- later segments: leave before the f64 set-up when no ray of the wave can still be running ----
+    // After j0 steps `length` is >= j0 * (1 - 2^-22) (every step adds |1 / sd| with |sd| <= 1 + 2^-23),
+    // and a ray stops once length >= ray_length - 1 (gvom.py:1127): a ray with ray_length <= j0 + 0.9
+    // takes no step in this segment.  Decided conservatively in f32 from the raw return, with a
+    // margin far above the rounding of this estimate; NaN/inf compare false and take the full path.
+    if (seg > 0) {
+        const float ax = (float)x * P.rinv[0], ay = (float)y * P.rinv[0], az = (float)z * P.rinv[1];
+        const float ux = ax - P.pt0[0], uy = ay - P.pt0[1], uz = az - P.pt0[2];
+        const float r = sqrtf((ux * ux + uy * uy) + uz * uz);
+        const float mag = ((fabsf(ax) + fabsf(ay)) + fabsf(az)) + ((fabsf(ux) + fabsf(uy)) + fabsf(uz));
+        const bool dead = !pass || (r + (r * 1e-5f + mag * 4e-6f) <= (float)j0 + 0.9f);
+        if (lanes(!dead) == 0ull) return;                                // wave-uniform
+    }
+    const RaySetup R = ray_setup<T>(P, x, y, z);
+    float px = P.pt0[0], py = P.pt0[1], pz = P.pt0[2];
+    bool run = pass && R.finite;
+    if (run) {                                           // step 1 outside the grid: no step at all
+        uint32_t wx, wy, wz;
+        run = window_voxel<true>(P, px + R.incx, py + R.incy, pz + R.incz, wx, wy, wz);
+    }
+    const uint32_t cnt = run ? ray_steps(R.lim, R.step_len, R.inv_step, 0x7ffffff0u) : 0u;     // steps the length test allows
+    const bool active = j0 < cnt && !GVOM_DBG(P, 8);
+    if (lanes(active) == 0ull) return;                   // wave-uniform: every ray of the bundle ends earlier
+    for (uint32_t k = j0; k > 0; --k) { px += R.incx; py += R.incy; pz += R.incz; }   // replay (exact accumulation)
+    __shared__ __attribute__((aligned(16))) uint32_t s_keys[4 * 64];
+    __shared__ uint32_t s_cnt[4 * 1024];
+    uint32_t *lck = s_keys + (threadIdx.x >> 6) * 64;
+    uint32_t *lcc = s_cnt + (threadIdx.x >> 6) * 1024;
+    LC_ST(&lck[lane], LC_EMPTY);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) LC_ST(&lcc[q * 64 + lane], 0u);
+    const int steps = seg == P.nsegs - 1 ? 0x3fffffff : P.seg_start[seg + 1] - (int)j0;
+    walk_item<BIG>(P, lane, j0, cnt, px, py, pz, R.incx, R.incy, R.incz, active, steps, P.lc_period, lck, lcc, total, tags);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_encode: visits only the tiles k_trace stamped with this scan's epoch.  Per voxel of a dirty tile:
+//   occupied (hit > 0): its row is the index of one of its returns (k_trace's endpoint blocks left it
+//                       in state[]) -> move hit / total / min-height to the compact arrays
+//                                                                      gvom.py:1164-1168,1303-1329
 //   else              : state = -total - 1                             gvom.py:1160
 //   and the accumulators are zeroed for the next scan (replaces the fills of gvom.py:114-121).
 // Untouched tiles are neither read nor written: their tag != epoch makes every consumer treat
 // them as "never observed" (-1), which is what the reference's -1 fill + __assign_indices yield.
-//
-// The same launch also carries the min-height pass (gvom.py:1303-1329) in its trailing blocks
-// [0, mh_blocks): one lane per return, f32 atomic-min of the fractional z inside its
-// voxel, keyed by the voxel's compact row.  The value is a - floor(a) >= 0, so the float order
-// equals the order of its bit pattern and an unsigned atomicMin is exact.  It only needs what
-// k_trace left behind (row ids of occupied voxels, rows initialised to 1.0f), and the encode
-// blocks never write those words, so both parts run concurrently.
+// Min-height arrives as a third dense accumulator (1.0f's bits minus the value's bits, atomicMax:
+// zero between scans like the other two), read only where a voxel is occupied.
 // ------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void k_encode(const ScanParams P, unsigned enc_blocks, unsigned mh_blocks,
-                                                uint32_t t_begin, uint32_t t_end,
-                                                uint32_t *hit, uint32_t *total, int32_t *state,
+__global__ __launch_bounds__(256) void k_encode(const ScanParams P, uint32_t t_begin, uint32_t t_end,
+                                                uint32_t *hit, uint32_t *total, uint32_t *mh, int32_t *state,
                                                 uint32_t *chit, uint32_t *ctotal, uint32_t *cminh,
                                                 const uint32_t *__restrict__ tags, uint32_t epoch,
-                                                const T *__restrict__ world, long n,
                                                 uint32_t *counters, unsigned long long *host_flag,
                                                 uint32_t seq)
 {
     const int xy = P.xy, nseg = P.nseg;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        // k_trace has completed: the scan's row count is final.  Publish {seq, count} as ONE
-        // 8-byte system-scope store to host-mapped memory (the host spins on it and returns to
-        // its caller while this kernel and k_minh still run) and re-arm the counter.
-        const uint32_t c = counters[GVOM_CNT_ROWS];
-        const uint32_t any = counters[GVOM_CNT_INGRID] ? 0x80000000u : 0u;     // some return landed in the grid (any rank)
-        counters[GVOM_CNT_ROWS] = 0; counters[GVOM_CNT_INGRID] = 0;
-        // order vote for k_trace (see there): long rays per cloud half -> 64-bit word 2 of the host block (1: second half is
-        // heavier, walk the cloud backwards; 0: forwards; 2: no clear difference, keep the order)
-        // (counted by the min-height blocks of the PREVIOUS scan's launch -- this launch's are adding to
-        // the other pair of counters right now)
-        const uint32_t vb = GVOM_CNT_VOTE + ((seq & 1u) ? 0u : 32u);
-        const uint32_t v0 = counters[vb], v1 = counters[vb + 16];
-        counters[vb] = 0; counters[vb + 16] = 0;
-        const unsigned long long verdict = (unsigned long long)v1 * 8 > (unsigned long long)v0 * 9 ? 1ull : ((unsigned long long)v0 * 8 > (unsigned long long)v1 * 9 ? 0ull : 2ull);
-        __hip_atomic_store(host_flag + 2, ((unsigned long long)seq << 32) | verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        counters[8] = c; counters[9] = 0;               // device-side copy (int64) for sharded runs
-        __hip_atomic_store(host_flag, ((unsigned long long)seq << 32) | any | c, __ATOMIC_RELEASE,
+        // k_trace has completed.  Publish {seq, any-in-grid} as ONE 8-byte system-scope store to
+        // host-mapped memory (the host spins on it and returns to its caller while this kernel
+        // still runs) and re-arm the flag.
+        const uint32_t any = counters[GVOM_CNT_INGRID] ? 0x80000000u : 0u;     // some return landed in the grid
+        counters[GVOM_CNT_INGRID] = 0;
+        __hip_atomic_store(host_flag, ((unsigned long long)seq << 32) | any, __ATOMIC_RELEASE,
                            __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    // The min-height blocks come FIRST in the grid: their dependent chain (point -> state -> atomicMin)
-    // then hides under the encode blocks instead of forming the kernel's tail.  They only read rows
-    // that k_trace claimed; the encode blocks rewrite those state words with the same value.
-    if (blockIdx.x < mh_blocks) {                        // ---- min-height blocks ----
-        if (P.dbg & 128) return;
-        const int lane = threadIdx.x & (WAVE - 1);
-        const long i = (long)blockIdx.x * 256 + threadIdx.x;
-        int32_t row = -1;
-        uint32_t vbits = 0xFFFFFFFFu;
-        bool longray = false;
-        if (i < n) {
-            const T x = world[3 * i + 0], y = world[3 * i + 1], z = world[3 * i + 2];
-            const T d2 = (x * x + y * y) + z * z;
-            const double qx = (double)x / P.xy_res, qy = (double)y / P.xy_res, qz = (double)z / P.z_res;
-            const double fx = floor(qx - P.origin[0]);
-            const double fy = floor(qy - P.origin[1]);
-            const double az = qz - P.origin[2];
-            const double fz = floor(az);
-            // a ray of about as many dominant-axis steps as k_trace's last segment starts at is "long"
-            const float reach = fmaxf(fmaxf(fabsf((float)qx - P.pt0[0]), fabsf((float)qy - P.pt0[1])), fabsf((float)qz - P.pt0[2]));
-            longray = reach > (float)P.seg_start[P.nsegs - 1];
-            if (!((double)d2 < P.min_d2) && fx >= 0.0 && fx < (double)P.xy && fy >= 0.0 && fy < (double)P.xy &&
-                fz >= 0.0 && fz < (double)P.zs) {
-                const int sy = wrap_add((int)fy, P.om[1], P.xy);
-                if (sy >= P.sy_lo && sy < P.sy_hi) {
-                    const int sx = wrap_add((int)fx, P.om[0], P.xy);
-                    const int sz = wrap_add((int)fz, P.om[2], P.zs);
-                    row = state[((uint32_t)sy * P.zs + sz) * P.xy + sx];
-                    vbits = __float_as_uint((float)(az - fz));   // local_point[2], f64 -> f32 (gvom.py:1326,1329)
-                }
-            }
-        }
-        // Neighbouring returns of a beam land in the same voxel (33 consecutive azimuths at 2 m range):
-        // fold each run of equal rows with a segmented min scan and let its LAST lane issue one atomic
-        // (same-address atomics are served one at a time; with N sensors in one map the near field gets
-        // N times the returns).  min is idempotent, so folding in a same-row lane twice is harmless.
-        const uint32_t key = row >= 0 ? (uint32_t)row : (0xFFFFFF00u | (uint32_t)lane);
-#pragma unroll
-        for (int o = 1; o < WAVE; o <<= 1) {
-            const uint32_t k2 = (uint32_t)__shfl_up((int)key, o), v2 = (uint32_t)__shfl_up((int)vbits, o);
-            if (lane >= o && k2 == key) vbits = min(vbits, v2);
-        }
-        const uint32_t knext = (uint32_t)__shfl_down((int)key, 1);
-        if (row >= 0 && (lane == WAVE - 1 || knext != key)) atomicMin(&cminh[row], vbits);
-        // order vote for the scan after the next one (k_trace "ADAPTIVE CLOUD ORDER"): long rays per
-        // cloud half; counters alternate with the scan's parity so the publishing thread above reads a
-        // finished pair
-        // (every 8th block votes: same-address atomics are served one at a time, 2048 of them cost 10 us)
-        const unsigned long long lm = (blockIdx.x & 7u) == 0u ? __ballot(longray) : 0ull;
-        if (lane == 0 && lm)
-            atomicAdd(&counters[GVOM_CNT_VOTE + ((seq & 1u) ? 32u : 0u) + (2 * i >= n ? 16u : 0u)], (uint32_t)__popcll(lm));
-        return;
-    }
-    // ---- encode blocks: one wave per QUAD = 4 storage rows (sy = 4q .. 4q+3) x 64 sx at one sz,
+    // one wave per QUAD = 4 storage rows (sy = 4q .. 4q+3) x 64 sx at one sz,
     // i.e. 4 tiles = 16 accumulator lines.  Lane (p = lane >> 2, r = lane & 3) owns the 4 voxels
     // sx = 64*seg + 4p .. +3 of row sy = 4q + r: one 16-byte load of hit and of total (its quarter of
     // a 4x4 patch line) and one 16-byte store of state.
     const int lane = threadIdx.x & (WAVE - 1);
-    const uint32_t wid = __builtin_amdgcn_readfirstlane(((blockIdx.x - mh_blocks) * blockDim.x + threadIdx.x) >> 6);
-    const uint32_t nw = (enc_blocks * blockDim.x) >> 6;
+    const uint32_t wid = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const uint32_t nw = (gridDim.x * blockDim.x) >> 6;
     const int p4 = lane >> 2, r = lane & 3;
     const bool vec_state = (xy & 3) == 0;                // 16-byte aligned state rows
     for (uint32_t u0 = t_begin + wid * 2; u0 < t_end; u0 += nw * 2) {
@@ -670,7 +511,7 @@ __global__ __launch_bounds__(256) void k_encode(const ScanParams P, unsigned enc
             const uint32_t syl = q * 4 + (lane & 3);
             const bool ok = lane < 8 && u < t_end && syl < (uint32_t)xy && (int)syl >= P.sy_lo && (int)syl < P.sy_hi;
             const uint32_t tagv = tags[ok ? (syl * P.zs + sz) * nseg + seg : 0];
-            dmask = (P.dbg & 64) ? 0u : (uint32_t)__ballot(ok && tagv == epoch);
+            dmask = GVOM_DBG(P, 64) ? 0u : (uint32_t)__ballot(ok && tagv == epoch);
         }
         if (dmask == 0) continue;                                    // wave-uniform
 #pragma unroll
@@ -690,18 +531,22 @@ __global__ __launch_bounds__(256) void k_encode(const ScanParams P, unsigned enc
             const uint32_t any_h = h[0] | h[1] | h[2] | h[3], any_t = t[0] | t[1] | t[2] | t[3];
 #pragma unroll
             for (int i = 0; i < 4; ++i) st[i] = -(int32_t)t[i] - 1;
-            if (any_h) {                                 // rare: an occupied voxel; its row was claimed in k_trace
+            if (any_h) {                                 // rare: an occupied voxel; its row was left in state[] by k_trace
                 int32_t rows[4];                         // all four fetched before the first use (one round trip)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) rows[i] = state[L0 + ((h[i] > 0 && sx0 + i < (uint32_t)xy) ? (uint32_t)i : 0u)];
+                const uint4 mv = *reinterpret_cast<const uint4 *>(mh + A0);
+                const uint32_t m[4] = {mv.x, mv.y, mv.z, mv.w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     if (h[i] > 0 && sx0 + i < (uint32_t)xy) {
                         chit[rows[i]] = h[i]; ctotal[rows[i]] = t[i];
+                        cminh[rows[i]] = 0x3f800000u - m[i];          // min-height (gvom.py:1014-1015, 1329)
                         st[i] = rows[i];
                     }
                 }
                 *reinterpret_cast<uint4 *>(hit + A0) = make_uint4(0, 0, 0, 0);
+                *reinterpret_cast<uint4 *>(mh + A0) = make_uint4(0, 0, 0, 0);
             }
             if (any_t) *reinterpret_cast<uint4 *>(total + A0) = make_uint4(0, 0, 0, 0);
             if (vec_state) {
@@ -794,7 +639,7 @@ __global__ __launch_bounds__(1024) void k_fuse(const FuseParams P, const FuseDes
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int ss = min(s0 + j, nsrc - 1);
-                const unsigned long long m = (P.debug & 4) ? 0ull : __ballot(valid_l && tv[j] == descs[ss].epoch);
+                const unsigned long long m = GVOM_DBG(P, 4) ? 0ull : __ballot(valid_l && tv[j] == descs[ss].epoch);
                 if (lane == 0 && s0 + j < nsrc) s_live[w][s0 + j] = m;
             }
         }
@@ -895,7 +740,7 @@ __global__ __launch_bounds__(1024) void k_fuse(const FuseParams P, const FuseDes
             const int z = z0 + k;
             const bool occ = (occbits >> k) & 1u;
             const bool inside = col_ok && z < z1;
-            if (!(P.debug & 1) && __any(inside && (occ || c[k] != -1))) {
+            if (!GVOM_DBG(P, 1) && __any(inside && (occ || c[k] != -1))) {
                 const int sz = wrap_add(z < P.zs ? z : 0, P.om[2], P.zs);
                 if (lane == 0) ftags[tbase + (uint32_t)sz * P.nseg] = P.epoch;
                 if (inside) {
@@ -913,7 +758,7 @@ __global__ __launch_bounds__(1024) void k_fuse(const FuseParams P, const FuseDes
         // rows of all occupied z levels are fetched together, then the three compact arrays are
         // gathered in batches of 16 independent loads -- not one dependent chain per voxel.
         for (int kg = 0; kg < 16; kg += 4) {             // groups of 4 z levels keep the registers low
-            const uint32_t gbits = (P.debug & 2) ? 0u : (occbits >> kg) & 0xfu;
+            const uint32_t gbits = GVOM_DBG(P, 2) ? 0u : (occbits >> kg) & 0xfu;
             if (!__any(gbits != 0)) continue;               // wave-uniform: most groups are empty
             uint32_t hh[4], tt[4], mm[4];
 #pragma unroll
@@ -1099,7 +944,7 @@ __global__ __launch_bounds__(1024) void k_fuse4(const FuseParams P, const FuseDe
             for (int j = 0; j < 4; ++j) tv[j] = ((gptr_u32)descs[min(s0 + j, nsrc - 1)].tags)[tl];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const unsigned long long m = (P.debug & 4) ? 0ull : __ballot(valid_l && tv[j] == descs[min(s0 + j, nsrc - 1)].epoch);
+                const unsigned long long m = GVOM_DBG(P, 4) ? 0ull : __ballot(valid_l && tv[j] == descs[min(s0 + j, nsrc - 1)].epoch);
                 if (lane == 0 && s0 + j < nsrc) s_live[w][s0 + j] = m;
             }
         }
@@ -1173,7 +1018,7 @@ __global__ __launch_bounds__(1024) void k_fuse4(const FuseParams P, const FuseDe
 #pragma unroll
             for (int i = 0; i < 4; ++i) nonempty = nonempty || ((occbits >> (4 * j + i)) & 1u) || c[4 * j + i] != -1;
             const unsigned long long nb = __ballot(inside && nonempty);
-            if (((nb >> (16 * q)) & 0xffffull) && !(P.debug & 1)) {           // some lane of MY tile (same q) has content
+            if (((nb >> (16 * q)) & 0xffffull) && !GVOM_DBG(P, 1)) {           // some lane of MY tile (same q) has content
                 if (g == 0 && zq[j] < z1)
                     ftags[tbase + (uint32_t)wrap_add(zq[j], P.om[2], P.zs) * P.nseg] = P.epoch;
                 if (inside) {
@@ -1192,7 +1037,7 @@ __global__ __launch_bounds__(1024) void k_fuse4(const FuseParams P, const FuseDe
         // levels and sources (the per-level, per-source form was a chain of up to 16 round trips).
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const uint32_t gbits = (P.debug & 2) ? 0u : (occbits >> (4 * j)) & 0xfu;
+            const uint32_t gbits = GVOM_DBG(P, 2) ? 0u : (occbits >> (4 * j)) & 0xfu;
             if (!__any(gbits != 0)) continue;               // wave-uniform
             uint32_t n = 0;
 #pragma unroll
@@ -1261,7 +1106,7 @@ __global__ __launch_bounds__(1024) void k_fuse4(const FuseParams P, const FuseDe
         blockcounts[blockIdx.y * gridDim.x + blockIdx.x] = tot;
     }
     const int sx = blockIdx.x * WAVE + lane;
-    if (w == 0 && sx < P.xy && !(P.debug & 16)) {
+    if (w == 0 && sx < P.xy && !GVOM_DBG(P, 16)) {
         const int x = wrap_sub(sx, P.om[0], P.xy);
         unsigned long long zh = ((unsigned long long)INT_MAX << 32) | 0x3f800000ull;
         uint32_t zfu = (uint32_t)INT_MAX;
@@ -1372,7 +1217,7 @@ __global__ __launch_bounds__(512) void k_map2d(const Map2dParams P, const int32_
     const int tx = cell & (M2_TX - 1), ty = cell / M2_TX;
     const int lane = tid & 63, wv = tid >> 6;
     const int X0 = blockIdx.x * M2_TX, Y0 = blockIdx.y * M2_TY;
-    if (host_counter && blockIdx.x == 0 && blockIdx.y == 0 && !(P.dbg & 16)) {
+    if (host_counter && blockIdx.x == 0 && blockIdx.y == 0 && !GVOM_DBG(P, 16)) {
         // k_fuse is complete: publish the fused occupied-voxel count (host-mapped memory)
         __shared__ unsigned long long s_red[512];
         publish_block_counts(blockcounts, nblocks, host_counter, s_red, tid, 512);
@@ -1417,7 +1262,7 @@ __global__ __launch_bounds__(512) void k_map2d(const Map2dParams P, const int32_
     mine = mine && sy0 >= P.y_lo && sy0 < P.y_hi;                      // else: another rank's row
     const int lx = tx + M2_HALO, ly = ty + M2_HALO;
     const size_t c_out = (size_t)y0 * xy + x0;                         // YX: [y][x] (column-major [x, y])
-    const bool wr = !(P.dbg & 1);
+    const bool wr = !GVOM_DBG(P, 1);
     double h00 = -1000.0, inf00 = 0.0, rv = -1.0;
     int dens_pos = 0, pos = 0, negv = 0, visv = 0;           // dens_pos: positive-obstacle density x100 (gvom.py:489-521)
     int8_t *const occ = reinterpret_cast<int8_t *>(out_pos);
@@ -1443,7 +1288,7 @@ __global__ __launch_bounds__(512) void k_map2d(const Map2dParams P, const int32_
 #pragma unroll
             for (int dy = -1; dy <= 1; ++dy)
                 if (ht[ly + dy][lx + dx] > -1000) ++n_good;
-        if (n_good >= 3 && !(P.dbg & 4)) {
+        if (n_good >= 3 && !GVOM_DBG(P, 4)) {
             double mean_x = 0.0, mean_y = 0.0, mean_z = 0.0;
 #pragma unroll
             for (int dx = -1; dx <= 1; ++dx)
@@ -1524,7 +1369,7 @@ __global__ __launch_bounds__(512) void k_map2d(const Map2dParams P, const int32_
     } else {
         const double fmin = floor(((h00 + P.pos_thr) / P.z_res) - P.origin_z) + 1.0;
         const double fmax = floor(((h00 + P.robot_height) / P.z_res) - P.origin_z);
-        if (fmin >= 0 && fmin < (double)P.zs && fmax >= 0 && fmax < (double)P.zs && !(P.dbg & 2)) {
+        if (fmin >= 0 && fmin < (double)P.zs && fmax >= 0 && fmax < (double)P.zs && !GVOM_DBG(P, 2)) {
             const int zmin = (int)fmin, zmax = (int)fmax;
             double density = 0.0, nn = 0.0;
             // 8 levels per round: tags, then states, then counts -- three dependent round trips
@@ -1573,7 +1418,7 @@ __global__ __launch_bounds__(512) void k_map2d(const Map2dParams P, const int32_
     //                   -x: column x0-i, dy in [-i+1, i];  +y: row y0+i, dx in [-i+1, i];
     //                   -y: row y0-i, dx in [-i, i)                               (gvom.py:588-638)
     double dh_out = 0.0;
-    if (!(h00 > -1000 || inf00 == -1000.0) && !(P.dbg & 8)) {
+    if (!(h00 > -1000 || inf00 == -1000.0) && !GVOM_DBG(P, 8)) {
         bool x_p_done = false, x_n_done = false, y_p_done = false, y_n_done = false;
         // position of each direction's first valid cell in the tile (row, col); -1: none.  The four
         // masks of a ring are read together and the heights only after the search: one LDS round
@@ -1634,7 +1479,7 @@ __global__ __launch_bounds__(512) void k_map2d(const Map2dParams P, const int32_
         __syncthreads();
         const int ox = tid >> 5, oy = tid & 31;              // 32 consecutive lanes -> 32 consecutive y
         const int gx = X0 + ox, gy = Y0 + oy;
-        if (tid < 256 && gx < xy && gy < xy && !(P.dbg & 1)) {
+        if (tid < 256 && gx < xy && gy < xy && !GVOM_DBG(P, 1)) {
             const size_t c_xy = (size_t)gx * xy + gy;
             out_pos[c_xy] = o_pos[ox][oy]; out_neg[c_xy] = o_neg[ox][oy];
             out_vis[c_xy] = o_vis[ox][oy]; out_rough[c_xy] = o_rgh[ox][oy];
@@ -1722,19 +1567,22 @@ __global__ __launch_bounds__(256) void k_stats_gather(const ScanParams P, const 
                                                       const uint32_t *__restrict__ tags, int xy_e, int z_e,
                                                       const double *__restrict__ base, double *sums,
                                                       const uint32_t *__restrict__ rowvox,
-                                                      const uint32_t *__restrict__ row_count, int direct_only)
+                                                      uint32_t nrows, int direct_only)
 {
     const int lane = threadIdx.x & (WAVE - 1);
     const uint32_t wid = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const uint32_t nw = (gridDim.x * blockDim.x) >> 6;
-    const uint32_t nrows = row_count[0];
     const int wx = 2 * xy_e + 1, wz = 2 * z_e + 1, nb = wx * wx * wz;
+    // a compact row is the index of one of the voxel's returns (k_trace): row `row` is in use iff the
+    // return claimed a voxel (rowvox != ~0, reset per scan) and that voxel's state still names it
     for (uint32_t row = wid; row < nrows; row += nw) {
+        const uint32_t Lr = rowvox[row];
+        if (Lr == 0xFFFFFFFFu || state[Lr] != (int32_t)row) continue;      // wave-uniform
         double m[10];
 #pragma unroll
         for (int k = 0; k < 10; ++k) m[k] = 0.0;
         if (!direct_only) {
-            const uint32_t L = rowvox[row];
+            const uint32_t L = Lr;
             const int sx = (int)(L % P.xy), sz = (int)((L / P.xy) % P.zs), sy = (int)(L / ((uint32_t)P.xy * P.zs));
             const int x = wrap_sub(sx, P.om[0], P.xy), y = wrap_sub(sy, P.om[1], P.xy), z = wrap_sub(sz, P.om[2], P.zs);
             for (int j = lane; j < nb; j += WAVE) {
@@ -1919,7 +1767,7 @@ __global__ __launch_bounds__(256) void k_voxel_cloud(const Map2dParams P, double
 
 hipError_t gvom_launch_stats(hipStream_t s, const ScanParams &P, int dtype, const void *world, int64_t n,
                              const int32_t *state, const uint32_t *tags, int xy_e, int z_e, double *base,
-                             double *sums, const uint32_t *rowvox, const uint32_t *row_count_dev, int64_t cap)
+                             double *sums, const uint32_t *rowvox)
 {
     // slab-sharded handles use the direct form only (a neighbour voxel's moments may live on another rank)
     const int direct_only = (P.sy_hi - P.sy_lo) < P.xy ? 1 : 0;
@@ -1930,11 +1778,11 @@ hipError_t gvom_launch_stats(hipStream_t s, const ScanParams &P, int dtype, cons
     else
         hipLaunchKernelGGL(k_stats<double>, dim3(blocks), dim3(256), 0, s, P, (const double *)world, (long)n, state,
                            tags, xy_e, z_e, base, sums, direct_only);
-    if (cap > 0) {
-        unsigned gb = (unsigned)((cap + 3) / 4);
+    if (n > 0) {
+        unsigned gb = (unsigned)((n + 3) / 4);
         if (gb > 4096) gb = 4096;
         hipLaunchKernelGGL(k_stats_gather, dim3(gb), dim3(256), 0, s, P, state, tags, xy_e, z_e, base, sums, rowvox,
-                           row_count_dev, direct_only);
+                           (uint32_t)n, direct_only);
     }
     return hipGetLastError();
 }
@@ -2089,65 +1937,53 @@ __global__ void k_debug_height(int xy, int om0, int om1, double o0, double o1, d
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-hipError_t gvom_launch_trace(hipStream_t s, const ScanParams &P, int dtype, const void *pts,
+hipError_t gvom_launch_trace(hipStream_t s, const ScanParams &P, int dtype, bool big_origin, const void *pts,
                              int64_t stride_elems, int64_t n, void *world, uint32_t *hit,
-                             uint32_t *total, int32_t *state, uint32_t *tags, uint32_t *cminh,
-                             uint32_t *counters, int variant, double *stat_sums, double *stat_base,
+                             uint32_t *total, uint32_t *mh, int32_t *state, uint32_t *tags,
+                             uint32_t *counters, double *stat_sums, double *stat_base,
                              uint32_t *stat_rowvox)
 {
     const unsigned blocks = (unsigned)((n + 255) / 256);
-    const unsigned nsegs = (variant == 0 || variant == 9) ? 1u : (unsigned)P.nsegs;
-#define TRACE_LAUNCH(TT, VV)                                                                     \
-    hipLaunchKernelGGL((k_trace<TT, VV>), dim3(blocks, nsegs), dim3(256), 0, s, P, (const TT *)pts, \
-                       (long)stride_elems, (long)n, (TT *)world, hit, total, state, tags, cminh, counters, \
+    if (blocks == 0) return hipSuccess;
+#define TRACE_LAUNCH(TT, BB)                                                                             \
+    hipLaunchKernelGGL((k_trace<TT, BB>), dim3(blocks, (unsigned)P.nsegs + 1u), dim3(256), 0, s, P, (const TT *)pts, \
+                       (long)stride_elems, (long)n, (TT *)world, hit, total, mh, state, tags, counters,     \
                        stat_sums, stat_base, stat_rowvox)
-#define TRACE_LAUNCH_NC(TT, VV)                                                                  \
-    hipLaunchKernelGGL((k_trace<TT, VV, false>), dim3(blocks, nsegs), dim3(256), 0, s, P, (const TT *)pts, \
-                       (long)stride_elems, (long)n, (TT *)world, hit, total, state, tags, cminh, counters, \
-                       stat_sums, stat_base, stat_rowvox)
-    if (dtype == 0) {
-        if (variant == 0) TRACE_LAUNCH(float, 0);
-        else if (variant == 9) TRACE_LAUNCH(float, 9);
-        else if (variant == 2) TRACE_LAUNCH(float, 2);
-        else if (variant == 5) TRACE_LAUNCH(float, 5);
-        else if (variant == 6) { if (P.cull) TRACE_LAUNCH(float, 6); else TRACE_LAUNCH_NC(float, 6); }
-        else TRACE_LAUNCH(float, 1);
-    } else {
-        if (variant == 0) TRACE_LAUNCH(double, 0);
-        else if (variant == 9) TRACE_LAUNCH(double, 9);
-        else if (variant == 5) TRACE_LAUNCH(double, 5);
-        else if (variant == 6) { if (P.cull) TRACE_LAUNCH(double, 6); else TRACE_LAUNCH_NC(double, 6); }
-        else TRACE_LAUNCH(double, 1);
-    }
+    if (dtype == 0) { if (big_origin) TRACE_LAUNCH(float, true); else TRACE_LAUNCH(float, false); }
+    else { if (big_origin) TRACE_LAUNCH(double, true); else TRACE_LAUNCH(double, false); }
 #undef TRACE_LAUNCH
-#undef TRACE_LAUNCH_NC
     return hipGetLastError();
 }
 
-hipError_t gvom_launch_encode(hipStream_t s, const ScanParams &P, int dtype, const void *world,
-                              int64_t n, uint32_t *hit, uint32_t *total, int32_t *state,
-                              uint32_t *chit, uint32_t *ctotal, uint32_t *cminh, const uint32_t *tags,
-                              uint32_t *counters, unsigned long long *host_flag, uint32_t seq)
+hipError_t gvom_launch_encode(hipStream_t s, const ScanParams &P, uint32_t *hit, uint32_t *total, uint32_t *mh,
+                              int32_t *state, uint32_t *chit, uint32_t *ctotal, uint32_t *cminh, const uint32_t *tags,
+                              uint32_t *counters, unsigned long long *host_flag, uint32_t seq, unsigned resident_blocks)
 {
-    // encode part: units = quads (4 rows x 64 sx at one sz) that intersect the slab; one wave handles
-    // 2 quads per iteration, 4 waves per block
+    // units = quads (4 rows x 64 sx at one sz) that intersect the slab; one wave handles 2 quads per
+    // iteration, 4 waves per block
     const uint32_t q_lo = (uint32_t)P.sy_lo >> 2, q_hi = ((uint32_t)P.sy_hi + 3) >> 2;
     const uint32_t t_begin = q_lo * P.zs * P.nseg, t_end = q_hi * P.zs * P.nseg;
     const uint32_t ntiles = t_end - t_begin;
     unsigned enc_blocks = (ntiles + 7) / 8;
-    unsigned enc_cap = 8192;                              // measured on 256^3: 4096 -> 20.0 us, 8192 (one pass per wave) -> 18.8 us
-    if (const char *v = gvom_tune_env("GVOM_ENCODE_BLOCKS")) enc_cap = atoi(v) > 0 ? (unsigned)atoi(v) : 8192u;
+    // at most four resident rounds (measured on 256^3 / 2048 resident blocks: 4096 -> 20.0 us, 8192 -> 18.8 us)
+    const unsigned enc_cap = resident_blocks > 0 ? 4u * resident_blocks : 8192u;
     if (enc_blocks > enc_cap) enc_blocks = enc_cap;
     if (enc_blocks < 1) enc_blocks = 1;
-    const unsigned mh_blocks = (unsigned)((n + 255) / 256);          // min-height part
-    if (dtype == 0)
-        hipLaunchKernelGGL(k_encode<float>, dim3(enc_blocks + mh_blocks), dim3(256), 0, s, P, enc_blocks, mh_blocks,
-                           t_begin, t_end, hit, total, state, chit, ctotal, cminh, tags, P.epoch,
-                           (const float *)world, (long)n, counters, host_flag, seq);
-    else
-        hipLaunchKernelGGL(k_encode<double>, dim3(enc_blocks + mh_blocks), dim3(256), 0, s, P, enc_blocks, mh_blocks,
-                           t_begin, t_end, hit, total, state, chit, ctotal, cminh, tags, P.epoch,
-                           (const double *)world, (long)n, counters, host_flag, seq);
+    hipLaunchKernelGGL(k_encode, dim3(enc_blocks), dim3(256), 0, s, P, t_begin, t_end, hit, total, mh, state,
+                       chit, ctotal, cminh, tags, P.epoch, counters, host_flag, seq);
+    return hipGetLastError();
+}
+
+// epoch renumbering (gvom_capi.hip renumber_epochs): live tiles get the map's new epoch, all others 0
+__global__ void k_retag(uint32_t *tags, size_t n, uint32_t old_epoch, uint32_t new_epoch)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        tags[i] = (new_epoch != 0u && tags[i] == old_epoch) ? new_epoch : 0u;
+}
+
+hipError_t gvom_launch_retag(hipStream_t s, uint32_t *tags, size_t n, uint32_t old_epoch, uint32_t new_epoch)
+{
+    hipLaunchKernelGGL(k_retag, dim3(1024), dim3(256), 0, s, tags, n, old_epoch, new_epoch);
     return hipGetLastError();
 }
 
@@ -2158,7 +1994,7 @@ hipError_t gvom_launch_fuse(hipStream_t s, const FuseParams &P, const FuseDescs 
 {
     const dim3 grid((P.xy + 63) / 64, P.sy_hi - P.sy_lo);
     if (grid.y == 0) return hipSuccess;
-    if (P.zc == 16 && (P.xy & 3) == 0 && !(P.debug & 8))
+    if (P.zc == 16 && (P.xy & 3) == 0 && !GVOM_DBG(P, 8))
         hipLaunchKernelGGL(k_fuse4, grid, dim3(64 * P.nz), 0, s, P, KD, descs_dev, fstate, fhit,
                            ftotal, fminh, ftags, blockcounts, height, inferred);
     else if (P.zc <= 16)

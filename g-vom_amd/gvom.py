@@ -108,7 +108,7 @@ ABI = [
     ("gvom_last_stage_ms", _I, [_P, ctypes.POINTER(ctypes.c_float * N_STAGES)]),
     ("gvom_set_profiling", _I, [_P, _I]),
     ("gvom_host_timing", _I, [_P, ctypes.POINTER(ctypes.c_double * 8)]),
-    ("gvom_debug_trace_counters", _I, [_P, _P]),
+    ("gvom_set_tuning", _I, [_P, ctypes.c_char_p, _I]),
     ("gvom_stream", _P, [_P]),
     ("gvom_last_error", ctypes.c_char_p, [_P]),
     ("gvom_backend_info", _I, [ctypes.c_char_p, ctypes.c_size_t]),
@@ -592,6 +592,10 @@ class Gvom(object):
         ms = (ctypes.c_float * N_STAGES)()
         self._check(self._lib.gvom_last_stage_ms(self._h, ctypes.byref(ms)))
         return dict(zip(STAGE_NAMES, [float(v) for v in ms]))
+
+    def set_tuning(self, name, value):
+        """Performance knobs that never change a result: "segs", "period", "ep_row" (include/gvom_hip.h)."""
+        self._check(self._lib.gvom_set_tuning(self._h, name.encode(), int(value)))
 
     def host_timing(self):
         us = (ctypes.c_double * 8)()

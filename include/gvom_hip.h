@@ -26,7 +26,8 @@
 extern "C" {
 #endif
 
-#define GVOM_ABI_VERSION 2   /* 2: *_into outputs column-major; occupancy and PointCloud2 entry points */
+#define GVOM_ABI_VERSION 3   /* 3: rank-exchange (shard) and communicator entry points, gvom_set_tuning, flags;
+                              *    2: *_into outputs column-major; occupancy and PointCloud2 entry points */
 
 /* return codes (>= 0: the reference's documented outcomes; < 0: failures) */
 #define GVOM_OK                0
@@ -68,6 +69,10 @@ typedef struct gvom_params {
                                         * 858-909, 1333-1378) that feeds only make_debug_voxel_map; off by
                                         * default: it is not on the north-star path and costs scan time.
                                         * The environment variable GVOM_VOXEL_STATISTICS=0/1 overrides. */
+#define GVOM_FLAG_CUDA_F32_SQRT    2   /* ray_length = sqrt(f32 sum) evaluated in float32, as Numba types
+                                        * math.sqrt(float32) when it compiles gvom.py:1109 for a real CUDA device
+                                        * (SURVEY App. A.2).  Default (flag clear): the float64 square root of
+                                        * Numba's simulator, which is what the golden fixtures were generated with. */
 
 /* Ring-buffer bookkeeping visible on the reference object (gvom.py:56-58,172-175). */
 typedef struct gvom_state {
@@ -240,9 +245,10 @@ int gvom_set_profiling(gvom_t *h, int on);
 /* Host-side phase times (microseconds per call, averaged; enabled by GVOM_HOST_TIMING=1):
  * [0] scan launches [1] scan wait [2] combine launches [3] combine wait [4] output copies. */
 int gvom_host_timing(gvom_t *h, double us[8]);
-/* Diagnostic (GVOM_TRACE_VARIANT=2): cumulative {merged-run heads, distinct-64B-line heads, atomic
- * wave instructions} issued by k_trace since creation. */
-int gvom_debug_trace_counters(gvom_t *h, uint32_t out[3]);
+/* Performance knobs that never change a result.  name: "segs" (step segments per ray in the trace
+ * kernel), "period" (committing steps between two flushes of a wave's LDS line cache), "ep_row"
+ * (dispatch row of the endpoint blocks); 0 / 0 / -1 = automatic. */
+int gvom_set_tuning(gvom_t *h, const char *name, int value);
 /* Raw HIP stream the library launches on (hipStream_t as void*), for external event timing. */
 void *gvom_stream(gvom_t *h);
 

@@ -305,15 +305,16 @@ def test_trace_far_origin_uses_f64_lookup(gvom_mod):
     assert compare_records(got, want, float_tol=1e-5) > 10
 
 
-def test_trace_variants_agree(gvom_mod, monkeypatch):
-    """GVOM_TRACE_VARIANT (read by gvom_create): the per-lane-atomic kernel (0), the f64 lock-step
-    kernel (1), the integer-lookup kernel (5) and the production LDS-line-cache kernel (6) leave
-    bit-identical scan slots."""
+def test_trace_tuning_knobs_leave_results_unchanged(gvom_mod):
+    """k_trace splits every ray into step segments handled by different waves (set-up + replay of the
+    earlier steps + the segment's own steps); the segment count, the flush period of a wave's LDS line
+    cache and the dispatch row of the endpoint blocks are performance knobs (gvom_set_tuning) and must
+    leave bit-identical scan slots.  segs=1 is the unsegmented walk, segs=9 / period=1 the extremes."""
     params, scans = synth.config_inputs("c2", n_scans=2)
     ref = None
-    for variant in ("0", "1", "5", "6"):
-        monkeypatch.setenv("GVOM_TRACE_VARIANT", variant)
+    for segs, period, ep_row in ((0, 0, -1), (1, 12, 0), (2, 1, 1), (3, 32, 3), (6, 12, 6), (9, 5, 4)):
         g = gvom_mod.Gvom(*params)
+        g.set_tuning("segs", segs); g.set_tuning("period", period); g.set_tuning("ep_row", ep_row)
         slots = []
         for pc, ego, tf in scans:
             g.process_pointcloud(pc, ego, tf)
@@ -325,7 +326,7 @@ def test_trace_variants_agree(gvom_mod, monkeypatch):
         else:
             for a, b_ in zip(ref, slots):
                 for x, y in zip(a, b_):
-                    assert np.array_equal(x, y), "variant %s differs" % variant
+                    assert np.array_equal(x, y), "segs %d / period %d / ep_row %d differs" % (segs, period, ep_row)
 
 
 @pytest.mark.parametrize("occ_params", [(50, -10, 0), (12.5, -6.0, 1.5)])
