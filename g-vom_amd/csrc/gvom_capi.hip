@@ -73,6 +73,16 @@ struct gvom_handle {
     uint32_t *hit = nullptr, *total = nullptr, *mh = nullptr;   // dense accumulators (hit, ray passes, min-height), zero between scans
     size_t acc_elems = 0;
     int tune_segs = 0, tune_ep_row = -1, tune_period = 0; // gvom_set_tuning (0 / -1: automatic)
+    // rank exchange of a sharded map (world > 1): send / receive regions, indexed by peer rank
+    uint32_t *x_send_ids = nullptr, *x_recv_ids = nullptr;     // quad ids: [Q] by owner / [world][myQ] by source
+    void *x_send_pay = nullptr, *x_recv_pay = nullptr;         // 1 KiB per quad, same indexing
+    Buf x_send_eps, x_recv_eps;                                 // endpoints {L, min-height}: [world][ep_cap] / concatenated by source
+    int64_t x_ep_cap = 0;
+    std::vector<int64_t> x_recv_ep_off;                         // receive offsets (endpoints) by source, [world + 1]
+    uint32_t *x_qcnt = nullptr, *x_ecnt = nullptr;              // device counters, [world * 16] each
+    unsigned long long *x_host = nullptr, *x_host_dev = nullptr;   // pinned, mapped: [2*world + 2]
+    size_t x_Q = 0, x_myQ = 0;
+    ScanParams pending_P;                                       // scan parameters between scan_local and scan_merge
     unsigned resident_blocks = 2048;                    // 256-thread workgroups resident on the device (queried)
     bool f32_sqrt = false;                              // GVOM_FLAG_CUDA_F32_SQRT
     std::vector<Slot> slots;                            // buffer_size + 1 (one is staging)
@@ -102,8 +112,7 @@ struct gvom_handle {
     double *height = nullptr, *inferred = nullptr;      // = hmaps, hmaps + xy  (row stride hs = 3*xy)
     int hs = 0;
     double *slope_x = nullptr, *slope_y = nullptr, *rough = nullptr, *guessed = nullptr;   // [sy][sx]
-    hipStream_t own_stream = nullptr;                   // created by the library (stream may be attached)
-    bool blocking = true;                               // split entry points synchronize before returning
+    hipStream_t own_stream = nullptr;                   // created by the library
     void *out_host = nullptr;                           // pinned, device-mapped staging for the 4 outputs
     char *out_host_dev = nullptr;                       // device view of out_host (zero-copy target)
     uint32_t scan_seq = 0;                              // sequence number of the {seq,count} flag
@@ -182,6 +191,7 @@ void fill_scan_params(const gvom_handle *h, const int64_t origin[3], const doubl
     P.in_f32 = h->in_f32 ? 1 : 0;
     P.nseg = h->nseg;
     P.sxq = h->sxq;
+    P.shard_world = h->world; P.shard_rank = h->rank; P.shard_rows = h->world > 1 ? p.xy_size / h->world : p.xy_size;
     // DDA step segments: the ego sits at the window centre, so a ray takes at most size/2 + 2 steps.
     // Segments exist to fill the chip with waves when a scan has few returns (a 131 k-point scan is 2
     // waves per SIMD); every segment wave repeats the ray set-up and replays the earlier steps, so
@@ -221,6 +231,10 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, g
         rank >= world)
         return GVOM_ERR_INVALID;
     if (params->buffer_size >= GVOM_MAX_SLOTS || params->z_size > 1024) return GVOM_ERR_CAPACITY;
+    // a sharded map: every rank owns xy/world storage rows, a multiple of 4 (accumulator patches are
+    // 4 rows high); per-voxel statistics need every return on the owner and are not exchanged
+    if (world > 1 && (params->xy_size % (4 * world) != 0 || (params->reserved0 & GVOM_FLAG_VOXEL_STATISTICS)))
+        return GVOM_ERR_INVALID;
     const double Vd = (double)params->xy_size * params->xy_size * params->z_size;
     if (Vd >= 2147483648.0) return GVOM_ERR_CAPACITY;
     int ndev = 0;
@@ -232,7 +246,7 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, g
     h->rank = rank; h->world = world;
     h->stats = (params->reserved0 & GVOM_FLAG_VOXEL_STATISTICS) != 0;
     h->f32_sqrt = (params->reserved0 & GVOM_FLAG_CUDA_F32_SQRT) != 0;
-    if (const char *v = getenv("GVOM_VOXEL_STATISTICS")) h->stats = atoi(v) != 0;
+    if (const char *v = getenv("GVOM_VOXEL_STATISTICS")) h->stats = atoi(v) != 0 && world == 1;
     if (const char *v = getenv("GVOM_HOST_TIMING")) h->host_timing = atoi(v) != 0;
     const int xy = params->xy_size, zs = params->z_size;
     h->sy_lo = (int)((int64_t)xy * rank / world);
@@ -304,6 +318,23 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, g
 
     CK(hipHostMalloc(&h->out_host, h->cells2d * 20, hipHostMallocMapped));
     CK(hipHostGetDevicePointer((void **)&h->out_host_dev, h->out_host, 0));
+    if (world > 1) {
+        // rank exchange regions (DESIGN.md "Multi-GPU"): a quad = 4 storage rows x 64 sx at one sz
+        h->x_Q = (size_t)(xy / 4) * zs * h->nseg;
+        h->x_myQ = h->x_Q / world;
+        CK(hipMalloc((void **)&h->x_send_ids, h->x_Q * 4));
+        CK(hipMalloc(&h->x_send_pay, h->x_Q * 1024));
+        CK(hipMalloc((void **)&h->x_recv_ids, h->x_Q * 4));
+        CK(hipMalloc(&h->x_recv_pay, h->x_Q * 1024));
+        CK(hipMalloc((void **)&h->x_qcnt, (size_t)world * 64));
+        CK(hipMalloc((void **)&h->x_ecnt, (size_t)world * 64));
+        CK(hipMemsetAsync(h->x_qcnt, 0, (size_t)world * 64, h->stream));
+        CK(hipMemsetAsync(h->x_ecnt, 0, (size_t)world * 64, h->stream));
+        CK(hipHostMalloc((void **)&h->x_host, (size_t)(2 * world + 2) * 8, hipHostMallocMapped | hipHostMallocCoherent));
+        CK(hipHostGetDevicePointer((void **)&h->x_host_dev, h->x_host, 0));
+        memset(h->x_host, 0, (size_t)(2 * world + 2) * 8);
+        h->x_recv_ep_off.assign(world + 1, 0);
+    }
     for (auto &e : h->ev) CK(hipEventCreate(&e));
     CK(hipStreamSynchronize(h->stream));
 #undef CK
@@ -331,7 +362,7 @@ int renumber_epochs(gvom_handle *h);
 
 // Scan kernels up to (not including) the commit.  `dev_pts` is device memory.
 int scan_launch(gvom_handle *h, const void *dev_pts, int64_t n, int64_t stride_elems, int dtype,
-                const double *tf)
+                const double *tf, bool shard_local = false)
 {
     const gvom_params &p = h->prm;
     int64_t origin[3];
@@ -347,7 +378,7 @@ int scan_launch(gvom_handle *h, const void *dev_pts, int64_t n, int64_t stride_e
     P.epoch = st.epoch;
     const size_t esz = dtype == GVOM_DTYPE_F32 ? 4 : 8;
     // compact rows are indexed by return (the row of an occupied voxel = the index of one of its returns)
-    const size_t cap = (size_t)n;
+    const size_t cap = std::max<size_t>(1, (size_t)n);
     if ((rc = ensure(h, st.chit, cap * 4))) return rc;
     if ((rc = ensure(h, st.ctotal, cap * 4))) return rc;
     if ((rc = ensure(h, st.cminh, cap * 4))) return rc;
@@ -362,13 +393,51 @@ int scan_launch(gvom_handle *h, const void *dev_pts, int64_t n, int64_t stride_e
     for (int k = 0; k < 3; ++k)
         if (origin[k] >= (1ll << 30) || origin[k] <= -(1ll << 30)) big = true;
     if (h->stats) HIPCHK(h, hipMemsetAsync(st.rowvox.p, 0xFF, cap * 4, h->stream));   // no row claimed yet
-    hipError_t le = gvom_launch_trace(h->stream, P, dtype, big, dev_pts, stride_elems, n,
+    ShardExchange X;
+    X.ep_send = nullptr; X.ep_cnt = nullptr; X.ep_cap = 0;
+    if (h->world > 1) {
+        if ((rc = ensure(h, h->x_send_eps, (size_t)h->world * (size_t)(n > 0 ? n : 1) * 8))) return rc;
+        h->x_ep_cap = n > 0 ? n : 1;
+        X.ep_send = (uint2 *)h->x_send_eps.p; X.ep_cnt = h->x_ecnt; X.ep_cap = (long)h->x_ep_cap;
+    }
+    hipError_t le = gvom_launch_trace(h->stream, P, X, dtype, big, dev_pts, stride_elems, n,
                                       h->stats ? h->world_pts.p : nullptr, h->hit, h->total, h->mh, st.state,
                                       st.tags, h->counters, h->stats ? (double *)st.metrics.p : nullptr,
                                       h->stats ? (double *)st.base.p : nullptr,
                                       h->stats ? (uint32_t *)st.rowvox.p : nullptr);
     if (le != hipSuccess) { scan_abort(h); HIPCHK(h, le); }
     if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+    if (shard_local) {
+        // sharded map: the ray passes in other ranks' rows are packed for their owners; the counts go
+        // to host-mapped memory (the caller sizes the exchange with them); k_encode follows in
+        // scan_merge, once the other ranks' contributions have been added
+        le = gvom_launch_pack(h->stream, P, h->total, st.tags, h->x_send_ids, h->x_send_pay, h->x_qcnt, h->x_ecnt,
+                              h->counters, h->x_host_dev, seq);
+        if (le != hipSuccess) { scan_abort(h); HIPCHK(h, le); }
+        volatile unsigned long long *flag = (volatile unsigned long long *)(h->x_host + 2 * h->world + 1);
+        const double deadline = now_ns() + 2.0e9;
+        unsigned spins = 0;
+        while ((uint32_t)*flag != seq) {
+            _mm_pause();
+            if ((++spins & 0x3ff) == 0 && now_ns() > deadline) {
+                hipError_t se = hipStreamSynchronize(h->stream);
+                if (se != hipSuccess || (uint32_t)*flag != seq) {
+                    scan_abort(h);
+                    h->err = "sharded scan: pack counts were never published";
+                    return GVOM_ERR_HIP;
+                }
+            }
+        }
+        h->pending_any = h->x_host[2 * h->world] != 0;
+        h->pending_P = P;
+        st.count = -1;
+        st.origin[0] = origin[0]; st.origin[1] = origin[1]; st.origin[2] = origin[2];
+        st.stats_valid = false;
+        st.stats.points = n;
+        h->pending = true;
+        h->pending_n = n;
+        return GVOM_OK;
+    }
     le = gvom_launch_encode(h->stream, P, h->hit, h->total, h->mh, st.state, (uint32_t *)st.chit.p,
                             (uint32_t *)st.ctotal.p, (uint32_t *)st.cminh.p, st.tags, h->counters,
                             (unsigned long long *)h->counters_host_dev, seq, h->resident_blocks);
@@ -478,16 +547,17 @@ int process_impl(gvom_handle *h, const void *xyz, bool on_device, int64_t n, int
     h->in_f32 = widen_f32;
     h->ego[0] = ego[0]; h->ego[1] = ego[1]; h->ego[2] = ego[2];       // gvom.py:102-104
     h->pending = false;
-    if (n == 0) return GVOM_EMPTY_CLOUD;                               // gvom.py:107-109
+    if (h->world > 1 && !defer) { h->err = "a sharded handle scans through gvom_shard_scan_local / gvom_shard_scan_merge"; return GVOM_ERR_INVALID; }
+    if (n == 0 && !defer) return GVOM_EMPTY_CLOUD;                     // gvom.py:107-109 (a rank's share of a sharded scan may be empty)
     const void *dev = xyz;
-    if (!on_device) {
+    if (!on_device && n > 0) {
         int rc = ensure(h, h->in_pts, (size_t)n * row_stride_bytes);
         if (rc) return rc;
         HIPCHK(h, hipMemcpyAsync(h->in_pts.p, xyz, (size_t)(n - 1) * row_stride_bytes + (size_t)last_field + esz,
                                  hipMemcpyHostToDevice, h->stream));
         dev = h->in_pts.p;
     }
-    int rc = scan_launch(h, dev, n, row_stride_bytes / (int64_t)esz, dtype, tf);
+    int rc = scan_launch(h, dev, n, row_stride_bytes / (int64_t)esz, dtype, tf, defer);
     if (rc) return rc;
     if (defer) return GVOM_OK;
     const bool accept = h->pending_any;                   // == (global occupied-voxel count > 0), gvom.py:147-150
@@ -707,6 +777,9 @@ VIS void gvom_destroy(gvom_t *h)
     if (h->stream) hipStreamSynchronize(h->stream);
     auto fb = [](Buf &b) { if (b.p) hipFree(b.p); b.p = nullptr; b.bytes = 0; };
     hipFree(h->hit); hipFree(h->total); hipFree(h->mh);
+    hipFree(h->x_send_ids); hipFree(h->x_send_pay); hipFree(h->x_recv_ids); hipFree(h->x_recv_pay);
+    hipFree(h->x_qcnt); hipFree(h->x_ecnt); fb(h->x_send_eps); fb(h->x_recv_eps);
+    if (h->x_host) hipHostFree(h->x_host);
     for (auto &s : h->slots) { hipFree(s.state); hipFree(s.tags); fb(s.chit); fb(s.ctotal); fb(s.cminh); fb(s.metrics); fb(s.base); fb(s.rowvox); }
     for (auto &f : h->fused) { hipFree(f.state); hipFree(f.tags); fb(f.hit); fb(f.total); fb(f.minh); fb(f.metrics); }
     fb(h->in_pts); fb(h->world_pts);
@@ -750,21 +823,108 @@ VIS int gvom_process_pointcloud2(gvom_t *h, const void *data, int64_t n_points, 
                         dtype == GVOM_DTYPE_F32);
 }
 
-// Sharded runs: run the scan kernels but leave the ring untouched until every rank's cell
-// count is known (the reference's "no overlap" test is on the global count, gvom.py:147-150).
-VIS int gvom_scan_begin(gvom_t *h, const void *xyz, int on_device, int64_t n, int64_t row_stride_bytes,
-                        int dtype, const double ego[3], const double *transform_4x4,
-                        int64_t *local_cells)
+// ---- scan of a sharded map (one rank per GPU; DESIGN.md "Multi-GPU") ---------------------------
+// gvom_shard_scan_local: this rank's share of the scan (possibly empty): traces ITS rays over the whole
+//   window, leaves what fell into its own rows in its accumulators and packs the rest for the owners.
+//   send_quads[d] / send_eps[d] = dirty quads (1 KiB each + a 4-byte id) / endpoints (8 bytes each) for
+//   rank d; *any_ingrid = some return of this rank landed in the grid.
+// gvom_shard_buffer: the send / receive regions, by peer rank, for the transport (RCCL: gvom_comm_*).
+// gvom_shard_recv_reserve: sizes the endpoint receive regions once the counts are known.
+// gvom_shard_scan_merge: adds what the other ranks sent, encodes this rank's rows and commits the scan
+//   iff `accept` (the reference's "no overlap" test, gvom.py:147-150, is on the whole scan).
+VIS int gvom_shard_scan_local(gvom_t *h, const void *xyz, int on_device, int64_t n, int64_t row_stride_bytes,
+                              int dtype, const double ego[3], const double *transform_4x4,
+                              int64_t *send_quads, int64_t *send_eps, int *any_ingrid)
 {
+    if (!h || h->world < 2) return GVOM_ERR_INVALID;
     int rc = process_impl(h, xyz, on_device != 0, n, row_stride_bytes, dtype, ego, transform_4x4, true);
-    if (local_cells) *local_cells = (rc == GVOM_OK && h->pending_any) ? 1 : 0;   // != 0: some return landed in the grid
-    return rc;
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(h->mu);
+    for (int d = 0; d < h->world; ++d) {
+        if (send_quads) send_quads[d] = (int64_t)h->x_host[d];
+        if (send_eps) send_eps[d] = (int64_t)h->x_host[h->world + d];
+    }
+    if (any_ingrid) *any_ingrid = h->pending_any ? 1 : 0;
+    return GVOM_OK;
 }
 
-VIS int gvom_scan_commit(gvom_t *h, int accept)
+VIS int gvom_shard_recv_reserve(gvom_t *h, const int64_t *recv_eps)
 {
-    if (!h) return GVOM_ERR_INVALID;
+    if (!h || h->world < 2 || !recv_eps) return GVOM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    int64_t tot = 0;
+    for (int sidx = 0; sidx < h->world; ++sidx) {
+        h->x_recv_ep_off[sidx] = tot;
+        if (recv_eps[sidx] < 0) return GVOM_ERR_INVALID;
+        tot += sidx == h->rank ? 0 : recv_eps[sidx];
+    }
+    h->x_recv_ep_off[h->world] = tot;
+    return ensure(h, h->x_recv_eps, (size_t)(tot > 0 ? tot : 1) * 8);
+}
+
+VIS int gvom_shard_buffer(gvom_t *h, int which, int peer, void **ptr, int64_t *capacity_bytes)
+{
+    if (!h || h->world < 2 || !ptr || peer < 0 || peer >= h->world) return GVOM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    const size_t myQ = h->x_myQ;
+    int64_t cap = 0;
+    switch (which) {
+    case GVOM_XBUF_SEND_IDS: *ptr = h->x_send_ids + (size_t)peer * myQ; cap = (int64_t)myQ * 4; break;
+    case GVOM_XBUF_SEND_QUADS: *ptr = (char *)h->x_send_pay + (size_t)peer * myQ * 1024; cap = (int64_t)myQ * 1024; break;
+    case GVOM_XBUF_SEND_EPS: *ptr = (char *)h->x_send_eps.p + (size_t)peer * (size_t)h->x_ep_cap * 8; cap = h->x_ep_cap * 8; break;
+    case GVOM_XBUF_RECV_IDS: *ptr = h->x_recv_ids + (size_t)peer * myQ; cap = (int64_t)myQ * 4; break;
+    case GVOM_XBUF_RECV_QUADS: *ptr = (char *)h->x_recv_pay + (size_t)peer * myQ * 1024; cap = (int64_t)myQ * 1024; break;
+    case GVOM_XBUF_RECV_EPS:
+        *ptr = (char *)h->x_recv_eps.p + (size_t)h->x_recv_ep_off[peer] * 8;
+        cap = (h->x_recv_ep_off[peer + 1] - h->x_recv_ep_off[peer]) * 8; break;
+    default: return GVOM_ERR_INVALID;
+    }
+    if (capacity_bytes) *capacity_bytes = cap;
+    return GVOM_OK;
+}
+
+VIS int gvom_shard_scan_merge(gvom_t *h, const int64_t *recv_quads, const int64_t *recv_eps, int accept)
+{
+    if (!h || h->world < 2 || !recv_quads || !recv_eps) return GVOM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!h->pending) return GVOM_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    Slot &st = h->slots[h->staging];
+    const ScanParams &P = h->pending_P;
+    int64_t tot_eps = 0;
+    for (int sidx = 0; sidx < h->world; ++sidx) {
+        if (sidx == h->rank) continue;
+        if (recv_quads[sidx] < 0 || recv_quads[sidx] > (int64_t)h->x_myQ || recv_eps[sidx] < 0 ||
+            recv_eps[sidx] != h->x_recv_ep_off[sidx + 1] - h->x_recv_ep_off[sidx]) {
+            h->err = "gvom_shard_scan_merge: receive counts do not match gvom_shard_recv_reserve / the slab size";
+            return GVOM_ERR_INVALID;
+        }
+        tot_eps += recv_eps[sidx];
+    }
+    // compact rows: this rank's returns first, the received endpoints behind them
+    // (at least one row: k_fuse redirects the loads of unoccupied voxels to row 0 of every source)
+    const size_t cap = std::max<size_t>(1, (size_t)h->pending_n + (size_t)tot_eps);
+    int rc;
+    if ((rc = ensure(h, st.chit, cap * 4)) || (rc = ensure(h, st.ctotal, cap * 4)) || (rc = ensure(h, st.cminh, cap * 4))) return rc;
+    double t0 = now_ns();
+    for (int sidx = 0; sidx < h->world; ++sidx) {
+        if (sidx == h->rank || (recv_quads[sidx] == 0 && recv_eps[sidx] == 0)) continue;
+        hipError_t le = gvom_launch_unpack(h->stream, P, (uint32_t)recv_quads[sidx], h->x_recv_ids + (size_t)sidx * h->x_myQ,
+                                           (char *)h->x_recv_pay + (size_t)sidx * h->x_myQ * 1024, (uint32_t)recv_eps[sidx],
+                                           (char *)h->x_recv_eps.p + (size_t)h->x_recv_ep_off[sidx] * 8,
+                                           (long)h->pending_n + (long)h->x_recv_ep_off[sidx], h->hit, h->total, h->mh, st.state,
+                                           st.tags);
+        if (le != hipSuccess) { scan_abort(h); HIPCHK(h, le); }
+    }
+    const uint32_t seq = ++h->scan_seq;
+    hipError_t le = gvom_launch_encode(h->stream, P, h->hit, h->total, h->mh, st.state, (uint32_t *)st.chit.p,
+                                       (uint32_t *)st.ctotal.p, (uint32_t *)st.cminh.p, st.tags, h->counters,
+                                       (unsigned long long *)h->counters_host_dev, seq, h->resident_blocks);
+    if (le != hipSuccess) { scan_abort(h); HIPCHK(h, le); }
+    if (h->profiling) { HIPCHK(h, hipEventRecord(h->ev[2], h->stream)); h->ev_scan = true; }
+    HT(h, 0, t0);
+    // (no host wait: everything the caller can do next with this handle is stream-ordered behind k_encode)
     scan_commit(h, accept != 0);
     return GVOM_OK;
 }
@@ -772,7 +932,7 @@ VIS int gvom_scan_commit(gvom_t *h, int accept)
 VIS int gvom_combine_maps(gvom_t *h, double origin_world[3], int32_t *positive, int32_t *negative,
                           double *roughness, int32_t *visibility)
 {
-    if (!h) return GVOM_ERR_INVALID;
+    if (!h || h->world > 1) return GVOM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->device));
     double t0 = now_ns();
@@ -828,7 +988,7 @@ VIS int gvom_output_buffer_free(gvom_t *h, void *host_ptr)
 
 VIS int gvom_combine_maps_into(gvom_t *h, double origin_world[3], void *pinned_out)
 {
-    if (!h || !pinned_out) return GVOM_ERR_INVALID;
+    if (!h || !pinned_out || h->world > 1) return GVOM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->device));
     double t0 = now_ns();
@@ -857,7 +1017,7 @@ VIS int gvom_combine_maps_into(gvom_t *h, double origin_world[3], void *pinned_o
 VIS int gvom_combine_occupancy_into(gvom_t *h, double origin_world[3], void *pinned_out,
                                     double density_threshold, double min_roughness, double max_roughness)
 {
-    if (!h || !pinned_out) return GVOM_ERR_INVALID;
+    if (!h || !pinned_out || h->world > 1) return GVOM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->device));
     double t0 = now_ns();
@@ -894,7 +1054,7 @@ VIS int gvom_combine_fuse(gvom_t *h, int64_t *local_cells)
     int rc = fuse_impl(h);
     if (rc) return rc;
     if ((rc = posdens_impl(h))) return rc;                // third row of the height buffer + the cell count
-    if (!h->blocking) {                                   // count stays on the device (GVOM_BUF_FUSED_CELLS)
+    if (h->world > 1) {                                   // no host wait: the count stays on the device (GVOM_BUF_FUSED_CELLS)
         if (local_cells) *local_cells = -1;
         return GVOM_OK;
     }
@@ -925,28 +1085,9 @@ static void *map_ptr(gvom_handle *h, int which, size_t *esz, int *stride)
     }
 }
 
-// ---- plumbing for the sharded layer: the library's own device buffers take part in the caller's
-// collectives directly (a rank's rows are one contiguous block of each buffer), on the caller's
-// stream, without host synchronisation in between.
-VIS int gvom_attach_stream(gvom_t *h, void *hip_stream)
-{
-    if (!h) return GVOM_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(h->mu);
-    HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    // NULL is a real stream (HIP's legacy default stream -- PyTorch's default); GVOM_OWN_STREAM detaches
-    h->stream = (hip_stream == GVOM_OWN_STREAM) ? h->own_stream : (hipStream_t)hip_stream;
-    return GVOM_OK;
-}
-
-VIS int gvom_set_blocking(gvom_t *h, int on)
-{
-    if (!h) return GVOM_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(h->mu);
-    h->blocking = on != 0;
-    return GVOM_OK;
-}
-
+// ---- plumbing for the sharded layer: the library's own device buffers take part in the collectives
+// directly (a rank's rows are one contiguous block of each buffer), on the library's stream, without
+// host synchronisation in between.
 VIS int gvom_sync(gvom_t *h)
 {
     if (!h) return GVOM_ERR_INVALID;
@@ -964,7 +1105,6 @@ VIS int gvom_device_buffer(gvom_t *h, int which, void **ptr, int64_t *bytes, int
     int64_t b = 0, rs = 0;
     switch (which) {
     case GVOM_BUF_HEIGHT_MAPS: *ptr = h->hmaps; rs = (int64_t)h->hs * 8; b = rs * h->prm.xy_size; break;
-    case GVOM_BUF_SCAN_CELLS: *ptr = h->counters + 8; b = 8; rs = 8; break;
     case GVOM_BUF_FUSED_CELLS: *ptr = h->counters + 10; b = 8; rs = 8; break;
     default: return GVOM_ERR_INVALID;
     }

@@ -1,0 +1,279 @@
+// gvom_comm.hip -- the transport between the ranks of a sharded map (include/gvom_hip.h, "one map
+// sharded over the GPUs of a node"): RCCL over xGMI, bound directly (no PyTorch).
+//
+//   * device data: grouped ncclSend / ncclRecv (the scan's quads and endpoints: a sparse all-to-all
+//     whose sizes are only known after the trace) and an in-place ncclAllGather (the combine's
+//     height-map rows), on the LIBRARY's stream -- no host synchronisation in between;
+//   * host data: the ranks are the processes of ONE node, so the small per-scan vectors (counts,
+//     in-grid flags) and the ncclUniqueId travel through a POSIX shared-memory segment
+//     (/dev/shm/<name>): ~1 us, no GPU involved.  Double-buffered slots, sequence numbers, C11 atomics.
+//
+// librccl.so is loaded on first use (dlopen), so a single-GPU user of libgvom_hip.so does not
+// depend on it.  The reference has no multi-GPU path; there is no interface to mirror.
+#include "../../include/gvom_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <atomic>
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <immintrin.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
+
+#define VIS __attribute__((visibility("default")))
+#define GVOM_COMM_MAX_RANKS 64
+#define GVOM_COMM_MAX_VALUES 160          // int64 values per rank and exchange (>= 2 * ranks + 4)
+
+namespace {
+
+struct Rccl {
+    void *lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool load(std::string &err)
+    {
+        if (lib) return true;
+        lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) { err = std::string("cannot load librccl.so: ") + dlerror(); return false; }
+#define SYM(field, name)                                                                     \
+        field = (decltype(field))dlsym(lib, name);                                            \
+        if (!field) { err = std::string("librccl.so lacks ") + name; return false; }
+        SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy")
+        SYM(GroupStart, "ncclGroupStart") SYM(GroupEnd, "ncclGroupEnd") SYM(Send, "ncclSend") SYM(Recv, "ncclRecv")
+        SYM(AllGather, "ncclAllGather") SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+        return true;
+    }
+};
+
+struct Slot {                                  // one rank's mailbox for one exchange parity
+    std::atomic<uint64_t> seq;
+    int64_t values[GVOM_COMM_MAX_VALUES];
+    char pad[64];
+};
+
+struct Segment {                               // the shared-memory rendezvous of one communicator
+    std::atomic<uint32_t> magic;               // set last by rank 0
+    uint32_t world;
+    std::atomic<uint32_t> id_ready;
+    std::atomic<uint32_t> attached;
+    double created_s;                          // CLOCK_REALTIME at creation: a segment left behind by a crashed run is not joined
+    ncclUniqueId id;
+    Slot slots[2][GVOM_COMM_MAX_RANKS];
+};
+
+inline double now_s() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + t.tv_nsec * 1e-9; }
+inline double wall_s() { timespec t; clock_gettime(CLOCK_REALTIME, &t); return t.tv_sec + t.tv_nsec * 1e-9; }
+
+}  // namespace
+
+struct gvom_comm {
+    int rank = 0, world = 1, device = 0;
+    Rccl rccl;
+    ncclComm_t nccl = nullptr;
+    Segment *seg = nullptr;
+    std::string shm_name, err;
+    uint64_t calls = 0;                        // host exchanges so far
+    double timeout_s = 60.0;
+};
+
+namespace {
+
+#define NCCLCHK(c, call)                                                                       \
+    do {                                                                                       \
+        ncclResult_t r_ = (call);                                                              \
+        if (r_ != ncclSuccess) {                                                               \
+            (c)->err = std::string(#call) + " failed: " + (c)->rccl.GetErrorString(r_);        \
+            return GVOM_ERR_HIP;                                                               \
+        }                                                                                      \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+// name: the same string on every rank of the communicator and unique to it on the node (e.g.
+// "gvom_<master port>"); rank 0 creates /dev/shm/<name>, the others wait for it.  device: the HIP
+// device this rank's handle lives on.  world == 1 is allowed (collectives degenerate to copies).
+VIS int gvom_comm_create(int rank, int world, int device, const char *name, gvom_comm_t **out)
+{
+    if (!out || !name || world < 1 || world > GVOM_COMM_MAX_RANKS || rank < 0 || rank >= world) return GVOM_ERR_INVALID;
+    *out = nullptr;
+    gvom_comm *c = new gvom_comm();
+    c->rank = rank; c->world = world; c->device = device;
+    c->shm_name = std::string("/") + name;
+    auto fail = [&](const std::string &why, int code) {
+        fprintf(stderr, "gvom_comm_create(rank %d of %d): %s\n", rank, world, why.c_str());
+        if (c->seg) munmap(c->seg, sizeof(Segment));
+        delete c;
+        return code;
+    };
+    if (!c->rccl.load(c->err)) return fail(c->err, GVOM_ERR_NO_DEVICE);
+    if (hipSetDevice(device) != hipSuccess) return fail("hipSetDevice failed", GVOM_ERR_NO_DEVICE);
+    if (rank == 0) {
+        shm_unlink(c->shm_name.c_str());                               // a stale segment of a crashed run
+        int fd = shm_open(c->shm_name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0 || ftruncate(fd, sizeof(Segment)) != 0) { if (fd >= 0) close(fd); return fail("cannot create the shared-memory rendezvous", GVOM_ERR_HIP); }
+        void *m = mmap(nullptr, sizeof(Segment), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (m == MAP_FAILED) return fail("mmap of the rendezvous failed", GVOM_ERR_HIP);
+        c->seg = (Segment *)m;
+        memset((void *)c->seg, 0, sizeof(Segment));
+        c->seg->world = (uint32_t)world;
+        c->seg->created_s = wall_s();
+        if (c->rccl.GetUniqueId(&c->seg->id) != ncclSuccess) return fail("ncclGetUniqueId failed", GVOM_ERR_HIP);
+        c->seg->id_ready.store(1, std::memory_order_release);
+        c->seg->magic.store(0x47564f4du, std::memory_order_release);
+    } else {
+        // join the segment rank 0 has created for THIS run: complete (magic), fresh, same world size
+        const double deadline = now_s() + c->timeout_s;
+        while (true) {
+            int fd = shm_open(c->shm_name.c_str(), O_RDWR, 0600);
+            struct stat sb;
+            if (fd >= 0 && fstat(fd, &sb) == 0 && (size_t)sb.st_size >= sizeof(Segment)) {
+                void *m = mmap(nullptr, sizeof(Segment), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+                if (m != MAP_FAILED) {
+                    Segment *sg = (Segment *)m;
+                    const double t_end = now_s() + 0.05;
+                    while (sg->magic.load(std::memory_order_acquire) != 0x47564f4du && now_s() < t_end) usleep(100);
+                    const double age = wall_s() - sg->created_s;
+                    if (sg->magic.load(std::memory_order_acquire) == 0x47564f4du && sg->id_ready.load(std::memory_order_acquire) == 1u &&
+                        age > -5.0 && age < c->timeout_s + 60.0 && sg->attached.load(std::memory_order_acquire) < (uint32_t)world) {
+                        close(fd);
+                        c->seg = sg;
+                        break;
+                    }
+                    munmap(m, sizeof(Segment));
+                }
+            }
+            if (fd >= 0) close(fd);
+            if (now_s() > deadline) return fail("rank 0 never created the shared-memory rendezvous", GVOM_ERR_HIP);
+            usleep(500);
+        }
+        if (c->seg->world != (uint32_t)world) return fail("world size differs from rank 0's", GVOM_ERR_INVALID);
+    }
+    ncclUniqueId id;
+    memcpy(&id, &c->seg->id, sizeof id);
+    ncclResult_t r = c->rccl.CommInitRank(&c->nccl, world, id, rank);
+    if (r != ncclSuccess) return fail(std::string("ncclCommInitRank failed: ") + c->rccl.GetErrorString(r), GVOM_ERR_HIP);
+    // the name can go once everybody is attached (the mapping stays valid)
+    if (c->seg->attached.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint32_t)world) shm_unlink(c->shm_name.c_str());
+    *out = c;
+    return GVOM_OK;
+}
+
+VIS void gvom_comm_destroy(gvom_comm_t *c)
+{
+    if (!c) return;
+    if (c->nccl) { hipSetDevice(c->device); c->rccl.CommDestroy(c->nccl); }
+    if (c->seg) munmap(c->seg, sizeof(Segment));
+    if (c->rank == 0) shm_unlink(c->shm_name.c_str());                 // harmless if already gone
+    delete c;
+}
+
+VIS const char *gvom_comm_last_error(gvom_comm_t *c) { return c ? c->err.c_str() : "null communicator"; }
+
+// host-side all-gather of k int64 values per rank (k <= GVOM_COMM_MAX_VALUES): all[r*k + j] = rank
+// r's mine[j].  Collective; ~1 us on one node.
+VIS int gvom_comm_exchange_host(gvom_comm_t *c, const int64_t *mine, int k, int64_t *all)
+{
+    if (!c || !mine || !all || k < 0 || k > GVOM_COMM_MAX_VALUES) return GVOM_ERR_INVALID;
+    const uint64_t call = ++c->calls;
+    Slot *slots = c->seg->slots[call & 1];
+    // (a rank can only be two calls ahead of the slowest one: it passes call n + 1 only after every
+    // rank has published n + 1, i.e. has finished reading call n -- so two parities are enough)
+    memcpy(slots[c->rank].values, mine, (size_t)k * 8);
+    slots[c->rank].seq.store(call, std::memory_order_release);
+    const double deadline = now_s() + c->timeout_s;
+    for (int r = 0; r < c->world; ++r) {
+        unsigned spins = 0;
+        while (slots[r].seq.load(std::memory_order_acquire) != call) {
+            _mm_pause();
+            if ((++spins & 0xffff) == 0 && now_s() > deadline) { c->err = "host exchange timed out (a rank is missing)"; return GVOM_ERR_HIP; }
+        }
+        memcpy(all + (size_t)r * k, slots[r].values, (size_t)k * 8);
+    }
+    return GVOM_OK;
+}
+
+VIS int gvom_comm_barrier(gvom_comm_t *c)
+{
+    int64_t z = 0, all[GVOM_COMM_MAX_RANKS];
+    return gvom_comm_exchange_host(c, &z, 1, all);
+}
+
+// The scan's exchange: SEND regions of `h` (gvom_shard_scan_local) -> the owners' RECV regions.
+// send_* / recv_*: [world] counts (quads: 4-byte id + 1 KiB each; endpoints: 8 bytes each); the
+// caller has exchanged them (gvom_comm_exchange_host) and called gvom_shard_recv_reserve.  One
+// grouped ncclSend / ncclRecv on the handle's stream; returns without synchronising.
+VIS int gvom_comm_exchange_scan(gvom_comm_t *c, gvom_t *h, const int64_t *send_quads, const int64_t *send_eps,
+                                const int64_t *recv_quads, const int64_t *recv_eps)
+{
+    if (!c || !h || !send_quads || !send_eps || !recv_quads || !recv_eps) return GVOM_ERR_INVALID;
+    if (c->world == 1) return GVOM_OK;
+    if (hipSetDevice(c->device) != hipSuccess) { c->err = "hipSetDevice failed"; return GVOM_ERR_HIP; }
+    hipStream_t st = (hipStream_t)gvom_stream(h);
+    NCCLCHK(c, c->rccl.GroupStart());
+    for (int p = 0; p < c->world; ++p) {
+        if (p == c->rank) continue;
+        void *ptr = nullptr;
+        if (send_quads[p] > 0) {
+            if (gvom_shard_buffer(h, GVOM_XBUF_SEND_IDS, p, &ptr, nullptr)) return GVOM_ERR_INVALID;
+            NCCLCHK(c, c->rccl.Send(ptr, (size_t)send_quads[p] * 4, ncclUint8, p, c->nccl, st));
+            if (gvom_shard_buffer(h, GVOM_XBUF_SEND_QUADS, p, &ptr, nullptr)) return GVOM_ERR_INVALID;
+            NCCLCHK(c, c->rccl.Send(ptr, (size_t)send_quads[p] * 1024, ncclUint8, p, c->nccl, st));
+        }
+        if (send_eps[p] > 0) {
+            if (gvom_shard_buffer(h, GVOM_XBUF_SEND_EPS, p, &ptr, nullptr)) return GVOM_ERR_INVALID;
+            NCCLCHK(c, c->rccl.Send(ptr, (size_t)send_eps[p] * 8, ncclUint8, p, c->nccl, st));
+        }
+        if (recv_quads[p] > 0) {
+            if (gvom_shard_buffer(h, GVOM_XBUF_RECV_IDS, p, &ptr, nullptr)) return GVOM_ERR_INVALID;
+            NCCLCHK(c, c->rccl.Recv(ptr, (size_t)recv_quads[p] * 4, ncclUint8, p, c->nccl, st));
+            if (gvom_shard_buffer(h, GVOM_XBUF_RECV_QUADS, p, &ptr, nullptr)) return GVOM_ERR_INVALID;
+            NCCLCHK(c, c->rccl.Recv(ptr, (size_t)recv_quads[p] * 1024, ncclUint8, p, c->nccl, st));
+        }
+        if (recv_eps[p] > 0) {
+            if (gvom_shard_buffer(h, GVOM_XBUF_RECV_EPS, p, &ptr, nullptr)) return GVOM_ERR_INVALID;
+            NCCLCHK(c, c->rccl.Recv(ptr, (size_t)recv_eps[p] * 8, ncclUint8, p, c->nccl, st));
+        }
+    }
+    NCCLCHK(c, c->rccl.GroupEnd());
+    return GVOM_OK;
+}
+
+// The combine's exchange: in-place all-gather of the handle's [height | inferred height | positive
+// density] rows (GVOM_BUF_HEIGHT_MAPS; a rank's rows are one contiguous block) on the handle's stream.
+VIS int gvom_comm_allgather_rows(gvom_comm_t *c, gvom_t *h)
+{
+    if (!c || !h) return GVOM_ERR_INVALID;
+    void *ptr = nullptr;
+    int64_t bytes = 0, row = 0;
+    int rc = gvom_device_buffer(h, GVOM_BUF_HEIGHT_MAPS, &ptr, &bytes, &row);
+    if (rc) return rc;
+    if (bytes % c->world) { c->err = "height-map rows do not divide among the ranks"; return GVOM_ERR_INVALID; }
+    if (hipSetDevice(c->device) != hipSuccess) { c->err = "hipSetDevice failed"; return GVOM_ERR_HIP; }
+    const size_t share = (size_t)(bytes / c->world);
+    NCCLCHK(c, c->rccl.AllGather((char *)ptr + share * c->rank, ptr, share, ncclUint8, c->nccl, (hipStream_t)gvom_stream(h)));
+    return GVOM_OK;
+}
+
+VIS int gvom_comm_rank(gvom_comm_t *c) { return c ? c->rank : -1; }
+VIS int gvom_comm_world(gvom_comm_t *c) { return c ? c->world : -1; }
+
+}  // extern "C"

@@ -72,7 +72,15 @@ struct ScanParams {
     int    off[3];        // element offsets of x, y, z inside a point record (0, 1, 2 unless PointCloud2 ingest)
     int    in_f32;        // 1: the records hold float32 fields that are widened to the (float64) compute type,
                           //    as ros_numpy hands the reference a float64 array (stride and offsets in 4-byte units)
+    int    shard_world, shard_rank, shard_rows;   // ranks of a sharded map (1, 0, xy when unsharded): rank r owns storage rows [r*shard_rows, (r+1)*shard_rows)
     int    dbg;           // diagnostic build only
+};
+
+// rank exchange, k_trace side: endpoints in another rank's rows are appended to that rank's send list
+struct ShardExchange {
+    uint2    *ep_send;    // [world][ep_cap] {voxel L, min-height sample}
+    uint32_t *ep_cnt;     // [world * 16] (one counter per 64-B line)
+    long      ep_cap;
 };
 
 struct MapDesc {          // one source map of the fusion (ring slot or previous fused map)
@@ -127,11 +135,17 @@ struct Map2dParams {
 };
 
 // ---- launchers (gvom_kernels.hip) --------------------------------------------------------
-hipError_t gvom_launch_trace(hipStream_t s, const ScanParams &P, int dtype, bool big_origin, const void *pts,
+hipError_t gvom_launch_trace(hipStream_t s, const ScanParams &P, const ShardExchange &X, int dtype, bool big_origin, const void *pts,
                              int64_t stride_elems, int64_t n, void *world, uint32_t *hit,
                              uint32_t *total, uint32_t *mh, int32_t *state, uint32_t *tags,
                              uint32_t *counters, double *stat_sums, double *stat_base,
                              uint32_t *stat_rowvox);
+hipError_t gvom_launch_pack(hipStream_t s, const ScanParams &P, uint32_t *total, const uint32_t *tags, uint32_t *send_ids,
+                            void *send_pay, uint32_t *qcnt, uint32_t *ecnt, uint32_t *counters,
+                            unsigned long long *host_out, uint32_t seq);
+hipError_t gvom_launch_unpack(hipStream_t s, const ScanParams &P, uint32_t nq, const uint32_t *ids, const void *pay,
+                              uint32_t ne, const void *eps, long row_base, uint32_t *hit, uint32_t *total, uint32_t *mh,
+                              int32_t *state, uint32_t *tags);
 hipError_t gvom_launch_encode(hipStream_t s, const ScanParams &P, uint32_t *hit, uint32_t *total, uint32_t *mh,
                               int32_t *state, uint32_t *chit, uint32_t *ctotal, uint32_t *cminh, const uint32_t *tags,
                               uint32_t *counters, unsigned long long *host_flag, uint32_t seq, unsigned resident_blocks);

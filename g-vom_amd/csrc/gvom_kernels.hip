@@ -200,37 +200,43 @@ __device__ __forceinline__ uint32_t ray_steps(double lim, double step_len, doubl
     return n;
 }
 
-// Endpoint voxel of one return: hit += 1, total += 1, min-height (gvom.py:1070-1090, 1303-1329); the
-// voxel's compact row is the index of (one of) its returns -- no row counter, no barrier.  All atomics
-// are fire-and-forget.
+// Endpoint voxel of one return (gvom.py:1070-1086): storage index L, accumulator index A, storage row
+// sy, and its min-height sample (gvom.py:1303-1329).
+struct Endpoint { bool ingrid; uint32_t L, A, mbits; int sy; };
 template <typename T>
-__device__ __forceinline__ void endpoint_update(const ScanParams &P, int lane, long i, bool pass, T x, T y, T z,
-                                                uint32_t *hit, uint32_t *total, uint32_t *mh, int32_t *state,
-                                                uint32_t *tags, uint32_t *counters, double *stat_sums,
-                                                double *stat_base, uint32_t *stat_rowvox)
+__device__ __forceinline__ Endpoint endpoint_of(const ScanParams &P, bool pass, T x, T y, T z)
 {
-    bool ingrid = false;
-    uint32_t L = 0, A = 0, mbits = 0;
+    Endpoint E;
+    E.ingrid = false; E.L = 0; E.A = 0; E.mbits = 0; E.sy = 0;
     if (pass) {
         const double fx = floor((double)x / P.xy_res - P.origin[0]);
         const double fy = floor((double)y / P.xy_res - P.origin[1]);
         const double az = (double)z / P.z_res - P.origin[2];
         const double fz = floor(az);
         if (fx >= 0.0 && fx < (double)P.xy && fy >= 0.0 && fy < (double)P.xy && fz >= 0.0 && fz < (double)P.zs) {
-            ingrid = true;
+            E.ingrid = true;
             const int sx = wrap_add((int)fx, P.om[0], P.xy);
             const int sy = wrap_add((int)fy, P.om[1], P.xy);
             const int sz = wrap_add((int)fz, P.om[2], P.zs);
-            L = ((uint32_t)sy * P.zs + sz) * P.xy + sx;
-            A = acc_idx(sx, sy, sz, P.zs, P.sxq);
+            E.sy = sy;
+            E.L = ((uint32_t)sy * P.zs + sz) * P.xy + sx;
+            E.A = acc_idx(sx, sy, sz, P.zs, P.sxq);
             // local_point[2], f64 -> f32 (gvom.py:1326,1329): in [0, 1], so the float order equals the
             // order of its bit pattern; kept as 1.0f's bits MINUS the value's (0 = the 1.0f the reference
             // initialises with, gvom.py:1014-1015) so that the accumulator is zero between scans
-            mbits = 0x3f800000u - __float_as_uint((float)(az - fz));
+            E.mbits = 0x3f800000u - __float_as_uint((float)(az - fz));
         }
     }
-    // some return landed in the grid: the scan will be committed (gvom.py:147-150)
-    if (lanes(ingrid) != 0ull && lane == 0) counters[GVOM_CNT_INGRID] = 1u;
+    return E;
+}
+
+// hit += 1, total += 1, min-height for the endpoints of a wave (gvom.py:1087-1090, 1329); the voxel's
+// compact row is `row` of (one of) its returns -- no row counter, no barrier.  All atomics are
+// fire-and-forget.
+__device__ __forceinline__ void endpoint_commit(const ScanParams &P, int lane, long row, bool ingrid, uint32_t L, uint32_t A,
+                                                uint32_t mbits, uint32_t *hit, uint32_t *total, uint32_t *mh, int32_t *state,
+                                                uint32_t *tags, double *stat_sums, double *stat_base, uint32_t *stat_rowvox)
+{
     // neighbouring returns of a beam end in the same voxel (33 consecutive azimuths at 2 m range):
     // the first lane of each run of equal voxels adds the whole run
     const uint32_t key = ingrid ? A : (0xFFFFFF00u | (uint32_t)lane);
@@ -243,12 +249,12 @@ __device__ __forceinline__ void endpoint_update(const ScanParams &P, int lane, l
         atomicAdd(&hit[A], run);
         atomicAdd(&total[A], run);
         tags[(L / P.xy) * P.nseg + ((L % P.xy) >> 6)] = P.epoch;   // stamp the tile (idempotent)
-        // the voxel's compact row = this return's index.  Several runs (other waves) may end in the
-        // same voxel: the last store wins, every candidate is a valid, unique row.
-        state[L] = (int32_t)i;
+        // the voxel's compact row = this return's.  Several runs (other waves) may end in the same
+        // voxel: the last store wins, every candidate is a valid, unique row.
+        state[L] = (int32_t)row;
         if (stat_sums) {                            // optional statistics: zeroed metrics (gvom.py:1011-1012)
-            for (int m = 0; m < 10; ++m) { stat_sums[(size_t)i * 10 + m] = 0.0; stat_base[(size_t)i * 10 + m] = 0.0; }
-            stat_rowvox[i] = L;                     // row -> voxel, for the per-row neighbour gather
+            for (int m = 0; m < 10; ++m) { stat_sums[(size_t)row * 10 + m] = 0.0; stat_base[(size_t)row * 10 + m] = 0.0; }
+            stat_rowvox[row] = L;                   // row -> voxel, for the per-row neighbour gather
         }
     }
 }
@@ -411,8 +417,8 @@ __device__ __forceinline__ void walk_item(const ScanParams &P, int lane, uint32_
 // ------------------------------------------------------------------------------------------
 template <typename T, bool BIG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_trace(
-    const ScanParams P, const T *__restrict__ in, long stride, long n, T *__restrict__ world, uint32_t *hit,
-    uint32_t *total, uint32_t *mh, int32_t *state, uint32_t *tags, uint32_t *counters, double *stat_sums,
+    const ScanParams P, const ShardExchange X, const T *__restrict__ in, long stride, long n, T *__restrict__ world,
+    uint32_t *hit, uint32_t *total, uint32_t *mh, int32_t *state, uint32_t *tags, uint32_t *counters, double *stat_sums,
     double *stat_base, uint32_t *stat_rowvox)
 {
     const int lane = threadIdx.x & (WAVE - 1);
@@ -424,7 +430,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const bool pass = live && !((double)d2 < P.min_d2);
     if ((int)blockIdx.y == P.ep_row) {
         if (live && world) { world[3 * i + 0] = x; world[3 * i + 1] = y; world[3 * i + 2] = z; }   // statistics only
-        endpoint_update<T>(P, lane, i, pass, x, y, z, hit, total, mh, state, tags, counters, stat_sums, stat_base, stat_rowvox);
+        const Endpoint E = endpoint_of<T>(P, pass, x, y, z);
+        // some return landed in the grid: the scan will be committed (gvom.py:147-150)
+        if (lanes(E.ingrid) != 0ull && lane == 0) counters[GVOM_CNT_INGRID] = 1u;
+        bool mine = E.ingrid;
+        if (P.shard_world > 1) {
+            // ranks of a sharded map: an endpoint in another rank's rows travels to its owner as
+            // {voxel, min-height sample} (8 bytes); one counter atomic per wave and destination
+            const int d = E.sy / P.shard_rows;
+            const bool foreign = E.ingrid && d != P.shard_rank;
+            mine = E.ingrid && !foreign;
+            unsigned long long fm = lanes(foreign);
+            while (fm != 0ull) {                                         // wave-uniform: the destinations present
+                const int first = __ffsll((long long)fm) - 1;
+                const int dd = __builtin_amdgcn_readlane(d, first);
+                const unsigned long long m = lanes(foreign && d == dd);
+                uint32_t base = 0;
+                if (lane == first) base = atomicAdd(&X.ep_cnt[dd * 16], (uint32_t)__popcll(m));
+                base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
+                if (foreign && d == dd) X.ep_send[(size_t)dd * X.ep_cap + base + (uint32_t)__popcll(m & lanemask_lt())] = make_uint2(E.L, E.mbits);
+                fm &= ~m;
+            }
+        }
+        endpoint_commit(P, lane, i, mine, E.L, E.A, E.mbits, hit, total, mh, state, tags, stat_sums, stat_base, stat_rowvox);
         return;
     }
     const int seg = (int)blockIdx.y - ((int)blockIdx.y > P.ep_row ? 1 : 0);
@@ -462,6 +490,130 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     for (int q = 0; q < 16; ++q) LC_ST(&lcc[q * 64 + lane], 0u);
     const int steps = seg == P.nsegs - 1 ? 0x3fffffff : P.seg_start[seg + 1] - (int)j0;
     walk_item<BIG>(P, lane, j0, cnt, px, py, pz, R.incx, R.incy, R.incz, active, steps, P.lc_period, lck, lcc, total, tags);
+}
+
+// ------------------------------------------------------------------------------------------
+// Rank exchange of a sharded map (DESIGN.md "Multi-GPU").  Every rank traces ITS OWN rays over the
+// whole window into private accumulators; the ray passes that fell into another rank's rows travel
+// to their owner as dirty QUADS (4 storage rows x 64 sx at one sz = 16 accumulator lines = 1 KiB of
+// `total`), the endpoints as {voxel, min-height} pairs (k_trace).  Integer sums and minima commute,
+// so the owner's accumulators end up exactly as if it had traced every ray itself.
+//
+// k_pack: grid (ceil(slab quads / 256), world - 1): block (c, p) looks at 256 consecutive quads of
+// peer p's rows; the dirty ones (a tile tag == this scan's epoch) are numbered with ONE counter
+// atomic per block, copied to the peer's send region (quad id + 1 KiB in the lane order k_encode
+// reads: lane (p4, r) = 4 voxels sx = 64*seg + 4*p4.. of row 4q + r) and zeroed.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack(const ScanParams P, uint32_t *total, const uint32_t *__restrict__ tags,
+                                              uint32_t *send_ids, uint4 *send_pay, uint32_t *qcnt)
+{
+    __shared__ uint32_t s_list[256];
+    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_base;
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
+    int d = (int)blockIdx.y;
+    if (d >= P.shard_rank) ++d;                          // peers in rank order, skipping this rank
+    const uint32_t nseg = (uint32_t)P.nseg, zs = (uint32_t)P.zs;
+    const uint32_t u_begin = ((uint32_t)(d * P.shard_rows) >> 2) * zs * nseg;
+    const uint32_t u_end = ((uint32_t)((d + 1) * P.shard_rows) >> 2) * zs * nseg;
+    const uint32_t u = u_begin + blockIdx.x * 256u + threadIdx.x;
+    bool dirty = false;
+    if (u < u_end) {
+        const uint32_t seg = u % nseg, sz = (u / nseg) % zs, q = u / (nseg * zs);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dirty = dirty || tags[((q * 4 + r) * zs + sz) * nseg + seg] == P.epoch;
+    }
+    const unsigned long long dm = lanes(dirty);
+    if (lane == 0) s_w[wv] = (uint32_t)__popcll(dm);
+    __syncthreads();
+    uint32_t before = 0;
+    for (int k = 0; k < wv; ++k) before += s_w[k];
+    const uint32_t count = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+    if (dirty) s_list[before + (uint32_t)__popcll(dm & lanemask_lt())] = u;
+    if (threadIdx.x == 0) s_base = count ? atomicAdd(&qcnt[d * 16], count) : 0u;
+    __syncthreads();
+    if (count == 0) return;
+    // the peer's regions start at its first quad: at most (u_end - u_begin) quads can be dirty
+    uint32_t *ids = send_ids + u_begin;
+    uint4 *pay = send_pay + (size_t)u_begin * 64;
+    const int p4 = lane >> 2, r = lane & 3;
+    for (uint32_t k = (uint32_t)wv; k < count; k += 4) {
+        const uint32_t uq = s_list[k];
+        const uint32_t seg = uq % nseg, sz = (uq / nseg) % zs, q = uq / (nseg * zs);
+        const uint32_t sx0 = seg * 64 + p4 * 4, sy = q * 4 + r;
+        const bool ok = sx0 < (uint32_t)P.xy;
+        uint4 tv = make_uint4(0, 0, 0, 0);
+        const uint32_t A0 = ok ? acc_idx((int)sx0, (int)sy, (int)sz, P.zs, P.sxq) : 0u;
+        if (ok) tv = *reinterpret_cast<const uint4 *>(total + A0);
+        pay[(size_t)(s_base + k) * 64 + lane] = tv;
+        if (ok && (tv.x | tv.y | tv.z | tv.w)) *reinterpret_cast<uint4 *>(total + A0) = make_uint4(0, 0, 0, 0);
+        if (lane == 0) ids[s_base + k] = uq;
+    }
+}
+
+// counts of k_pack / k_trace's endpoint lists -> host-mapped memory (the host sizes the exchange with
+// them) and re-armed: out[d] = quads for rank d, out[world + d] = endpoints, out[2*world] = some return
+// of THIS rank landed in the grid, then the sequence number
+__global__ void k_shard_publish(int world, uint32_t *qcnt, uint32_t *ecnt, uint32_t *counters,
+                                unsigned long long *host_out, uint32_t seq)
+{
+    const int d = threadIdx.x;
+    if (d < world) {
+        __hip_atomic_store(&host_out[d], (unsigned long long)qcnt[d * 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&host_out[world + d], (unsigned long long)ecnt[d * 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        qcnt[d * 16] = 0; ecnt[d * 16] = 0;
+    }
+    __syncthreads();
+    if (d == 0) {
+        __hip_atomic_store(&host_out[2 * world], (unsigned long long)(counters[GVOM_CNT_INGRID] ? 1u : 0u), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&host_out[2 * world + 1], (unsigned long long)seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// k_unpack_quads: one wave per received quad: total += the sender's 1 KiB (16 lanes per 64-B line =
+// one memory-side request per line), tile tags of the rows that carry something
+__global__ __launch_bounds__(256) void k_unpack_quads(const ScanParams P, uint32_t nq, const uint32_t *__restrict__ ids,
+                                                      const uint4 *__restrict__ pay, uint32_t *total, uint32_t *tags)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+    const uint32_t k = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (k >= nq) return;
+    const uint32_t nseg = (uint32_t)P.nseg, zs = (uint32_t)P.zs;
+    const uint32_t uq = ids[k];
+    const uint32_t seg = uq % nseg, sz = (uq / nseg) % zs, q = uq / (nseg * zs);
+    const int p4 = lane >> 2, r = lane & 3;
+    const uint32_t sx0 = seg * 64 + p4 * 4, sy = q * 4 + r;
+    const uint4 tv = pay[(size_t)k * 64 + lane];
+    const bool any = (tv.x | tv.y | tv.z | tv.w) != 0u && sx0 < (uint32_t)P.xy;
+    if (any) {
+        const uint32_t A0 = acc_idx((int)sx0, (int)sy, (int)sz, P.zs, P.sxq);
+        if (tv.x) atomicAdd(&total[A0 + 0], tv.x);
+        if (tv.y) atomicAdd(&total[A0 + 1], tv.y);
+        if (tv.z) atomicAdd(&total[A0 + 2], tv.z);
+        if (tv.w) atomicAdd(&total[A0 + 3], tv.w);
+    }
+    const unsigned long long am = lanes(any);
+    if (lane < 4 && (am & (0x1111111111111111ull << lane)) != 0ull)
+        tags[((q * 4 + (uint32_t)lane) * zs + sz) * nseg + seg] = P.epoch;
+}
+
+// k_unpack_eps: one lane per received endpoint {voxel, min-height sample}: the owner's share of
+// k_trace's endpoint work; rows continue behind this rank's own returns
+__global__ __launch_bounds__(256) void k_unpack_eps(const ScanParams P, uint32_t ne, const uint2 *__restrict__ eps, long row_base,
+                                                    uint32_t *hit, uint32_t *total, uint32_t *mh, int32_t *state, uint32_t *tags)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < ne;
+    uint32_t L = 0, A = 0, mbits = 0;
+    if (live) {
+        const uint2 e = eps[i];
+        L = e.x; mbits = e.y;
+        const uint32_t sx = L % (uint32_t)P.xy, rz = L / (uint32_t)P.xy;
+        A = acc_idx((int)sx, (int)(rz / (uint32_t)P.zs), (int)(rz % (uint32_t)P.zs), P.zs, P.sxq);
+    }
+    endpoint_commit(P, lane, row_base + (long)i, live, L, A, mbits, hit, total, mh, state, tags, nullptr, nullptr, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1937,7 +2089,7 @@ __global__ void k_debug_height(int xy, int om0, int om1, double o0, double o1, d
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-hipError_t gvom_launch_trace(hipStream_t s, const ScanParams &P, int dtype, bool big_origin, const void *pts,
+hipError_t gvom_launch_trace(hipStream_t s, const ScanParams &P, const ShardExchange &X, int dtype, bool big_origin, const void *pts,
                              int64_t stride_elems, int64_t n, void *world, uint32_t *hit,
                              uint32_t *total, uint32_t *mh, int32_t *state, uint32_t *tags,
                              uint32_t *counters, double *stat_sums, double *stat_base,
@@ -1946,12 +2098,34 @@ hipError_t gvom_launch_trace(hipStream_t s, const ScanParams &P, int dtype, bool
     const unsigned blocks = (unsigned)((n + 255) / 256);
     if (blocks == 0) return hipSuccess;
 #define TRACE_LAUNCH(TT, BB)                                                                             \
-    hipLaunchKernelGGL((k_trace<TT, BB>), dim3(blocks, (unsigned)P.nsegs + 1u), dim3(256), 0, s, P, (const TT *)pts, \
+    hipLaunchKernelGGL((k_trace<TT, BB>), dim3(blocks, (unsigned)P.nsegs + 1u), dim3(256), 0, s, P, X, (const TT *)pts, \
                        (long)stride_elems, (long)n, (TT *)world, hit, total, mh, state, tags, counters,     \
                        stat_sums, stat_base, stat_rowvox)
     if (dtype == 0) { if (big_origin) TRACE_LAUNCH(float, true); else TRACE_LAUNCH(float, false); }
     else { if (big_origin) TRACE_LAUNCH(double, true); else TRACE_LAUNCH(double, false); }
 #undef TRACE_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t gvom_launch_pack(hipStream_t s, const ScanParams &P, uint32_t *total, const uint32_t *tags, uint32_t *send_ids,
+                            void *send_pay, uint32_t *qcnt, uint32_t *ecnt, uint32_t *counters,
+                            unsigned long long *host_out, uint32_t seq)
+{
+    const uint32_t slab_quads = ((uint32_t)P.shard_rows >> 2) * (uint32_t)P.zs * (uint32_t)P.nseg;
+    if (P.shard_world > 1 && slab_quads > 0)
+        hipLaunchKernelGGL(k_pack, dim3((slab_quads + 255) / 256, (unsigned)P.shard_world - 1u), dim3(256), 0, s, P, total, tags,
+                           send_ids, (uint4 *)send_pay, qcnt);
+    hipLaunchKernelGGL(k_shard_publish, dim3(1), dim3(64), 0, s, P.shard_world, qcnt, ecnt, counters, host_out, seq);
+    return hipGetLastError();
+}
+
+hipError_t gvom_launch_unpack(hipStream_t s, const ScanParams &P, uint32_t nq, const uint32_t *ids, const void *pay,
+                              uint32_t ne, const void *eps, long row_base, uint32_t *hit, uint32_t *total, uint32_t *mh,
+                              int32_t *state, uint32_t *tags)
+{
+    if (nq) hipLaunchKernelGGL(k_unpack_quads, dim3((nq + 3) / 4), dim3(256), 0, s, P, nq, ids, (const uint4 *)pay, total, tags);
+    if (ne) hipLaunchKernelGGL(k_unpack_eps, dim3((ne + 255) / 256), dim3(256), 0, s, P, ne, (const uint2 *)eps, row_base, hit,
+                               total, mh, state, tags);
     return hipGetLastError();
 }
 

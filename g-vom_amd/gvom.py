@@ -30,7 +30,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 GVOM_OK, GVOM_EMPTY_CLOUD, GVOM_NO_OVERLAP, GVOM_EMPTY_BUFFER, GVOM_NO_DATA = 0, 1, 2, 3, 4
 GVOM_WHICH_FUSED = -1
 MAP_HEIGHT, MAP_INFERRED, MAP_SLOPE_X, MAP_SLOPE_Y, MAP_ROUGHNESS, MAP_GUESSED = range(6)
-BUF_HEIGHT_MAPS, BUF_SCAN_CELLS, BUF_FUSED_CELLS = 0, 2, 3
+BUF_HEIGHT_MAPS, BUF_FUSED_CELLS = 0, 3
 N_STAGES = 5
 STAGE_NAMES = ("trace", "encode", "min_height", "fuse", "map2d")
 
@@ -87,15 +87,26 @@ ABI = [
     ("gvom_output_buffer_free", _I, [_P, _P]),
     ("gvom_combine_maps_into", _I, [_P, _P, _P]),
     ("gvom_combine_occupancy_into", _I, [_P, _P, _P, ctypes.c_double, ctypes.c_double, ctypes.c_double]),
-    ("gvom_scan_begin", _I, [_P, _P, _I, _I64, _I64, _I, _DP, _P, ctypes.POINTER(_I64)]),
-    ("gvom_scan_commit", _I, [_P, _I]),
+    ("gvom_shard_scan_local", _I, [_P, _P, _I, _I64, _I64, _I, _DP, _P, ctypes.POINTER(_I64), ctypes.POINTER(_I64),
+                                   ctypes.POINTER(_I)]),
+    ("gvom_shard_buffer", _I, [_P, _I, _I, ctypes.POINTER(_P), ctypes.POINTER(_I64)]),
+    ("gvom_shard_recv_reserve", _I, [_P, ctypes.POINTER(_I64)]),
+    ("gvom_shard_scan_merge", _I, [_P, ctypes.POINTER(_I64), ctypes.POINTER(_I64), _I]),
     ("gvom_combine_fuse", _I, [_P, ctypes.POINTER(_I64)]),
     ("gvom_set_combined_cell_count", _I, [_P, _I64]),
-    ("gvom_attach_stream", _I, [_P, _P]),
-    ("gvom_set_blocking", _I, [_P, _I]),
     ("gvom_sync", _I, [_P]),
     ("gvom_device_buffer", _I, [_P, _I, ctypes.POINTER(_P), ctypes.POINTER(_I64), ctypes.POINTER(_I64)]),
     ("gvom_combine_map2d_into", _I, [_P, _P, _P]),
+    ("gvom_comm_create", _I, [_I, _I, _I, ctypes.c_char_p, ctypes.POINTER(_P)]),
+    ("gvom_comm_destroy", None, [_P]),
+    ("gvom_comm_exchange_host", _I, [_P, ctypes.POINTER(_I64), _I, ctypes.POINTER(_I64)]),
+    ("gvom_comm_barrier", _I, [_P]),
+    ("gvom_comm_exchange_scan", _I, [_P, _P, ctypes.POINTER(_I64), ctypes.POINTER(_I64), ctypes.POINTER(_I64),
+                                     ctypes.POINTER(_I64)]),
+    ("gvom_comm_allgather_rows", _I, [_P, _P]),
+    ("gvom_comm_rank", _I, [_P]),
+    ("gvom_comm_world", _I, [_P]),
+    ("gvom_comm_last_error", ctypes.c_char_p, [_P]),
     ("gvom_slot_filled", _I, [_P, _I]),
     ("gvom_get_state", _I, [_P, ctypes.POINTER(GvomState)]),
     ("gvom_get_scan_stats", _I, [_P, ctypes.POINTER(GvomScanStats)]),

@@ -1,183 +1,287 @@
 """gvom_sharded -- one G-VOM map sharded over the GPUs of one node (one process per GPU).
 
-Partitioning (DESIGN.md "Multi-GPU"): the voxel grid is stored world-anchored (toroidal),
-so its storage y axis is cut into `world` contiguous slabs that NEVER migrate when the
-robot-centred window moves.  Rank r owns storage rows [r*xy/world, (r+1)*xy/world) of every
-per-voxel array (accumulators, ring slots, fused map).
+The reference has no multi-GPU path; semantics are SURVEY 8(e): rays are data-parallel,
+the per-voxel accumulators (hit / total: int32 sum, min-height: f32 min) are reduced onto the rank
+that owns the voxel, everything after is per voxel / per column on the owner.  The result equals
+gvom.Gvom fed with the concatenated cloud, bit for bit.
 
-Per scan (process_pointcloud) -- ONE collective:
-    all_gather      every rank's share of the cloud (12 B/point; 1.5 MB per 131k points)
-    local           each rank traces the rays that can reach its slab (window-y culling + early
-                    exit in k_trace) and commits only voxels of its slab; integer atomics commute,
-                    so the result is bit-identical to one GPU.  Every rank sees every point, so
-                    each counts the in-grid returns of ALL slabs itself: the reference's "no
-                    overlap" test (gvom.py:147-150) needs no collective.
-Per combine (combine_maps) -- ONE collective:
-    local           temporal fusion + column reductions of the slab -> its rows of the height and
-                    inferred-height maps, plus the positive-obstacle density of its cells (the only
-                    2-D quantity that needs voxel data)
-    all_gather      IN PLACE on the library's row-interleaved buffer [sy][height | inferred |
-                    density] (24 B x xy^2 = 1.5 MB at xy=256): the slope stencil needs +-1 row,
-                    __guess_height +-15 rows
-    local           every rank computes ALL rows of slope / roughness / guess / positive /
-                    negative / visibility (20 us of redundant 2-D work instead of a second
-                    collective) straight into pinned host memory; every rank returns the maps
-There is NO collective on per-voxel data: the only exchanged bytes are the cloud and 2-D rows.
-The library runs on the caller's (torch) stream and its own buffer is the collective buffer,
-so a combine has no host synchronisation before the final one.
+Partitioning: the voxel grid is stored world-anchored (toroidal), so its storage y axis is cut
+into `world` contiguous slabs that NEVER migrate when the robot-centred window moves.  Rank r owns
+storage rows [r*xy/world, (r+1)*xy/world) of every ring slot and of the fused map.
 
-The collectives are torch.distributed calls (backend "nccl" == RCCL over xGMI on ROCm; "gloo"
-in the CPU tests); the compute is behind a small backend interface: `HipShardBackend` (the
-product: libgvom_hip.so, slab-sharded handle) or a test double injected by tests/.
+Per scan (process_pointcloud; every rank passes ITS share, shares may differ in length or be empty):
+    local      k_trace over the rank's own rays and the WHOLE window into private accumulators
+               (balanced: every rank walks exactly its own rays); endpoints that fall into another
+               rank's rows are listed for their owner instead of being added locally
+    local      k_pack: the dirty quads (4 rows x 64 sx at one sz = 1 KiB of ray-pass counts) of
+               every other rank's rows -> that rank's send region; counts -> host-mapped memory
+    host       the per-destination counts and the "some return in the grid" flags are exchanged
+               through shared memory (the ranks are the processes of one node): ~1 us, no GPU
+    exchange   sparse all-to-all: grouped ncclSend / ncclRecv of {quad ids, quads, endpoints}
+               (RCCL over xGMI, on the library's stream, sizes exact)
+    local      k_unpack: total += received quads, endpoint work of the received endpoints;
+               k_encode over the rank's own rows; commit iff ANY rank saw a return in the grid
+Per combine (combine_maps):
+    local      temporal fusion + column reductions of the slab -> its rows of the height and
+               inferred-height maps, plus the positive-obstacle density of its cells
+    exchange   in-place ncclAllGather of the library's [sy][height | inferred | density] rows
+               (24 B x xy^2 = 1.5 MB at xy = 256): the slope stencil needs +-1 row, __guess_height +-15
+    local      every rank computes ALL rows of slope / roughness / guess / positive / negative /
+               visibility (20 us of redundant 2-D work instead of a second collective) straight
+               into pinned host memory; every rank returns the maps
+
+No PyTorch: the collectives are RCCL calls made by libgvom_hip.so itself (csrc/gvom_comm.hip), bound
+here with ctypes.  The orchestration below is transport-agnostic: `RcclComm` is the product,
+`ThreadComm` runs several ranks as threads of ONE process on ONE GPU (tests, tools), and tests/ holds
+a gloo double for CPU-only runs.
 """
 import ctypes
+import os
+import threading
 
 import numpy as np
 
 import gvom as _gvom
 
+XBUF_SEND_IDS, XBUF_SEND_QUADS, XBUF_SEND_EPS, XBUF_RECV_IDS, XBUF_RECV_QUADS, XBUF_RECV_EPS = range(6)
+_I64P = ctypes.POINTER(ctypes.c_int64)
 
-class _DevBuf(object):
-    """Exposes a raw device pointer to torch (zero-copy) through __cuda_array_interface__."""
 
-    def __init__(self, ptr, shape, typestr):
-        self.__cuda_array_interface__ = {"data": (int(ptr), False), "shape": tuple(shape),
-                                         "typestr": typestr, "version": 2}
+def _vec(values):
+    a = (ctypes.c_int64 * len(values))(*[int(v) for v in values])
+    return a
 
 
 class HipShardBackend(object):
-    """Per-rank compute on one MI355X through the C ABI (include/gvom_hip.h, split entry points).
-    The library is attached to torch's current stream and set non-blocking; its own device
-    buffer is wrapped as a torch tensor and used directly by the collective."""
+    """Per-rank compute on one MI355X through the C ABI (include/gvom_hip.h, gvom_shard_* entry points)."""
 
     def __init__(self, params, rank, world, device):
-        import torch
-        self.torch = torch
         self.rank, self.world = rank, world
-        self.device = torch.device("cuda", device)
-        torch.cuda.set_device(self.device)
         self.g = _gvom.Gvom(*params, device=device, _shard=(rank, world))
         self.lib, self.h = self.g._lib, self.g._h
         self.xy = params[2]
-        stream = torch.cuda.current_stream(self.device).cuda_stream
-        self.g._check(self.lib.gvom_attach_stream(self.h, ctypes.c_void_p(stream)))
-        self.g._check(self.lib.gvom_set_blocking(self.h, 0))
-        self.height_full = self._wrap(_gvom.BUF_HEIGHT_MAPS, np.float64)      # [xy, 3*xy]
-        self.fused_cells = self._wrap(_gvom.BUF_FUSED_CELLS, np.int64)        # [1]
 
-    def _wrap(self, which, dtype):
-        p, nbytes, rs = ctypes.c_void_p(), ctypes.c_int64(), ctypes.c_int64()
-        self.g._check(self.lib.gvom_device_buffer(self.h, which, ctypes.byref(p), ctypes.byref(nbytes),
-                                                  ctypes.byref(rs)))
-        item = np.dtype(dtype).itemsize
-        shape = (nbytes.value // rs.value, rs.value // item) if nbytes.value > rs.value else (nbytes.value // item,)
-        return self.torch.as_tensor(_DevBuf(p.value, shape, np.dtype(dtype).str), device=self.device)
+    def scan_local(self, pointcloud, ego, tf):
+        """This rank's share of the scan -> (send_quads[world], send_eps[world], any_in_grid, n)."""
+        g = self.g
+        g.ego_position = ego
+        pc, n, stride, code = g._prepare_cloud(pointcloud)
+        ego_c = (ctypes.c_double * 3)(float(ego[0]), float(ego[1]), float(ego[2]))
+        t = None
+        if tf is not None:
+            t = np.ascontiguousarray(np.asarray(tf, dtype=np.float64))
+            if t.shape != (4, 4):
+                raise ValueError("transform must be 4x4")
+        sq = (ctypes.c_int64 * self.world)()
+        se = (ctypes.c_int64 * self.world)()
+        any_ = ctypes.c_int(0)
+        g._check(self.lib.gvom_shard_scan_local(self.h, _gvom._ptr(pc) if n else None, 0, n, stride, code, ego_c,
+                                                _gvom._ptr(t), sq, se, ctypes.byref(any_)))
+        return list(sq), list(se), int(any_.value), n
 
-    def cloud_tensor(self, pc):
-        return self.torch.from_numpy(np.ascontiguousarray(pc[:, :3])).to(self.device)
+    def recv_reserve(self, recv_eps):
+        self.g._check(self.lib.gvom_shard_recv_reserve(self.h, _vec(recv_eps)))
 
-    def process(self, cloud, ego, tf):
-        """The whole cloud (torch CUDA tensor (n,3), contiguous, on the attached stream) against
-        this rank's slab.  Returns the reference's outcome code (same on every rank)."""
-        self.g.ego_position = ego
-        return self.g.process_pointcloud_device(cloud.data_ptr(), int(cloud.shape[0]),
-                                                np.float32 if cloud.dtype == self.torch.float32 else np.float64,
-                                                ego, tf)
+    def buffer(self, which, peer):
+        p, cap = ctypes.c_void_p(), ctypes.c_int64()
+        self.g._check(self.lib.gvom_shard_buffer(self.h, which, peer, ctypes.byref(p), ctypes.byref(cap)))
+        return p.value, cap.value
+
+    def scan_merge(self, recv_quads, recv_eps, accept):
+        self.g._check(self.lib.gvom_shard_scan_merge(self.h, _vec(recv_quads), _vec(recv_eps), 1 if accept else 0))
 
     def combine_fuse(self):
         return self.g._check(self.lib.gvom_combine_fuse(self.h, None))
 
-    def set_cell_count(self, n):
-        self.g._check(self.lib.gvom_set_combined_cell_count(self.h, int(n)))
+    def height_rows(self):
+        p, nbytes, rs = ctypes.c_void_p(), ctypes.c_int64(), ctypes.c_int64()
+        self.g._check(self.lib.gvom_device_buffer(self.h, _gvom.BUF_HEIGHT_MAPS, ctypes.byref(p), ctypes.byref(nbytes),
+                                                  ctypes.byref(rs)))
+        return p.value, nbytes.value
 
     def combine_map2d(self):
         rc, out = self.g._combine_into(self.lib.gvom_combine_map2d_into)
         return out
 
+    def local_fused_cells(self):
+        return int(self.g._state().combined_cell_count)
+
+    def set_cell_count(self, n):
+        self.g._check(self.lib.gvom_set_combined_cell_count(self.h, int(n)))
+
+    def sync(self):
+        self.g._check(self.lib.gvom_sync(self.h))
+
+
+class RcclComm(object):
+    """The product transport: RCCL over xGMI for device data, a shared-memory segment for the small
+    host-side vectors (libgvom_hip.so: gvom_comm_*).  One per rank; `name` must be the same on all
+    ranks and unique to this job on the node."""
+
+    def __init__(self, rank, world, device, name):
+        self.rank, self.world = rank, world
+        self.lib = _gvom.load_library()
+        self.c = ctypes.c_void_p()
+        rc = self.lib.gvom_comm_create(rank, world, device, name.encode(), ctypes.byref(self.c))
+        if rc != 0:
+            self.c = ctypes.c_void_p()
+            raise _gvom.GvomBackendError("gvom_comm_create failed with code %d (rank %d of %d)" % (rc, rank, world))
+
+    def _check(self, rc):
+        if rc != 0:
+            raise _gvom.GvomBackendError("communicator call failed (%d): %s"
+                                         % (rc, self.lib.gvom_comm_last_error(self.c).decode()))
+
+    def exchange_host(self, values):
+        k = len(values)
+        out = (ctypes.c_int64 * (k * self.world))()
+        self._check(self.lib.gvom_comm_exchange_host(self.c, _vec(values), k, out))
+        return [list(out[r * k:(r + 1) * k]) for r in range(self.world)]
+
+    def barrier(self):
+        self._check(self.lib.gvom_comm_barrier(self.c))
+
+    def exchange_scan(self, backend, send_q, send_e, recv_q, recv_e):
+        self._check(self.lib.gvom_comm_exchange_scan(self.c, backend.h, _vec(send_q), _vec(send_e), _vec(recv_q),
+                                                     _vec(recv_e)))
+
+    def allgather_rows(self, backend):
+        self._check(self.lib.gvom_comm_allgather_rows(self.c, backend.h))
+
+    def close(self):
+        c, self.c = self.c, ctypes.c_void_p()
+        if c:
+            self.lib.gvom_comm_destroy(c)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ThreadFabric(object):
+    """Shared state of `world` ThreadComm objects: the ranks are threads of one process that share
+    one GPU (ctypes drops the GIL around library calls).  Device data moves with hipMemcpy between
+    the handles' own exchange regions -- the same regions, counts and order as the RCCL path."""
+
+    def __init__(self, world):
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.slots = [None] * world
+        self.backends = [None] * world
+        self.rt = ctypes.CDLL("libamdhip64.so")
+        self.rt.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+
+    def comm(self, rank):
+        return ThreadComm(self, rank)
+
+
+class ThreadComm(object):
+    def __init__(self, fabric, rank):
+        self.f, self.rank, self.world = fabric, rank, fabric.world
+
+    def exchange_host(self, values):
+        self.f.slots[self.rank] = list(values)
+        self.f.barrier.wait()
+        out = [list(v) for v in self.f.slots]
+        self.f.barrier.wait()
+        return out
+
+    def barrier(self):
+        self.f.barrier.wait()
+
+    def _copy(self, dst, src, nbytes):
+        if nbytes and self.f.rt.hipMemcpy(ctypes.c_void_p(dst), ctypes.c_void_p(src), nbytes, 3) != 0:
+            raise RuntimeError("hipMemcpy (device to device) failed")
+
+    def exchange_scan(self, backend, send_q, send_e, recv_q, recv_e):
+        f = self.f
+        f.backends[self.rank] = backend
+        backend.sync()                                   # my send regions are complete
+        f.barrier.wait()
+        for s in range(self.world):                      # pull what every other rank packed for me
+            if s == self.rank:
+                continue
+            src = f.backends[s]
+            for which_s, which_r, n, unit in ((XBUF_SEND_IDS, XBUF_RECV_IDS, recv_q[s], 4),
+                                              (XBUF_SEND_QUADS, XBUF_RECV_QUADS, recv_q[s], 1024),
+                                              (XBUF_SEND_EPS, XBUF_RECV_EPS, recv_e[s], 8)):
+                if n:
+                    self._copy(backend.buffer(which_r, s)[0], src.buffer(which_s, self.rank)[0], n * unit)
+        f.barrier.wait()                                 # nobody repacks before everyone has pulled
+
+    def allgather_rows(self, backend):
+        f = self.f
+        f.backends[self.rank] = backend
+        backend.sync()
+        f.barrier.wait()
+        ptr, nbytes = backend.height_rows()
+        share = nbytes // self.world
+        for s in range(self.world):
+            if s != self.rank:
+                sp, _ = f.backends[s].height_rows()
+                self._copy(ptr + s * share, sp + s * share, share)
+        f.barrier.wait()
+
 
 class ShardedGvom(object):
-    """Same surface as gvom.Gvom (14 positional ctor args, process_pointcloud, combine_maps),
-    for `world` cooperating ranks.  Every rank calls every method (SPMD).  process_pointcloud
-    takes THIS RANK'S share of the scan; the union of the shares is one logical scan, and the
-    result equals gvom.Gvom fed with the concatenated cloud, bit for bit."""
+    """Same surface as gvom.Gvom (14 positional ctor args, process_pointcloud, combine_maps), for
+    `world` cooperating ranks.  Every rank calls every method (SPMD).  process_pointcloud takes THIS
+    RANK'S share of the scan (any length, possibly empty); the union of the shares is one logical
+    scan, and the result equals gvom.Gvom fed with the concatenated cloud, bit for bit.
+
+    keyword arguments: comm (RcclComm / ThreadComm / a test double), device, backend (test double)."""
 
     def __init__(self, *params, **kw):
-        import torch
-        import torch.distributed as dist
-        self.torch, self.dist = torch, dist
-        self.group = kw.pop("group", None)
-        self.rank = dist.get_rank(self.group)
-        self.world = dist.get_world_size(self.group)
+        self.comm = kw.pop("comm")
+        self.rank, self.world = self.comm.rank, self.comm.world
         self.params = params
         self.xy_size, self.z_size, self.buffer_size = params[2], params[3], params[4]
-        if self.xy_size % self.world:
-            raise ValueError("xy_size (%d) must be divisible by the number of ranks (%d)"
+        if self.xy_size % (4 * self.world):
+            raise ValueError("xy_size (%d) must be a multiple of 4 x the number of ranks (%d)"
                              % (self.xy_size, self.world))
         backend = kw.pop("backend", None)
         device = kw.pop("device", None)
         if backend is None:
             backend = HipShardBackend(params, self.rank, self.world, 0 if device is None else device)
         self.b = backend
-        self.rows = self.xy_size // self.world
         self.ego_position = [0, 0, 0]
         self._cells_dirty = False
         self._cell_count = None
-        self._staged = self.dist.get_backend(self.group) == "gloo"
-        self._gather_buf, self._gather_key = None, None
-
-    # -- collectives ------------------------------------------------------------------------
-    def _all_gather_cloud(self, local):
-        torch = self.torch
-        dev = local.device
-        if local.is_cuda and self._staged:
-            local = local.cpu()          # gloo has no GPU all_gather: stage through the host (tests only)
-        key = (local.shape, local.dtype, local.device)
-        out = self._gather_buf if self._gather_key == key else None
-        if out is None:                  # reused from scan to scan (the trace of the previous scan has
-            out = torch.empty((self.world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype,
-                              device=local.device)       # finished: the caller saw its return code)
-            self._gather_buf, self._gather_key = out, key
-        self.dist.all_gather_into_tensor(out, local if local.is_contiguous() else local.contiguous(),
-                                         group=self.group)
-        return out if out.device == dev else out.to(dev)
-
-    def _all_gather_rows_inplace(self, full):
-        """full: [xy, width] tensor whose rows [rank*rows, (rank+1)*rows) are valid on this rank."""
-        lo = self.rank * self.rows
-        if full.is_cuda and self._staged:
-            mine = full[lo:lo + self.rows].cpu()
-            out = self.torch.empty((full.shape[0],) + tuple(full.shape[1:]), dtype=full.dtype)
-            self.dist.all_gather_into_tensor(out, mine.contiguous(), group=self.group)
-            full.copy_(out.to(full.device))
-        else:
-            self.dist.all_gather_into_tensor(full, full[lo:lo + self.rows], group=self.group)
 
     @property
     def combined_cell_count_cpu(self):
-        """Global occupied-voxel count of the fused map (gvom.py:217).  Collective: every rank
-        must read it (it is not needed on the hot path, so it costs nothing unless asked for)."""
+        """Global occupied-voxel count of the fused map (gvom.py:217).  Collective: every rank must
+        read it (it is not needed on the hot path, so it costs nothing unless asked for)."""
         if self._cells_dirty:
-            t = self.b.fused_cells.clone()
-            if t.is_cuda and self._staged:
-                t = t.cpu()
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
-            self._cell_count = int(t.item())
+            rows = self.comm.exchange_host([self.b.local_fused_cells()])
+            self._cell_count = int(sum(r[0] for r in rows))
             self.b.set_cell_count(self._cell_count)
             self._cells_dirty = False
         return self._cell_count
 
-    # -- API -----------------------------------------------------------------------------
     def process_pointcloud(self, pointcloud, ego_position, transform=None):
-        """pointcloud: this rank's share, numpy (n,>=3) or a torch tensor already on the
-        backend's device ((n,3) contiguous; every rank must pass the same n and dtype)."""
+        """pointcloud: this rank's share, numpy (n, >=3) float32 / float64; n may differ between ranks."""
         self.ego_position = ego_position
-        local = pointcloud if isinstance(pointcloud, self.torch.Tensor) else self.b.cloud_tensor(pointcloud)
-        full = self._all_gather_cloud(local)                      # the scan's only collective
-        rc = self.b.process(full, ego_position, transform)
-        if self.rank == 0:
-            if rc == _gvom.GVOM_EMPTY_CLOUD:
+        W, me = self.world, self.rank
+        send_q, send_e, any_, n = self.b.scan_local(pointcloud, ego_position, transform)
+        # one host-side exchange: what every rank packed for every other rank, who saw a return in
+        # the grid, how many returns the scan has
+        table = self.comm.exchange_host(list(send_q) + list(send_e) + [any_, n])
+        recv_q = [table[s][me] if s != me else 0 for s in range(W)]
+        recv_e = [table[s][W + me] if s != me else 0 for s in range(W)]
+        accept = any(row[2 * W] for row in table)
+        total_n = sum(row[2 * W + 1] for row in table)
+        self.b.recv_reserve(recv_e)
+        sq = [send_q[d] if d != me else 0 for d in range(W)]
+        se = [send_e[d] if d != me else 0 for d in range(W)]
+        self.comm.exchange_scan(self.b, sq, se, recv_q, recv_e)      # the scan's only device exchange
+        self.b.scan_merge(recv_q, recv_e, accept)
+        if me == 0:
+            if total_n == 0:
                 print("[WARNING] Processing an empty pointcloud, nothing will happen!")
-            elif rc == _gvom.GVOM_NO_OVERLAP:
+            elif not accept:
                 print("[WARNING] The pointcloud points don't overlap with any voxels, nothing will happen!")
         return None
 
@@ -188,5 +292,11 @@ class ShardedGvom(object):
                 print("[WARNING] The map buffer is empty, nothing will happen!")
             return None
         self._cells_dirty = True
-        self._all_gather_rows_inplace(self.b.height_full)         # the combine's only collective
+        self.comm.allgather_rows(self.b)                              # the combine's only exchange
         return self.b.combine_map2d()
+
+
+def rendezvous_name():
+    """Name of the shared-memory rendezvous for the job this process belongs to: launchers set
+    MASTER_PORT (torchrun and bench.py do), which is unique to a job on one node."""
+    return "gvom_%s_%s" % (os.environ.get("MASTER_PORT", "29500"), os.environ.get("GVOM_JOB_NONCE", "0"))

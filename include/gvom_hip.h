@@ -95,8 +95,7 @@ typedef struct gvom_scan_stats {
 
 /* --- lifetime: replaces Gvom.__init__ (gvom.py:29-97) ------------------------------------ */
 int  gvom_create(const gvom_params *params, int device_id, gvom_t **out);
-/* Slab-sharded instance for multi-GPU runs: this rank owns storage rows
- * [rank*xy/world, (rank+1)*xy/world) of the world-anchored y axis (DESIGN.md "Multi-GPU"). */
+/* One rank of a map sharded over `world` GPUs (see "one map sharded over the GPUs of a node" below). */
 int  gvom_create_sharded(const gvom_params *params, int device_id, int rank, int world,
                          gvom_t **out);
 void gvom_destroy(gvom_t *h);
@@ -153,49 +152,63 @@ int gvom_combine_maps_into(gvom_t *h, double origin_world[3], void *pinned_out);
 int gvom_combine_occupancy_into(gvom_t *h, double origin_world[3], void *pinned_out,
                                 double density_threshold, double min_roughness, double max_roughness);
 
-/* --- split entry points for slab-sharded (multi-GPU) runs ---------------------------------
- * Used by g-vom_amd/gvom_sharded.py; each rank holds a gvom_create_sharded() handle and
- * drives these between its torch.distributed (RCCL) collectives.  Single-GPU callers never
- * need them: gvom_process_pointcloud == scan_begin + scan_commit(local_cells > 0) and
- * gvom_combine_maps == combine_fuse + combine_map2d + finalize_outputs.
+/* --- one map sharded over the GPUs of a node (one rank = one process = one GPU) -------------------
+ * No counterpart in the reference (it has no multi-GPU path); semantics = SURVEY 8(e):
+ * the rays are data-parallel, the per-voxel accumulators (hit / total: int32 sum, min-height: f32 min)
+ * are reduced onto the rank that owns the voxel's storage row, everything after is per voxel / per
+ * column on the owner.  Rank r owns storage rows [r*xy/world, (r+1)*xy/world) of the world-anchored y
+ * axis (xy must be a multiple of 4*world).  The result is bit-identical to one GPU fed with the
+ * concatenated cloud.
  *
- * gvom_scan_begin   runs the scan kernels of process_pointcloud on this rank's slab but leaves
- *                   the ring untouched; *local_cells = occupied voxels found in the slab.
- * gvom_scan_commit  accept != 0 commits the pending scan to the ring (gvom.py:163-175); the
- *                   reference's "no overlap" test (gvom.py:147-150) is on the GLOBAL count.
- * gvom_combine_fuse fusion + column reductions of this rank's slab (gvom.py:183-304); the
- *                   rank's rows of the height / inferred-height maps become valid.
- * gvom_attach_stream / gvom_set_blocking / gvom_sync / gvom_device_buffer
- *                   the sharded layer runs the library on ITS stream (e.g. torch's current stream)
- *                   and hands the library's own device buffer to the collective: a rank's rows are
- *                   one contiguous block of GVOM_BUF_HEIGHT_MAPS ([sy][height row | inferred-height
- *                   row | positive-obstacle density row], f64), so all_gather over RCCL works in
- *                   place with no pack/unpack copies; with blocking off, gvom_combine_fuse does not
- *                   synchronise the host and the cell counts stay on the device
- *                   (GVOM_BUF_SCAN_CELLS / GVOM_BUF_FUSED_CELLS, one int64 each).
- * gvom_combine_map2d_into  after that all_gather: ALL rows of slope/roughness/guess/positive/
- *                   negative/visibility on every rank (20 us of redundant 2-D work instead of a
- *                   second collective), written straight into a pinned output buffer.
- * In sharded handles gvom_process_pointcloud[_device] needs no collective for the reference's
- * "no overlap" test: every rank is handed the whole cloud, so each counts the in-grid returns of
- * ALL slabs and takes the same commit decision. */
-int gvom_scan_begin(gvom_t *h, const void *xyz, int on_device, int64_t n, int64_t row_stride_bytes,
-                    int dtype, const double ego[3], const double *transform_4x4,
-                    int64_t *local_cells);
-int gvom_scan_commit(gvom_t *h, int accept);
+ * Per scan:  gvom_shard_scan_local   trace this rank's share (it may be empty) over the whole window;
+ *                                    returns, per owner rank d, how many dirty quads (4 rows x 64 sx at
+ *                                    one sz = 1 KiB of ray-pass counts + a 4-byte id) and endpoints
+ *                                    ({voxel, min-height sample}, 8 bytes) are packed for d
+ *            -- the transport exchanges the counts, then moves SEND regions to the owners' RECV
+ *               regions (gvom_shard_buffer; RCCL: gvom_comm_exchange_scan) --
+ *            gvom_shard_recv_reserve  size the endpoint receive regions from the counts
+ *            gvom_shard_scan_merge    add the received contributions, encode this rank's rows, commit
+ *                                     iff `accept` (any rank saw an in-grid return: gvom.py:147-150)
+ * Per combine: gvom_combine_fuse (fusion + column reductions + positive-obstacle densities of this
+ *            rank's rows) -> all-gather of GVOM_BUF_HEIGHT_MAPS rows -> gvom_combine_map2d_into (all rows
+ *            of slope / roughness / guess / positive / negative / visibility on every rank).
+ * gvom_process_pointcloud* / gvom_combine_maps* return GVOM_ERR_INVALID on a sharded handle. */
+int gvom_shard_scan_local(gvom_t *h, const void *xyz, int on_device, int64_t n, int64_t row_stride_bytes,
+                          int dtype, const double ego[3], const double *transform_4x4,
+                          int64_t *send_quads, int64_t *send_eps, int *any_ingrid);
+#define GVOM_XBUF_SEND_IDS   0   /* uint32 quad ids for rank `peer`                      */
+#define GVOM_XBUF_SEND_QUADS 1   /* 1 KiB per quad, same order                          */
+#define GVOM_XBUF_SEND_EPS   2   /* {uint32 voxel, uint32 min-height sample} per endpoint */
+#define GVOM_XBUF_RECV_IDS   3
+#define GVOM_XBUF_RECV_QUADS 4
+#define GVOM_XBUF_RECV_EPS   5   /* valid after gvom_shard_recv_reserve                  */
+int gvom_shard_buffer(gvom_t *h, int which, int peer, void **ptr, int64_t *capacity_bytes);
+int gvom_shard_recv_reserve(gvom_t *h, const int64_t *recv_eps);
+int gvom_shard_scan_merge(gvom_t *h, const int64_t *recv_quads, const int64_t *recv_eps, int accept);
 int gvom_combine_fuse(gvom_t *h, int64_t *local_cells);
 int gvom_set_combined_cell_count(gvom_t *h, int64_t global_cells);
-#define GVOM_BUF_HEIGHT_MAPS  0
-#define GVOM_BUF_SCAN_CELLS   2
-#define GVOM_BUF_FUSED_CELLS  3
-#define GVOM_OWN_STREAM ((void *)(intptr_t)-1)
-/* hip_stream: a hipStream_t; NULL is HIP's legacy default stream (PyTorch's default stream);
- * GVOM_OWN_STREAM returns to the library's private stream. */
-int gvom_attach_stream(gvom_t *h, void *hip_stream);
-int gvom_set_blocking(gvom_t *h, int on);
+#define GVOM_BUF_HEIGHT_MAPS  0   /* [sy][height row | inferred-height row | positive-density row], f64 */
+#define GVOM_BUF_FUSED_CELLS  3   /* one int64: occupied voxels of this rank's rows of the fused map */
 int gvom_sync(gvom_t *h);
 int gvom_device_buffer(gvom_t *h, int which, void **ptr, int64_t *bytes, int64_t *row_stride_bytes);
 int gvom_combine_map2d_into(gvom_t *h, double origin_world[3], void *pinned_out);
+
+/* --- transport between the ranks of a sharded map: RCCL over xGMI, bound directly ------------------
+ * name: the same string on every rank and unique to this communicator on the node (rank 0 creates
+ * /dev/shm/<name> for the ncclUniqueId and the small host-side exchanges).  gvom_comm_exchange_host:
+ * all[r*k + j] = rank r's mine[j] (k <= 160).  gvom_comm_exchange_scan / gvom_comm_allgather_rows run
+ * on the handle's stream and do not synchronise. */
+typedef struct gvom_comm gvom_comm_t;
+int  gvom_comm_create(int rank, int world, int device, const char *name, gvom_comm_t **out);
+void gvom_comm_destroy(gvom_comm_t *c);
+int  gvom_comm_exchange_host(gvom_comm_t *c, const int64_t *mine, int k, int64_t *all);
+int  gvom_comm_barrier(gvom_comm_t *c);
+int  gvom_comm_exchange_scan(gvom_comm_t *c, gvom_t *h, const int64_t *send_quads, const int64_t *send_eps,
+                             const int64_t *recv_quads, const int64_t *recv_eps);
+int  gvom_comm_allgather_rows(gvom_comm_t *c, gvom_t *h);
+int  gvom_comm_rank(gvom_comm_t *c);
+int  gvom_comm_world(gvom_comm_t *c);
+const char *gvom_comm_last_error(gvom_comm_t *c);
 
 /* --- accessors of the reference object ------------------------------------------------- */
 /* 1 if ring slot `slot` holds a scan (origin_buffer[slot] is not None, gvom.py:201). */

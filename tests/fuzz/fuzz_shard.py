@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
-"""Slab-sharded scan + fusion kernels against the unsharded handle on ONE GPU: for every seed of
-tests/test_hip_parity.py::_fuzz_case (grid size rounded to a multiple of the world size), W sharded
-handles are fed the whole cloud and the rows each owns must equal the unsharded handle's, for every
-ring slot after every scan and for the fused map after every combine (the 2-D stage needs the
-collective and is covered by tests/test_hip_sharded.py).  Usage: tests/fuzz/fuzz_shard.py <first> <count>"""
-import os, sys, io, contextlib, ctypes
+"""Sharded map against the unsharded handle on ONE GPU: for every seed of
+tests/test_hip_parity.py::_fuzz_case (grid size rounded to a multiple of 4 x the world size), W
+ranks run as threads (tests/shard_threads.py), each fed a RAGGED share of every cloud (shares differ
+in length, some are empty); after every scan the rows each rank owns of the ring slot, and after every
+combine those of the fused map, must equal the unsharded handle's, and every rank's returned 2-D maps
+must equal the unsharded ones.  Usage: tests/fuzz/fuzz_shard.py <first> <count>"""
+import os, sys, io, contextlib
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in ("tests", "tests/golden", "g-vom_amd", ""):
@@ -12,6 +13,8 @@ for p in ("tests", "tests/golden", "g-vom_amd", ""):
 import importlib
 thp = importlib.import_module("test_hip_parity")
 import gvom
+from shard_threads import run_ranks
+
 
 def owned_rows_mask(origin_y, xy, r, W):
     om = int(origin_y) % xy
@@ -19,66 +22,95 @@ def owned_rows_mask(origin_y, xy, r, W):
     rows = xy // W
     return (sy >= r * rows) & (sy < (r + 1) * rows)
 
-def merged(handles, which, xy, zs, W):
-    out = None
-    for r, h in enumerate(handles):
-        d = h.read_dense(which)
-        if d is None:
-            return None
-        if out is None:
-            out = [np.array(a, copy=True) for a in d[:4]]
-        m = owned_rows_mask(d[4][1], xy, r, W)
-        m3 = np.broadcast_to(m[None, :, None], (zs, xy, xy)).reshape(-1)
-        for k in range(4):
-            out[k][m3] = d[k][m3]
-    return out
 
-first, count = int(sys.argv[1]), int(sys.argv[2])
-bad = []
-for seed in range(first, first + count):
+def shares_of(pc, W, rng):
+    """ragged split of a cloud: random cut points, so shares differ in length and may be empty"""
+    n = pc.shape[0]
+    cuts = np.sort(rng.integers(0, n + 1, W - 1)) if n else np.zeros(W - 1, np.int64)
+    idx = np.concatenate([[0], cuts, [n]])
+    return [pc[idx[r]:idx[r + 1]] for r in range(W)]
+
+
+def check_case(seed):
     W = (2, 4, 8)[seed % 3]
     params, steps = thp._fuzz_case(seed)
-    xy = max(W, (params[2] // W) * W)
+    xy = max(4 * W, (params[2] // (4 * W)) * 4 * W)
     params = params[:2] + (xy,) + params[3:]
     zs = params[3]
-    try:
-        with contextlib.redirect_stdout(io.StringIO()):
-            g0 = gvom.Gvom(*params)
-            hs = [gvom.Gvom(*params, _shard=(r, W)) for r in range(W)]
-            for st in steps:
-                if st[0] == "scan":
-                    g0.process_pointcloud(*st[1:])
-                    for h in hs:
-                        h.process_pointcloud(*st[1:])
-                    b = g0.last_buffer_index
-                    want = g0.read_dense(b)
-                    got = merged(hs, b, xy, zs, W)
-                    assert (want is None) == (got is None), "slot presence"
-                    if want is not None:
-                        for k, nm in enumerate(("state", "hit", "total", "minh")):
-                            wk, gk = want[k], got[k]
-                            if nm == "state":            # rows are numbered per handle: compare the classes
-                                assert np.array_equal(np.where(wk >= 0, 0, wk), np.where(gk >= 0, 0, gk)), "slot state"
-                            else:
-                                assert np.array_equal(wk, gk), "slot " + nm
-                else:
-                    r0 = g0.combine_maps()
-                    rcs = [h._lib.gvom_combine_fuse(h._h, None) for h in hs]
-                    for h in hs:
-                        h._lib.gvom_sync(h._h)
-                    if r0 is None:
-                        assert all(rc == gvom.GVOM_EMPTY_BUFFER for rc in rcs), "empty ring"
-                        continue
-                    want = g0.read_dense(gvom.GVOM_WHICH_FUSED)
-                    got = merged(hs, gvom.GVOM_WHICH_FUSED, xy, zs, W)
-                    for k, nm in enumerate(("state", "hit", "total", "minh")):
-                        wk, gk = want[k], got[k]
-                        if nm == "state":
-                            assert np.array_equal(np.where(wk >= 0, 0, wk), np.where(gk >= 0, 0, gk)), "fused state"
-                        else:
-                            assert np.array_equal(wk, gk), "fused " + nm
-    except AssertionError as e:
-        bad.append((seed, W, str(e)[:80]))
-print("checked %d seeds, %d failures" % (count, len(bad)))
-for b in bad[:20]:
-    print("  seed %d world %d: %s" % b)
+    rng = np.random.default_rng(seed)
+    plan = []
+    for st in steps:
+        if st[0] == "scan":
+            plan.append(("scan", shares_of(np.asarray(st[1]), W, rng), st[2], st[3]))
+        else:
+            plan.append(("combine",))
+    verbose = bool(os.environ.get("GVOM_FUZZ_VERBOSE"))
+    say = (lambda *a: print(*a, file=sys.stderr, flush=True)) if verbose else (lambda *a: None)
+    say("world", W, "params", params)
+    g0 = gvom.Gvom(*params)
+    want = []
+    for st, pl in zip(steps, plan):
+        if st[0] == "scan":
+            say("unsharded scan", np.asarray(st[1]).shape)
+            g0.process_pointcloud(*st[1:])
+            b = g0.last_buffer_index
+            want.append(("scan", b, g0.read_dense(b), g0.buffer_index))
+        else:
+            say("unsharded combine")
+            out = g0.combine_maps()
+            want.append(("combine", out, g0.read_dense(gvom.GVOM_WHICH_FUSED) if out is not None else None,
+                         g0.combined_cell_count_cpu))
+
+    def body(r, sh):
+        for pl, wt in zip(plan, want):
+            if pl[0] == "scan":
+                say("rank", r, "scan", pl[1][r].shape)
+                sh.process_pointcloud(pl[1][r], pl[2], pl[3])
+                sh.b.sync()
+                say("rank", r, "scan done")
+                assert sh.b.g.buffer_index == wt[3], "ring index"
+                if wt[2] is None:
+                    continue
+                got = sh.b.g.read_dense(wt[1])
+                assert got is not None, "slot presence"
+                m = np.broadcast_to(owned_rows_mask(got[4][1], xy, r, W)[None, :, None], (zs, xy, xy)).reshape(-1)
+                for k, nm in enumerate(("state", "hit", "total", "minh")):
+                    a, b = wt[2][k][m], got[k][m]
+                    if nm == "state":                    # rows are numbered per handle: compare the classes
+                        a, b = np.where(a >= 0, 0, a), np.where(b >= 0, 0, b)
+                    assert np.array_equal(a, b), "slot " + nm
+            else:
+                say("rank", r, "combine")
+                out = sh.combine_maps()
+                say("rank", r, "combine done")
+                assert (out is None) == (wt[1] is None), "combine presence"
+                if out is None:
+                    continue
+                for a, b in zip(out, wt[1]):
+                    assert a.dtype == b.dtype and np.array_equal(a, b), "returned maps"
+                assert sh.combined_cell_count_cpu == wt[3], "cell count"
+                got = sh.b.g.read_dense(gvom.GVOM_WHICH_FUSED)
+                m = np.broadcast_to(owned_rows_mask(got[4][1], xy, r, W)[None, :, None], (zs, xy, xy)).reshape(-1)
+                for k, nm in enumerate(("state", "hit", "total", "minh")):
+                    a, b = wt[2][k][m], got[k][m]
+                    if nm == "state":
+                        a, b = np.where(a >= 0, 0, a), np.where(b >= 0, 0, b)
+                    assert np.array_equal(a, b), "fused " + nm
+        return True
+
+    run_ranks(W, params, body)
+    return W
+
+
+if __name__ == "__main__":
+    first, count = int(sys.argv[1]), int(sys.argv[2])
+    bad = []
+    for seed in range(first, first + count):
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                check_case(seed)
+        except AssertionError as e:
+            bad.append((seed, (2, 4, 8)[seed % 3], str(e)[:80]))
+    print("checked %d seeds, %d failures" % (count, len(bad)))
+    for b in bad[:20]:
+        print("  seed %d world %d: %s" % b)

@@ -1,63 +1,104 @@
-"""GPU test of the slab-sharded HIP path: 2 and 4 ranks share the one GPU of the test box (the
-collectives run over gloo, staged through the host), so the slab filters of k_trace / k_encode
-/ k_fuse / k_map2d and the split C-ABI entry points run on real hardware; the result must be
-bit-identical to the unsharded handle."""
+"""GPU tests of the sharded map (g-vom_amd/gvom_sharded.py, include/gvom_hip.h gvom_shard_* /
+gvom_comm_*): the ranks run as threads of one process on the test box's one GPU
+(tests/shard_threads.py) -- real pack / unpack / slab kernels and split C-ABI entry points, the SPMD
+orchestration of the product, only the wire is hipMemcpy instead of xGMI.  Every rank's rows of every
+ring slot and of the fused map, and every rank's returned maps, must equal the unsharded handle's,
+bit for bit.  The RCCL binding itself is exercised with one rank."""
+import io
+import contextlib
 import os
-import socket
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
-HERE = os.path.dirname(os.path.abspath(__file__))
-
-
-def _free_port():
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
-    return p
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("world", [2, 4])
-def test_sharded_hip_equals_single_handle(world):
-    port = _free_port()
-    procs = []
-    for r in range(world):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0",
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_sharded_hip_worker.py")], env=env,
-                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
-    for r, p in enumerate(procs):
-        try:
-            out, _ = p.communicate(timeout=900)
-        except subprocess.TimeoutExpired:
-            for q in procs:
-                q.kill()
-            raise
-        assert p.returncode == 0, "rank %d failed:\n%s" % (r, out.decode()[-3000:])
+def test_sharded_map_equals_single_handle_over_a_moving_window(world):
+    import gvom
+    import synth
+    from shard_threads import run_ranks
+    params = (0.2, 0.2, 128, 32, 3, 1.0, 0.5, 0.5, 0.3, 2.0, 4.0, 1.0, 1, 1)
+    scene = synth.make_scene(2, extent=11.0)
+    steps = []
+    for k in range(5):
+        ego = (0.7 * k, -0.45 * k, 0.05 * k)
+        # every rank its own sensor, with a different number of returns (ragged shares)
+        shares = [synth.lidar_scan(scene, beams=16, azimuths=1024, sensor=ego, yaw=0.001 * r, noise_seed=10 * k + r)[:16384 - 997 * r]
+                  for r in range(world)]
+        if k == 3:
+            shares = [s + 900.0 for s in shares]                 # globally rejected scan
+        steps.append((shares, ego))
+    ref = gvom.Gvom(*params)
+    want = []
+    with contextlib.redirect_stdout(io.StringIO()):
+        for shares, ego in steps:
+            ref.process_pointcloud(np.concatenate(shares, 0), ego)
+            want.append((ref.combine_maps(), ref.combined_cell_count_cpu, ref.buffer_index))
+
+    def body(r, sh):
+        assert sh.combine_maps() is None
+        for (shares, ego), (wout, wcnt, wbuf) in zip(steps, want):
+            sh.process_pointcloud(shares[r], ego)
+            got = sh.combine_maps()
+            for a, b in zip(got, wout):
+                assert a.dtype == b.dtype and np.array_equal(a, b)
+            assert sh.combined_cell_count_cpu == wcnt
+            assert sh.b.g.buffer_index == wbuf
+        return True
+
+    with contextlib.redirect_stdout(io.StringIO()):
+        assert run_ranks(world, params, body) == [True] * world
 
 
-@pytest.mark.gpu
 def test_sharded_kernels_fuzz_against_unsharded_handle():
-    """tests/fuzz/fuzz_shard.py on 90 edge-case seeds: 2/4/8 sharded handles on one GPU, every rank's rows of
-    every ring slot and of the fused map equal the unsharded handle's (scan culling, per-segment
-    culling, slab encode and slab fusion)."""
-    import subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz", "fuzz_shard.py"), "70000", "90"],
+    """tests/fuzz/fuzz_shard.py on 90 edge-case seeds: 2 / 4 / 8 ranks, ragged and empty shares, tiny
+    grids, rejected scans."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", "fuzz_shard.py"), "70000", "90"],
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "checked 90 seeds, 0 failures" in out.stdout, out.stdout[-2000:]
 
 
-@pytest.mark.gpu
-def test_sharded_kernels_on_weak_scaling_clouds():
-    """tests/fuzz/shard_big.py: 4 and 8 sharded handles on one GPU fed the bench's weak-scaling clouds
-    (524 k / 1 M returns: the 3-segment trace path of sharded handles); every rank's rows of the slot
-    and of the fused map equal the unsharded handle's over three moving scans."""
-    import subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz", "shard_big.py"), "4,8"],
-                         capture_output=True, text=True, timeout=900)
+@pytest.mark.parametrize("cfg,worlds,scans,buffer", [("c2", "4,8", "3", "1"), ("c4", "4", "2", "1")])
+def test_sharded_map_at_full_size(cfg, worlds, scans, buffer):
+    """tests/fuzz/shard_big.py: the weak-scaling clouds of the bench on the c2 grid (4 and 8 ranks x
+    131,072 returns) and BASELINE c4 (512 x 512 x 128, 4 ranks x 262,144 returns): slots, fused map and
+    returned maps of every rank equal the unsharded handle's."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", "shard_big.py"), cfg, worlds, scans, buffer],
+                         capture_output=True, text=True, timeout=1200)
     assert out.returncode == 0, (out.stdout + out.stderr)[-2000:]
     assert "shard_big: 0 mismatches" in out.stdout
+
+
+def test_rccl_binding_with_one_rank():
+    """librccl.so is loaded by libgvom_hip.so itself (no PyTorch): communicator creation through the
+    shared-memory rendezvous, the host-side exchange and an in-place all-gather of the library's own
+    height-map buffer on the library's stream, with world = 1 (the test box has one GPU)."""
+    import ctypes
+    import gvom
+    import gvom_sharded
+    import synth
+    comm = gvom_sharded.RcclComm(0, 1, 0, "gvom_test_%d" % os.getpid())
+    try:
+        assert comm.exchange_host([7, -3, 1 << 40]) == [[7, -3, 1 << 40]]
+        comm.barrier()
+        params, scans = synth.config_inputs("c2")
+        g = gvom.Gvom(*params)
+        pc, ego, tf = scans[0]
+        g.process_pointcloud(pc, ego, tf)
+        out = g.combine_maps()
+        before = g._map2d(gvom.MAP_HEIGHT)
+
+        class B(object):
+            h = g._h
+        comm.allgather_rows(B)
+        g._check(g._lib.gvom_sync(g._h))
+        assert np.array_equal(g._map2d(gvom.MAP_HEIGHT), before)
+        assert out is not None
+    finally:
+        comm.close()
