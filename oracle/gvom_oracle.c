@@ -25,6 +25,29 @@
 
 #define ORC_API __attribute__((visibility("default")))
 
+/* ALL-CORE BUILD (libgvom_oracle_omp.so: -fopenmp -DORC_OMP; SURVEY 8d "B-cpu-N").  The same
+ * source; loops over points / voxels / map cells run on all host threads.  int32 sums and the f32
+ * min are order-independent, so the results equal the one-thread build's; compact rows of the fused
+ * map are numbered in completion order there (value-neutral, as on the GPU: gvom.py:964,993).
+ * tests/test_oracle_golden.py holds the all-core build to the same golden vectors. */
+#ifdef ORC_OMP
+#include <omp.h>
+#define ORC_PRAGMA(x) _Pragma(#x)
+#define ORC_PFOR ORC_PRAGMA(omp parallel for schedule(static))
+#define ORC_PFOR_DYN ORC_PRAGMA(omp parallel for schedule(dynamic, 512))
+#define ORC_ATOMIC ORC_PRAGMA(omp atomic)
+#define ORC_PRAGMA_REDUCE_UPDATES ORC_PRAGMA(omp parallel for schedule(dynamic, 512) reduction(+ : updates))
+#define ORC_PRAGMA_REDUCE_NIN ORC_PRAGMA(omp parallel for schedule(static) reduction(+ : n_in))
+#define ORC_PRAGMA_CAPTURE ORC_PRAGMA(omp atomic capture)
+#else
+#define ORC_PRAGMA_CAPTURE
+#define ORC_PRAGMA_REDUCE_UPDATES
+#define ORC_PRAGMA_REDUCE_NIN
+#define ORC_PFOR
+#define ORC_PFOR_DYN
+#define ORC_ATOMIC
+#endif
+
 /* ------------------------------------------------------------------------------------
  * helpers
  * ---------------------------------------------------------------------------------- */
@@ -45,6 +68,22 @@ static inline int floor_in_range(double v, int64_t size, int64_t *out)
     return 1;
 }
 
+/* f32 min into shared memory (the reference's cuda.atomic.min, gvom.py:1329) */
+static inline void orc_min_f32(float *dst, float v)
+{
+#ifdef ORC_OMP
+    uint32_t expect = __atomic_load_n((uint32_t *)dst, __ATOMIC_RELAXED), want;
+    float cur;
+    memcpy(&cur, &expect, 4); memcpy(&want, &v, 4);
+    while (v < cur) {
+        if (__atomic_compare_exchange_n((uint32_t *)dst, &expect, want, 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) break;
+        memcpy(&cur, &expect, 4);
+    }
+#else
+    if (v < *dst) *dst = v;
+#endif
+}
+
 /* ------------------------------------------------------------------------------------
  * Per-point kernels, generated for float32 and float64 clouds.  `stride` is the row
  * stride in ELEMENTS (>= 3): the reference indexes points[i, 0..2] of an (N, >=3) array.
@@ -56,6 +95,7 @@ static inline int floor_in_range(double v, int64_t size, int64_t *out)
  * the 4x4 (row-major double[16]); written back in the cloud's dtype. */                       \
 ORC_API void orc_transform_pointcloud_##SUF(T *pts, int64_t n, int64_t stride, const double *tf)\
 {                                                                                               \
+    ORC_PFOR                                                                                    \
     for (int64_t i = 0; i < n; ++i) {                                                           \
         T *p = pts + i * stride;                                                                \
         double x = (double)p[0], y = (double)p[1], z = (double)p[2];                            \
@@ -75,6 +115,7 @@ ORC_API int64_t orc_point_2_map_##SUF(double xy_res, double z_res, int64_t xy, i
 {                                                                                               \
     int64_t updates = 0;                                                                        \
     const double md2 = min_distance * min_distance;                                             \
+    ORC_PRAGMA_REDUCE_UPDATES                                                                   \
     for (int64_t i = 0; i < n; ++i) {                                                           \
         const T *p = pts + i * stride;                                                          \
         /* :1064 d2 in the cloud's dtype, (x*x + y*y) + z*z */                                  \
@@ -86,7 +127,11 @@ ORC_API int64_t orc_point_2_map_##SUF(double xy_res, double z_res, int64_t xy, i
         int inz = floor_in_range((double)p[2] / z_res - origin[2], zs, &zi);    /* :1080 */    \
         if (inx && iny && inz) {                                                                \
             int64_t idx = xi + yi * xy + zi * xy * xy;                /* :1086 */               \
-            hit[idx] += 1; total[idx] += 1; updates += 2;             /* :1089-1090 */          \
+            ORC_ATOMIC                                                                          \
+            hit[idx] += 1;                                            /* :1089 */               \
+            ORC_ATOMIC                                                                          \
+            total[idx] += 1;                                          /* :1090 */               \
+            updates += 2;                                                                       \
         }                                                                                       \
         float pt[3], end[3], slope[3];                                /* :1093-1095 f32 */      \
         pt[0] = (float)(ego[0] / xy_res);                             /* :1097-1099 */          \
@@ -124,6 +169,7 @@ ORC_API int64_t orc_point_2_map_##SUF(double xy_res, double z_res, int64_t xy, i
             if (!floor_in_range((double)pt[0] - origin[0], xy, &xi)) break;   /* :1134-1136 */  \
             if (!floor_in_range((double)pt[1] - origin[1], xy, &yi)) break;   /* :1138-1140 */  \
             if (!floor_in_range((double)pt[2] - origin[2], zs, &zi)) break;   /* :1142-1144 */  \
+            ORC_ATOMIC                                                                          \
             total[xi + yi * xy + zi * xy * xy] += 1;                  /* :1146-1148 */          \
             updates += 1;                                                                       \
             length += step_len;                                       /* :1150 */               \
@@ -140,6 +186,7 @@ ORC_API int64_t orc_calculate_min_height_##SUF(double xy_res, double z_res, int6
 {                                                                                               \
     int64_t n_in = 0;                                                                           \
     const double md2 = min_distance * min_distance;                                             \
+    ORC_PRAGMA_REDUCE_NIN                                                                       \
     for (int64_t i = 0; i < n; ++i) {                                                           \
         const T *p = pts + i * stride;                                                          \
         T d2 = (T)((T)((T)(p[0] * p[0]) + (T)(p[1] * p[1])) + (T)(p[2] * p[2]));                \
@@ -151,7 +198,7 @@ ORC_API int64_t orc_calculate_min_height_##SUF(double xy_res, double z_res, int6
         double lz = ((double)p[2] / z_res - origin[2]) - (double)zi;  /* :1326 */               \
         int32_t row = index_map[xi + yi * xy + zi * xy * xy];         /* :1328 */               \
         float v = (float)lz;                                          /* :1329 f64 -> f32 */    \
-        if (row >= 0) { if (v < min_height[row]) min_height[row] = v; ++n_in; }                 \
+        if (row >= 0) { orc_min_f32(&min_height[row], v); ++n_in; }                             \
     }                                                                                           \
     return n_in;                                                                                \
 }                                                                                               \
@@ -214,10 +261,36 @@ ORC_API int32_t orc_assign_indices(const int32_t *hit, const int32_t *total, int
                                    int64_t voxel_count)
 {
     int32_t cell_count = 0;
+#ifdef ORC_OMP
+    /* the one-thread numbering (voxel order), in two passes: occupied voxels per chunk, then rows */
+    enum { CH = 1 << 15 };
+    const int64_t nch = (voxel_count + CH - 1) / CH;
+    int32_t base[nch + 1];
+    ORC_PFOR
+    for (int64_t c = 0; c < nch; ++c) {
+        int32_t k = 0;
+        const int64_t e = (c + 1) * CH < voxel_count ? (c + 1) * CH : voxel_count;
+        for (int64_t i = c * CH; i < e; ++i) k += hit[i] > 0;
+        base[c + 1] = k;
+    }
+    base[0] = 0;
+    for (int64_t c = 0; c < nch; ++c) base[c + 1] += base[c];
+    cell_count = base[nch];
+    ORC_PFOR
+    for (int64_t c = 0; c < nch; ++c) {
+        int32_t k = base[c];
+        const int64_t e = (c + 1) * CH < voxel_count ? (c + 1) * CH : voxel_count;
+        for (int64_t i = c * CH; i < e; ++i) {
+            if (hit[i] > 0) index_map[i] = k++;
+            else index_map[i] = -total[i] - 1;
+        }
+    }
+#else
     for (int64_t i = 0; i < voxel_count; ++i) {
         if (hit[i] > 0) index_map[i] = cell_count++;
         else index_map[i] = -total[i] - 1;
     }
+#endif
     return cell_count;
 }
 
@@ -225,6 +298,7 @@ ORC_API int32_t orc_assign_indices(const int32_t *hit, const int32_t *total, int
 ORC_API void orc_move_data(const int32_t *old, int32_t *neu, const int32_t *index_map,
                            int64_t voxel_count)
 {
+    ORC_PFOR
     for (int64_t i = 0; i < voxel_count; ++i)
         if (index_map[i] >= 0) neu[index_map[i]] = old[i];
 }
@@ -252,14 +326,19 @@ ORC_API void orc_combine_indices(int64_t *combined_cell_count, int32_t *combined
 {
     double d[3] = { combined_origin[0] - old_origin[0], combined_origin[1] - old_origin[1],
                     combined_origin[2] - old_origin[2] };
+    ORC_PFOR
     for (int64_t z = 0; z < zs; ++z)
         for (int64_t y = 0; y < xy; ++y)
             for (int64_t x = 0; x < xy; ++x) {
                 int64_t io;
                 if (!shifted_index(x, y, z, d, xy, zs, &io)) continue;
                 int64_t idx = x + y * xy + z * xy * xy;
-                if (old_index_map[io] >= 0 && combined_index_map[idx] <= -1)          /* :963 */
-                    combined_index_map[idx] = (int32_t)((*combined_cell_count)++);
+                if (old_index_map[io] >= 0 && combined_index_map[idx] <= -1) {        /* :963 */
+                    int64_t row;
+                    ORC_PRAGMA_CAPTURE
+                    row = (*combined_cell_count)++;
+                    combined_index_map[idx] = (int32_t)row;
+                }
                 else if (old_index_map[io] < -1 && combined_index_map[idx] <= -1)     /* :967 */
                     combined_index_map[idx] += old_index_map[io] + 1;
             }
@@ -272,6 +351,7 @@ ORC_API void orc_combine_old_indices(int64_t *combined_cell_count, int32_t *comb
 {
     double d[3] = { combined_origin[0] - old_origin[0], combined_origin[1] - old_origin[1],
                     combined_origin[2] - old_origin[2] };
+    ORC_PFOR
     for (int64_t z = 0; z < zs; ++z)
         for (int64_t y = 0; y < xy; ++y)
             for (int64_t x = 0; x < xy; ++x) {
@@ -279,8 +359,12 @@ ORC_API void orc_combine_old_indices(int64_t *combined_cell_count, int32_t *comb
                 if (!shifted_index(x, y, z, d, xy, zs, &io)) continue;
                 int64_t idx = x + y * xy + z * xy * xy;
                 int32_t c = combined_index_map[idx];
-                if (old_index_map[io] >= 0 && c <= -1 && c >= -11)                    /* :992 */
-                    combined_index_map[idx] = (int32_t)((*combined_cell_count)++);
+                if (old_index_map[io] >= 0 && c <= -1 && c >= -11) {                  /* :992 */
+                    int64_t row;
+                    ORC_PRAGMA_CAPTURE
+                    row = (*combined_cell_count)++;
+                    combined_index_map[idx] = (int32_t)row;
+                }
                 else if (old_index_map[io] < -1 && c <= -1)                           /* :996 */
                     combined_index_map[idx] += old_index_map[io] + 1;
             }
@@ -296,6 +380,7 @@ ORC_API void orc_combine_metrics(int32_t *combined_hit, int32_t *combined_total,
 {
     double d[3] = { combined_origin[0] - old_origin[0], combined_origin[1] - old_origin[1],
                     combined_origin[2] - old_origin[2] };
+    ORC_PFOR
     for (int64_t z = 0; z < zs; ++z)
         for (int64_t y = 0; y < xy; ++y)
             for (int64_t x = 0; x < xy; ++x) {
@@ -320,6 +405,7 @@ ORC_API void orc_make_height_map(const double *combined_origin, const int32_t *c
         const float *min_height, int64_t xy, int64_t zs, double xy_res, double z_res,
         const double *ego, double radius, double ground_to_lidar_height, double *height_map)
 {
+    ORC_PFOR
     for (int64_t x = 0; x < xy; ++x)
         for (int64_t y = 0; y < xy; ++y) {
             double xp = ((combined_origin[0] + (double)x) * xy_res) - ego[0];         /* :531 */
@@ -342,6 +428,7 @@ ORC_API void orc_make_inferred_height_map(const double *combined_origin,
         const int32_t *combined_index_map, int64_t xy, int64_t zs, double z_res,
         double *inferred_height_map)
 {
+    ORC_PFOR
     for (int64_t x = 0; x < xy; ++x)
         for (int64_t y = 0; y < xy; ++y)
             for (int64_t z = 0; z < zs; ++z) {
@@ -358,6 +445,7 @@ ORC_API void orc_calculate_slope(const double *height_map, int64_t xy, double xy
         double *slope_x, double *slope_y, double *roughness)
 {
     const int64_t radius = 1;
+    ORC_PFOR
     for (int64_t x0 = 0; x0 < xy; ++x0)
         for (int64_t y0 = 0; y0 < xy; ++y0) {
             int64_t xlo = x0 - radius < 0 ? 0 : x0 - radius, xhi = x0 + radius + 1 > xy ? xy : x0 + radius + 1;
@@ -412,6 +500,7 @@ ORC_API void orc_calculate_slope(const double *height_map, int64_t xy, double xy
 ORC_API void orc_guess_height(const double *height_map, const double *inferred_height_map,
         int64_t xy, double *guessed_height_delta)
 {
+    ORC_PFOR
     for (int64_t x0 = 0; x0 < xy; ++x0)
         for (int64_t y0 = 0; y0 < xy; ++y0) {
             if (height_map[x0 * xy + y0] > -1000 || inferred_height_map[x0 * xy + y0] == -1000.0)
@@ -481,6 +570,7 @@ ORC_API void orc_make_positive_obstacle_map(const int32_t *combined_index_map,
         double robot_height, const double *origin, const double *x_slope, const double *y_slope,
         double slope_threshold, int32_t *obstacle_map)
 {
+    ORC_PFOR
     for (int64_t x = 0; x < xy; ++x)
         for (int64_t y = 0; y < xy; ++y) {
             double sx = x_slope[x * xy + y], sy = y_slope[x * xy + y];
@@ -531,6 +621,7 @@ ORC_API void orc_make_height_map_pointcloud(const double *height_map, const doub
         const double *x_slope, const double *y_slope, const double *origin, float *out,
         int64_t xy, double xy_res, double z_res)
 {
+    ORC_PFOR
     for (int64_t x = 0; x < xy; ++x)
         for (int64_t y = 0; y < xy; ++y) {
             int64_t index = x + y * xy;
@@ -550,6 +641,7 @@ ORC_API void orc_make_height_map_pointcloud(const double *height_map, const doub
 ORC_API void orc_make_inferred_height_map_pointcloud(const double *map, const double *origin,
         float *out, int64_t xy, double xy_res, double z_res)
 {
+    ORC_PFOR
     for (int64_t x = 0; x < xy; ++x)
         for (int64_t y = 0; y < xy; ++y) {
             int64_t index = x + y * xy;
@@ -692,3 +784,21 @@ ORC_API void orc_make_voxel_pointcloud(const int32_t *combined_index_map, const 
 }
 
 ORC_API int orc_abi_version(void) { return 1; }
+
+/* threads the all-core build runs on (1 in the one-thread build) */
+ORC_API int orc_threads(void)
+{
+#ifdef ORC_OMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+ORC_API void orc_set_threads(int n)
+{
+#ifdef ORC_OMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}

@@ -18,6 +18,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libgvom_oracle.so")
+_OMP_PATH = os.path.join(_HERE, "libgvom_oracle_omp.so")       # the same source on all host cores (-fopenmp -DORC_OMP)
 
 _c = ctypes
 _i64, _f64 = _c.c_int64, _c.c_double
@@ -27,20 +28,38 @@ _P = _c.c_void_p
 def build(force=False):
     """Compile the oracle with gcc (oracle/Makefile)."""
     src = os.path.join(_HERE, "gvom_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-B", "libgvom_oracle.so"],
-                              stdout=subprocess.DEVNULL)
+    for path in (_LIB_PATH, _OMP_PATH):
+        if force or not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", _HERE, "-B", os.path.basename(path)], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
 
 _lib = None
+_libs = {}
 
 
-def lib():
+def use_all_cores(on=True, threads=None):
+    """Switches every oracle call of this process to the all-core (OpenMP) build of the same source,
+    or back to the one-thread build.  Returns the number of threads in use."""
     global _lib
-    if _lib is None:
+    _lib = None
+    L = lib(_OMP_PATH if on else _LIB_PATH)
+    if on and threads:
+        L.orc_set_threads(int(threads))
+    return int(L.orc_threads())
+
+
+def lib(path=None):
+    global _lib
+    if _lib is None or path is not None:
         build()
-        L = ctypes.CDLL(_LIB_PATH)
+        path = path or _LIB_PATH
+        if path in _libs:
+            _lib = _libs[path]
+            return _lib
+        L = ctypes.CDLL(path)
+        L.orc_threads.restype = _c.c_int
+        L.orc_set_threads.argtypes = [_c.c_int]
         for suf in ("f32", "f64"):
             f = getattr(L, "orc_transform_pointcloud_" + suf)
             f.argtypes = [_P, _i64, _i64, _P]; f.restype = None
@@ -82,6 +101,7 @@ def lib():
         L.orc_make_height_map_pointcloud.restype = None
         L.orc_make_inferred_height_map_pointcloud.argtypes = [_P, _P, _P, _i64, _f64, _f64]
         L.orc_make_inferred_height_map_pointcloud.restype = None
+        _libs[path] = L
         _lib = L
     return _lib
 

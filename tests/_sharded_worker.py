@@ -9,7 +9,7 @@ import numpy as np
 import torch.distributed as dist
 
 import gvom_sharded
-from shard_fake import OracleShardBackend
+from shard_fake import OracleShardBackend, GlooComm
 from oracle import oracle
 
 
@@ -17,7 +17,7 @@ def main():
     dist.init_process_group("gloo", init_method="env://")
     rank, world = dist.get_rank(), dist.get_world_size()
     params = (0.4, 0.2, 24, 12, 2, 0.5, 0.5, 0.5, 0.3, 2.0, 2.0, 1.0, 1, 1)
-    sh = gvom_sharded.ShardedGvom(*params, backend=OracleShardBackend(params, rank, world))
+    sh = gvom_sharded.ShardedGvom(*params, comm=GlooComm(), backend=OracleShardBackend(params, rank, world))
     ref = oracle.OracleGvom(*params)
     assert sh.combine_maps() is None
     rng = np.random.default_rng(5)
@@ -29,7 +29,11 @@ def main():
                          rng.normal(-0.6, 0.4, world * n_per_rank)], axis=1)
         if k == 2:
             full = full + 500.0                                 # no overlap: must be rejected globally
-        share = full[rank * n_per_rank:(rank + 1) * n_per_rank]
+        # ragged shares: rank 0 gets a third, the last rank the rest; in step 1 rank 0's share is empty
+        cut = [0] + [world * n_per_rank // 3 * (r + 1) // world for r in range(world - 1)] + [world * n_per_rank]
+        if k == 1:
+            cut[1] = 0
+        share = full[cut[rank]:cut[rank + 1]]
         sh.process_pointcloud(share, ego)
         ref.process_pointcloud(full, ego)
         got, want = sh.combine_maps(), ref.combine_maps()

@@ -1,21 +1,70 @@
-"""Test double for the per-rank compute of g-vom_amd/gvom_sharded.py: the CPU oracle stands in
-for the HIP library so that the SHARDING LOGIC (cloud all-gather, asynchronous global cell
-count + lazy commit, in-place all-gather of the row-interleaved height buffer and of the packed
-output rows, storage<->window reordering) runs under gloo on CPU.
+"""Test doubles for g-vom_amd/gvom_sharded.py so that the ORCHESTRATION of the sharded map (ragged
+shares, the host-side count exchange, the sparse all-to-all of accumulator contributions, the global
+commit decision, the row all-gather, storage<->window reordering) runs under gloo on CPU:
 
-Each rank computes with the full oracle but only ever PUBLISHES the rows of its own slab
-(everything else is poisoned), and derives its 2-D outputs from the GATHERED height rows -- so a
-wrong row order / wrong window<->storage conversion / missing gather changes the final maps."""
+  * OracleShardBackend: the per-rank compute, with the CPU oracle standing in for the HIP library.
+    A rank traces ITS OWN points over the whole window (orc_point_2_map), keeps what falls into its
+    own storage rows and ships the rest -- per voxel {index, hit, total, min-height} -- to the owners;
+    the owner sums / minimises, encodes its rows and commits.  Every rank only ever PUBLISHES the rows
+    of its own slab (everything else is poisoned) and derives its 2-D outputs from the GATHERED rows.
+  * GlooComm: the transport, torch.distributed (gloo) in place of RCCL + shared memory.
+"""
 import contextlib
 import io
+import math
 
 import numpy as np
 import torch
+import torch.distributed as dist
 
 import gvom as _gvom
 from oracle import oracle
 
 POISON = -7777.0
+
+
+class GlooComm(object):
+    def __init__(self, group=None):
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+
+    def exchange_host(self, values):
+        mine = torch.tensor([int(v) for v in values], dtype=torch.int64)
+        out = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(out, mine, group=self.group)
+        return [[int(x) for x in t] for t in out]
+
+    def barrier(self):
+        dist.barrier(group=self.group)
+
+    def exchange_scan(self, backend, send_q, send_e, recv_q, recv_e):
+        """send_q[d] / recv_q[s]: "quads" = voxel records of ray passes; send_e / recv_e: endpoints.
+        The double ships float64 rows: quads {voxel, total}, endpoints {voxel, hit, min-height}."""
+        reqs = []
+        inbox_q = [np.zeros((recv_q[s], 2)) for s in range(self.world)]
+        inbox_e = [np.zeros((recv_e[s], 3)) for s in range(self.world)]
+        for p in range(self.world):
+            if p == self.rank:
+                continue
+            if send_q[p]:
+                reqs.append(dist.isend(torch.from_numpy(backend.out_q[p]), p, group=self.group, tag=1))
+            if send_e[p]:
+                reqs.append(dist.isend(torch.from_numpy(backend.out_e[p]), p, group=self.group, tag=2))
+            if recv_q[p]:
+                reqs.append(dist.irecv(torch.from_numpy(inbox_q[p]), p, group=self.group, tag=1))
+            if recv_e[p]:
+                reqs.append(dist.irecv(torch.from_numpy(inbox_e[p]), p, group=self.group, tag=2))
+        for r in reqs:
+            r.wait()
+        backend.in_q, backend.in_e = inbox_q, inbox_e
+
+    def allgather_rows(self, backend):
+        full = backend.height_full                      # [xy, 3*xy] tensor, my rows valid
+        rows = full.shape[0] // self.world
+        mine = full[self.rank * rows:(self.rank + 1) * rows].contiguous()
+        out = torch.empty_like(full)
+        dist.all_gather_into_tensor(out, mine, group=self.group)
+        full.copy_(out)
 
 
 class OracleShardBackend(object):
@@ -28,7 +77,7 @@ class OracleShardBackend(object):
         self.lo, self.hi = rank * self.rows, (rank + 1) * self.rows
         xy = self.xy
         self.height_full = torch.full((xy, 3 * xy), POISON, dtype=torch.float64)
-        self.fused_cells = torch.zeros(1, dtype=torch.int64)
+        self.out_q, self.out_e, self.in_q, self.in_e = {}, {}, [], []
 
     # -- layout helpers ---------------------------------------------------------------------
     def _om(self, origin):
@@ -42,27 +91,102 @@ class OracleShardBackend(object):
         om0, om1 = self._om(origin)
         return np.ascontiguousarray(np.roll(s_yx, (-om1, -om0), (0, 1)).T)
 
-    def _own_cells(self, index_map, origin):
-        occ = (np.asarray(index_map) >= 0).reshape(self.zs, self.xy, self.xy)   # [z][y][x]
-        om1 = int(origin[1]) % self.xy
-        sy = (np.arange(self.xy) + om1) % self.xy
-        own = (sy >= self.lo) & (sy < self.hi)
-        return int(occ[:, own, :].sum())
+    def _owner_of_voxels(self, origin):
+        """owner rank of every voxel (reference order x + y*xy + z*xy*xy): storage row sy = (y + origin_y) mod xy"""
+        xy, zs = self.xy, self.zs
+        y = (np.arange(xy * xy * zs) // xy) % xy
+        sy = (y + int(origin[1])) % xy
+        return sy // self.rows
 
     # -- interface used by ShardedGvom ----------------------------------------------------------
-    def cloud_tensor(self, pc):
-        return torch.from_numpy(np.ascontiguousarray(pc[:, :3]))
+    def scan_local(self, pointcloud, ego, tf):
+        g, L = self.g, oracle.lib()
+        g.ego_position = ego
+        W = self.world
+        pc = oracle._as_cloud(np.asarray(pointcloud)) if len(pointcloud) else np.zeros((0, 3))
+        n = pc.shape[0]
+        V = g.voxel_count
+        origin = np.zeros(3)
+        origin[0] = math.floor((ego[0] / g.xy_resolution) - g.xy_size / 2)
+        origin[1] = math.floor((ego[1] / g.xy_resolution) - g.xy_size / 2)
+        origin[2] = math.floor((ego[2] / g.z_resolution) - g.z_size / 2)
+        hit = np.zeros(V, np.int32); total = np.zeros(V, np.int32)
+        minh = np.ones(V, np.float32)
+        if n:
+            suf = "f32" if pc.dtype == np.float32 else "f64"
+            if tf is not None:
+                t = np.ascontiguousarray(np.asarray(tf, np.float64))
+                getattr(L, "orc_transform_pointcloud_" + suf)(oracle._p(pc), n, pc.shape[1], oracle._p(t))
+            egoa = np.asarray(ego, dtype=np.float64)
+            getattr(L, "orc_point_2_map_" + suf)(g.xy_resolution, g.z_resolution, g.xy_size, g.z_size, g.min_distance,
+                                                 oracle._p(pc), n, pc.shape[1], oracle._p(hit), oracle._p(total),
+                                                 oracle._p(egoa), oracle._p(origin))
+            idx = np.full(V, -1, np.int32)
+            cells = L.orc_assign_indices(oracle._p(hit.copy()), oracle._p(total.copy()), oracle._p(idx), V)
+            if cells:
+                mh = np.ones(cells * 3, np.float32)
+                getattr(L, "orc_calculate_min_height_" + suf)(g.xy_resolution, g.z_resolution, g.xy_size, g.z_size,
+                                                              g.min_distance, oracle._p(idx), oracle._p(pc), n, pc.shape[1],
+                                                              oracle._p(mh), oracle._p(origin))
+                occ = idx >= 0
+                minh[occ] = mh[idx[occ]]
+        owner = self._owner_of_voxels(origin)
+        # endpoints: voxels with hit > 0 carry {hit, min-height} and their endpoint share of total (= hit);
+        # "quads": the ray passes, total - hit
+        passes = total - hit
+        send_q, send_e = [0] * W, [0] * W
+        self.out_q, self.out_e = {}, {}
+        for d in range(W):
+            if d == self.rank:
+                continue
+            vq = np.nonzero((owner == d) & (passes > 0))[0]
+            ve = np.nonzero((owner == d) & (hit > 0))[0]
+            self.out_q[d] = np.stack([vq.astype(np.float64), passes[vq].astype(np.float64)], 1) if len(vq) else np.zeros((0, 2))
+            self.out_e[d] = np.stack([ve.astype(np.float64), hit[ve].astype(np.float64), minh[ve].astype(np.float64)], 1) if len(ve) else np.zeros((0, 3))
+            send_q[d], send_e[d] = len(vq), len(ve)
+        mine = owner == self.rank
+        self._acc = (np.where(mine, hit, 0).astype(np.int32), np.where(mine, total, 0).astype(np.int32),
+                     np.where(mine, minh, np.float32(1.0)).astype(np.float32), origin)
+        return send_q, send_e, int(hit.any()), n
 
-    def process(self, cloud, ego, tf):
-        pc = cloud.numpy()
-        if pc.shape[0] == 0:
-            self.g.ego_position = ego
-            return _gvom.GVOM_EMPTY_CLOUD
-        slot = self.g.buffer_index
-        was = self.g.origin_buffer[slot]
-        with contextlib.redirect_stdout(io.StringIO()):
-            self.g.process_pointcloud(pc, ego, tf)
-        return _gvom.GVOM_NO_OVERLAP if self.g.origin_buffer[slot] is was else _gvom.GVOM_OK
+    def recv_reserve(self, recv_eps):
+        pass
+
+    def scan_merge(self, recv_quads, recv_eps, accept):
+        g, L = self.g, oracle.lib()
+        hit, total, minh, origin = self._acc
+        for s in range(self.world):
+            if s == self.rank:
+                continue
+            if recv_quads[s]:
+                q = self.in_q[s]
+                np.add.at(total, q[:, 0].astype(np.int64), q[:, 1].astype(np.int32))
+            if recv_eps[s]:
+                e = self.in_e[s]
+                v = e[:, 0].astype(np.int64)
+                np.add.at(hit, v, e[:, 1].astype(np.int32))
+                np.add.at(total, v, e[:, 1].astype(np.int32))
+                np.minimum.at(minh, v, e[:, 2].astype(np.float32))
+        if not accept:
+            return
+        V = g.voxel_count
+        index_map = np.full(V, -1, np.int32)
+        cells = L.orc_assign_indices(oracle._p(hit), oracle._p(total), oracle._p(index_map), V)
+        chit = np.empty(cells, np.int32); ctotal = np.empty(cells, np.int32)
+        L.orc_move_data(oracle._p(hit), oracle._p(chit), oracle._p(index_map), V)
+        L.orc_move_data(oracle._p(total), oracle._p(ctotal), oracle._p(index_map), V)
+        min_height = np.ones(max(cells, 1) * 3, np.float32)
+        occ = index_map >= 0
+        min_height[index_map[occ]] = minh[occ]
+        b = g.buffer_index                                                                   # gvom.py:163-175
+        g.metrics_buffer[b] = None
+        g.index_buffer[b] = index_map
+        g.hit_count_buffer[b] = chit
+        g.total_count_buffer[b] = ctotal
+        g.min_height_buffer[b] = min_height
+        g.origin_buffer[b] = origin
+        g.last_buffer_index = b
+        g.buffer_index = (b + 1) % g.buffer_size
 
     def combine_fuse(self):
         with contextlib.redirect_stdout(io.StringIO()):
@@ -82,8 +206,10 @@ class OracleShardBackend(object):
         hf[self.lo:self.hi, :xy] = self._to_storage(g.height_map, self.origin)[self.lo:self.hi]
         hf[self.lo:self.hi, xy:2 * xy] = self._to_storage(g.inferred_height_map, self.origin)[self.lo:self.hi]
         hf[self.lo:self.hi, 2 * xy:] = self._to_storage(dens.astype(np.float64), self.origin)[self.lo:self.hi]
-        self.fused_cells[0] = self._own_cells(g.combined_index_map, self.origin)
         return _gvom.GVOM_OK
+
+    def local_fused_cells(self):
+        return int(self.g.combined_cell_count_cpu)
 
     def set_cell_count(self, n):
         self.cell_count = n
