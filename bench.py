@@ -1,26 +1,41 @@
 #!/usr/bin/env python3
 """bench.py -- G-VOM hot path (process_pointcloud -> combine_maps) on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config m256|c2|c3|m256b8]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config m256|c1|c2|c3|m256b8|c4|c5]
 
-A "step" is one pass of the hot path over one synthetic lidar scan that is already resident
-in HBM: gvom_process_pointcloud_device (transform/hit/DDA trace, encode, min-height) followed
-by gvom_combine_maps (temporal fusion + column reductions + 2-D maps + D2H of the four
-returned maps).  Metric: M points/s (whole job), with end-to-end map Hz beside it.
+A "step" is one pass of the hot path over one synthetic lidar scan: process_pointcloud
+(transform / hit / DDA trace, encode) followed by combine_maps (temporal fusion + column
+reductions + 2-D maps + the four returned maps landing in host memory).  Metric: M points/s
+(whole job), with end-to-end map Hz beside it.
 
-N = 1 runs the headline configuration of BASELINE.json's metric: the 256^3 voxel grid at
-0.2 m with the OS1-64-shaped 131,072-point scan (BASELINE.md row "M").  N > 1 runs the
-slab-sharded mapper (g-vom_amd/gvom_sharded.py): one rank per GPU, the grid partitioned into
-world-anchored y-slabs, N sensors' scans per step (weak scaling: per-GPU point count fixed).
+`value` is measured with the cloud already resident in HBM (the driver's contract).  The same
+steps through the reference's own calling conventions are reported beside it, never as `value`:
+`value_host_f32` (host numpy in, gvom.py:110) and `value_ros_f64_tf` (what an unchanged
+gvom_ros.py:106-109 hands over: a float64 host array + a 4x4 transform).
 
-Rank 0 prints ONE JSON line with the `roofline` (dominant kernel, HIP-event timed inside the
-timed region on the library's own stream) and `cpu_baseline` (the CPU oracle, a "port" of the
-reference's algorithm, timed on this host's cores on a bounded sample) objects.
+N = 1 runs the headline configuration of BASELINE.json's metric: the 256^3 voxel grid at 0.2 m
+with the OS1-64-shaped 131,072-point scan (BASELINE.md row "M"), cycling 8 sensor poses that
+move 0.2 m per scan (the window shifts).  Whatever --steps says, timed blocks of K steps are
+repeated until >= 0.5 s has been timed; `ms_per_step` is the MEDIAN block.  Short runs of the
+other single-GPU BASELINE configs ride along under `configs`.
+
+N > 1 runs one map sharded over N GPUs (g-vom_amd/gvom_sharded.py): one rank per GPU, every
+rank its own sensor (weak scaling: per-GPU point count fixed), RCCL over xGMI called from
+libgvom_hip.so.  Started without a launcher (`python bench.py --gpus N`) this process only
+spawns the N ranks -- it never touches the GPU itself -- and relays rank 0's JSON line; under
+torchrun (RANK / WORLD_SIZE / MASTER_* in the environment) it is one of the ranks.
+
+Rank 0 prints ONE JSON line with `roofline` (dominant kernel, HIP-event timed on the library's
+own stream) and `cpu_baseline` (the CPU oracle, a "port" of the reference's algorithm: one thread
+and all host cores, on a bounded sample of the same workload).
 """
 import argparse
 import ctypes
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,9 +44,11 @@ for p in (ROOT, os.path.join(ROOT, "g-vom_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import numpy as np          # noqa: E402
-
 HBM_PEAK_GBS = 8000.0       # MI355X spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+VALU_ISSUE_RATE = 1.2288e12  # wave64 VALU instructions / s: 1024 SIMDs x 2.4 GHz / 2 cycles (MI355X_MICROARCH.md:54,473)
+MIN_TIMED_S = 0.5
+METRIC = "M points/sec (process_pointcloud + combine_maps, 256^3 voxel grid); map Hz beside it"
+DTYPE = "int32 atomics + f32 ray state + f64 compares/maps"
 
 
 class Hip(object):
@@ -62,8 +79,7 @@ class Hip(object):
 def pin_to_gpu_numa(device):
     """Benchmark hygiene (what `numactl --cpunodebind` does): run this process on the CPUs of the
     NUMA node the GPU hangs off, so kernel launches (doorbell writes) and completion flags (GPU
-    writes to host memory the host spins on) do not cross the socket interconnect (2-socket test
-    hosts: 130.0-131.2 us/step pinned, 130.9-131.5 unpinned).
+    writes to host memory the host spins on) do not cross the socket interconnect.
     Best effort: returns the CPU list used, or None (GVOM_BENCH_NO_PIN=1 disables it)."""
     if os.environ.get("GVOM_BENCH_NO_PIN") or not hasattr(os, "sched_setaffinity"):
         return None
@@ -90,71 +106,114 @@ def pin_to_gpu_numa(device):
 
 
 def cpu_baseline(params, scans, budget_s=20.0):
-    """Times the CPU oracle (single thread, C restatement of the reference's algorithm) on a
-    bounded sample of the same workload: whole steps (one scan + one combine) until the
-    budget is used, at least one."""
+    """Times the CPU oracle (C restatement of the reference's algorithm, oracle/gvom_oracle.c) on a
+    bounded sample of the same workload -- whole steps (one scan + one combine) -- first on ONE
+    thread, then its OpenMP build on ALL host cores this process may use."""
     from oracle import oracle
-    g = oracle.OracleGvom(*params)
-    pts = 0
-    steps = 0
-    t0 = time.perf_counter()
-    while True:
-        pc, ego, tf = scans[steps % len(scans)]
-        g.process_pointcloud(pc, ego, tf)
-        g.combine_maps()
-        pts += pc.shape[0]
-        steps += 1
-        el = time.perf_counter() - t0
-        if el > budget_s and steps >= 3:
-            break
-    return {"value": pts / el / 1e6, "unit": "M points/s", "cores": 1, "kind": "port",
-            "sample": "%d whole steps (scan+combine) of the same workload, %.1f s, "
-                      "oracle/gvom_oracle.c single thread" % (steps, el),
-            "ms_per_step": el / steps * 1e3}
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    out = {}
+    # (beyond ~32 threads the scattered int32 atomics of the DDA, 10 M per scan, mostly onto the voxels near
+    # the sensor, cost more than the extra threads bring: 128 threads measured SLOWER than one)
+    for key, all_cores, share in (("one", False, 0.6), ("all", True, 0.4)):
+        threads = oracle.use_all_cores(all_cores, threads=min(cores, 32) if all_cores else None)
+        g = oracle.OracleGvom(*params)
+        pts = steps = 0
+        t0 = time.perf_counter()
+        while True:
+            pc, ego, tf = scans[steps % len(scans)]
+            g.process_pointcloud(pc, ego, tf)
+            g.combine_maps()
+            pts += pc.shape[0]
+            steps += 1
+            el = time.perf_counter() - t0
+            if el > budget_s * share and steps >= 3:
+                break
+        out[key] = (pts / el / 1e6, steps, el, threads)
+    oracle.use_all_cores(False)
+    v1, s1, e1, _ = out["one"]
+    vn, sn, en, tn = out["all"]
+    return {"value": v1, "unit": "M points/s", "cores": 1, "kind": "port",
+            "value_all_cores": vn, "cores_all": tn, "host_cores_available": cores,
+            "sample": "%d whole steps (scan+combine) of the same workload in %.1f s on one thread, %d steps in %.1f s "
+                      "on %d OpenMP threads; oracle/gvom_oracle.c" % (s1, e1, sn, en, tn),
+            "ms_per_step": e1 / s1 * 1e3, "ms_per_step_all_cores": en / sn * 1e3}
+
+
+def _newest_profile(pattern, kernel):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
+        try:
+            ks = json.load(open(f))["kernels"]
+        except Exception:
+            continue
+        for name, k in ks.items():
+            if name.split("<")[0] == kernel:
+                return k, os.path.basename(f)
+    return None, None
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/
-    *_traffic.json, written by tools/summarize_pmc.py: separate FETCH_SIZE / WRITE_SIZE passes,
-    corrected with the factors calibrated on known-byte kernels in the same session), newest
-    file first.  None if no profile covers the kernel."""
-    import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
-        try:
-            k = json.load(open(f))["kernels"].get(kernel)
-        except Exception:
-            k = None
-        if k and k.get("hbm_bytes_corrected"):
-            return {"bytes_per_launch": k["hbm_bytes_corrected"], "source": os.path.basename(f),
-                    "atomic_requests_per_launch": k.get("TCC_EA0_ATOMIC_sum")}
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*_traffic.json:
+    separate FETCH_SIZE / WRITE_SIZE passes, corrected with the factors calibrated on known-byte
+    kernels in the same session), newest file first.  None if no profile covers the kernel."""
+    k, src = _newest_profile("*_traffic.json", kernel)
+    if k and k.get("hbm_bytes_corrected"):
+        return {"bytes_per_launch": k["hbm_bytes_corrected"], "source": src,
+                "atomic_requests_per_launch": k.get("TCC_EA0_ATOMIC_sum")}
     return None
 
 
-def atomic_ceiling(kernel, ms):
-    """k_trace's memory traffic is scattered atomics: report its memory-side atomic REQUEST rate
-    beside the HBM roofline.  Requests per launch come from the committed
-    TCC_EA0_ATOMIC_sum pass; the ceiling is the scattered-request rate measured with
-    tools/atomic_calib on the same part (profiles/r1e_atomic_calib.txt: 24.8 G requests/s when every
-    request goes to a different line; requests to ONE line are served at 11.4 ns each)."""
-    if kernel != "trace":
-        return None
-    t = pmc_traffic("k_trace") or {}
-    req = t.get("atomic_requests_per_launch")
-    if not req:
-        return None
-    return {"bound": "memory-side atomic requests", "requests_per_launch": req,
-            "achieved": req / (ms * 1e-3) / 1e9, "peak": 24.8, "unit": "G requests/s",
-            "frac": req / (ms * 1e-3) / 1e9 / 24.8, "source": t.get("source")}
+def sq_counters(kernel):
+    """SQ counters per launch of `kernel` from the committed passes (profiles/*_sq.json, tools/pmc_sq.sh)."""
+    k, src = _newest_profile("*_sq.json", kernel)
+    return (k, src) if k else (None, None)
 
 
-def run_single(args):
+def _median(xs):
+    xs = sorted(xs)
+    return xs[len(xs) // 2] if xs else None
+
+
+def timed_blocks(step, k0, steps, min_s=MIN_TIMED_S, max_blocks=400):
+    """Blocks of exactly `steps` steps until >= min_s has been timed; returns the block times (s)."""
+    import gc
+    gc.collect(); gc.disable()            # no cyclic-GC pauses inside the timed region (buffers recycle by refcount)
+    blocks, total, k = [], 0.0, k0
+    try:
+        while (total < min_s or len(blocks) < 3) and len(blocks) < max_blocks:
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step(k); k += 1
+            dt = time.perf_counter() - t0
+            blocks.append(dt); total += dt
+    finally:
+        gc.enable()
+    return blocks, k
+
+
+def stage_samples(g, step, k0, n=40):
+    """HIP-event times of the kernels (events on the library's own stream) of n steps, outside the
+    timed blocks: a sampled step is ~80 us longer (event records + a stream sync)."""
+    import gvom
+    acc = {s: [] for s in gvom.STAGE_NAMES}
+    g.set_profiling(True)
+    for k in range(n):
+        step(k0 + k)
+        ms = g.last_stage_ms()
+        for s in acc:
+            acc[s].append(ms[s])
+    g.set_profiling(False)
+    acc.pop("min_height", None)           # rides in k_trace / k_encode since round 2
+    return {s: {"median": _median(v), "p10": sorted(v)[len(v) // 10], "p90": sorted(v)[(9 * len(v)) // 10], "samples": len(v)}
+            for s, v in acc.items()}
+
+
+def run_config(hip, name, steps, warmup, poses, full):
+    """One BASELINE configuration on one GPU.  full: headline treatment (all calling conventions, the
+    occupancy API, roofline accounting); otherwise a short device-resident run."""
+    import numpy as np
     import gvom
     import synth
-    affinity = pin_to_gpu_numa(0)
-    hip = Hip()
-    hip.set_device(0)
-    name = args.config
-    params, scans = synth.config_inputs(name, n_scans=max(1, args.poses))
+    params, scans = synth.config_inputs(name, n_scans=max(1, poses))
     g = gvom.Gvom(*params, device=0)
     dev = [(hip.to_device(pc), pc.shape[0], pc.dtype, ego, tf) for (pc, ego, tf) in scans]
     n_pts = scans[0][0].shape[0]
@@ -164,128 +223,179 @@ def run_single(args):
         g.process_pointcloud_device(d.value, n, dt, ego, tf)
         return g.combine_maps()
 
-    for k in range(args.warmup):
+    for k in range(warmup):
         step(k)
-    # HIP-event timing of the kernels happens INSIDE the timed region, on the library's own
-    # stream, on every `sample`-th step (a sampled step is ~80 us longer: event records between the
-    # kernels and a stream sync to read them)
-    acc = dict.fromkeys(gvom.STAGE_NAMES, 0.0)
-    sample, n_sampled = max(1, args.sample), 0
-    import gc
-    gc.collect(); gc.disable()            # no cyclic-GC pauses inside the timed region (buffers recycle by refcount)
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        prof = (k % sample) == 0
-        if prof:
-            g.set_profiling(True)
-        step(args.warmup + k)
-        if prof:
-            ms = g.last_stage_ms()
-            g.set_profiling(False)
-            n_sampled += 1
-            for s in acc:
-                acc[s] += ms[s]
-    elapsed = time.perf_counter() - t0
-    gc.enable()
-    stage_ms = {s: acc[s] / n_sampled for s in acc}
-    # PCIe-inclusive rate (never `value`): the same steps with the cloud handed over as a HOST
-    # buffer, the reference's own calling convention (gvom.py:110 cuda.to_device)
-    n_pcie = max(10, args.steps // 4)
-    t1 = time.perf_counter()
-    for k in range(n_pcie):
+    blocks, k = timed_blocks(step, warmup, steps, MIN_TIMED_S if full else 0.1)
+    med = _median(blocks)
+    out = {"workload": synth.CONFIGS[name][2], "points_per_scan": n_pts, "grid": [params[2], params[2], params[3]],
+           "buffer_size": params[4], "poses": len(scans), "steps": steps, "blocks": len(blocks),
+           "ms_per_step": med / steps * 1e3, "ms_per_step_min": min(blocks) / steps * 1e3,
+           "ms_per_step_max": max(blocks) / steps * 1e3, "value": n_pts * steps / med / 1e6, "map_hz": steps / med}
+    stages = stage_samples(g, step, k, 40 if full else 20)
+    out["stage_ms"] = {s: v["median"] for s, v in stages.items()}
+    if not full:
+        del g
+        return out, None
+    out["stage_ms_spread"] = stages
+
+    # the same steps through the reference's calling conventions (never `value`)
+    def step_host(k):
         pc, ego, tf = scans[k % len(scans)]
         g.process_pointcloud(pc, ego, tf)
-        g.combine_maps()
-    pcie_elapsed = time.perf_counter() - t1
-    # the same steps through combine_maps_occupancy (combine + the ROS node's post-processing on the
-    # GPU, 5 B/cell over PCIe instead of 20): reported beside the headline, never `value`
-    n_occ = max(10, args.steps // 4)
-    t2 = time.perf_counter()
-    for k in range(n_occ):
+        return g.combine_maps()
+
+    b2, k = timed_blocks(step_host, k, steps, 0.2)
+    out["value_host_f32"] = n_pts * steps / _median(b2) / 1e6
+    scans64 = [(pc.astype(np.float64), ego, np.eye(4)) for (pc, ego, tf) in scans]   # gvom_ros.py:106-109
+
+    def step_ros(k):
+        pc, ego, tf = scans64[k % len(scans64)]
+        g.process_pointcloud(pc, ego, tf)
+        return g.combine_maps()
+
+    b3, k = timed_blocks(step_ros, k, steps, 0.2)
+    out["value_ros_f64_tf"] = n_pts * steps / _median(b3) / 1e6
+
+    # combine_maps_occupancy (combine + the ROS node's post-processing on the GPU, 5 B/cell over PCIe)
+    def step_occ(k):
         d, n, dt, ego, tf = dev[k % len(dev)]
         g.process_pointcloud_device(d.value, n, dt, ego, tf)
-        g.combine_maps_occupancy()
-    occ_elapsed = time.perf_counter() - t2
-    # exact integer accounting for the roofline (algorithmic bytes).  AFTER the timed regions:
-    # the dense read-back allocates and frees 16*V bytes, and that free shows up as one 7-15 ms step
-    # shortly afterwards (tools/step_hist.py), i.e. +4-8 us on the average of 1000 steps
-    stats = g.scan_stats()
+        return g.combine_maps_occupancy()
 
+    b4, k = timed_blocks(step_occ, k, steps, 0.2)
+    out["value_occupancy_api"] = n_pts * steps / _median(b4) / 1e6
+    out["host_us"] = g.host_timing()
+    # exact integer accounting for the roofline (algorithmic bytes), AFTER the timed regions:
+    # the dense read-back allocates and frees 16*V bytes
+    stats = g.scan_stats()
     V = params[2] * params[2] * params[3]
     P = 12 if scans[0][0].dtype == np.float32 else 24
-    n_in = stats["sum_hit"]
-    alg = {                                                          # bytes per launch
-        "trace": n_pts * P + 4 * (stats["sum_hit"] + stats["sum_total"]),
-        "encode": 20 * V + n_pts * P + 4 * n_in,          # min-height pass rides in the k_encode launch
-        "min_height": 0,
-        "fuse": 4 * V * (min(args.poses, params[4]) + 1) + 4 * V + 4 * V,
-        "map2d": 68 * params[2] * params[2],
-    }
-    stage_ms.pop("min_height", None)
-    alg.pop("min_height", None)
-    dom = max(stage_ms, key=lambda s: stage_ms[s])
-    achieved = alg[dom] / (stage_ms[dom] * 1e-3) / 1e9
+    filled = min(warmup + steps, params[4])
+    alg = {"trace": n_pts * P + 4 * (stats["sum_hit"] + stats["sum_total"]),
+           "encode": 20 * V + 4 * stats["sum_hit"],
+           "fuse": 4 * V * (filled + 1) + 4 * V + 4 * V,
+           "map2d": 68 * params[2] * params[2]}
+    out.update({"sum_hit": stats["sum_hit"], "sum_total": stats["sum_total"], "cells": stats["cells"]})
+    del g
+    return out, (alg, stages, params, scans)
+
+
+def roofline_of(alg, stages):
+    kern = {"trace": "k_trace", "encode": "k_encode", "fuse": "k_fuse4", "map2d": "k_map2d"}
+    ms = {s: v["median"] for s, v in stages.items()}
+    dom = max(ms, key=lambda s: ms[s])
+    achieved = alg[dom] / (ms[dom] * 1e-3) / 1e9
+    traf = pmc_traffic(kern[dom])
+    sq, sq_src = sq_counters(kern[dom])
+    valu = None
+    if sq and sq.get("SQ_INSTS_VALU"):
+        bound_us = sq["SQ_INSTS_VALU"] / VALU_ISSUE_RATE * 1e6
+        valu = {"insts_per_launch": sq["SQ_INSTS_VALU"], "issue_rate_per_s": VALU_ISSUE_RATE,
+                "bound_us": bound_us, "frac": bound_us / (ms[dom] * 1e3),
+                "measured_quad_cycles_per_inst": (sq.get("SQ_ACTIVE_INST_VALU") or 0) / sq["SQ_INSTS_VALU"],
+                "note": "frac = the kernel's VALU wave-instructions / 1.2288e12 per s / its measured time; the SQ "
+                        "counters of this kernel show one quad-cycle (4 cycles) of SQ_ACTIVE_INST_VALU per "
+                        "instruction, i.e. half that rate is what the integer / compare mix sustains", "source": sq_src}
+    # measured (PMC) HBM traffic per stage over measured time -- NOT the algorithmic count, which assumes
+    # V-sized streams that the tile tags no longer perform
+    stage_gbs = {}
+    for s, kname in kern.items():
+        t = pmc_traffic(kname)
+        if t and ms.get(s):
+            stage_gbs[s] = t["bytes_per_launch"] / (ms[s] * 1e-3) / 1e9
+    req = (traf or {}).get("atomic_requests_per_launch")
+    return {"bound": "hbm", "kernel": kern[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": (traf or {}).get("bytes_per_launch"), "traffic_detail": traf,
+            "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": ms[dom],
+            "launch_ms_spread": {k: stages[dom][k] for k in ("p10", "p90", "samples")},
+            "valu": valu,
+            "secondary_ceiling": ({"bound": "memory-side atomic requests", "requests_per_launch": req,
+                                   "achieved": req / (ms[dom] * 1e-3) / 1e9, "peak": 24.8, "unit": "G requests/s",
+                                   "frac": req / (ms[dom] * 1e-3) / 1e9 / 24.8} if req and dom == "trace" else None),
+            "measured_hbm_GBs_per_stage": stage_gbs}
+
+
+def run_single(args):
+    import synth
+    affinity = pin_to_gpu_numa(0)
+    hip = Hip()
+    hip.set_device(0)
+    name = args.config
+    big = name in ("c4", "c5")
+    poses = 1 if name == "c1" else (min(args.poses, 4) if big else args.poses)
+    steps = min(args.steps, 40) if big else args.steps            # a c5 step is ~3 ms; 4 M-point clouds take a while to generate
+    res, extra = run_config(hip, name, steps, min(args.warmup, 10) if big else args.warmup, poses, True)
+    args.steps = steps
+    alg, stages, params, scans = extra
     out = {
-        "metric": "M points/sec (process_pointcloud + combine_maps, 256^3 voxel grid); map Hz beside it",
-        "value": n_pts * args.steps / elapsed / 1e6,
-        "unit": "M points/s",
-        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "int32 atomics + f32 ray state + f64 compares/maps",
-        "data": "synthetic",
-        "config": {"workload": synth.CONFIGS[name][2], "name": name, "points_per_scan": n_pts,
-                   "grid": [params[2], params[2], params[3]], "buffer_size": params[4],
-                   "poses": len(scans), "input": "device-resident f32 xyz",
-                   "step": "1 scan + 1 combine incl. D2H of the 4 maps",
+        "metric": METRIC, "value": res["value"], "unit": "M points/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
+        "config": {"workload": synth.CONFIGS[name][2], "name": name, "points_per_scan": res["points_per_scan"],
+                   "grid": res["grid"], "buffer_size": res["buffer_size"], "poses": res["poses"],
+                   "pose_motion": "0.2 m per scan in +x (the window shifts every scan)",
+                   "input": "device-resident f32 xyz", "step": "1 scan + 1 combine incl. the 4 maps in host memory",
+                   "timing": "median of %d blocks of %d steps (>= %.1f s timed)" % (res["blocks"], args.steps, MIN_TIMED_S),
                    "host_affinity": affinity},
-        "map_hz": args.steps / elapsed,
-        "value_pcie_inclusive": n_pts * n_pcie / pcie_elapsed / 1e6,
-        "value_occupancy_api": n_pts * n_occ / occ_elapsed / 1e6,
-        "stage_ms": stage_ms,
-        "host_us": g.host_timing(),
-        "sum_hit": stats["sum_hit"], "sum_total": stats["sum_total"], "cells": stats["cells"],
-        "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": (pmc_traffic("k_" + dom) or {}).get("bytes_per_launch"),
-                     "traffic_detail": pmc_traffic("k_" + dom),
-                     "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": stage_ms[dom],
-                     "secondary_ceiling": atomic_ceiling(dom, stage_ms[dom]),
-                     "all_stages_GBs": {s: alg[s] / (stage_ms[s] * 1e-3) / 1e9 if stage_ms[s] > 0 else None
-                                        for s in alg}},
+        "map_hz": res["map_hz"],
+        "ms_per_step_min": res["ms_per_step_min"], "ms_per_step_max": res["ms_per_step_max"], "blocks": res["blocks"],
+        "value_host_f32": res["value_host_f32"], "value_ros_f64_tf": res["value_ros_f64_tf"],
+        "value_occupancy_api": res["value_occupancy_api"],
+        "value_semantics": "value: cloud resident in HBM (driver contract); value_host_f32: host numpy in (gvom.py:110); "
+                           "value_ros_f64_tf: float64 host array + 4x4 transform, the unchanged gvom_ros.py:106-109 path",
+        "stage_ms": res["stage_ms"], "host_us": res["host_us"],
+        "sum_hit": res["sum_hit"], "sum_total": res["sum_total"], "cells": res["cells"],
+        "roofline": roofline_of(alg, stages),
     }
+    if not args.no_extra and name == "m256":
+        out["configs"] = {}
+        for other, poses in (("c2", 8), ("c3", 8), ("m256b8", 8)):
+            r, _ = run_config(hip, other, 100, 30, poses, False)
+            out["configs"][other] = r
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(params, scans, args.cpu_budget)
     return out
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: this process starts the N ranks (one per GPU) and
+    relays rank 0's JSON line.  It makes NO HIP call itself."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), GVOM_JOB_NONCE=str(os.getpid()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    if any(rcs):
+        sys.stderr.write("bench.py: rank exit codes %s\n" % rcs)
+        sys.exit(1)
+    lines = [ln for ln in out0.decode().splitlines() if ln.startswith("{")]
+    if not lines:
+        sys.stderr.write("bench.py: rank 0 printed no JSON line\n")
+        sys.exit(1)
+    print(lines[-1])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--config", default="m256", choices=["c2", "c3", "m256", "m256b8"])
-    ap.add_argument("--poses", type=int, default=1, help="distinct sensor poses cycled through")
-    ap.add_argument("--sample", type=int, default=50,
-                    help="HIP-event-time the kernels on every n-th timed step (a sampled step costs ~80 us more: "
-                         "event records + a stream sync; every 8th step inflated the step average by 10 us)")
+    ap.add_argument("--config", default="m256", choices=["c1", "c2", "c3", "m256", "m256b8", "c4", "c5"])
+    ap.add_argument("--poses", type=int, default=8, help="distinct sensor poses cycled through (0.2 m apart)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--no-extra", action="store_true", help="skip the short runs of the other configs")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1 or os.environ.get("GVOM_BENCH_FORCE_SHARDED"):
+    world = int(os.environ.get("WORLD_SIZE", "0"))
+    if args.gpus > 1 and world == 0:
+        return spawn_ranks(args)
+    if args.gpus > 1 or world > 1:
         import bench_sharded
-        # RCCL prints its version banner on stdout: keep stdout for the ONE JSON line (fd-level, the
-        # banner comes from native code)
-        sys.stdout.flush()
-        saved = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            out = bench_sharded.run(args)
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved, 1)
-            os.close(saved)
+        out = bench_sharded.run(args)
         if out is None:
             return
     else:

@@ -1,8 +1,7 @@
-"""N > 1 leg of bench.py: one rank per GPU (torch.distributed over RCCL), one G-VOM map sharded
-into world-anchored y-slabs (g-vom_amd/gvom_sharded.py).  Weak scaling: every rank contributes
-one OS1-64-shaped 131,072-point scan per step (a rig of N sensors), so a step processes
-N x 131,072 points into ONE shared 256^3 map, followed by one combine_maps."""
-import json
+"""N > 1 leg of bench.py: one rank per GPU, one G-VOM map sharded into world-anchored y-slabs
+(g-vom_amd/gvom_sharded.py), RCCL over xGMI called from libgvom_hip.so -- no PyTorch.  Weak scaling:
+every rank contributes one OS1-64-shaped 131,072-point scan per step (a rig of N sensors), so a step
+processes N x 131,072 points into ONE shared 256^3 map, followed by one combine_maps."""
 import os
 import sys
 import time
@@ -16,95 +15,85 @@ import numpy as np
 
 
 def run(args):
-    import torch
-    import torch.distributed as dist
+    import bench
     import gvom
     import gvom_sharded
     import synth
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    import bench
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     affinity = bench.pin_to_gpu_numa(local_rank)      # each rank next to its own GPU
-    torch.cuda.set_device(local_rank)
-    dist.init_process_group("nccl", init_method="env://", device_id=torch.device("cuda", local_rank))
-    name = args.config
+    hip = bench.Hip()
+    hip.set_device(local_rank)
+    name = args.config if args.config in ("m256", "c2", "c3", "m256b8") else "m256"
     params, beams, desc = synth.CONFIGS[name]
     scene = synth.make_scene(2)
+    poses = max(1, min(args.poses, 8))
     # this rank's sensor: same pose, azimuth comb shifted by a fraction of the azimuth step
-    pc = synth.lidar_scan(scene, beams=beams, sensor=(0.0, 0.0, 0.0),
-                          yaw=2.0 * np.pi / 2048 * rank / world, noise_seed=rank)
-    n_local = pc.shape[0]
-    sh = gvom_sharded.ShardedGvom(*params, device=local_rank)
-    local = torch.from_numpy(pc).to(torch.device("cuda", local_rank))
-    ego = (0.0, 0.0, 0.0)
+    scans = []
+    for k in range(poses):
+        sensor = (0.2 * k, 0.0, 0.0)
+        pc = synth.lidar_scan(scene, beams=beams, sensor=sensor, yaw=2.0 * np.pi / 2048 * rank / world,
+                              noise_seed=100 * k + rank)
+        scans.append(((hip.to_device(pc).value, pc.shape[0], pc.dtype), sensor))
+    n_local = scans[0][0][1]
+    comm = gvom_sharded.RcclComm(rank, world, local_rank, gvom_sharded.rendezvous_name())
+    sh = gvom_sharded.ShardedGvom(*params, comm=comm, device=local_rank)
 
-    def step():
-        sh.process_pointcloud(local, ego)
+    def step(k):
+        share, ego = scans[k % poses]
+        sh.process_pointcloud(share, ego)
         return sh.combine_maps()
 
-    for _ in range(args.warmup):
-        step()
-    acc = dict.fromkeys(gvom.STAGE_NAMES, 0.0)
-    sample, n_sampled = max(1, getattr(args, "sample", 50)), 0
+    def fence():                                     # device idle on every rank, then a barrier, both sides of the timed region
+        sh.b.sync(); comm.barrier(); sh.b.sync()
+
+    for k in range(args.warmup):
+        step(k)
     import gc
-    gc.collect(); gc.disable()            # no cyclic-GC pauses inside the timed region
-    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        prof = (k % sample) == 0            # HIP-event-time this rank's kernels on every n-th step
-        if prof:
-            sh.b.g.set_profiling(True)
-        step()
-        if prof:
-            ms = sh.b.g.last_stage_ms()
-            sh.b.g.set_profiling(False)
-            n_sampled += 1
-            for s in acc:
-                acc[s] += ms[s]
-    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    gc.collect(); gc.disable()
+    blocks, total, k = [], 0.0, args.warmup
+    # blocks of exactly `steps` steps until >= 0.5 s has been timed on rank 0's clock (the ranks agree on the count)
+    while True:
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(k); k += 1
+        fence()
+        dt = time.perf_counter() - t0
+        dt = max(r[0] for r in comm.exchange_host([int(dt * 1e9)])) * 1e-9      # MAX over ranks
+        blocks.append(dt); total += dt
+        if (total >= bench.MIN_TIMED_S and len(blocks) >= 3) or len(blocks) >= 200:
+            break
     gc.enable()
-    stats = sh.b.g.scan_stats()             # exact accumulator sums of THIS rank's slab (roofline accounting;
-                                            # after the timed region: its 16*V-byte temporary costs a hiccup)
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-    stage_ms = {s: acc[s] / max(1, n_sampled) for s in acc}
-    stage_ms.pop("min_height", None)
+    med = sorted(blocks)[len(blocks) // 2]
+    stages = bench.stage_samples(sh.b.g, step, k, 20)   # this rank's kernels (HIP events on the library's stream)
+    stage_ms = {s: v["median"] for s, v in stages.items()}
     out = None
     if rank == 0:
         n_total = n_local * world
-        V = params[2] * params[2] * params[3]
-        dom = max(stage_ms, key=lambda s: stage_ms[s])
-        # algorithmic bytes of rank 0's launches (on its slab of V / world voxels; k_trace
-        # reads the whole gathered cloud and adds the slab's share of the accumulator updates)
-        alg = {"trace": n_total * 12 + 4 * (stats["sum_hit"] + stats["sum_total"]),
-               "encode": 20 * V // world + n_total * 12 + 4 * stats["sum_hit"],
-               "fuse": (4 * (min(1, params[4]) + 1) + 8) * V // world,
-               "map2d": 68 * params[2] * params[2]}
-        achieved = alg[dom] / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else None
         out = {
-            "metric": "M points/sec (process_pointcloud + combine_maps, 256^3 voxel grid); map Hz beside it",
-            "value": n_total * args.steps / elapsed / 1e6, "unit": "M points/s",
+            "metric": bench.METRIC, "value": n_total * args.steps / med / 1e6, "unit": "M points/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "int32 atomics + f32 ray state + f64 compares/maps",
-            "data": "synthetic",
-            "config": {"workload": desc + "; %d sensors, one shared map, grid sharded into %d y-slabs"
-                       % (world, world), "name": name, "points_per_step": n_total,
-                       "points_per_gpu": n_local, "grid": [params[2], params[2], params[3]],
-                       "buffer_size": params[4], "host_affinity_rank0": affinity,
-                       "collectives": "per step: all_gather(cloud, 12 B/pt) + in-place all_gather(height|inferred|"
-                       "density rows, 24 B/cell) over RCCL; none on per-voxel data"},
-            "map_hz": args.steps / elapsed,
+            "ms_per_step": med / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": bench.DTYPE, "data": "synthetic",
+            "config": {"workload": desc + "; %d sensors, one shared map, grid sharded into %d y-slabs" % (world, world),
+                       "name": name, "points_per_step": n_total, "points_per_gpu": n_local,
+                       "grid": [params[2], params[2], params[3]], "buffer_size": params[4], "poses": poses,
+                       "input": "device-resident f32 xyz", "host_affinity_rank0": affinity,
+                       "timing": "median of %d blocks of %d steps, max over ranks" % (len(blocks), args.steps),
+                       "exchange": "per scan: sparse all-to-all of dirty accumulator quads (1 KiB + id) and endpoints (8 B), "
+                                   "grouped ncclSend/ncclRecv; per combine: in-place ncclAllGather of height|inferred|density "
+                                   "rows (24 B/cell); counts through shared memory"},
+            "map_hz": args.steps / med, "blocks": len(blocks),
+            "ms_per_step_min": min(blocks) / args.steps * 1e3, "ms_per_step_max": max(blocks) / args.steps * 1e3,
             "stage_ms_rank0": stage_ms,
-            "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": 8000.0,
-                         "unit": "GB/s", "frac": achieved / 8000.0 if achieved else None, "traffic": None,
-                         "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": stage_ms[dom],
-                         "note": "rank 0's launches on its slab of V/%d voxels (V=%d); PMC traffic is "
-                                 "profiled on the N=1 run" % (world, V)},
+            "roofline": {"bound": "hbm", "kernel": "k_trace", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None,
+                         "traffic": None, "avg_launch_ms": stage_ms.get("trace"),
+                         "note": "rank 0's launches: k_trace walks this rank's own 131,072 rays over the whole window "
+                                 "(the same launch as on one GPU); algorithmic bytes and PMC traffic are profiled on "
+                                 "the N = 1 run"},
         }
-    dist.barrier()
-    dist.destroy_process_group()
+    fence()
+    comm.close()
     return out

@@ -62,10 +62,17 @@ class HipShardBackend(object):
         self.xy = params[2]
 
     def scan_local(self, pointcloud, ego, tf):
-        """This rank's share of the scan -> (send_quads[world], send_eps[world], any_in_grid, n)."""
+        """This rank's share of the scan -> (send_quads[world], send_eps[world], any_in_grid, n).
+        pointcloud: numpy (n, >=3), or (device pointer, n, numpy dtype) for a share already in HBM."""
         g = self.g
         g.ego_position = ego
-        pc, n, stride, code = g._prepare_cloud(pointcloud)
+        on_device = isinstance(pointcloud, tuple)
+        if on_device:
+            dptr, n, dt = pointcloud
+            code = 0 if np.dtype(dt) == np.float32 else 1
+            stride = 12 if code == 0 else 24
+        else:
+            pc, n, stride, code = g._prepare_cloud(pointcloud)
         ego_c = (ctypes.c_double * 3)(float(ego[0]), float(ego[1]), float(ego[2]))
         t = None
         if tf is not None:
@@ -75,7 +82,8 @@ class HipShardBackend(object):
         sq = (ctypes.c_int64 * self.world)()
         se = (ctypes.c_int64 * self.world)()
         any_ = ctypes.c_int(0)
-        g._check(self.lib.gvom_shard_scan_local(self.h, _gvom._ptr(pc) if n else None, 0, n, stride, code, ego_c,
+        src = ctypes.c_void_p(int(dptr)) if on_device else (_gvom._ptr(pc) if n else None)
+        g._check(self.lib.gvom_shard_scan_local(self.h, src, 1 if on_device else 0, int(n), stride, code, ego_c,
                                                 _gvom._ptr(t), sq, se, ctypes.byref(any_)))
         return list(sq), list(se), int(any_.value), n
 
@@ -262,7 +270,8 @@ class ShardedGvom(object):
         return self._cell_count
 
     def process_pointcloud(self, pointcloud, ego_position, transform=None):
-        """pointcloud: this rank's share, numpy (n, >=3) float32 / float64; n may differ between ranks."""
+        """pointcloud: this rank's share, numpy (n, >=3) float32 / float64 (or a (device pointer, n, dtype)
+        tuple for a share already in HBM); n may differ between ranks."""
         self.ego_position = ego_position
         W, me = self.world, self.rank
         send_q, send_e, any_, n = self.b.scan_local(pointcloud, ego_position, transform)

@@ -117,7 +117,11 @@ CONFIGS = {
     "c3": ((0.2, 0.2, 256, 64, 8) + REF_TAIL, 128, "256x256x64 @0.2 m, OS1-128 262,144-pt scan, buffer=8"),
     "m256": ((0.2, 0.2, 256, 256, 1) + REF_TAIL, 64, "256x256x256 @0.2 m (metric grid), OS1-64 131,072-pt scan, buffer=1"),
     "m256b8": ((0.2, 0.2, 256, 256, 8) + REF_TAIL, 64, "256x256x256 @0.2 m (metric grid), OS1-64 scan, buffer=8"),
+    # the multi-GPU configs of BASELINE.json, also runnable on ONE GPU (sensors = 128-beam scans interleaved in azimuth)
+    "c4": ((0.2, 0.2, 512, 128, 1) + REF_TAIL, 128, "512x512x128 @0.2 m, 4 x OS1-128 = 1,048,576-pt cloud, buffer=1"),
+    "c5": ((0.2, 0.2, 1024, 128, 1) + REF_TAIL, 128, "1024x1024x128 @0.2 m, 16 x OS1-128 = 4,194,304-pt cloud per tick, buffer=1"),
 }
+SENSORS = {"c4": 4, "c5": 16}
 
 
 def config_inputs(name, n_scans=1, dtype=np.float32):
@@ -128,6 +132,15 @@ def config_inputs(name, n_scans=1, dtype=np.float32):
     if name == "c1":
         pc = uniform_cloud(50000, 1234, (-14, 14), (-14, 14), (-3.5, 3.5))
         return params, [(pc, (0.3, -0.2, 0.1), None)]
+    if name in SENSORS:
+        nsens = SENSORS[name]
+        scene = make_scene(2, extent=0.2 * params[2] / 2 * 0.9)
+        for k in range(n_scans):
+            sensor = (0.2 * k, -0.1 * k, 0.0)
+            scans.append((np.concatenate([lidar_scan(scene, beams=beams, sensor=sensor, yaw=2 * np.pi / 2048 * r / nsens,
+                                                     noise_seed=100 * k + r, dtype=dtype) for r in range(nsens)], 0),
+                          sensor, None))
+        return params, scans
     scene = make_scene(2)
     for k in range(n_scans):
         sensor = (0.2 * k, 0.0, 0.0)

@@ -22,6 +22,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <string.h>
+#include <stdlib.h>
 
 #define ORC_API __attribute__((visibility("default")))
 
@@ -36,12 +37,34 @@
 #define ORC_PFOR ORC_PRAGMA(omp parallel for schedule(static))
 #define ORC_PFOR_DYN ORC_PRAGMA(omp parallel for schedule(dynamic, 512))
 #define ORC_ATOMIC ORC_PRAGMA(omp atomic)
-#define ORC_PRAGMA_REDUCE_UPDATES ORC_PRAGMA(omp parallel for schedule(dynamic, 512) reduction(+ : updates))
+#define ORC_NF 32
+#define ORC_PARALLEL_UPDATES ORC_PRAGMA(omp parallel reduction(+ : updates))
+#define ORC_FOR_DYN ORC_PRAGMA(omp for schedule(dynamic, 512))
+#define ORC_NF_DECL int32_t *nf = (int32_t *)calloc((size_t)ORC_NF * ORC_NF * ORC_NF, 4);
+#define ORC_NF_ADD(X, Y, Z)                                                                     \
+    {                                                                                           \
+        const uint64_t bx = (uint64_t)((X) - nfx), by = (uint64_t)((Y) - nfy), bz = (uint64_t)((Z) - nfz); \
+        if (nf && bx < ORC_NF && by < ORC_NF && bz < ORC_NF) nf[bx + ORC_NF * (by + ORC_NF * bz)] += 1;    \
+        else { ORC_ATOMIC total[(X) + (Y) * xy + (Z) * xy * xy] += 1; }                         \
+    }
+#define ORC_NF_FLUSH                                                                            \
+    if (nf) {                                                                                   \
+        for (int64_t bz = 0; bz < ORC_NF; ++bz) for (int64_t by = 0; by < ORC_NF; ++by) for (int64_t bx = 0; bx < ORC_NF; ++bx) { \
+            const int32_t v = nf[bx + ORC_NF * (by + ORC_NF * bz)];                             \
+            if (v) { ORC_ATOMIC total[(bx + nfx) + (by + nfy) * xy + (bz + nfz) * xy * xy] += v; } \
+        }                                                                                       \
+        free(nf);                                                                               \
+    }
 #define ORC_PRAGMA_REDUCE_NIN ORC_PRAGMA(omp parallel for schedule(static) reduction(+ : n_in))
 #define ORC_PRAGMA_CAPTURE ORC_PRAGMA(omp atomic capture)
 #else
 #define ORC_PRAGMA_CAPTURE
-#define ORC_PRAGMA_REDUCE_UPDATES
+#define ORC_PARALLEL_UPDATES
+#define ORC_FOR_DYN
+#define ORC_NF 32
+#define ORC_NF_DECL
+#define ORC_NF_ADD(X, Y, Z) total[(X) + (Y) * xy + (Z) * xy * xy] += 1;
+#define ORC_NF_FLUSH
 #define ORC_PRAGMA_REDUCE_NIN
 #define ORC_PFOR
 #define ORC_PFOR_DYN
@@ -115,7 +138,17 @@ ORC_API int64_t orc_point_2_map_##SUF(double xy_res, double z_res, int64_t xy, i
 {                                                                                               \
     int64_t updates = 0;                                                                        \
     const double md2 = min_distance * min_distance;                                             \
-    ORC_PRAGMA_REDUCE_UPDATES                                                                   \
+    /* all-core build: every ray crosses the voxels around the sensor, so their `total` words  \
+     * would be hammered by all threads; a thread-private copy of the ORC_NF^3 box around the    \
+     * sensor takes those adds and is summed into `total` at the end (same sums) */             \
+    const int64_t nfx = (int64_t)floor(ego[0] / xy_res - origin[0]) - ORC_NF / 2;              \
+    const int64_t nfy = (int64_t)floor(ego[1] / xy_res - origin[1]) - ORC_NF / 2;              \
+    const int64_t nfz = (int64_t)floor(ego[2] / z_res - origin[2]) - ORC_NF / 2;               \
+    (void)nfx; (void)nfy; (void)nfz;                                                            \
+    ORC_PARALLEL_UPDATES                                                                        \
+    {                                                                                           \
+    ORC_NF_DECL                                                                                 \
+    ORC_FOR_DYN                                                                                 \
     for (int64_t i = 0; i < n; ++i) {                                                           \
         const T *p = pts + i * stride;                                                          \
         /* :1064 d2 in the cloud's dtype, (x*x + y*y) + z*z */                                  \
@@ -169,11 +202,12 @@ ORC_API int64_t orc_point_2_map_##SUF(double xy_res, double z_res, int64_t xy, i
             if (!floor_in_range((double)pt[0] - origin[0], xy, &xi)) break;   /* :1134-1136 */  \
             if (!floor_in_range((double)pt[1] - origin[1], xy, &yi)) break;   /* :1138-1140 */  \
             if (!floor_in_range((double)pt[2] - origin[2], zs, &zi)) break;   /* :1142-1144 */  \
-            ORC_ATOMIC                                                                          \
-            total[xi + yi * xy + zi * xy * xy] += 1;                  /* :1146-1148 */          \
+            ORC_NF_ADD(xi, yi, zi)                                    /* :1146-1148 */          \
             updates += 1;                                                                       \
             length += step_len;                                       /* :1150 */               \
         }                                                                                       \
+    }                                                                                           \
+    ORC_NF_FLUSH                                                                                \
     }                                                                                           \
     return updates;                                                                             \
 }                                                                                               \
