@@ -393,9 +393,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "0"))
     if args.gpus > 1 and world == 0:
         return spawn_ranks(args)
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or os.environ.get("GVOM_BENCH_FORCE_SHARDED"):    # (the last: one rank through the sharded path)
         import bench_sharded
-        out = bench_sharded.run(args)
+        # RCCL prints its version banner on stdout: keep stdout for the ONE JSON line (fd-level, the
+        # banner comes from native code)
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            out = bench_sharded.run(args)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
         if out is None:
             return
     else:

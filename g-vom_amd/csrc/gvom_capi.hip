@@ -62,6 +62,7 @@ struct gvom_handle {
     gvom_params prm;
     int device = 0;
     int rank = 0, world = 1;
+    bool sharded = false;                               // created by gvom_create_sharded: scans / combines go through the split entry points
     int sy_lo = 0, sy_hi = 0;
     size_t V = 0, slabV = 0, cells2d = 0, ntiles = 0;
     int nseg = 1;
@@ -222,7 +223,7 @@ void fill_scan_params(const gvom_handle *h, const int64_t origin[3], const doubl
     P.epoch = 0;
 }
 
-int create_impl(const gvom_params *params, int device_id, int rank, int world, gvom_t **out)
+int create_impl(const gvom_params *params, int device_id, int rank, int world, bool sharded, gvom_t **out)
 {
     if (!params || !out) return GVOM_ERR_INVALID;
     *out = nullptr;
@@ -230,10 +231,10 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, g
         !(params->xy_resolution > 0) || !(params->z_resolution > 0) || world <= 0 || rank < 0 ||
         rank >= world)
         return GVOM_ERR_INVALID;
-    if (params->buffer_size >= GVOM_MAX_SLOTS || params->z_size > 1024) return GVOM_ERR_CAPACITY;
+    if (params->buffer_size >= GVOM_MAX_SLOTS || params->z_size > 1024 || world > GVOM_MAX_SLOTS) return GVOM_ERR_CAPACITY;
     // a sharded map: every rank owns xy/world storage rows, a multiple of 4 (accumulator patches are
     // 4 rows high); per-voxel statistics need every return on the owner and are not exchanged
-    if (world > 1 && (params->xy_size % (4 * world) != 0 || (params->reserved0 & GVOM_FLAG_VOXEL_STATISTICS)))
+    if (sharded && (params->xy_size % (4 * world) != 0 || (params->reserved0 & GVOM_FLAG_VOXEL_STATISTICS)))
         return GVOM_ERR_INVALID;
     const double Vd = (double)params->xy_size * params->xy_size * params->z_size;
     if (Vd >= 2147483648.0) return GVOM_ERR_CAPACITY;
@@ -243,10 +244,10 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, g
     gvom_handle *h = new gvom_handle();
     h->prm = *params;
     h->device = device_id;
-    h->rank = rank; h->world = world;
+    h->rank = rank; h->world = world; h->sharded = sharded;
     h->stats = (params->reserved0 & GVOM_FLAG_VOXEL_STATISTICS) != 0;
     h->f32_sqrt = (params->reserved0 & GVOM_FLAG_CUDA_F32_SQRT) != 0;
-    if (const char *v = getenv("GVOM_VOXEL_STATISTICS")) h->stats = atoi(v) != 0 && world == 1;
+    if (const char *v = getenv("GVOM_VOXEL_STATISTICS")) h->stats = atoi(v) != 0 && !sharded;
     if (const char *v = getenv("GVOM_HOST_TIMING")) h->host_timing = atoi(v) != 0;
     const int xy = params->xy_size, zs = params->z_size;
     h->sy_lo = (int)((int64_t)xy * rank / world);
@@ -318,7 +319,7 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, g
 
     CK(hipHostMalloc(&h->out_host, h->cells2d * 20, hipHostMallocMapped));
     CK(hipHostGetDevicePointer((void **)&h->out_host_dev, h->out_host, 0));
-    if (world > 1) {
+    if (sharded) {
         // rank exchange regions (DESIGN.md "Multi-GPU"): a quad = 4 storage rows x 64 sx at one sz
         h->x_Q = (size_t)(xy / 4) * zs * h->nseg;
         h->x_myQ = h->x_Q / world;
@@ -395,7 +396,7 @@ int scan_launch(gvom_handle *h, const void *dev_pts, int64_t n, int64_t stride_e
     if (h->stats) HIPCHK(h, hipMemsetAsync(st.rowvox.p, 0xFF, cap * 4, h->stream));   // no row claimed yet
     ShardExchange X;
     X.ep_send = nullptr; X.ep_cnt = nullptr; X.ep_cap = 0;
-    if (h->world > 1) {
+    if (h->sharded) {
         if ((rc = ensure(h, h->x_send_eps, (size_t)h->world * (size_t)(n > 0 ? n : 1) * 8))) return rc;
         h->x_ep_cap = n > 0 ? n : 1;
         X.ep_send = (uint2 *)h->x_send_eps.p; X.ep_cnt = h->x_ecnt; X.ep_cap = (long)h->x_ep_cap;
@@ -547,7 +548,7 @@ int process_impl(gvom_handle *h, const void *xyz, bool on_device, int64_t n, int
     h->in_f32 = widen_f32;
     h->ego[0] = ego[0]; h->ego[1] = ego[1]; h->ego[2] = ego[2];       // gvom.py:102-104
     h->pending = false;
-    if (h->world > 1 && !defer) { h->err = "a sharded handle scans through gvom_shard_scan_local / gvom_shard_scan_merge"; return GVOM_ERR_INVALID; }
+    if (h->sharded && !defer) { h->err = "a sharded handle scans through gvom_shard_scan_local / gvom_shard_scan_merge"; return GVOM_ERR_INVALID; }
     if (n == 0 && !defer) return GVOM_EMPTY_CLOUD;                     // gvom.py:107-109 (a rank's share of a sharded scan may be empty)
     const void *dev = xyz;
     if (!on_device && n > 0) {
@@ -762,12 +763,12 @@ extern "C" {
 
 VIS int gvom_create(const gvom_params *params, int device_id, gvom_t **out)
 {
-    return create_impl(params, device_id, 0, 1, out);
+    return create_impl(params, device_id, 0, 1, false, out);
 }
 
 VIS int gvom_create_sharded(const gvom_params *params, int device_id, int rank, int world, gvom_t **out)
 {
-    return create_impl(params, device_id, rank, world, out);
+    return create_impl(params, device_id, rank, world, true, out);
 }
 
 VIS void gvom_destroy(gvom_t *h)
@@ -836,7 +837,7 @@ VIS int gvom_shard_scan_local(gvom_t *h, const void *xyz, int on_device, int64_t
                               int dtype, const double ego[3], const double *transform_4x4,
                               int64_t *send_quads, int64_t *send_eps, int *any_ingrid)
 {
-    if (!h || h->world < 2) return GVOM_ERR_INVALID;
+    if (!h || !h->sharded) return GVOM_ERR_INVALID;
     int rc = process_impl(h, xyz, on_device != 0, n, row_stride_bytes, dtype, ego, transform_4x4, true);
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(h->mu);
@@ -850,7 +851,7 @@ VIS int gvom_shard_scan_local(gvom_t *h, const void *xyz, int on_device, int64_t
 
 VIS int gvom_shard_recv_reserve(gvom_t *h, const int64_t *recv_eps)
 {
-    if (!h || h->world < 2 || !recv_eps) return GVOM_ERR_INVALID;
+    if (!h || !h->sharded || !recv_eps) return GVOM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->device));
     int64_t tot = 0;
@@ -865,7 +866,7 @@ VIS int gvom_shard_recv_reserve(gvom_t *h, const int64_t *recv_eps)
 
 VIS int gvom_shard_buffer(gvom_t *h, int which, int peer, void **ptr, int64_t *capacity_bytes)
 {
-    if (!h || h->world < 2 || !ptr || peer < 0 || peer >= h->world) return GVOM_ERR_INVALID;
+    if (!h || !h->sharded || !ptr || peer < 0 || peer >= h->world) return GVOM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     const size_t myQ = h->x_myQ;
     int64_t cap = 0;
@@ -886,7 +887,7 @@ VIS int gvom_shard_buffer(gvom_t *h, int which, int peer, void **ptr, int64_t *c
 
 VIS int gvom_shard_scan_merge(gvom_t *h, const int64_t *recv_quads, const int64_t *recv_eps, int accept)
 {
-    if (!h || h->world < 2 || !recv_quads || !recv_eps) return GVOM_ERR_INVALID;
+    if (!h || !h->sharded || !recv_quads || !recv_eps) return GVOM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     if (!h->pending) return GVOM_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
@@ -908,13 +909,15 @@ VIS int gvom_shard_scan_merge(gvom_t *h, const int64_t *recv_quads, const int64_
     int rc;
     if ((rc = ensure(h, st.chit, cap * 4)) || (rc = ensure(h, st.ctotal, cap * 4)) || (rc = ensure(h, st.cminh, cap * 4))) return rc;
     double t0 = now_ns();
-    for (int sidx = 0; sidx < h->world; ++sidx) {
-        if (sidx == h->rank || (recv_quads[sidx] == 0 && recv_eps[sidx] == 0)) continue;
-        hipError_t le = gvom_launch_unpack(h->stream, P, (uint32_t)recv_quads[sidx], h->x_recv_ids + (size_t)sidx * h->x_myQ,
-                                           (char *)h->x_recv_pay + (size_t)sidx * h->x_myQ * 1024, (uint32_t)recv_eps[sidx],
-                                           (char *)h->x_recv_eps.p + (size_t)h->x_recv_ep_off[sidx] * 8,
-                                           (long)h->pending_n + (long)h->x_recv_ep_off[sidx], h->hit, h->total, h->mh, st.state,
-                                           st.tags);
+    {   // everything received, whatever the source, in one launch each (quads, endpoints)
+        ShardUnpack X;
+        uint32_t acc = 0;
+        for (int sidx = 0; sidx <= GVOM_MAX_SLOTS; ++sidx) {
+            X.q_off[sidx] = acc;
+            if (sidx < h->world && sidx != h->rank) acc += (uint32_t)recv_quads[sidx];
+        }
+        hipError_t le = gvom_launch_unpack(h->stream, P, X, h->x_recv_ids, h->x_recv_pay, (uint32_t)h->x_myQ, (uint32_t)tot_eps,
+                                           h->x_recv_eps.p, (long)h->pending_n, h->hit, h->total, h->mh, st.state, st.tags);
         if (le != hipSuccess) { scan_abort(h); HIPCHK(h, le); }
     }
     const uint32_t seq = ++h->scan_seq;
@@ -932,7 +935,7 @@ VIS int gvom_shard_scan_merge(gvom_t *h, const int64_t *recv_quads, const int64_
 VIS int gvom_combine_maps(gvom_t *h, double origin_world[3], int32_t *positive, int32_t *negative,
                           double *roughness, int32_t *visibility)
 {
-    if (!h || h->world > 1) return GVOM_ERR_INVALID;
+    if (!h || h->sharded) return GVOM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->device));
     double t0 = now_ns();
@@ -988,7 +991,7 @@ VIS int gvom_output_buffer_free(gvom_t *h, void *host_ptr)
 
 VIS int gvom_combine_maps_into(gvom_t *h, double origin_world[3], void *pinned_out)
 {
-    if (!h || !pinned_out || h->world > 1) return GVOM_ERR_INVALID;
+    if (!h || !pinned_out || h->sharded) return GVOM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->device));
     double t0 = now_ns();
@@ -1017,7 +1020,7 @@ VIS int gvom_combine_maps_into(gvom_t *h, double origin_world[3], void *pinned_o
 VIS int gvom_combine_occupancy_into(gvom_t *h, double origin_world[3], void *pinned_out,
                                     double density_threshold, double min_roughness, double max_roughness)
 {
-    if (!h || !pinned_out || h->world > 1) return GVOM_ERR_INVALID;
+    if (!h || !pinned_out || h->sharded) return GVOM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->device));
     double t0 = now_ns();
@@ -1054,7 +1057,7 @@ VIS int gvom_combine_fuse(gvom_t *h, int64_t *local_cells)
     int rc = fuse_impl(h);
     if (rc) return rc;
     if ((rc = posdens_impl(h))) return rc;                // third row of the height buffer + the cell count
-    if (h->world > 1) {                                   // no host wait: the count stays on the device (GVOM_BUF_FUSED_CELLS)
+    if (h->sharded) {                                     // no host wait: the count stays on the device (GVOM_BUF_FUSED_CELLS)
         if (local_cells) *local_cells = -1;
         return GVOM_OK;
     }

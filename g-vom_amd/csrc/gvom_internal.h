@@ -83,6 +83,10 @@ struct ShardExchange {
     long      ep_cap;
 };
 
+#define GVOM_PACK_CHUNK 64     // quads per k_pack workgroup
+// rank exchange, owner side: received quads of all source ranks are unpacked by one launch
+struct ShardUnpack { uint32_t q_off[GVOM_MAX_SLOTS + 1]; };    // q_off[s] = first quad (wave) of source s, q_off[world] = total
+
 struct MapDesc {          // one source map of the fusion (ring slot or previous fused map)
     const int32_t  *state;
     const uint32_t *hit;
@@ -143,9 +147,9 @@ hipError_t gvom_launch_trace(hipStream_t s, const ScanParams &P, const ShardExch
 hipError_t gvom_launch_pack(hipStream_t s, const ScanParams &P, uint32_t *total, const uint32_t *tags, uint32_t *send_ids,
                             void *send_pay, uint32_t *qcnt, uint32_t *ecnt, uint32_t *counters,
                             unsigned long long *host_out, uint32_t seq);
-hipError_t gvom_launch_unpack(hipStream_t s, const ScanParams &P, uint32_t nq, const uint32_t *ids, const void *pay,
-                              uint32_t ne, const void *eps, long row_base, uint32_t *hit, uint32_t *total, uint32_t *mh,
-                              int32_t *state, uint32_t *tags);
+hipError_t gvom_launch_unpack(hipStream_t s, const ScanParams &P, const ShardUnpack &X, const uint32_t *ids_all,
+                              const void *pay_all, uint32_t my_quads, uint32_t ne, const void *eps, long row_base,
+                              uint32_t *hit, uint32_t *total, uint32_t *mh, int32_t *state, uint32_t *tags);
 hipError_t gvom_launch_encode(hipStream_t s, const ScanParams &P, uint32_t *hit, uint32_t *total, uint32_t *mh,
                               int32_t *state, uint32_t *chit, uint32_t *ctotal, uint32_t *cminh, const uint32_t *tags,
                               uint32_t *counters, unsigned long long *host_flag, uint32_t seq, unsigned resident_blocks);

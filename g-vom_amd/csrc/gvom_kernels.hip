@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 // `total`), the endpoints as {voxel, min-height} pairs (k_trace).  Integer sums and minima commute,
 // so the owner's accumulators end up exactly as if it had traced every ray itself.
 //
-// k_pack: grid (ceil(slab quads / 256), world - 1): block (c, p) looks at 256 consecutive quads of
+// k_pack: grid (ceil(slab quads / 64), world - 1): block (c, p) looks at 64 consecutive quads of
 // peer p's rows; the dirty ones (a tile tag == this scan's epoch) are numbered with ONE counter
 // atomic per block, copied to the peer's send region (quad id + 1 KiB in the lane order k_encode
 // reads: lane (p4, r) = 4 voxels sx = 64*seg + 4*p4.. of row 4q + r) and zeroed.
@@ -507,31 +507,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 __global__ __launch_bounds__(256) void k_pack(const ScanParams P, uint32_t *total, const uint32_t *__restrict__ tags,
                                               uint32_t *send_ids, uint4 *send_pay, uint32_t *qcnt)
 {
-    __shared__ uint32_t s_list[256];
-    __shared__ uint32_t s_w[4];
-    __shared__ uint32_t s_base;
+    __shared__ uint32_t s_list[GVOM_PACK_CHUNK];
+    __shared__ uint32_t s_count, s_base;
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
     int d = (int)blockIdx.y;
     if (d >= P.shard_rank) ++d;                          // peers in rank order, skipping this rank
     const uint32_t nseg = (uint32_t)P.nseg, zs = (uint32_t)P.zs;
     const uint32_t u_begin = ((uint32_t)(d * P.shard_rows) >> 2) * zs * nseg;
     const uint32_t u_end = ((uint32_t)((d + 1) * P.shard_rows) >> 2) * zs * nseg;
-    const uint32_t u = u_begin + blockIdx.x * 256u + threadIdx.x;
-    bool dirty = false;
-    if (u < u_end) {
-        const uint32_t seg = u % nseg, sz = (u / nseg) % zs, q = u / (nseg * zs);
+    if (wv == 0) {                                       // wave 0: which of the block's quads are dirty (4 tile tags each)
+        const uint32_t u = u_begin + blockIdx.x * GVOM_PACK_CHUNK + (uint32_t)lane;
+        bool dirty = false;
+        if (u < u_end) {
+            const uint32_t seg = u % nseg, sz = (u / nseg) % zs, q = u / (nseg * zs);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dirty = dirty || tags[((q * 4 + r) * zs + sz) * nseg + seg] == P.epoch;
+            for (int r = 0; r < 4; ++r) dirty = dirty || tags[((q * 4 + r) * zs + sz) * nseg + seg] == P.epoch;
+        }
+        const unsigned long long dm = lanes(dirty);
+        if (dirty) s_list[__popcll(dm & lanemask_lt())] = u;
+        if (lane == 0) {
+            const uint32_t count = (uint32_t)__popcll(dm);
+            s_count = count;
+            s_base = count ? atomicAdd(&qcnt[d * 16], count) : 0u;    // ONE counter atomic per block
+        }
     }
-    const unsigned long long dm = lanes(dirty);
-    if (lane == 0) s_w[wv] = (uint32_t)__popcll(dm);
     __syncthreads();
-    uint32_t before = 0;
-    for (int k = 0; k < wv; ++k) before += s_w[k];
-    const uint32_t count = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
-    if (dirty) s_list[before + (uint32_t)__popcll(dm & lanemask_lt())] = u;
-    if (threadIdx.x == 0) s_base = count ? atomicAdd(&qcnt[d * 16], count) : 0u;
-    __syncthreads();
+    const uint32_t count = s_count;
     if (count == 0) return;
     // the peer's regions start at its first quad: at most (u_end - u_begin) quads can be dirty
     uint32_t *ids = send_ids + u_begin;
@@ -545,7 +546,7 @@ __global__ __launch_bounds__(256) void k_pack(const ScanParams P, uint32_t *tota
         uint4 tv = make_uint4(0, 0, 0, 0);
         const uint32_t A0 = ok ? acc_idx((int)sx0, (int)sy, (int)sz, P.zs, P.sxq) : 0u;
         if (ok) tv = *reinterpret_cast<const uint4 *>(total + A0);
-        pay[(size_t)(s_base + k) * 64 + lane] = tv;
+        pay[(size_t)(s_base + k) * 64 + lane] = tv;      // = the quad's 16 accumulator lines in memory order
         if (ok && (tv.x | tv.y | tv.z | tv.w)) *reinterpret_cast<uint4 *>(total + A0) = make_uint4(0, 0, 0, 0);
         if (lane == 0) ids[s_base + k] = uq;
     }
@@ -571,35 +572,42 @@ __global__ void k_shard_publish(int world, uint32_t *qcnt, uint32_t *ecnt, uint3
     }
 }
 
-// k_unpack_quads: one wave per received quad: total += the sender's 1 KiB (16 lanes per 64-B line =
-// one memory-side request per line), tile tags of the rows that carry something
-__global__ __launch_bounds__(256) void k_unpack_quads(const ScanParams P, uint32_t nq, const uint32_t *__restrict__ ids,
-                                                      const uint4 *__restrict__ pay, uint32_t *total, uint32_t *tags)
+// k_unpack_quads: one wave per received quad, all source ranks in ONE launch (X.q_off[s] = first wave of
+// source s): total += the sender's 1 KiB.  A quad's 16 accumulator lines are contiguous, so lane l
+// adds words l, l + 64, l + 128, l + 192: every instruction covers 4 whole lines (16 lanes per 64-B
+// line = one memory-side request per line); tile tags of the rows that carry something.
+__global__ __launch_bounds__(256) void k_unpack_quads(const ScanParams P, const ShardUnpack X, const uint32_t *__restrict__ ids_all,
+                                                      const uint32_t *__restrict__ pay_all, uint32_t my_quads, uint32_t *total,
+                                                      uint32_t *tags)
 {
     const int lane = threadIdx.x & (WAVE - 1);
-    const uint32_t k = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    if (k >= nq) return;
+    const uint32_t w = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (w >= X.q_off[P.shard_world]) return;
+    int src = 0;
+    while (w >= X.q_off[src + 1]) ++src;                 // wave-uniform, <= world steps
+    const uint32_t k = w - X.q_off[src];
     const uint32_t nseg = (uint32_t)P.nseg, zs = (uint32_t)P.zs;
-    const uint32_t uq = ids[k];
+    const uint32_t uq = ids_all[(size_t)src * my_quads + k];
+    const uint32_t *pay = pay_all + ((size_t)src * my_quads + k) * 256;
     const uint32_t seg = uq % nseg, sz = (uq / nseg) % zs, q = uq / (nseg * zs);
-    const int p4 = lane >> 2, r = lane & 3;
-    const uint32_t sx0 = seg * 64 + p4 * 4, sy = q * 4 + r;
-    const uint4 tv = pay[(size_t)k * 64 + lane];
-    const bool any = (tv.x | tv.y | tv.z | tv.w) != 0u && sx0 < (uint32_t)P.xy;
-    if (any) {
-        const uint32_t A0 = acc_idx((int)sx0, (int)sy, (int)sz, P.zs, P.sxq);
-        if (tv.x) atomicAdd(&total[A0 + 0], tv.x);
-        if (tv.y) atomicAdd(&total[A0 + 1], tv.y);
-        if (tv.z) atomicAdd(&total[A0 + 2], tv.z);
-        if (tv.w) atomicAdd(&total[A0 + 3], tv.w);
+    if (seg * 64 >= (uint32_t)P.xy || q * 4 + 3 >= (uint32_t)P.xy) return;    // (a malformed id: never from k_pack)
+    const uint32_t base = acc_idx((int)(seg * 64), (int)(q * 4), (int)sz, P.zs, P.sxq);
+    uint32_t rows = 0;                                   // bit r: row 4q + r carries something
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t v = pay[i * 64 + lane];
+        // word i*64 + lane = line 4i + (lane >> 4) (columns beyond xy hold zeros), row (lane >> 2) & 3
+        if (v) atomicAdd(&total[base + (uint32_t)(i * 64 + lane)], v);
+        const unsigned long long m = lanes(v != 0u);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (m & (0x000F000F000F000Full << (4 * r))) rows |= 1u << r;
     }
-    const unsigned long long am = lanes(any);
-    if (lane < 4 && (am & (0x1111111111111111ull << lane)) != 0ull)
-        tags[((q * 4 + (uint32_t)lane) * zs + sz) * nseg + seg] = P.epoch;
+    if (lane < 4 && ((rows >> lane) & 1u)) tags[((q * 4 + (uint32_t)lane) * zs + sz) * nseg + seg] = P.epoch;
 }
 
-// k_unpack_eps: one lane per received endpoint {voxel, min-height sample}: the owner's share of
-// k_trace's endpoint work; rows continue behind this rank's own returns
+// k_unpack_eps: one lane per received endpoint {voxel, min-height sample} (the receive regions are
+// concatenated by source rank): the owner's share of k_trace's endpoint work; rows continue behind
+// this rank's own returns
 __global__ __launch_bounds__(256) void k_unpack_eps(const ScanParams P, uint32_t ne, const uint2 *__restrict__ eps, long row_base,
                                                     uint32_t *hit, uint32_t *total, uint32_t *mh, int32_t *state, uint32_t *tags)
 {
@@ -2113,17 +2121,19 @@ hipError_t gvom_launch_pack(hipStream_t s, const ScanParams &P, uint32_t *total,
 {
     const uint32_t slab_quads = ((uint32_t)P.shard_rows >> 2) * (uint32_t)P.zs * (uint32_t)P.nseg;
     if (P.shard_world > 1 && slab_quads > 0)
-        hipLaunchKernelGGL(k_pack, dim3((slab_quads + 255) / 256, (unsigned)P.shard_world - 1u), dim3(256), 0, s, P, total, tags,
-                           send_ids, (uint4 *)send_pay, qcnt);
+        hipLaunchKernelGGL(k_pack, dim3((slab_quads + GVOM_PACK_CHUNK - 1) / GVOM_PACK_CHUNK, (unsigned)P.shard_world - 1u),
+                           dim3(256), 0, s, P, total, tags, send_ids, (uint4 *)send_pay, qcnt);
     hipLaunchKernelGGL(k_shard_publish, dim3(1), dim3(64), 0, s, P.shard_world, qcnt, ecnt, counters, host_out, seq);
     return hipGetLastError();
 }
 
-hipError_t gvom_launch_unpack(hipStream_t s, const ScanParams &P, uint32_t nq, const uint32_t *ids, const void *pay,
-                              uint32_t ne, const void *eps, long row_base, uint32_t *hit, uint32_t *total, uint32_t *mh,
-                              int32_t *state, uint32_t *tags)
+hipError_t gvom_launch_unpack(hipStream_t s, const ScanParams &P, const ShardUnpack &X, const uint32_t *ids_all,
+                              const void *pay_all, uint32_t my_quads, uint32_t ne, const void *eps, long row_base,
+                              uint32_t *hit, uint32_t *total, uint32_t *mh, int32_t *state, uint32_t *tags)
 {
-    if (nq) hipLaunchKernelGGL(k_unpack_quads, dim3((nq + 3) / 4), dim3(256), 0, s, P, nq, ids, (const uint4 *)pay, total, tags);
+    const uint32_t nq = X.q_off[P.shard_world];
+    if (nq) hipLaunchKernelGGL(k_unpack_quads, dim3((nq + 3) / 4), dim3(256), 0, s, P, X, ids_all, (const uint32_t *)pay_all,
+                               my_quads, total, tags);
     if (ne) hipLaunchKernelGGL(k_unpack_eps, dim3((ne + 255) / 256), dim3(256), 0, s, P, ne, (const uint2 *)eps, row_base, hit,
                                total, mh, state, tags);
     return hipGetLastError();

@@ -75,6 +75,28 @@ def test_sharded_map_at_full_size(cfg, worlds, scans, buffer):
     assert "shard_big: 0 mismatches" in out.stdout
 
 
+def test_sharded_product_path_over_rccl_with_one_rank():
+    """The product path end to end -- ShardedGvom + RcclComm (ncclCommInitRank, the shared-memory count
+    exchange, grouped send/recv with no peers, in-place ncclAllGather) -- with the one rank a one-GPU box
+    allows; results equal the plain handle's."""
+    import gvom
+    import gvom_sharded
+    import synth
+    params, scans = synth.config_inputs("c2", n_scans=3)
+    comm = gvom_sharded.RcclComm(0, 1, 0, "gvom_test1_%d" % os.getpid())
+    try:
+        sh = gvom_sharded.ShardedGvom(*params, comm=comm, device=0)
+        ref = gvom.Gvom(*params)
+        for pc, ego, tf in scans:
+            sh.process_pointcloud(pc, ego, tf)
+            ref.process_pointcloud(pc, ego, tf)
+            for a, b in zip(sh.combine_maps(), ref.combine_maps()):
+                assert a.dtype == b.dtype and np.array_equal(a, b)
+            assert sh.combined_cell_count_cpu == ref.combined_cell_count_cpu
+    finally:
+        comm.close()
+
+
 def test_rccl_binding_with_one_rank():
     """librccl.so is loaded by libgvom_hip.so itself (no PyTorch): communicator creation through the
     shared-memory rendezvous, the host-side exchange and an in-place all-gather of the library's own
