@@ -217,7 +217,7 @@ class Gvom(object):
     def __init__(self, xy_resolution, z_resolution, xy_size, z_size, buffer_size, min_distance,
                  positive_obstacle_threshold, negative_obstacle_threshold, slope_obstacle_threshold,
                  robot_height, robot_radius, ground_to_lidar_height, xy_eigen_dist, z_eigen_dist,
-                 device=0, voxel_statistics=False, _shard=None):
+                 device=0, voxel_statistics=False, cuda_f32_sqrt=False, _shard=None):
         self.xy_resolution = xy_resolution
         self.z_resolution = z_resolution
         self.xy_size = xy_size
@@ -242,7 +242,7 @@ class Gvom(object):
         self._lib = load_library()
         self._h = ctypes.c_void_p()
         prm = GvomParams(float(xy_resolution), float(z_resolution), int(xy_size), int(z_size),
-                         int(buffer_size), 1 if voxel_statistics else 0, float(min_distance),
+                         int(buffer_size), (1 if voxel_statistics else 0) | (2 if cuda_f32_sqrt else 0), float(min_distance),
                          float(positive_obstacle_threshold), float(negative_obstacle_threshold),
                          float(slope_obstacle_threshold), float(robot_height), float(robot_radius),
                          float(ground_to_lidar_height), int(xy_eigen_dist), int(z_eigen_dist))

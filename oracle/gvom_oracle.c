@@ -91,6 +91,10 @@ static inline int floor_in_range(double v, int64_t size, int64_t *out)
     return 1;
 }
 
+/* 0 (default): ray_length = sqrt((double)ss), what Numba's simulator executes and the fixtures pin;
+ * 1: sqrtf(ss) -- gvom.py:1109 as typed for a real CUDA device.  Set through orc_set_cuda_f32_sqrt. */
+static int orc_cuda_f32_sqrt = 0;
+
 /* f32 min into shared memory (the reference's cuda.atomic.min, gvom.py:1329) */
 static inline void orc_min_f32(float *dst, float v)
 {
@@ -179,7 +183,8 @@ ORC_API int64_t orc_point_2_map_##SUF(double xy_res, double z_res, int64_t xy, i
         /* :1109 f32 products and sums, then math.sqrt -> Python float (f64) */                 \
         float ss = (float)((float)((float)(slope[0] * slope[0]) + (float)(slope[1] * slope[1])) \
                            + (float)(slope[2] * slope[2]));                                     \
-        double ray_length = sqrt((double)ss);                                                   \
+        /* orc_cuda_f32_sqrt: real Numba-CUDA types math.sqrt(float32) as float32 */ \
+        double ray_length = orc_cuda_f32_sqrt ? (double)sqrtf(ss) : sqrt((double)ss);           \
         slope[0] = (float)((double)slope[0] / ray_length);            /* :1112-1114 */          \
         slope[1] = (float)((double)slope[1] / ray_length);                                      \
         slope[2] = (float)((double)slope[2] / ray_length);                                      \
@@ -818,6 +823,7 @@ ORC_API void orc_make_voxel_pointcloud(const int32_t *combined_index_map, const 
 }
 
 ORC_API int orc_abi_version(void) { return 1; }
+ORC_API void orc_set_cuda_f32_sqrt(int on) { orc_cuda_f32_sqrt = on ? 1 : 0; }
 
 /* threads the all-core build runs on (1 in the one-thread build) */
 ORC_API int orc_threads(void)

@@ -59,6 +59,7 @@ def lib(path=None):
             return _lib
         L = ctypes.CDLL(path)
         L.orc_threads.restype = _c.c_int
+        L.orc_set_cuda_f32_sqrt.argtypes = [_c.c_int]
         L.orc_set_threads.argtypes = [_c.c_int]
         for suf in ("f32", "f64"):
             f = getattr(L, "orc_transform_pointcloud_" + suf)
@@ -186,7 +187,10 @@ class OracleGvom:
     def __init__(self, xy_resolution, z_resolution, xy_size, z_size, buffer_size, min_distance,
                  positive_obstacle_threshold, negative_obstacle_threshold, slope_obstacle_threshold,
                  robot_height, robot_radius, ground_to_lidar_height, xy_eigen_dist, z_eigen_dist,
-                 voxel_statistics=False):
+                 voxel_statistics=False, cuda_f32_sqrt=False):
+        # cuda_f32_sqrt: ray_length = sqrt(float32) evaluated in float32, as Numba types gvom.py:1109 for a
+        # real CUDA device; default = the simulator's float64 square root (the fixtures)
+        self.cuda_f32_sqrt = cuda_f32_sqrt
         # voxel_statistics: also restate the per-voxel mean/covariance/eigenvalue path (SURVEY 8f
         # rank 2: gvom.py:1172-1299, 858-909, 1333-1378, 363-378).  Off by default so that the
         # timed CPU baseline covers the same work as the GPU hot path.
@@ -261,6 +265,7 @@ class OracleGvom:
         if transform is not None:                                                            # :134
             tf = np.ascontiguousarray(np.asarray(transform, np.float64))
             getattr(L, "orc_transform_pointcloud_" + suf)(_p(pc), point_count, pc.shape[1], _p(tf))
+        L.orc_set_cuda_f32_sqrt(1 if self.cuda_f32_sqrt else 0)
         self.last_scan_updates = getattr(L, "orc_point_2_map_" + suf)(                      # :138
             self.xy_resolution, self.z_resolution, self.xy_size, self.z_size, self.min_distance,
             _p(pc), point_count, pc.shape[1], _p(tmp_hit), _p(tmp_total), _p(ego), _p(origin))

@@ -124,15 +124,52 @@ def test_hip_matches_oracle_c2_full_size(gvom_mod):
     assert compare_records(got, want, float_tol=1e-5) > 10
 
 
-def test_hip_matches_oracle_c3_temporal_fusion(gvom_mod):
-    """BASELINE c3 (reduced to 4 of the 8 poses to keep the CPU oracle under a minute):
-    OS1-128 262,144-point scans, buffer=8, combine after every scan, moving sensor."""
-    params, scans = synth.config_inputs("c3", n_scans=4)
-    steps = []
-    for s in scans:
-        steps += [("scan",) + s, ("combine",)]
-    got, want = _run_both(gvom_mod, params, steps, record_debug=False)
-    assert compare_records(got, want, float_tol=1e-5) > 20
+def _stream_against_oracle(gvom_mod, params, scans, dense_at, threads=16):
+    """scan + combine per element of `scans`, HIP and oracle side by side: the returned maps are compared
+    after EVERY step (ints exact, roughness 1e-5), the newest ring slot and the fused map densely at
+    the steps in `dense_at` (keeps memory bounded at 256^3).  The oracle runs its all-core build (held
+    to the reference's vectors by tests/test_oracle_golden.py)."""
+    oracle.use_all_cores(True, threads=threads)
+    try:
+        g, want = gvom_mod.Gvom(*params), oracle.OracleGvom(*params)
+        for k, (pc, ego, tf) in enumerate(scans):
+            g.process_pointcloud(pc, ego, tf)
+            want.process_pointcloud(pc, ego, tf)
+            a, b = g.combine_maps(), want.combine_maps()
+            assert np.array_equal(a[0], b[0])
+            for i in (1, 2, 4):
+                assert np.array_equal(a[i], b[i]), "step %d map %d differs" % (k, i)
+            assert np.allclose(a[3], b[3], rtol=0, atol=1e-5), "step %d roughness" % k
+            assert g.combined_cell_count_cpu == want.combined_cell_count_cpu
+            assert (g.buffer_index, g.last_buffer_index) == (want.buffer_index, want.last_buffer_index)
+            if k in dense_at:
+                slot = want.last_buffer_index
+                ws = scenarios.dense_from_compact(want.index_buffer[slot], want.hit_count_buffer[slot],
+                                                  want.total_count_buffer[slot], want.min_height_buffer[slot])
+                gs = g.read_dense(slot)
+                wf = scenarios.dense_from_compact(want.combined_index_map, want.combined_hit_count,
+                                                  want.combined_total_count, want.combined_min_height)
+                gf = g.read_dense(gvom_mod.GVOM_WHICH_FUSED)
+                for got_d, want_d, what in ((gs, ws, "slot"), (gf, wf, "fused")):
+                    for j, nm in enumerate(("state", "hit", "total", "minh")):
+                        assert np.array_equal(np.asarray(want_d[j]), got_d[j]), "step %d %s %s" % (k, what, nm)
+    finally:
+        oracle.use_all_cores(False)
+
+
+def test_hip_matches_oracle_c3_ring_fills_wraps_and_evicts(gvom_mod):
+    """BASELINE c3 at full size: OS1-128 262,144-point scans, buffer=8, combine after every scan, sensor
+    moving 0.2 m per scan -- all 8 poses PLUS 4 more: the ring fills (scan 8 = the steady state
+    BASELINE.md asks for), wraps and evicts four slots (gvom.py:163-175, 198-216, 238-274)."""
+    params, scans = synth.config_inputs("c3", n_scans=12)
+    _stream_against_oracle(gvom_mod, params, scans, dense_at=(7, 11))
+
+
+def test_hip_matches_oracle_m256b8_ring(gvom_mod):
+    """BASELINE row "M", second half (a bench.py config): 256^3 voxels, buffer=8, 11 moving scans (the
+    ring wraps and evicts three slots)."""
+    params, scans = synth.config_inputs("m256b8", n_scans=11)
+    _stream_against_oracle(gvom_mod, params, scans, dense_at=(8, 10))
 
 
 def test_hip_matches_oracle_metric_grid_256cubed(gvom_mod):
@@ -476,6 +513,132 @@ def test_c5_full_size_properties(gvom_mod):
     for x, y in zip(c.combine_maps(), d.combine_maps()):
         assert np.array_equal(x, y)
     assert c.scan_stats() == d.scan_stats()
+
+
+def test_c5_moving_window_buffer4_and_sharded_equal_unsharded(gvom_mod):
+    """BASELINE c5 (1024 x 1024 x 128, 4,194,304 returns per tick) with buffer=4 over 6 ticks of a moving
+    window -- the ring wraps and evicts, tile epochs and slots are reused at 134 M voxels (too large for
+    the CPU oracle): (i) point-order invariance of every returned map at every tick and of the fused map
+    at the end; (ii) the map sharded over 8 ranks (threads on this GPU, 16 sensors -> 2 per rank) returns
+    the same maps as the unsharded handle at every tick."""
+    from shard_threads import run_ranks
+    params = (0.2, 0.2, 1024, 128, 4) + synth.REF_TAIL
+    scene = synth.make_scene(2, extent=90.0)
+    W = 8
+    ticks = []
+    for k in range(6):
+        ego = (0.4 + 0.3 * k, -0.2 - 0.25 * k, 0.02 * k)
+        sens = [synth.lidar_scan(scene, beams=128, sensor=ego, yaw=2 * np.pi / 2048 * r / 16, noise_seed=50 * k + r)
+                for r in range(16)]
+        ticks.append((sens, ego))
+    a, b = gvom_mod.Gvom(*params), gvom_mod.Gvom(*params)
+    want = []
+    for k, (sens, ego) in enumerate(ticks):
+        pc = np.concatenate(sens, axis=0)
+        a.process_pointcloud(pc, ego)
+        b.process_pointcloud(np.ascontiguousarray(pc[np.random.default_rng(k).permutation(pc.shape[0])]), ego)
+        oa, ob = a.combine_maps(), b.combine_maps()
+        for x, y in zip(oa, ob):
+            assert np.array_equal(x, y), "tick %d: point order changed a returned map" % k
+        assert a.combined_cell_count_cpu == b.combined_cell_count_cpu
+        want.append(([np.array(x, copy=True) for x in oa], a.combined_cell_count_cpu, a.buffer_index))
+        del pc, oa, ob
+    assert want[-1][2] == 6 % 4
+    da, db = a.read_dense(gvom_mod.GVOM_WHICH_FUSED), b.read_dense(gvom_mod.GVOM_WHICH_FUSED)
+    for j in range(4):
+        assert np.array_equal(da[j], db[j])
+    assert int((da[0] >= 0).sum()) == want[-1][1]
+    del a, b, da, db
+
+    def body(r, sh):
+        for (sens, ego), (wout, wcnt, wbuf) in zip(ticks, want):
+            sh.process_pointcloud(np.concatenate(sens[2 * r:2 * r + 2], axis=0), ego)
+            got = sh.combine_maps()
+            for x, y in zip(got, wout):
+                assert np.array_equal(x, y)
+            assert sh.combined_cell_count_cpu == wcnt and sh.b.g.buffer_index == wbuf
+        return True
+
+    assert run_ranks(W, params, body) == [True] * W
+
+
+def test_non_finite_returns_have_no_effect(gvom_mod):
+    """One contract for NaN / +-inf on BOTH entry points: a return with a non-finite coordinate (ros_numpy
+    drops them before the reference sees the cloud, gvom_ros.py:108) has no effect on the map.
+    process_pointcloud with such rows == the same cloud without them == the oracle on the clean cloud;
+    float32 and float64, with and without a transform."""
+    params = (0.2, 0.2, 64, 32, 2) + synth.REF_TAIL
+    rng = np.random.default_rng(77)
+    for dtype, with_tf in ((np.float32, False), (np.float64, True), (np.float32, True), (np.float64, False)):
+        clean = (rng.uniform(-6, 6, (5000, 3)) * np.array([1, 1, 0.3])).astype(dtype)
+        dirty = np.repeat(clean, 2, axis=0)
+        bad = np.array([np.nan, np.inf, -np.inf], dtype)
+        for i in range(clean.shape[0]):                   # every second row gets one or more non-finite fields
+            row = dirty[2 * i + 1]
+            row[rng.integers(0, 3)] = bad[rng.integers(0, 3)]
+            if i % 5 == 0:
+                row[:] = bad[rng.integers(0, 3)]
+        tf = scenarios.rot_z(0.3, (0.2, -0.1, 0.05)) if with_tf else None
+        ego = (0.11, -0.07, 0.02)
+        gd, gc, want = gvom_mod.Gvom(*params), gvom_mod.Gvom(*params), oracle.OracleGvom(*params)
+        for k in range(3):
+            gd.process_pointcloud(dirty, ego, tf); gc.process_pointcloud(clean, ego, tf)
+            want.process_pointcloud(clean.copy(), ego, tf)
+            od, oc, ow = gd.combine_maps(), gc.combine_maps(), want.combine_maps()
+            for i in (0, 1, 2, 4):
+                assert np.array_equal(od[i], oc[i]) and np.array_equal(od[i], ow[i])
+            assert np.array_equal(od[3], oc[3]) and np.allclose(od[3], ow[3], rtol=0, atol=1e-5)
+            sd, sc_ = gd.read_dense(gd.last_buffer_index), gc.read_dense(gc.last_buffer_index)
+            for j in range(4):
+                assert np.array_equal(sd[j], sc_[j])
+    # a cloud of ONLY non-finite returns is rejected like one that misses the grid (gvom.py:148-150)
+    g = gvom_mod.Gvom(*params)
+    g.process_pointcloud(np.full((100, 3), np.nan, np.float32), (0, 0, 0))
+    assert g.combine_maps() is None and g.buffer_index == 0
+
+
+@pytest.mark.parametrize("grid", [(32, 300, 2), (16, 1024, 3), (24, 513, 1)])
+def test_tall_grids_use_the_generic_fusion_kernel(gvom_mod, grid):
+    """z_size in (256, 1024]: chunks of more than 16 levels, i.e. the generic k_fuse<false> (per-wave static
+    row ranges, liveness per level, column tail) -- no other test launches it.  Moving window, buffer > 1."""
+    xy, zs, buf = grid
+    params = (0.4, 0.05, xy, zs, buf, 0.5, 0.5, 0.5, 0.3, 2.0, 2.0, 1.0, 1, 1)
+    rng = np.random.default_rng(zs)
+    steps = []
+    for k in range(4):
+        ego = (0.9 * k, -0.5 * k, 0.3 * k)
+        n = 6000
+        pc = np.stack([rng.uniform(-0.2 * xy, 0.2 * xy, n) + ego[0], rng.uniform(-0.2 * xy, 0.2 * xy, n) + ego[1],
+                       rng.uniform(-0.024 * zs, 0.024 * zs, n) + ego[2]], axis=1).astype(np.float32 if k % 2 else np.float64)
+        steps += [("scan", pc, ego, None), ("combine",)]
+    got, want = _run_both(gvom_mod, params, steps, record_debug=False)
+    assert compare_records(got, want, float_tol=1e-5) > 20
+
+
+def test_cuda_f32_sqrt_flag(gvom_mod):
+    """GVOM_FLAG_CUDA_F32_SQRT: real Numba-CUDA types math.sqrt(float32) as float32
+    (gvom.py:1109-1114); the simulator -- and therefore the fixtures and the default -- takes the float64
+    square root.  Two returns, found by search, whose rays mark different voxels under the two typings;
+    the HIP path follows the oracle in both modes (this mode has no reference-generated vector: the
+    simulator cannot produce one)."""
+    params = (0.2, 0.2, 64, 32, 1, 0.5, 0.5, 0.5, 0.3, 2.0, 4.0, 1.0, 1, 1)
+    ego = (0.013, -0.027, 0.004)
+    rays = np.array([[4.66099739074707, -5.127684116363525, -0.5784711241722107],
+                     [4.96124792098999, 4.209757328033447, 0.7061797380447388]], np.float32)
+    rng = np.random.default_rng(9)
+    cloud = np.concatenate([rays, (rng.uniform(-6, 6, (20000, 3)) * np.array([1, 1, 0.3])).astype(np.float32)])
+    dense = {}
+    for flag in (False, True):
+        for pc, tag in ((rays, "rays"), (cloud, "cloud")):
+            g = gvom_mod.Gvom(*params, cuda_f32_sqrt=flag)
+            w = oracle.OracleGvom(*params, cuda_f32_sqrt=flag)
+            g.process_pointcloud(pc, ego); w.process_pointcloud(pc.copy(), ego)
+            gd = g.read_dense(0)
+            wd = scenarios.dense_from_compact(w.index_buffer[0], w.hit_count_buffer[0], w.total_count_buffer[0], w.min_height_buffer[0])
+            for j in range(4):
+                assert np.array_equal(np.asarray(wd[j]), gd[j]), (flag, tag, j)
+            dense[(flag, tag)] = gd[0].copy()
+    assert not np.array_equal(dense[(False, "rays")], dense[(True, "rays")])
 
 
 def test_long_run_moving_window_matches_oracle(gvom_mod):
