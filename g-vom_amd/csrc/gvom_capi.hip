@@ -1187,7 +1187,7 @@ VIS int gvom_read_dense(gvom_t *h, int which, int32_t *state, int32_t *hit, int3
                  (int)floor_mod(org[2], h->prm.z_size)};
     hipError_t e = gvom_launch_read_dense(h->stream, h->prm.xy_size, h->prm.z_size, om, h->sy_lo, h->sy_hi,
                                           tg, ep, st, ch, ct, cm,
-                                          tmp, tmp + V, tmp + 2 * V, (float *)(tmp + 3 * V));
+                                          tmp, tmp + V, tmp + 2 * V, (float *)(tmp + 3 * V), nullptr);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e == hipSuccess && state) e = hipMemcpy(state, tmp, V * 4, hipMemcpyDeviceToHost);
     if (e == hipSuccess && hit) e = hipMemcpy(hit, tmp + V, V * 4, hipMemcpyDeviceToHost);
@@ -1203,6 +1203,70 @@ VIS int gvom_read_dense(gvom_t *h, int which, int32_t *state, int32_t *hit, int3
     HIPCHK(h, e);
     if (origin) for (int k = 0; k < 3; ++k) origin[k] = (double)org[k];
     if (cell_count) *cell_count = cnt;
+    return GVOM_OK;
+}
+
+// Test hook / reference attributes metrics_buffer, combined_metrics (gvom.py:54-83,234,281; statistics
+// handles only): rows_dense[V] = compact row of every occupied voxel of slot / fused map `which` in the
+// reference's voxel order, -1 elsewhere.
+VIS int gvom_read_rows(gvom_t *h, int which, int32_t *rows_dense)
+{
+    if (!h || !rows_dense) return GVOM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    const int32_t *st; const uint32_t *tg; uint32_t ep; const int64_t *org;
+    if (which == GVOM_WHICH_FUSED) {
+        if (!h->has_combined) return GVOM_NO_DATA;
+        const Fused &F = h->fused[h->cur];
+        st = F.state; org = F.origin; tg = F.tags; ep = F.epoch;
+    } else {
+        if (which < 0 || which >= h->prm.buffer_size) return GVOM_ERR_INVALID;
+        const Slot &sl = h->slots[h->ring[which]];
+        if (!sl.filled) return GVOM_NO_DATA;
+        st = sl.state; org = sl.origin; tg = sl.tags; ep = sl.epoch;
+    }
+    const size_t V = h->V;
+    int32_t *tmp = nullptr;
+    HIPCHK(h, hipMalloc((void **)&tmp, V * 4));
+    int om[3] = {(int)floor_mod(org[0], h->prm.xy_size), (int)floor_mod(org[1], h->prm.xy_size),
+                 (int)floor_mod(org[2], h->prm.z_size)};
+    hipError_t e = gvom_launch_read_dense(h->stream, h->prm.xy_size, h->prm.z_size, om, h->sy_lo, h->sy_hi, tg, ep, st,
+                                          nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, tmp);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) e = hipMemcpy(rows_dense, tmp, V * 4, hipMemcpyDeviceToHost);
+    hipFree(tmp);
+    HIPCHK(h, e);
+    return GVOM_OK;
+}
+
+// out[j][0..9] = the statistics of compact row rows[j] of slot `which` (float64: {mean xyz, covariance
+// xx xy xz yy yz zz, count}) or of the fused map (float32).  GVOM_NO_DATA without GVOM_FLAG_VOXEL_STATISTICS.
+VIS int gvom_gather_metrics(gvom_t *h, int which, const int32_t *rows, int64_t n, void *out)
+{
+    if (!h || !rows || !out || n < 0) return GVOM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!h->stats) return GVOM_NO_DATA;
+    HIPCHK(h, hipSetDevice(h->device));
+    const void *src; int f64;
+    if (which == GVOM_WHICH_FUSED) {
+        if (!h->has_combined) return GVOM_NO_DATA;
+        src = h->fused[h->cur].metrics.p; f64 = 0;
+    } else {
+        if (which < 0 || which >= h->prm.buffer_size) return GVOM_ERR_INVALID;
+        const Slot &sl = h->slots[h->ring[which]];
+        if (!sl.filled) return GVOM_NO_DATA;
+        src = sl.metrics.p; f64 = 1;
+    }
+    if (n == 0) return GVOM_OK;
+    const size_t esz = f64 ? 8 : 4;
+    char *tmp = nullptr;
+    HIPCHK(h, hipMalloc((void **)&tmp, (size_t)n * 4 + (size_t)n * 10 * esz));
+    hipError_t e = hipMemcpy(tmp + (size_t)n * 10 * esz, rows, (size_t)n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = gvom_launch_gather_rows10(h->stream, f64, src, (const int32_t *)(tmp + (size_t)n * 10 * esz), n, tmp);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, tmp, (size_t)n * 10 * esz, hipMemcpyDeviceToHost);
+    hipFree(tmp);
+    HIPCHK(h, e);
     return GVOM_OK;
 }
 
@@ -1272,6 +1336,13 @@ static int debug_maps(gvom_t *h, float *out7, float *out3)
 // Gvom.make_debug_voxel_map (gvom.py:363-378, kernels :1333-1378, :454-473)
 VIS int gvom_debug_voxel_map(gvom_t *h, float *out, int64_t max_rows, int64_t *rows)
 {
+    return gvom_debug_voxel_eigen(h, out, nullptr, max_rows, rows);
+}
+
+// the same, also returning the three eigenvalues of every row (reference attribute voxels_eigenvalues,
+// gvom.py:1333-1378), row for row with `out`
+VIS int gvom_debug_voxel_eigen(gvom_t *h, float *out, float *eigen, int64_t max_rows, int64_t *rows)
+{
     if (!h || !out || max_rows < 0) return GVOM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     if (!h->has_combined || !h->stats) return GVOM_NO_DATA;
@@ -1288,18 +1359,21 @@ VIS int gvom_debug_voxel_map(gvom_t *h, float *out, int64_t max_rows, int64_t *r
     P.xy_res = p.xy_resolution; P.z_res = p.z_resolution;
     P.nseg = h->nseg; P.epoch = F.epoch;
     float *tmp = nullptr;
-    HIPCHK(h, hipMalloc((void **)&tmp, (size_t)(max_rows > 0 ? max_rows : 1) * 32));
+    const size_t mr = (size_t)(max_rows > 0 ? max_rows : 1);
+    HIPCHK(h, hipMalloc((void **)&tmp, mr * 44));         // 8 + 3 floats per row
+    float *tmp_e = eigen ? tmp + mr * 8 : nullptr;
     hipError_t e = hipMemsetAsync(h->counters + 12, 0, 8, h->stream);
     if (e == hipSuccess)
         e = gvom_launch_voxel_cloud(h->stream, P, (double)F.origin[0], (double)F.origin[1], (double)F.origin[2],
                                     F.state, F.tags, (const uint32_t *)F.hit.p, (const uint32_t *)F.total.p,
-                                    (const float *)F.metrics.p, tmp, max_rows,
+                                    (const float *)F.metrics.p, tmp, tmp_e, max_rows,
                                     (unsigned long long *)(h->counters + 12));
     unsigned long long cnt = 0;
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e == hipSuccess) e = hipMemcpy(&cnt, h->counters + 12, 8, hipMemcpyDeviceToHost);
     const int64_t nrows = (int64_t)cnt < max_rows ? (int64_t)cnt : max_rows;
     if (e == hipSuccess && nrows > 0) e = hipMemcpy(out, tmp, (size_t)nrows * 32, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && nrows > 0 && eigen) e = hipMemcpy(eigen, tmp_e, (size_t)nrows * 12, hipMemcpyDeviceToHost);
     hipFree(tmp);
     HIPCHK(h, e);
     if (rows) *rows = (int64_t)cnt;

@@ -170,14 +170,15 @@ hipError_t gvom_launch_fuse_stats(hipStream_t s, const FuseParams &P, const Fuse
                                   const int32_t *fstate, const uint32_t *ftags, float *fmetrics);
 hipError_t gvom_launch_voxel_cloud(hipStream_t s, const Map2dParams &P, double o0, double o1, double o2,
                                    const int32_t *fstate, const uint32_t *ftags, const uint32_t *fhit,
-                                   const uint32_t *ftotal, const float *fmetrics, float *out, int64_t max_rows,
+                                   const uint32_t *ftotal, const float *fmetrics, float *out, float *eig, int64_t max_rows,
                                    unsigned long long *row_counter);
+hipError_t gvom_launch_gather_rows10(hipStream_t s, int is_f64, const void *src, const int32_t *rows, int64_t n, void *out);
 hipError_t gvom_launch_retag(hipStream_t s, uint32_t *tags, size_t n, uint32_t old_epoch, uint32_t new_epoch);
 // test hooks / debug accessors
 hipError_t gvom_launch_read_dense(hipStream_t s, int xy, int zs, const int om[3], int sy_lo, int sy_hi,
                                   const uint32_t *tags, uint32_t epoch, const int32_t *state, const uint32_t *chit,
                                   const uint32_t *ctotal, const uint32_t *cminh, int32_t *o_state,
-                                  int32_t *o_hit, int32_t *o_total, float *o_minh);
+                                  int32_t *o_hit, int32_t *o_total, float *o_minh, int32_t *o_row);
 // storage order [sy][sx] -> reference order [x][y] (window coordinates)
 hipError_t gvom_launch_unwrap_f64(hipStream_t s, int xy, int om0, int om1, const double *in, int in_stride, double *out_xy);
 hipError_t gvom_launch_posdens(hipStream_t s, const Map2dParams &P, const int32_t *fstate,

@@ -1864,7 +1864,7 @@ __global__ __launch_bounds__(256) void k_voxel_cloud(const Map2dParams P, double
                                                      const uint32_t *__restrict__ ftags,
                                                      const uint32_t *__restrict__ fhit,
                                                      const uint32_t *__restrict__ ftotal,
-                                                     const float *__restrict__ fmetrics, float *out,
+                                                     const float *__restrict__ fmetrics, float *out, float *eig,
                                                      long max_rows, unsigned long long *row_counter)
 {
     const int lane = threadIdx.x & (WAVE - 1);
@@ -1922,6 +1922,7 @@ __global__ __launch_bounds__(256) void k_voxel_cloud(const Map2dParams P, double
         o[3] = (float)((double)(int32_t)hc / (double)(int32_t)tc);
         o[4] = (float)(int32_t)hc;
         o[5] = e0 - e1; o[6] = e1 - e2; o[7] = e2;
+        if (eig) { eig[pos * 3 + 0] = e0; eig[pos * 3 + 1] = e1; eig[pos * 3 + 2] = e2; }   // voxels_eigenvalues (gvom.py:1374-1377)
     }
 }
 
@@ -1960,7 +1961,7 @@ hipError_t gvom_launch_fuse_stats(hipStream_t s, const FuseParams &P, const Fuse
 
 hipError_t gvom_launch_voxel_cloud(hipStream_t s, const Map2dParams &P, double o0, double o1, double o2,
                                    const int32_t *fstate, const uint32_t *ftags, const uint32_t *fhit,
-                                   const uint32_t *ftotal, const float *fmetrics, float *out, int64_t max_rows,
+                                   const uint32_t *ftotal, const float *fmetrics, float *out, float *eig, int64_t max_rows,
                                    unsigned long long *row_counter)
 {
     const uint32_t ntiles = (uint32_t)(P.y_hi - P.y_lo) * P.zs * P.nseg;
@@ -1968,7 +1969,7 @@ hipError_t gvom_launch_voxel_cloud(hipStream_t s, const Map2dParams &P, double o
     unsigned blocks = (ntiles + 3) / 4;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(k_voxel_cloud, dim3(blocks), dim3(256), 0, s, P, o0, o1, o2, fstate, ftags, fhit, ftotal,
-                       fmetrics, out, (long)max_rows, row_counter);
+                       fmetrics, out, eig, (long)max_rows, row_counter);
     return hipGetLastError();
 }
 
@@ -1980,7 +1981,7 @@ __global__ void k_read_dense(int xy, int zs, int om0, int om1, int om2, int sy_l
                              const uint32_t *__restrict__ tags, uint32_t epoch,
                              const int32_t *__restrict__ state, const uint32_t *__restrict__ chit,
                              const uint32_t *__restrict__ ctotal, const uint32_t *__restrict__ cminh,
-                             int32_t *o_state, int32_t *o_hit, int32_t *o_total, float *o_minh)
+                             int32_t *o_state, int32_t *o_hit, int32_t *o_total, float *o_minh, int32_t *o_row)
 {
     const size_t V = (size_t)xy * xy * zs;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < V;
@@ -1991,6 +1992,7 @@ __global__ void k_read_dense(int xy, int zs, int om0, int om1, int om2, int sy_l
         int32_t st = -1;
         if (sy >= sy_lo && sy < sy_hi && tags[((size_t)sy * zs + sz) * nseg + (sx >> 6)] == epoch)
             st = state[((size_t)sy * zs + sz) * xy + sx];
+        if (o_row) { o_row[idx] = st >= 0 ? st : -1; continue; }     // compact row of every occupied voxel
         if (st >= 0) {
             o_state[idx] = 0; o_hit[idx] = (int32_t)chit[st]; o_total[idx] = (int32_t)ctotal[st];
             o_minh[idx] = __uint_as_float(cminh[st]);
@@ -2213,11 +2215,30 @@ hipError_t gvom_launch_map2d(hipStream_t s, const Map2dParams &P, const int32_t 
 hipError_t gvom_launch_read_dense(hipStream_t s, int xy, int zs, const int om[3], int sy_lo, int sy_hi,
                                   const uint32_t *tags, uint32_t epoch, const int32_t *state, const uint32_t *chit,
                                   const uint32_t *ctotal, const uint32_t *cminh, int32_t *o_state,
-                                  int32_t *o_hit, int32_t *o_total, float *o_minh)
+                                  int32_t *o_hit, int32_t *o_total, float *o_minh, int32_t *o_row)
 {
     hipLaunchKernelGGL(k_read_dense, dim3(2048), dim3(256), 0, s, xy, zs, om[0], om[1], om[2], sy_lo, sy_hi,
                        tags, epoch, state,
-                       chit, ctotal, cminh, o_state, o_hit, o_total, o_minh);
+                       chit, ctotal, cminh, o_state, o_hit, o_total, o_minh, o_row);
+    return hipGetLastError();
+}
+
+// rows[j] -> out[j][0..9]: the statistics of selected compact rows (reference attributes metrics_buffer /
+// combined_metrics, gvom.py:54-83,234,281)
+template <typename E>
+__global__ void k_gather_rows10(const E *__restrict__ src, const int32_t *__restrict__ rows, long n, E *out)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * 10) return;
+    out[i] = src[(size_t)rows[i / 10] * 10 + (i % 10)];
+}
+
+hipError_t gvom_launch_gather_rows10(hipStream_t s, int is_f64, const void *src, const int32_t *rows, int64_t n, void *out)
+{
+    if (n <= 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((n * 10 + 255) / 256);
+    if (is_f64) hipLaunchKernelGGL(k_gather_rows10<double>, dim3(blocks), dim3(256), 0, s, (const double *)src, rows, (long)n, (double *)out);
+    else hipLaunchKernelGGL(k_gather_rows10<float>, dim3(blocks), dim3(256), 0, s, (const float *)src, rows, (long)n, (float *)out);
     return hipGetLastError();
 }
 

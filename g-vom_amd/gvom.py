@@ -112,6 +112,9 @@ ABI = [
     ("gvom_get_scan_stats", _I, [_P, ctypes.POINTER(GvomScanStats)]),
     ("gvom_get_occupancy", _I, [_P, _P]),
     ("gvom_debug_voxel_map", _I, [_P, _P, _I64, ctypes.POINTER(_I64)]),
+    ("gvom_debug_voxel_eigen", _I, [_P, _P, _P, _I64, ctypes.POINTER(_I64)]),
+    ("gvom_read_rows", _I, [_P, _I, _P]),
+    ("gvom_gather_metrics", _I, [_P, _I, _P, _I64, _P]),
     ("gvom_debug_height_map", _I, [_P, _P]),
     ("gvom_debug_inferred_height_map", _I, [_P, _P]),
     ("gvom_read_dense", _I, [_P, _I, _P, _P, _P, _P, _P, ctypes.POINTER(_I64)]),
@@ -173,10 +176,36 @@ class _DeviceArrayView(object):
         return a if dtype is None else a.astype(dtype)
 
 
+class _OutputPool(object):
+    """Free pinned output buffers of one Gvom.  Outlives the Gvom if returned arrays do: a buffer that
+    comes back after the mapper is gone is released at once (pinned host memory is not tied to the
+    handle: hipHostFree works without it)."""
+
+    def __init__(self):
+        self.free = []
+        self.closed = False
+
+    def give_back(self, ptr):
+        if not self.closed:
+            self.free.append(ptr)           # recycled by the next combine_maps
+        else:
+            _host_free(ptr)
+
+
+def _host_free(ptr):
+    try:
+        rt = ctypes.CDLL("libamdhip64.so")
+        rt.hipHostFree.argtypes = [ctypes.c_void_p]
+        rt.hipHostFree(ctypes.c_void_p(ptr))
+    except Exception:
+        pass
+
+
 class _PinnedOutput(object):
     """One pinned, device-mapped output buffer of combine_maps.  The four returned numpy arrays
     are views whose base chain ends here; when the caller drops them all, the buffer goes back to
-    the owning Gvom's pool (so every call still returns FRESH arrays, as the reference does)."""
+    the owning Gvom's pool (so every call still returns FRESH arrays, as the reference does) -- or is
+    freed, if that Gvom no longer exists."""
 
     def __init__(self, owner_pool, ptr, nbytes):
         self._pool = owner_pool
@@ -187,7 +216,7 @@ class _PinnedOutput(object):
     def __del__(self):
         pool = self._pool
         if pool is not None:
-            pool.append(self.ptr)           # recycled by the next combine_maps (or freed on close)
+            pool.give_back(self.ptr)
 
 
 def transform_from_translation_rotation(translation, rotation):
@@ -251,7 +280,7 @@ class Gvom(object):
         else:
             rc = self._lib.gvom_create_sharded(ctypes.byref(prm), int(device), int(_shard[0]),
                                                int(_shard[1]), ctypes.byref(self._h))
-        self._out_pool = []                 # free pinned output buffers (host pointers)
+        self._out_pool = _OutputPool()      # free pinned output buffers (host pointers)
         if rc != GVOM_OK:
             info = ctypes.create_string_buffer(256)
             self._lib.gvom_backend_info(info, 256)
@@ -263,10 +292,14 @@ class Gvom(object):
         h, self._h = getattr(self, "_h", None), None
         if h:
             try:
-                # buffers still referenced by live arrays are left to the OS (pinned host memory
-                # is not tied to the handle); free the idle ones
-                for p in getattr(self, "_out_pool", []):
-                    self._lib.gvom_output_buffer_free(h, ctypes.c_void_p(p))
+                # idle buffers go now; those still referenced by live arrays are freed by the pool when
+                # the last array of their call is collected
+                pool = getattr(self, "_out_pool", None)
+                if pool is not None:
+                    pool.closed = True
+                    for p in pool.free:
+                        self._lib.gvom_output_buffer_free(h, ctypes.c_void_p(p))
+                    pool.free = []
                 self._lib.gvom_destroy(h)
             except Exception:
                 pass
@@ -390,8 +423,8 @@ class Gvom(object):
         xy = self.xy_size
         n2 = xy * xy
         origin = np.zeros(3, np.float64)
-        if self._out_pool:
-            ptr = self._out_pool.pop()
+        if self._out_pool.free:
+            ptr = self._out_pool.free.pop()
         else:
             p = ctypes.c_void_p()
             self._check(self._lib.gvom_output_buffer_alloc(self._h, ctypes.byref(p)))
@@ -415,8 +448,8 @@ class Gvom(object):
         xy = self.xy_size
         n2 = xy * xy
         origin = np.zeros(3, np.float64)
-        if self._out_pool:
-            ptr = self._out_pool.pop()
+        if self._out_pool.free:
+            ptr = self._out_pool.free.pop()
         else:
             p = ctypes.c_void_p()
             self._check(self._lib.gvom_output_buffer_alloc(self._h, ctypes.byref(p)))
@@ -460,6 +493,66 @@ class Gvom(object):
         if rc == GVOM_NO_DATA:
             return None
         return out[:min(n, int(rows.value))]
+
+    def _rows(self, which):
+        rows = np.empty(self.voxel_count, np.int32)
+        rc = self._check(self._lib.gvom_read_rows(self._h, int(which), _ptr(rows)))
+        return None if rc == GVOM_NO_DATA else rows[rows >= 0]          # occupied voxels, in voxel order
+
+    def _metrics(self, which, dtype):
+        """(C, 10) statistics {mean xyz, covariance xx xy xz yy yz zz, count} of the occupied voxels of a
+        ring slot (float64) or of the fused map (float32), rows in voxel order (row order is unspecified
+        in the reference, gvom.py:1158); None without voxel statistics."""
+        rows = self._rows(which)
+        if rows is None:
+            return None
+        out = np.empty((rows.shape[0], 10), dtype)
+        rc = self._check(self._lib.gvom_gather_metrics(self._h, int(which), _ptr(np.ascontiguousarray(rows)),
+                                                       rows.shape[0], _ptr(out)))
+        return None if rc == GVOM_NO_DATA else out
+
+    @property
+    def metrics_buffer(self):
+        """reference attribute (gvom.py:62,166): per ring slot None or a device-array stand-in of (C, 10) float64"""
+        out = []
+        for i in range(self.buffer_size):
+            if self._lib.gvom_slot_filled(self._h, i) != 1 or self._metrics(i, np.float64) is None:
+                out.append(None)
+            else:
+                out.append(_DeviceArrayView(lambda i=i: self._metrics(i, np.float64)))
+        return out
+
+    @property
+    def combined_metrics(self):
+        """reference attribute (gvom.py:72,234): (Cc, 10) float32 of the fused map, rows in voxel order"""
+        if not self._state().has_combined or self._metrics(GVOM_WHICH_FUSED, np.float32) is None:
+            return None
+        return _DeviceArrayView(lambda: self._metrics(GVOM_WHICH_FUSED, np.float32))
+
+    last_combined_metrics = combined_metrics
+
+    @property
+    def voxels_eigenvalues(self):
+        """reference attribute (gvom.py:83,281, set by make_debug_voxel_map): (Cc, 3) float32 eigenvalues
+        l0 >= l1 >= l2 of the fused voxels' covariances, rows in voxel order"""
+        n = self.combined_cell_count_cpu
+        if n is None:
+            return None
+        out = np.empty((max(n, 1), 8), np.float32)
+        eig = np.empty((max(n, 1), 3), np.float32)
+        rows = ctypes.c_int64(0)
+        rc = self._check(self._lib.gvom_debug_voxel_eigen(self._h, _ptr(out), _ptr(eig), n, ctypes.byref(rows)))
+        if rc == GVOM_NO_DATA:
+            return None
+        k = min(n, int(rows.value))
+        st = self._state()
+        # voxel order: the rows carry their world coordinates (gvom.py:462-466)
+        x = np.rint(out[:k, 0] / self.xy_resolution - st.combined_origin[0]).astype(np.int64)
+        y = np.rint(out[:k, 1] / self.xy_resolution - st.combined_origin[1]).astype(np.int64)
+        z = np.rint(out[:k, 2] / self.z_resolution - st.combined_origin[2]).astype(np.int64)
+        order = np.argsort(x + y * self.xy_size + z * self.xy_size * self.xy_size, kind="stable")
+        arr = np.ascontiguousarray(eig[:k][order])
+        return _DeviceArrayView(lambda: arr.copy())
 
     def make_debug_height_map(self):
         out = np.empty((self.xy_size * self.xy_size, 7), np.float32)

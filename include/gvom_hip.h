@@ -223,6 +223,9 @@ int gvom_get_occupancy(gvom_t *h, uint8_t *out_xyz);
  * unspecified (as in the reference).  *rows = number of occupied voxels; at most max_rows are written.
  * GVOM_NO_DATA unless the handle was created with GVOM_FLAG_VOXEL_STATISTICS and has combined. */
 int gvom_debug_voxel_map(gvom_t *h, float *out, int64_t max_rows, int64_t *rows);
+/* The same with the three eigenvalues of every row (reference attribute voxels_eigenvalues,
+ * gvom.py:1333-1378): eigen[row][3] = {l0, l1, l2}, row for row with `out`. */
+int gvom_debug_voxel_eigen(gvom_t *h, float *out, float *eigen, int64_t max_rows, int64_t *rows);
 /* Gvom.make_debug_height_map (gvom.py:380-394, kernel :426-438): float32[xy*xy][7]. */
 int gvom_debug_height_map(gvom_t *h, float *out);
 /* Gvom.make_debug_inferred_height_map (gvom.py:396-410, kernel :442-450): float32[xy*xy][3]. */
@@ -237,6 +240,12 @@ int gvom_debug_inferred_height_map(gvom_t *h, float *out);
 #define GVOM_WHICH_FUSED (-1)
 int gvom_read_dense(gvom_t *h, int which, int32_t *state, int32_t *hit, int32_t *total,
                     float *min_h, double origin[3], int64_t *cell_count);
+/* Reference attributes metrics_buffer[slot] / combined_metrics (gvom.py:54-83,234,281; handles with
+ * GVOM_FLAG_VOXEL_STATISTICS): gvom_read_rows gives the compact row of every occupied voxel in the
+ * reference's voxel order (-1 elsewhere), gvom_gather_metrics the 10 statistics {mean xyz, covariance
+ * xx xy xz yy yz zz, count} of selected rows: float64 for a ring slot, float32 for the fused map. */
+int gvom_read_rows(gvom_t *h, int which, int32_t *rows_dense);
+int gvom_gather_metrics(gvom_t *h, int which, const int32_t *rows, int64_t n, void *out);
 /* which2d: internal float64 maps of the last combine, [x][y] C-order like the reference's
  * attributes (gvom.py:85-88,310-313). */
 #define GVOM_MAP_HEIGHT          0

@@ -68,6 +68,65 @@ def test_hip_voxel_statistics_match_oracle_c2(gvom_mod):
     assert compare_records(got, want, float_tol=1e-5, stats_rtol=1e-4, stats_atol=2e-5) > 20
 
 
+def test_reference_statistics_attributes(gvom_mod):
+    """SURVEY App. B.12 attributes that exist on the reference object when the statistics path runs:
+    metrics_buffer[slot] (float64 (C,10)), combined_metrics / last_combined_metrics (float32 (Cc,10)) and
+    voxels_eigenvalues (float32 (Cc,3), set by make_debug_voxel_map) -- compared with the oracle's, rows
+    in voxel order on both sides (row order is unspecified in the reference, gvom.py:964,1158).
+    Counts exact; means / covariances to float-atomic-order tolerance."""
+    params = (0.4, 0.2, 32, 16, 2, 0.5, 0.5, 0.5, 0.3, 2.0, 4.0, 1.0, 1, 1)
+    rng = np.random.default_rng(12)
+    g, w = gvom_mod.Gvom(*params, voxel_statistics=True), oracle.OracleGvom(*params, voxel_statistics=True)
+    assert gvom_mod.Gvom(*params).combined_metrics is None
+    for k in range(3):
+        ego = (0.5 * k, -0.3 * k, 0.05 * k)
+        pc = np.stack([rng.uniform(-5, 5, 6000) + ego[0], rng.uniform(-5, 5, 6000) + ego[1], rng.normal(-0.8, 0.3, 6000)], 1)
+        g.process_pointcloud(pc, ego); w.process_pointcloud(pc.copy(), ego)
+        g.combine_maps(); w.combine_maps()
+        assert w.make_debug_voxel_map() is not None and g.make_debug_voxel_map() is not None
+        slot = w.last_buffer_index
+
+        def voxel_order(index_map, arr):
+            im = np.asarray(index_map)
+            return np.asarray(arr)[im[im >= 0]]
+        wm = voxel_order(w.index_buffer[slot], w.metrics_buffer[slot])
+        gm = g.metrics_buffer[slot].copy_to_host()
+        assert gm.dtype == np.float64 and gm.shape == wm.shape
+        assert np.array_equal(gm[:, 9], wm[:, 9])
+        np.testing.assert_allclose(gm, wm, rtol=1e-9, atol=1e-9)
+        wc = voxel_order(w.combined_index_map, w.combined_metrics)
+        gc_ = g.combined_metrics.copy_to_host()
+        assert gc_.dtype == np.float32 and gc_.shape == wc.shape
+        assert np.array_equal(gc_[:, 9], wc[:, 9])
+        np.testing.assert_allclose(gc_, wc, rtol=1e-4, atol=1e-5)
+        we = voxel_order(w.combined_index_map, w.voxels_eigenvalues)
+        ge = g.voxels_eigenvalues.copy_to_host()
+        assert ge.dtype == np.float32 and ge.shape == we.shape
+        np.testing.assert_allclose(ge, we, rtol=1e-3, atol=2e-5)
+        assert np.array_equal(g.last_combined_metrics.copy_to_host(), gc_)
+
+
+def test_returned_arrays_outlive_the_mapper(gvom_mod):
+    """combine_maps' arrays are views of a pinned buffer: they stay valid after the Gvom is gone, and the
+    buffer is released when the last of them is collected (no leak per orphaned result)."""
+    import gc
+    params, scans = synth.config_inputs("c2")
+    g = gvom_mod.Gvom(*params)
+    pc, ego, tf = scans[0]
+    g.process_pointcloud(pc, ego, tf)
+    out = g.combine_maps()
+    pool = g._out_pool
+    keep = [np.array(o, copy=True) for o in out]
+    del g
+    gc.collect()
+    assert pool.closed and pool.free == []
+    for a, b in zip(out, keep):
+        assert np.array_equal(a, b)
+    del out, a
+    gc.collect()
+    assert pool.free == []                   # given back after the mapper's death: freed, not pooled
+
+
 def _run_both(gvom_mod, params, steps, record_debug=True):
     sc = {"params": params, "steps": steps}
     want = scenarios.run_and_record(oracle.OracleGvom, sc, record_debug=record_debug)
