@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <unistd.h>
 #include <immintrin.h>
 #include <algorithm>
 #include <mutex>
@@ -68,7 +69,8 @@ struct gvom_handle {
     int nseg = 1;
     uint32_t epoch = 0;                                 // last tile epoch handed out
     hipStream_t stream = nullptr;
-    std::mutex mu;
+    std::mutex mu;                                      // handle state
+    std::mutex scan_mu;                                 // one scan at a time (held across the wait for k_trace, during which `mu` is free)
     std::string err;
 
     uint32_t *hit = nullptr, *total = nullptr, *mh = nullptr;   // dense accumulators (hit, ray passes, min-height), zero between scans
@@ -362,8 +364,32 @@ void scan_abort(gvom_handle *h)
 int renumber_epochs(gvom_handle *h);
 
 // Scan kernels up to (not including) the commit.  `dev_pts` is device memory.
-int scan_launch(gvom_handle *h, const void *dev_pts, int64_t n, int64_t stride_elems, int dtype,
-                const double *tf, bool shard_local = false)
+// Waits until the GPU has published sequence number `seq` in the 64-bit host-mapped word `flag` (high
+// half, or the whole word).  `lk` (the handle mutex) is RELEASED while waiting, so combine_maps from
+// another thread is not locked out for the length of a trace; a long wait (c5: milliseconds) stops
+// spinning and yields the core.
+bool wait_published(gvom_handle *h, std::unique_lock<std::mutex> &lk, volatile unsigned long long *flag, uint32_t seq,
+                    bool high_half)
+{
+    auto done = [&]() { return (uint32_t)(high_half ? (*flag >> 32) : *flag) == seq; };
+    lk.unlock();
+    const double start = now_ns();
+    unsigned spins = 0;
+    bool ok = true;
+    while (!done()) {
+        _mm_pause();
+        if ((++spins & 0x3ff) == 0) {
+            const double waited = now_ns() - start;
+            if (waited > 2.0e9) { ok = false; break; }                // device trouble: the caller falls back
+            if (waited > 2.0e5) usleep(20);                           // beyond 200 us: yield instead of burning the core
+        }
+    }
+    lk.lock();
+    return ok;
+}
+
+int scan_launch(gvom_handle *h, std::unique_lock<std::mutex> &lk, const void *dev_pts, int64_t n, int64_t stride_elems,
+                int dtype, const double *tf, bool shard_local = false)
 {
     const gvom_params &p = h->prm;
     int64_t origin[3];
@@ -416,17 +442,12 @@ int scan_launch(gvom_handle *h, const void *dev_pts, int64_t n, int64_t stride_e
                               h->counters, h->x_host_dev, seq);
         if (le != hipSuccess) { scan_abort(h); HIPCHK(h, le); }
         volatile unsigned long long *flag = (volatile unsigned long long *)(h->x_host + 2 * h->world + 1);
-        const double deadline = now_ns() + 2.0e9;
-        unsigned spins = 0;
-        while ((uint32_t)*flag != seq) {
-            _mm_pause();
-            if ((++spins & 0x3ff) == 0 && now_ns() > deadline) {
-                hipError_t se = hipStreamSynchronize(h->stream);
-                if (se != hipSuccess || (uint32_t)*flag != seq) {
-                    scan_abort(h);
-                    h->err = "sharded scan: pack counts were never published";
-                    return GVOM_ERR_HIP;
-                }
+        if (!wait_published(h, lk, flag, seq, false)) {
+            hipError_t se = hipStreamSynchronize(h->stream);
+            if (se != hipSuccess || (uint32_t)*flag != seq) {
+                scan_abort(h);
+                h->err = "sharded scan: pack counts were never published";
+                return GVOM_ERR_HIP;
             }
         }
         h->pending_any = h->x_host[2 * h->world] != 0;
@@ -455,18 +476,13 @@ int scan_launch(gvom_handle *h, const void *dev_pts, int64_t n, int64_t stride_e
     // with this handle is stream-ordered behind it.
     {
         volatile unsigned long long *flag = (volatile unsigned long long *)h->counters_host;
-        const double deadline = now_ns() + 2.0e9;
-        unsigned spins = 0;
-        while ((uint32_t)(*flag >> 32) != seq) {
-            _mm_pause();
-            if ((++spins & 0x3ff) == 0 && now_ns() > deadline) {      // device trouble: fall back
-                hipError_t se = hipStreamSynchronize(h->stream);
-                if (se != hipSuccess || (uint32_t)(*flag >> 32) != seq) {
-                    scan_abort(h);
-                    h->err = se != hipSuccess ? std::string("scan failed: ") + hipGetErrorString(se)
-                                              : "scan completion was never published";
-                    return GVOM_ERR_HIP;
-                }
+        if (!wait_published(h, lk, flag, seq, true)) {
+            hipError_t se = hipStreamSynchronize(h->stream);
+            if (se != hipSuccess || (uint32_t)(*flag >> 32) != seq) {
+                scan_abort(h);
+                h->err = se != hipSuccess ? std::string("scan failed: ") + hipGetErrorString(se)
+                                          : "scan completion was never published";
+                return GVOM_ERR_HIP;
             }
         }
     }
@@ -542,7 +558,8 @@ int process_impl(gvom_handle *h, const void *xyz, bool on_device, int64_t n, int
             if (off_bytes[k] > last_field) last_field = off_bytes[k];
         }
     }
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::lock_guard<std::mutex> scan_lk(h->scan_mu);      // scans of one handle are serialised (one staging slot, one set of accumulators)
+    std::unique_lock<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->device));
     for (int k = 0; k < 3; ++k) h->in_off[k] = off_bytes ? (int)(off_bytes[k] / (int64_t)esz) : k;
     h->in_f32 = widen_f32;
@@ -558,7 +575,7 @@ int process_impl(gvom_handle *h, const void *xyz, bool on_device, int64_t n, int
                                  hipMemcpyHostToDevice, h->stream));
         dev = h->in_pts.p;
     }
-    int rc = scan_launch(h, dev, n, row_stride_bytes / (int64_t)esz, dtype, tf, defer);
+    int rc = scan_launch(h, lk, dev, n, row_stride_bytes / (int64_t)esz, dtype, tf, defer);
     if (rc) return rc;
     if (defer) return GVOM_OK;
     const bool accept = h->pending_any;                   // == (global occupied-voxel count > 0), gvom.py:147-150
