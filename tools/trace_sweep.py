@@ -14,9 +14,9 @@ hip = bench.Hip(); hip.set_device(0)
 params, scans = synth.config_inputs(name, n_scans=4)
 dev = [(hip.to_device(pc), pc.shape[0], pc.dtype, ego, tf) for (pc, ego, tf) in scans]
 g = gvom.Gvom(*params)
-settings = [("segs", 6, 12), ("segs", 5, 12), ("segs", 5, 8), ("segs", 5, 16), ("segs", 5, 24), ("segs", 7, 12), ("segs", 6, 16)]
+settings = [("segs", 5, 16), ("segs", 4, 16), ("segs", 6, 16), ("segs", 5, 12), ("segs", 5, 24), ("segs", 3, 16)]
 for kind, chunk, ep in settings:
-    g.set_tuning("segs", chunk if kind == "segs" else 0); g.set_tuning("ep_row", 0); g.set_tuning("period", ep)
+    g.set_tuning("segs", chunk); g.set_tuning("period", ep)
     for k in range(30):
         d, n, dt, ego, tf = dev[k % 4]; g.process_pointcloud_device(d.value, n, dt, ego, tf); g.combine_maps()
     t0 = time.perf_counter()
