@@ -75,7 +75,7 @@ struct gvom_handle {
 
     uint32_t *hit = nullptr, *total = nullptr, *mh = nullptr;   // dense accumulators (hit, ray passes, min-height), zero between scans
     size_t acc_elems = 0;
-    int tune_segs = 0, tune_ep_row = -1, tune_period = 0; // gvom_set_tuning (0 / -1: automatic)
+    int tune_segs = 0, tune_ep_row = -2, tune_period = 0; // gvom_set_tuning (0 / -2: automatic)
     // rank exchange of a sharded map (world > 1): send / receive regions, indexed by peer rank
     uint32_t *x_send_ids = nullptr, *x_recv_ids = nullptr;     // quad ids: [Q] by owner / [world][myQ] by source
     void *x_send_pay = nullptr, *x_recv_pay = nullptr;         // 1 KiB per quad, same indexing
@@ -210,7 +210,7 @@ void fill_scan_params(const gvom_handle *h, const int64_t origin[3], const doubl
         P.nsegs = nsegs;
         P.lc_period = h->tune_period > 0 ? h->tune_period : 16;
         if (P.lc_period > 32) P.lc_period = 32;          // the line cache is direct-mapped with 64 entries
-        P.ep_row = h->tune_ep_row >= 0 ? h->tune_ep_row : 0;   // endpoint blocks first: their atomics retire under the walk
+        P.ep_row = h->tune_ep_row >= -1 ? h->tune_ep_row : 0;  // endpoint blocks first: their atomics retire under the walk (-1: inside segment 0's waves)
         if (P.ep_row > P.nsegs) P.ep_row = P.nsegs;
         P.f32_sqrt = h->f32_sqrt ? 1 : 0;
         P.dbg = gvom_diag_env("GVOM_TRACE_DEBUG");

@@ -312,8 +312,8 @@ __device__ __forceinline__ RaySetup ray_setup(const ScanParams &P, T x, T y, T z
 // one memory-side request per line; tile tags stamped on cache misses only.
 // ------------------------------------------------------------------------------------------
 template <bool LIT, bool P2>
-__device__ __forceinline__ void walk_steps(const ScanParams &P, int lane, uint32_t j, uint32_t cnt, float px, float py, float pz,
-                                           float incx, float incy, float incz, bool active, int steps, int period,
+__device__ __forceinline__ void walk_steps(const ScanParams &P, int lane, uint32_t &j, uint32_t cnt, float &px, float &py, float &pz,
+                                           float incx, float incy, float incz, bool &active, int steps,
                                            uint32_t *lck, uint32_t *lcc, uint32_t *total, uint32_t *tags)
 {
     const uint32_t uxy = (uint32_t)P.xy, uzs = (uint32_t)P.zs, usxq = (uint32_t)P.sxq, unseg = (uint32_t)P.nseg;
@@ -322,7 +322,7 @@ __device__ __forceinline__ void walk_steps(const ScanParams &P, int lane, uint32
     lds_u32 *const cnt3 = (lds_u32 *)lcc;
     glb_u32 *const total1 = (glb_u32 *)total;
     uint32_t memo = LC_EMPTY; int memo_slot = 0;
-    int dirty = 0;                                        // committing steps since the last flush
+    bool dirty = false;
     for (int left = steps; left > 0 && lanes(active) != 0ull; --left) {
         ++j;
         // every lane computes (a finished ray's lanes produce values nobody uses): no divergent
@@ -334,8 +334,7 @@ __device__ __forceinline__ void walk_steps(const ScanParams &P, int lane, uint32
         active = commit & (j < cnt);                                      // gvom.py:1127 (length test), 1135-1144 (left the grid)
         const unsigned long long cmask = lanes(commit);
         if (cmask == 0ull) break;                                         // wave-uniform: no lane is active any more
-        if (dirty == period) { lc_flush(P, lck, lcc, total, lane); dirty = 0; memo = LC_EMPTY; }
-        ++dirty;
+        dirty = true;
         uint32_t sx, sy, sz;                                              // toroidal storage coordinates
         if (P2) { sx = (wx + om0) & (uxy - 1u); sy = (wy + om1) & (uxy - 1u); sz = (wz + om2) & (uzs - 1u); }
         else { sx = min(wx + om0, wx + om0 - uxy); sy = min(wy + om1, wy + om1 - uxy); sz = min(wz + om2, wz + om2 - uzs); }
@@ -375,34 +374,39 @@ __device__ __forceinline__ void walk_steps(const ScanParams &P, int lane, uint32
     if (dirty) lc_flush(P, lck, lcc, total, lane);
 }
 
-// Dispatch of the four step-loop forms: literal f64 lookup iff a coordinate of some active ray may come
-// within 2^-21 of zero during these `steps` steps (or the origin is beyond 2^30); power-of-two grids
-// wrap by masking.
+// A wave's steps, in runs of at most `period` steps (the line cache is flushed after each run): per run the
+// step loop takes the literal f64 lookup iff a coordinate of some active ray may come within 2^-21 of
+// zero during the run (or the origin is beyond 2^30) -- a ray that crosses a coordinate plane costs one
+// run of the slow form, not its whole segment; power-of-two grids wrap by masking.
 template <bool BIG>
 __device__ __forceinline__ void walk_item(const ScanParams &P, int lane, uint32_t j, uint32_t cnt, float px, float py, float pz,
                                           float incx, float incy, float incz, bool active, int steps, int period,
                                           uint32_t *lck, uint32_t *lcc, uint32_t *total, uint32_t *tags)
 {
-    // (the positions visited run monotonically from p + inc -- the first one, an exact f32 add as in
-    // the loop -- to about p + steps * inc; the margin is far above the rounding of that estimate, which
-    // is below steps * ulp(steps) wherever the hull is near zero; NaN estimates compare false: such a
-    // lane is inactive or leaves the grid at once)
-    bool lit = BIG;
-    if (!BIG) {
-        const float fs = (float)min((uint32_t)steps, cnt - j);            // steps this ray can still take here (active lanes: cnt > j)
-        const float ax = px + incx, ay = py + incy, az = pz + incz;
-        const float qx = px + fs * incx, qy = py + fs * incy, qz = pz + fs * incz;
-        const bool nz = (fminf(ax, qx) <= 1e-4f && fmaxf(ax, qx) >= -1e-4f) || (fminf(ay, qy) <= 1e-4f && fmaxf(ay, qy) >= -1e-4f) ||
-                        (fminf(az, qz) <= 1e-4f && fmaxf(az, qz) >= -1e-4f);
-        lit = lanes(active & nz) != 0ull;
-    }
     const bool p2 = ((P.xy & (P.xy - 1)) | (P.zs & (P.zs - 1))) == 0;
-    if (lit) {
-        if (p2) walk_steps<true, true>(P, lane, j, cnt, px, py, pz, incx, incy, incz, active, steps, period, lck, lcc, total, tags);
-        else walk_steps<true, false>(P, lane, j, cnt, px, py, pz, incx, incy, incz, active, steps, period, lck, lcc, total, tags);
-    } else {
-        if (p2) walk_steps<false, true>(P, lane, j, cnt, px, py, pz, incx, incy, incz, active, steps, period, lck, lcc, total, tags);
-        else walk_steps<false, false>(P, lane, j, cnt, px, py, pz, incx, incy, incz, active, steps, period, lck, lcc, total, tags);
+    while (steps > 0 && lanes(active) != 0ull) {
+        const int run = min(steps, period);
+        steps -= run;
+        // (the positions visited run monotonically from p + inc -- the first one, an exact f32 add as in
+        // the loop -- to about p + run * inc; the margin is far above the rounding of that estimate, which
+        // is below run * ulp(run) wherever the hull is near zero; NaN estimates compare false: such a
+        // lane is inactive or leaves the grid at once)
+        bool lit = BIG;
+        if (!BIG) {
+            const float fs = (float)min((uint32_t)run, cnt - j);              // steps this ray can still take here (active lanes: cnt > j)
+            const float ax = px + incx, ay = py + incy, az = pz + incz;
+            const float qx = px + fs * incx, qy = py + fs * incy, qz = pz + fs * incz;
+            const bool nz = (fminf(ax, qx) <= 1e-4f && fmaxf(ax, qx) >= -1e-4f) || (fminf(ay, qy) <= 1e-4f && fmaxf(ay, qy) >= -1e-4f) ||
+                            (fminf(az, qz) <= 1e-4f && fmaxf(az, qz) >= -1e-4f);
+            lit = lanes(active & nz) != 0ull;
+        }
+        if (lit) {
+            if (p2) walk_steps<true, true>(P, lane, j, cnt, px, py, pz, incx, incy, incz, active, run, lck, lcc, total, tags);
+            else walk_steps<true, false>(P, lane, j, cnt, px, py, pz, incx, incy, incz, active, run, lck, lcc, total, tags);
+        } else {
+            if (p2) walk_steps<false, true>(P, lane, j, cnt, px, py, pz, incx, incy, incz, active, run, lck, lcc, total, tags);
+            else walk_steps<false, false>(P, lane, j, cnt, px, py, pz, incx, incy, incz, active, run, lck, lcc, total, tags);
+        }
     }
 }
 
@@ -428,7 +432,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     if (live) load_return(P, in, stride, i, x, y, z);
     const T d2 = (x * x + y * y) + z * z;
     const bool pass = live && !((double)d2 < P.min_d2);
-    if ((int)blockIdx.y == P.ep_row) {
+    // endpoint work: in the blocks of grid row P.ep_row, or (P.ep_row < 0) in the waves of segment 0
+    const bool ep_here = P.ep_row >= 0 ? (int)blockIdx.y == P.ep_row : blockIdx.y == 0;
+    if (ep_here) {
         if (live && world) { world[3 * i + 0] = x; world[3 * i + 1] = y; world[3 * i + 2] = z; }   // statistics only
         const Endpoint E = endpoint_of<T>(P, pass, x, y, z);
         // some return landed in the grid: the scan will be committed (gvom.py:147-150)
@@ -453,9 +459,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             }
         }
         endpoint_commit(P, lane, i, mine, E.L, E.A, E.mbits, hit, total, mh, state, tags, stat_sums, stat_base, stat_rowvox);
-        return;
+        if (P.ep_row >= 0) return;
     }
-    const int seg = (int)blockIdx.y - ((int)blockIdx.y > P.ep_row ? 1 : 0);
+    const int seg = P.ep_row >= 0 ? (int)blockIdx.y - ((int)blockIdx.y > P.ep_row ? 1 : 0) : (int)blockIdx.y;
     const uint32_t j0 = (uint32_t)P.seg_start[seg];
     // ---- later segments: leave before the f64 set-up when no ray of the wave can still be running ----
     // After j0 steps `length` is >= j0 * (1 - 2^-22) (every step adds |1 / sd| with |sd| <= 1 + 2^-23),
@@ -2108,7 +2114,7 @@ hipError_t gvom_launch_trace(hipStream_t s, const ScanParams &P, const ShardExch
     const unsigned blocks = (unsigned)((n + 255) / 256);
     if (blocks == 0) return hipSuccess;
 #define TRACE_LAUNCH(TT, BB)                                                                             \
-    hipLaunchKernelGGL((k_trace<TT, BB>), dim3(blocks, (unsigned)P.nsegs + 1u), dim3(256), 0, s, P, X, (const TT *)pts, \
+    hipLaunchKernelGGL((k_trace<TT, BB>), dim3(blocks, (unsigned)P.nsegs + (P.ep_row >= 0 ? 1u : 0u)), dim3(256), 0, s, P, X, (const TT *)pts, \
                        (long)stride_elems, (long)n, (TT *)world, hit, total, mh, state, tags, counters,     \
                        stat_sums, stat_base, stat_rowvox)
     if (dtype == 0) { if (big_origin) TRACE_LAUNCH(float, true); else TRACE_LAUNCH(float, false); }

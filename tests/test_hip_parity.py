@@ -408,7 +408,7 @@ def test_trace_tuning_knobs_leave_results_unchanged(gvom_mod):
     leave bit-identical scan slots.  segs=1 is the unsegmented walk, segs=9 / period=1 the extremes."""
     params, scans = synth.config_inputs("c2", n_scans=2)
     ref = None
-    for segs, period, ep_row in ((0, 0, -1), (1, 12, 0), (2, 1, 1), (3, 32, 3), (6, 12, 6), (9, 5, 4)):
+    for segs, period, ep_row in ((0, 0, -2), (1, 12, 0), (2, 1, 1), (3, 32, 3), (6, 12, 6), (9, 5, 4), (5, 16, -1), (1, 7, -1)):
         g = gvom_mod.Gvom(*params)
         g.set_tuning("segs", segs); g.set_tuning("period", period); g.set_tuning("ep_row", ep_row)
         slots = []

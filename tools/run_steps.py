@@ -9,6 +9,7 @@ name = sys.argv[1] if len(sys.argv) > 1 else "m256"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 hip = bench.Hip(); hip.set_device(0)
 params, scans = synth.config_inputs(name, n_scans=4)
+scans = (scans * 4)[:4]
 dev = [(hip.to_device(pc), pc.shape[0], pc.dtype, ego, tf) for (pc, ego, tf) in scans]
 g = gvom.Gvom(*params)
 stage = "stage" in sys.argv[3:]
