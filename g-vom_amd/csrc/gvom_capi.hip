@@ -35,6 +35,7 @@ struct Buf {                                   // grow-only device buffer
 
 struct Slot {                                  // one scan in sparse form
     int32_t *state = nullptr;                  // [V] storage order
+    uint16_t *code16 = nullptr;                // [V] 16-bit codes of the same voxels (xy % 4 == 0 grids), read by k_fuse4
     uint32_t *tags = nullptr;                  // [ntiles] tile epochs (live iff == epoch)
     uint32_t epoch = 0;
     Buf chit, ctotal, cminh;                   // compact rows
@@ -292,6 +293,7 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, b
     h->slots.resize(params->buffer_size + 1);
     for (auto &s : h->slots) {
         CK(hipMalloc((void **)&s.state, h->V * 4));
+        if ((params->xy_size & 3) == 0) CK(hipMalloc((void **)&s.code16, h->V * 2));
         CK(hipMalloc((void **)&s.tags, h->ntiles * 4));
         CK(hipMemsetAsync(s.tags, 0, h->ntiles * 4, h->stream));
     }
@@ -460,7 +462,7 @@ int scan_launch(gvom_handle *h, std::unique_lock<std::mutex> &lk, const void *de
         h->pending_n = n;
         return GVOM_OK;
     }
-    le = gvom_launch_encode(h->stream, P, h->hit, h->total, h->mh, st.state, (uint32_t *)st.chit.p,
+    le = gvom_launch_encode(h->stream, P, h->hit, h->total, h->mh, st.state, st.code16, (uint32_t *)st.chit.p,
                             (uint32_t *)st.ctotal.p, (uint32_t *)st.cminh.p, st.tags, h->counters,
                             (unsigned long long *)h->counters_host_dev, seq, h->resident_blocks);
     if (le != hipSuccess) { scan_abort(h); HIPCHK(h, le); }
@@ -606,6 +608,8 @@ int fuse_impl(gvom_handle *h)
     const gvom_params &p = h->prm;
     const Slot &last = h->slots[h->ring[h->last_buffer_index]];
     if (!last.filled) return GVOM_EMPTY_BUFFER;                        // gvom.py:179-181
+    // before any map descriptor below copies an epoch
+    if (h->epoch >= 0xFFFFFF00u) { int rc0 = renumber_epochs(h); if (rc0) return rc0; }
     const int nxt = h->has_combined ? 1 - h->cur : 0;
     Fused &F = h->fused[nxt];
     const Fused *prev = (h->has_combined && h->fused[h->cur].valid) ? &h->fused[h->cur] : nullptr;
@@ -627,6 +631,7 @@ int fuse_impl(gvom_handle *h)
         d.d[1] = clamp_delta(F.origin[1] - s.origin[1], p.xy_size);
         d.d[2] = clamp_delta(F.origin[2] - s.origin[2], p.z_size);
         d.epoch = s.epoch; d.tags = s.tags; d.metrics = h->stats ? s.metrics.p : nullptr;
+        d.code16 = s.code16;
     }
     P.nslots = ns;
     P.has_prev = prev ? 1 : 0;
@@ -638,13 +643,13 @@ int fuse_impl(gvom_handle *h)
         d.d[1] = clamp_delta(F.origin[1] - prev->origin[1], p.xy_size);
         d.d[2] = clamp_delta(F.origin[2] - prev->origin[2], p.z_size);
         d.epoch = prev->epoch; d.tags = prev->tags; d.metrics = h->stats ? prev->metrics.p : nullptr;
+        d.code16 = nullptr;
     }
     P.sy_lo = h->sy_lo; P.sy_hi = h->sy_hi;
     P.nz = choose_nz(p.z_size, &P.zc, &P.cpw);
     P.dbg = gvom_diag_env("GVOM_FUSE_DEBUG");
     P.nseg = h->nseg;
     P.hs = h->hs;
-    if (h->epoch >= 0xFFFFFF00u) { int rc0 = renumber_epochs(h); if (rc0) return rc0; }
     F.epoch = ++h->epoch;
     P.epoch = F.epoch;
     // every wave of k_fuse owns a static range of 64*zc compact rows (no global reservation)
@@ -798,7 +803,7 @@ VIS void gvom_destroy(gvom_t *h)
     hipFree(h->x_send_ids); hipFree(h->x_send_pay); hipFree(h->x_recv_ids); hipFree(h->x_recv_pay);
     hipFree(h->x_qcnt); hipFree(h->x_ecnt); fb(h->x_send_eps); fb(h->x_recv_eps);
     if (h->x_host) hipHostFree(h->x_host);
-    for (auto &s : h->slots) { hipFree(s.state); hipFree(s.tags); fb(s.chit); fb(s.ctotal); fb(s.cminh); fb(s.metrics); fb(s.base); fb(s.rowvox); }
+    for (auto &s : h->slots) { hipFree(s.state); hipFree(s.code16); hipFree(s.tags); fb(s.chit); fb(s.ctotal); fb(s.cminh); fb(s.metrics); fb(s.base); fb(s.rowvox); }
     for (auto &f : h->fused) { hipFree(f.state); hipFree(f.tags); fb(f.hit); fb(f.total); fb(f.minh); fb(f.metrics); }
     fb(h->in_pts); fb(h->world_pts);
     hipFree(h->counters); if (h->counters_host) hipHostFree(h->counters_host);
@@ -938,7 +943,7 @@ VIS int gvom_shard_scan_merge(gvom_t *h, const int64_t *recv_quads, const int64_
         if (le != hipSuccess) { scan_abort(h); HIPCHK(h, le); }
     }
     const uint32_t seq = ++h->scan_seq;
-    hipError_t le = gvom_launch_encode(h->stream, P, h->hit, h->total, h->mh, st.state, (uint32_t *)st.chit.p,
+    hipError_t le = gvom_launch_encode(h->stream, P, h->hit, h->total, h->mh, st.state, st.code16, (uint32_t *)st.chit.p,
                                        (uint32_t *)st.ctotal.p, (uint32_t *)st.cminh.p, st.tags, h->counters,
                                        (unsigned long long *)h->counters_host_dev, seq, h->resident_blocks);
     if (le != hipSuccess) { scan_abort(h); HIPCHK(h, le); }
@@ -1462,6 +1467,7 @@ VIS int gvom_set_tuning(gvom_t *h, const char *name, int value)
     if (!strcmp(name, "segs")) h->tune_segs = value;
     else if (!strcmp(name, "ep_row")) h->tune_ep_row = value;
     else if (!strcmp(name, "period")) h->tune_period = value;
+    else if (!strcmp(name, "epoch_bias")) h->epoch += (uint32_t)value;   // test hook: advances the tile-epoch counter (towards its wrap)
     else return GVOM_ERR_INVALID;
     return GVOM_OK;
 }

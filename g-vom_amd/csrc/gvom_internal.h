@@ -96,6 +96,7 @@ struct MapDesc {          // one source map of the fusion (ring slot or previous
     uint32_t epoch;         // tile (T) of this map is live iff tags[T] == epoch
     const uint32_t *tags;
     const void *metrics;    // optional per-row statistics: double[rows][10] (ring slot) or float[rows][10] (fused)
+    const uint16_t *code16; // ring slots of xy % 4 == 0 grids: 16-bit codes (see k_encode); nullptr for the previous map
 };
 
 #define GVOM_KARG_DESCS 17   // ring slots + previous map passed by kernel argument when they fit
@@ -151,7 +152,7 @@ hipError_t gvom_launch_unpack(hipStream_t s, const ScanParams &P, const ShardUnp
                               const void *pay_all, uint32_t my_quads, uint32_t ne, const void *eps, long row_base,
                               uint32_t *hit, uint32_t *total, uint32_t *mh, int32_t *state, uint32_t *tags);
 hipError_t gvom_launch_encode(hipStream_t s, const ScanParams &P, uint32_t *hit, uint32_t *total, uint32_t *mh,
-                              int32_t *state, uint32_t *chit, uint32_t *ctotal, uint32_t *cminh, const uint32_t *tags,
+                              int32_t *state, uint16_t *code16, uint32_t *chit, uint32_t *ctotal, uint32_t *cminh, const uint32_t *tags,
                               uint32_t *counters, unsigned long long *host_flag, uint32_t seq, unsigned resident_blocks);
 hipError_t gvom_launch_fuse(hipStream_t s, const FuseParams &P, const FuseDescs &KD,
                             const MapDesc *descs_dev, int32_t *fstate, uint32_t *fhit, uint32_t *ftotal, uint32_t *fminh,

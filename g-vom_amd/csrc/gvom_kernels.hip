@@ -29,9 +29,22 @@
 // it they point to global memory so it emits global_load (vmcnt only) instead of flat_load.
 typedef const __attribute__((address_space(1))) int32_t *gptr_i32;
 typedef const __attribute__((address_space(1))) uint32_t *gptr_u32;
+typedef const __attribute__((address_space(1))) uint16_t *gptr_u16;
+typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(1))) v2u *gptr_u2;
+// The fusion kernels index their source descriptors with wave-uniform values.  Through a pointer that
+// may be kernel-argument or global memory (one generic pointer) every field read was a FLAT vector
+// load + readfirstlane and a round trip of its own ahead of the load it feeds; as constant-address-space
+// reads they are scalar loads.  MEM (template) = the descriptors did not fit the kernel arguments.
+typedef const __attribute__((address_space(4))) MapDesc *cptr_desc;
 typedef int v4i __attribute__((ext_vector_type(4)));                       // 16-byte vector of 4 ints
 typedef const __attribute__((address_space(1))) v4i *gptr_v4i;
 
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_add_sat_u16(uint32_t a, uint32_t b) {     // v_pk_add_u16 ... clamp
+    const us2 r = __builtin_elementwise_add_sat(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b));
+    return __builtin_bit_cast(uint32_t, r);
+}
 __device__ __forceinline__ int wrap_add(int a, int b, int n) { int s = a + b; return s >= n ? s - n : s; }
 __device__ __forceinline__ int wrap_sub(int a, int b, int n) { int s = a - b; return s < 0 ? s + n : s; }
 // accumulator (hit/total) index of storage voxel (sx, sy, sz): 4x4 (x,y) patches per 64-B line
@@ -637,6 +650,11 @@ __global__ __launch_bounds__(256) void k_unpack_eps(const ScanParams P, uint32_t
 //                                                                      gvom.py:1164-1168,1303-1329
 //   else              : state = -total - 1                             gvom.py:1160
 //   and the accumulators are zeroed for the next scan (replaces the fills of gvom.py:114-121).
+// The same information goes out a second time as a 16-bit code per voxel (code16, xy % 4 == 0 grids):
+// min(passes, 65535) of a free voxel (0: never observed), 65535 if occupied -- what k_fuse4 reads of
+// a ring slot: the slots' codes are summed with saturating packed adds (2 voxels per instruction, no
+// compare), and a sum of 65535 = "occupied in some slot, or more than 65534 passes" sends the voxel
+// to the per-voxel path that reads the 32-bit states.
 // Untouched tiles are neither read nor written: their tag != epoch makes every consumer treat
 // them as "never observed" (-1), which is what the reference's -1 fill + __assign_indices yield.
 // Min-height arrives as a third dense accumulator (1.0f's bits minus the value's bits, atomicMax:
@@ -644,7 +662,7 @@ __global__ __launch_bounds__(256) void k_unpack_eps(const ScanParams P, uint32_t
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_encode(const ScanParams P, uint32_t t_begin, uint32_t t_end,
                                                 uint32_t *hit, uint32_t *total, uint32_t *mh, int32_t *state,
-                                                uint32_t *chit, uint32_t *ctotal, uint32_t *cminh,
+                                                uint16_t *code16, uint32_t *chit, uint32_t *ctotal, uint32_t *cminh,
                                                 const uint32_t *__restrict__ tags, uint32_t epoch,
                                                 uint32_t *counters, unsigned long long *host_flag,
                                                 uint32_t seq)
@@ -717,6 +735,10 @@ __global__ __launch_bounds__(256) void k_encode(const ScanParams P, uint32_t t_b
             if (any_t) *reinterpret_cast<uint4 *>(total + A0) = make_uint4(0, 0, 0, 0);
             if (vec_state) {
                 *reinterpret_cast<int4 *>(state + L0) = make_int4(st[0], st[1], st[2], st[3]);
+                uint32_t cd[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cd[i] = st[i] >= 0 ? 0xffffu : min(t[i], 0xffffu);
+                *reinterpret_cast<uint2 *>(code16 + L0) = make_uint2(cd[0] | (cd[1] << 16), cd[2] | (cd[3] << 16));
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) if (sx0 + i < (uint32_t)xy) state[L0 + i] = st[i];
@@ -747,7 +769,7 @@ __global__ __launch_bounds__(256) void k_encode(const ScanParams P, uint32_t t_b
 //    are combined across the nz waves through LDS (the kernel's only barrier)
 //    -> height_map (gvom.py:525-540) / inferred_height_map (gvom.py:544-554).
 // ------------------------------------------------------------------------------------------
-template <bool ZC16>
+template <bool ZC16, bool MEM>
 __global__ __launch_bounds__(1024) void k_fuse(const FuseParams P, const FuseDescs KD,
                                                const MapDesc *__restrict__ descs_mem,
                                                int32_t *fstate, uint32_t *fhit, uint32_t *ftotal,
@@ -761,7 +783,7 @@ __global__ __launch_bounds__(1024) void k_fuse(const FuseParams P, const FuseDes
     __shared__ int s_zfree[16][WAVE];
 
     // source descriptors: by kernel argument when they fit (no H2D copy per combine)
-    const MapDesc *__restrict__ descs = descs_mem ? descs_mem : KD.d;
+    const cptr_desc descs = MEM ? (cptr_desc)descs_mem : (cptr_desc)KD.d;
     const int lane = threadIdx.x & (WAVE - 1);
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform by construction
     const int sx = blockIdx.x * WAVE + lane;
@@ -1054,6 +1076,11 @@ __global__ __launch_bounds__(1024) void k_fuse(const FuseParams P, const FuseDes
 // Cell (j, i) of a lane is voxel (sx = 4g + i, z = z0 + 4j + q); its fold state lives in
 // c[4j + i] / bit 4j + i of occbits.
 // ------------------------------------------------------------------------------------------
+// Ring slots are read through their 16-bit codes (k_encode), SPR slots per round trip, and summed with
+// saturating packed adds; the previous fused map through its 32-bit states, loaded alongside and
+// folded last.  A saturated sum marks a CANDIDATE: occupied in some slot, or more than 65534 passes
+// (the sensor's own voxel); the per-voxel path below settles which from the 32-bit states.
+template <int SPR, bool MEM>
 __global__ __launch_bounds__(1024) void k_fuse4(const FuseParams P, const FuseDescs KD,
                                                 const MapDesc *__restrict__ descs_mem,
                                                 int32_t *fstate, uint32_t *fhit, uint32_t *ftotal,
@@ -1064,9 +1091,9 @@ __global__ __launch_bounds__(1024) void k_fuse4(const FuseParams P, const FuseDe
     __shared__ unsigned long long s_live[16][GVOM_MAX_SLOTS + 1];
     __shared__ unsigned long long s_zh[16][WAVE];          // per wave and column: min of (z << 32 | min-height bits) over occupied voxels
     __shared__ uint32_t s_zf[16][WAVE];                    // per wave and column: lowest observed-free z
-    __shared__ uint32_t s_list[16][4 * WAVE];              // per wave: the occupied voxels of one 4-level group, compacted
+    __shared__ uint16_t s_list[16][8 * WAVE];              // per wave: the occupied voxels of a chunk, compacted (j << 8 | lane << 2 | i)
 
-    const MapDesc *__restrict__ descs = descs_mem ? descs_mem : KD.d;
+    const cptr_desc descs = MEM ? (cptr_desc)descs_mem : (cptr_desc)KD.d;
     const int lane = threadIdx.x & (WAVE - 1);
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane & 15, q = lane >> 4;
@@ -1157,23 +1184,53 @@ __global__ __launch_bounds__(1024) void k_fuse4(const FuseParams P, const FuseDe
                 }
             }
         };
-        for (int s0 = 0; s0 < nsrc; s0 += 2) {
-            const int sA = s0, sB = min(s0 + 1, nsrc - 1);
-            const bool hasB = s0 + 1 < nsrc;
-            const gptr_i32 spA = (gptr_i32)descs[sA].state, spB = (gptr_i32)descs[sB].state;
-            const uint32_t liveA = (uint32_t)(s_live[w][sA] >> (16 * cc)) & 0xffffu;
-            const uint32_t liveB = hasB ? ((uint32_t)(s_live[w][sB] >> (16 * cc)) & 0xffffu) : 0u;
-            v4i vA[4], vB[4];
+        // codes of one ring slot: 4 x 16 bit = this lane's 4 columns at one level.  A slot's free counts
+        // only matter while no slot has the voxel occupied, so the sum is order-free (gvom.py:963-967).
+        uint32_t cpk[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};    // cell k = 4j + i: half (i & 1) of cpk[2j + (i >> 1)]
+        auto fold16 = [&](const v2u (&b)[4], uint32_t live, int dz, int s) {
+            const uint32_t cm0 = (((okm[0] >> s) & 1ull) ? 0xffffu : 0u) | (((okm[1] >> s) & 1ull) ? 0xffff0000u : 0u);
+            const uint32_t cm1 = (((okm[2] >> s) & 1ull) ? 0xffffu : 0u) | (((okm[3] >> s) & 1ull) ? 0xffff0000u : 0u);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {               // 8 unconditional 16-byte loads in flight
-                const uint32_t aA = ((liveA >> (4 * j + q)) & 1u) ? roff[j] : (uint32_t)(4 * lane);
-                const uint32_t aB = ((liveB >> (4 * j + q)) & 1u) ? roff[j] : (uint32_t)(4 * lane);
-                vA[j] = *(gptr_v4i)(spA + aA);
-                vB[j] = *(gptr_v4i)(spB + aB);
+            for (int j = 0; j < 4; ++j) {
+                const bool zin = ((live >> (4 * j + q)) & 1u) && zq[j] < z1 && zq[j] + dz >= 0 && zq[j] + dz < P.zs;
+                cpk[2 * j] = pk_add_sat_u16(cpk[2 * j], zin ? (b[j].x & cm0) : 0u);
+                cpk[2 * j + 1] = pk_add_sat_u16(cpk[2 * j + 1], zin ? (b[j].y & cm1) : 0u);
             }
-            fold(vA, liveA, descs[sA].d[2], sA, sA >= P.nslots);
-            if (hasB) fold(vB, liveB, descs[sB].d[2], sB, sB >= P.nslots);
+        };
+        v4i vp[4];
+        uint32_t livep = 0;
+        if (P.has_prev) {                                 // in flight while the slots are folded
+            livep = (uint32_t)(s_live[w][P.nslots] >> (16 * cc)) & 0xffffu;
+            const gptr_i32 sp = (gptr_i32)descs[P.nslots].state;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                vp[j] = *(gptr_v4i)(sp + (((livep >> (4 * j + q)) & 1u) ? roff[j] : (uint32_t)(4 * lane)));
         }
+        for (int s0 = 0; s0 < P.nslots; s0 += SPR) {
+            v2u b[SPR][4];
+            uint32_t live[SPR];
+#pragma unroll
+            for (int u = 0; u < SPR; ++u) {               // 4 * SPR unconditional 8-byte loads in flight
+                const int sI = min(s0 + u, P.nslots - 1);
+                const gptr_u16 cp = (gptr_u16)descs[sI].code16;
+                live[u] = s0 + u < P.nslots ? ((uint32_t)(s_live[w][sI] >> (16 * cc)) & 0xffffu) : 0u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    b[u][j] = *(gptr_u2)(cp + (((live[u] >> (4 * j + q)) & 1u) ? roff[j] : (uint32_t)(4 * lane)));
+            }
+#pragma unroll
+            for (int u = 0; u < SPR; ++u) {
+                const int sI = min(s0 + u, P.nslots - 1);
+                if (s0 + u < P.nslots) fold16(b[u], live[u], descs[sI].d[2], sI);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const uint32_t half = (cpk[k >> 1] >> (16 * (k & 1))) & 0xffffu;
+            c[k] = -1 - (int)half;
+            if (half == 0xffffu) occbits |= 1u << k;                       // candidate
+        }
+        if (P.has_prev) fold(vp, livep, descs[P.nslots].d[2], P.nslots, true);
         if (!col_ok) occbits = 0;
 
         // codes: one int4 store per live-or-new tile row segment; first free / occupied z per column
@@ -1197,66 +1254,86 @@ __global__ __launch_bounds__(1024) void k_fuse4(const FuseParams P, const FuseDe
             }
         }
 
-        // occupied voxels (sparse): the (<= 256) occupied voxels of a 4-level group are compacted
-        // across the wave and handled ONE LANE PER VOXEL: every source's state at that voxel is
-        // fetched in one round trip and the rows' counts in a second one, whatever the number of
-        // levels and sources (the per-level, per-source form was a chain of up to 16 round trips).
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t gbits = GVOM_DBG(P, 2) ? 0u : (occbits >> (4 * j)) & 0xfu;
-            if (!__any(gbits != 0)) continue;               // wave-uniform
-            uint32_t n = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bool occ = (gbits >> i) & 1u;
-                const unsigned long long b = __ballot(occ);
-                if (occ) s_list[w][n + (uint32_t)__popcll(b & lanemask_lt())] = ((uint32_t)lane << 2) | (uint32_t)i;
-                n += (uint32_t)__popcll(b);
-            }
+        // occupied voxels (sparse): the occupied voxels of the chunk are compacted across the wave and
+        // handled ONE LANE PER VOXEL: every source's state at that voxel is fetched in one round trip
+        // and the rows' counts in a second one, whatever the number of levels and sources (the
+        // per-level, per-source form was a chain of up to 16 round trips; per 4-level group and 4
+        // sources at a time it still was 2 x 4 x ceil(sources / 4)).
+        uint32_t n = 0;
+        auto emit = [&]() {
             for (uint32_t base = 0; base < n; base += WAVE) {
                 const uint32_t t = base + (uint32_t)lane;
                 const bool on = t < n;
                 const uint32_t e = s_list[w][on ? t : 0u];
-                const int ci = (int)(e & 3u), go = (int)((e >> 2) & 15u), qo = (int)(e >> 6);
-                const int zv = z0 + 4 * j + qo;                                  // window level of my voxel
+                const int ci = (int)(e & 3u), go = (int)((e >> 2) & 15u), qo = (int)((e >> 6) & 3u), jo = (int)(e >> 8);
+                const int zv = z0 + 4 * jo + qo;                                 // window level of my voxel
                 const int col = 4 * go + ci;                                     // column within the workgroup
                 const int sxc = blockIdx.x * WAVE + col;
                 const int xwc = wrap_sub(sxc, P.om[0], P.xy);
                 const uint32_t off = (uint32_t)sy * P.zs * P.xy + (uint32_t)wrap_add(zv, P.om[2], P.zs) * P.xy + (uint32_t)sxc;
-                const int lbit = 16 * cc + 4 * j + qo;                            // my tile in s_live
+                const int lbit = 16 * cc + 4 * jo + qo;                           // my tile in s_live
                 uint32_t hh = 0, tt = 0, mm = 0x3f800000u;
-                for (int s0 = 0; s0 < nsrc; s0 += 4) {
-                    int st[4];
-                    bool ok[4];
+                bool slot_occ = false;                                        // occupied in some ring slot
+                int cnt = -1, stp = -1;                                        // exact free count of the slots; the previous map's state
+                constexpr int NG = 4;
+                for (int s0 = 0; s0 < nsrc; s0 += NG) {
+                    int st[NG];
+                    bool ok[NG];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < NG; ++u) {
                         const int sI = min(s0 + u, nsrc - 1);
                         const int xs = xwc + descs[sI].d[0], ys = y + descs[sI].d[1], zs2 = zv + descs[sI].d[2];
                         ok[u] = on && s0 + u < nsrc && ((s_live[w][sI] >> lbit) & 1ull) &&
                                 xs >= 0 && xs < P.xy && ys >= 0 && ys < P.xy && zs2 >= 0 && zs2 < P.zs;
                         st[u] = ((gptr_i32)descs[sI].state)[ok[u] ? off : (uint32_t)lane];
                     }
-                    uint32_t gh[4], gt[4], gm[4];
+                    uint32_t gh[NG], gt[NG], gm[NG];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < NG; ++u) {
                         const int sI = min(s0 + u, nsrc - 1);
                         if (!ok[u]) st[u] = -1;
                         const uint32_t r = st[u] >= 0 ? (uint32_t)st[u] : 0u;
                         gh[u] = ((gptr_u32)descs[sI].hit)[r]; gt[u] = ((gptr_u32)descs[sI].total)[r]; gm[u] = ((gptr_u32)descs[sI].minh)[r];
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
+                    for (int u = 0; u < NG; ++u) {
                         if (st[u] >= 0) { hh += gh[u]; tt += gt[u]; mm = min(mm, gm[u]); }          // gvom.py:910-912
+                        if (s0 + u < P.nslots) {
+                            if (st[u] >= 0) slot_occ = true;                                      // gvom.py:963
+                            else if (st[u] < -1) cnt += st[u] + 1;                                // gvom.py:967
+                        } else if (s0 + u == P.nslots) stp = st[u];
+                    }
                 }
-                if (on) {
-                    const uint32_t row = rbase + running + t;
+                // a candidate is occupied (gvom.py:963, 992) -- or free with more passes than a code holds
+                const bool occupied = on && (slot_occ || (stp >= 0 && cnt >= -11));
+                const unsigned long long ob = __ballot(occupied);
+                if (occupied) {
+                    const uint32_t row = rbase + running + (uint32_t)__popcll(ob & lanemask_lt());
                     fstate[off] = (int32_t)row;
                     fhit[row] = hh; ftotal[row] = tt; fminh[row] = mm;
                     atomicMin(&s_zh[w][col], ((unsigned long long)(uint32_t)zv << 32) | mm);   // lowest occupied level wins
+                } else if (on) {
+                    fstate[off] = cnt + (stp < -1 ? stp + 1 : 0);                                 // gvom.py:996
+                    atomicMin(&s_zf[w][col], (uint32_t)zv);                                       // gvom.py:551
                 }
+                running += (uint32_t)__popcll(ob);
             }
-            running += n;
+            n = 0;
+        };
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t gbits = GVOM_DBG(P, 2) ? 0u : (occbits >> (4 * j)) & 0xfu;
+            if (!__any(gbits != 0)) continue;               // wave-uniform
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool occ = (gbits >> i) & 1u;
+                const unsigned long long b = __ballot(occ);
+                if (occ) s_list[w][n + (uint32_t)__popcll(b & lanemask_lt())] = (uint16_t)(((uint32_t)j << 8) | ((uint32_t)lane << 2) | (uint32_t)i);
+                n += (uint32_t)__popcll(b);
+            }
+            if (n > 4 * WAVE) emit();                       // the next group (<= 256 voxels) might not fit
         }
+        if (n) emit();
     }   // chunks
 
     // ---- column tail: lowest occupied z (+ its min-height) / lowest free z per column: LDS minima
@@ -1826,12 +1903,13 @@ __device__ __forceinline__ void merge_metrics(float (&c)[10], const TO *o)
 
 // k_fuse_stats: the covariance half of gvom.py:821-912 for every occupied voxel of the fused map
 // written by k_fuse: sources in the reference's order (ring slots, then the previous fused map).
+template <bool MEM>
 __global__ __launch_bounds__(256) void k_fuse_stats(const FuseParams P, const FuseDescs KD,
                                                     const MapDesc *__restrict__ descs_mem,
                                                     const int32_t *__restrict__ fstate,
                                                     const uint32_t *__restrict__ ftags, float *fmetrics)
 {
-    const MapDesc *__restrict__ descs = descs_mem ? descs_mem : KD.d;
+    const cptr_desc descs = MEM ? (cptr_desc)descs_mem : (cptr_desc)KD.d;
     const int lane = threadIdx.x & (WAVE - 1);
     const uint32_t wid = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const uint32_t nw = (gridDim.x * blockDim.x) >> 6;
@@ -1961,7 +2039,8 @@ hipError_t gvom_launch_fuse_stats(hipStream_t s, const FuseParams &P, const Fuse
     if (ntiles == 0) return hipSuccess;
     unsigned blocks = (ntiles + 3) / 4;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(k_fuse_stats, dim3(blocks), dim3(256), 0, s, P, KD, descs_dev, fstate, ftags, fmetrics);
+    if (descs_dev) hipLaunchKernelGGL(k_fuse_stats<true>, dim3(blocks), dim3(256), 0, s, P, KD, descs_dev, fstate, ftags, fmetrics);
+    else hipLaunchKernelGGL(k_fuse_stats<false>, dim3(blocks), dim3(256), 0, s, P, KD, descs_dev, fstate, ftags, fmetrics);
     return hipGetLastError();
 }
 
@@ -2148,7 +2227,7 @@ hipError_t gvom_launch_unpack(hipStream_t s, const ScanParams &P, const ShardUnp
 }
 
 hipError_t gvom_launch_encode(hipStream_t s, const ScanParams &P, uint32_t *hit, uint32_t *total, uint32_t *mh,
-                              int32_t *state, uint32_t *chit, uint32_t *ctotal, uint32_t *cminh, const uint32_t *tags,
+                              int32_t *state, uint16_t *code16, uint32_t *chit, uint32_t *ctotal, uint32_t *cminh, const uint32_t *tags,
                               uint32_t *counters, unsigned long long *host_flag, uint32_t seq, unsigned resident_blocks)
 {
     // units = quads (4 rows x 64 sx at one sz) that intersect the slab; one wave handles 2 quads per
@@ -2162,7 +2241,7 @@ hipError_t gvom_launch_encode(hipStream_t s, const ScanParams &P, uint32_t *hit,
     if (enc_blocks > enc_cap) enc_blocks = enc_cap;
     if (enc_blocks < 1) enc_blocks = 1;
     hipLaunchKernelGGL(k_encode, dim3(enc_blocks), dim3(256), 0, s, P, t_begin, t_end, hit, total, mh, state,
-                       chit, ctotal, cminh, tags, P.epoch, counters, host_flag, seq);
+                       code16, chit, ctotal, cminh, tags, P.epoch, counters, host_flag, seq);
     return hipGetLastError();
 }
 
@@ -2186,15 +2265,18 @@ hipError_t gvom_launch_fuse(hipStream_t s, const FuseParams &P, const FuseDescs 
 {
     const dim3 grid((P.xy + 63) / 64, P.sy_hi - P.sy_lo);
     if (grid.y == 0) return hipSuccess;
-    if (P.zc == 16 && (P.xy & 3) == 0 && !GVOM_DBG(P, 8))
-        hipLaunchKernelGGL(k_fuse4, grid, dim3(64 * P.nz), 0, s, P, KD, descs_dev, fstate, fhit,
-                           ftotal, fminh, ftags, blockcounts, height, inferred);
-    else if (P.zc <= 16)
-        hipLaunchKernelGGL(k_fuse<true>, grid, dim3(64 * P.nz), 0, s, P, KD, descs_dev, fstate, fhit,
-                           ftotal, fminh, ftags, blockcounts, height, inferred);
-    else
-        hipLaunchKernelGGL(k_fuse<false>, grid, dim3(64 * P.nz), 0, s, P, KD, descs_dev, fstate, fhit,
-                           ftotal, fminh, ftags, blockcounts, height, inferred);
+#define FUSE_LAUNCH(...) hipLaunchKernelGGL((__VA_ARGS__), grid, dim3(64 * P.nz), 0, s, P, KD, descs_dev, fstate, fhit, \
+                                          ftotal, fminh, ftags, blockcounts, height, inferred)
+    const bool mem = descs_dev != nullptr;
+    if (P.zc == 16 && (P.xy & 3) == 0 && !GVOM_DBG(P, 8)) {
+        if (P.nslots <= 2) { if (mem) FUSE_LAUNCH(k_fuse4<2, true>); else FUSE_LAUNCH(k_fuse4<2, false>); }
+        else { if (mem) FUSE_LAUNCH(k_fuse4<4, true>); else FUSE_LAUNCH(k_fuse4<4, false>); }
+    } else if (P.zc <= 16) {
+        if (mem) FUSE_LAUNCH(k_fuse<true, true>); else FUSE_LAUNCH(k_fuse<true, false>);
+    } else {
+        if (mem) FUSE_LAUNCH(k_fuse<false, true>); else FUSE_LAUNCH(k_fuse<false, false>);
+    }
+#undef FUSE_LAUNCH
     return hipGetLastError();
 }
 

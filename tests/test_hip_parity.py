@@ -106,6 +106,32 @@ def test_reference_statistics_attributes(gvom_mod):
         assert np.array_equal(g.last_combined_metrics.copy_to_host(), gc_)
 
 
+@pytest.mark.parametrize("site", ["combine", "scan"])
+def test_tile_epoch_renumbering_before_the_counter_wraps(gvom_mod, site):
+    """Tile epochs are 32-bit and advance twice per step (2^32 = ~3 days at 7.7 kHz).  Before the counter
+    can wrap, every live map is re-tagged with a small epoch and all other tags are zeroed: pushed to
+    just below the limit, a run with ring wrap + previous-map carry continues to match the oracle."""
+    params = (0.4, 0.2, 32, 16, 3, 0.5, 0.5, 0.5, 0.3, 2.0, 4.0, 1.0, 1, 1)
+    rng = np.random.default_rng(4)
+    g, w = gvom_mod.Gvom(*params), oracle.OracleGvom(*params)
+    for k in range(12):
+        if k == 4:
+            # 8 epochs used so far; the threshold is crossed by the next combine / the scan after it
+            g.set_tuning("epoch_bias", 0xFFFFFF00 - 2 * 4 - (3 if site == "combine" else 2))
+        ego = (0.45 * k, -0.3 * k, 0.04 * k)
+        pc = np.stack([rng.uniform(-5, 5, 3000) + ego[0], rng.uniform(-5, 5, 3000) + ego[1], rng.normal(-0.8, 0.3, 3000)], 1)
+        g.process_pointcloud(pc, ego); w.process_pointcloud(pc.copy(), ego)
+        a, b = g.combine_maps(), w.combine_maps()
+        for i in (0, 1, 2, 4):
+            assert np.array_equal(a[i], b[i]), (k, i)
+        assert np.allclose(a[3], b[3], rtol=0, atol=1e-5)
+        assert g.combined_cell_count_cpu == w.combined_cell_count_cpu
+        gd = g.read_dense(gvom_mod.GVOM_WHICH_FUSED)
+        wd = scenarios.dense_from_compact(w.combined_index_map, w.combined_hit_count, w.combined_total_count, w.combined_min_height)
+        for j in range(4):
+            assert np.array_equal(np.asarray(wd[j]), gd[j]), (k, j)
+
+
 def test_returned_arrays_outlive_the_mapper(gvom_mod):
     """combine_maps' arrays are views of a pinned buffer: they stay valid after the Gvom is gone, and the
     buffer is released when the last of them is collected (no leak per orphaned result)."""

@@ -14,7 +14,7 @@ hip = bench.Hip(); hip.set_device(0)
 params, scans = synth.config_inputs(name, n_scans=4)
 dev = [(hip.to_device(pc), pc.shape[0], pc.dtype, ego, tf) for (pc, ego, tf) in scans]
 g = gvom.Gvom(*params)
-settings = [("segs", 5, 16), ("segs", 4, 16), ("segs", 6, 16), ("segs", 5, 12), ("segs", 5, 24), ("segs", 3, 16)]
+settings = [("segs", int(v), 16) for v in (sys.argv[3].split(",") if len(sys.argv) > 3 else "2,3,4,5,6".split(","))]
 for kind, chunk, ep in settings:
     g.set_tuning("segs", chunk); g.set_tuning("period", ep)
     for k in range(30):
