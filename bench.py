@@ -264,6 +264,22 @@ def run_config(hip, name, steps, warmup, poses, full):
 
     b4, k = timed_blocks(step_occ, k, steps, 0.2)
     out["value_occupancy_api"] = n_pts * steps / _median(b4) / 1e6
+
+    # combine_maps_async (an extension of the reference's API): scan k+1 is handed over while the maps of
+    # combine k are still being stored to host memory; every step still delivers its four maps
+    pend = [None]
+
+    def step_async(k):
+        d, n, dt, ego, tf = dev[k % len(dev)]
+        g.process_pointcloud_device(d.value, n, dt, ego, tf)
+        maps = pend[0].result() if pend[0] is not None else None
+        pend[0] = g.combine_maps_async()
+        return maps
+
+    b5, k = timed_blocks(step_async, k, steps, 0.3)
+    pend[0].result()
+    out["value_async_combine"] = n_pts * steps / _median(b5) / 1e6
+    out["ms_per_step_async_combine"] = _median(b5) / steps * 1e3
     out["host_us"] = g.host_timing()
     # exact integer accounting for the roofline (algorithmic bytes), AFTER the timed regions:
     # the dense read-back allocates and frees 16*V bytes
@@ -341,8 +357,11 @@ def run_single(args):
         "ms_per_step_min": res["ms_per_step_min"], "ms_per_step_max": res["ms_per_step_max"], "blocks": res["blocks"],
         "value_host_f32": res["value_host_f32"], "value_ros_f64_tf": res["value_ros_f64_tf"],
         "value_occupancy_api": res["value_occupancy_api"],
+        "value_async_combine": res["value_async_combine"], "ms_per_step_async_combine": res["ms_per_step_async_combine"],
         "value_semantics": "value: cloud resident in HBM (driver contract); value_host_f32: host numpy in (gvom.py:110); "
-                           "value_ros_f64_tf: float64 host array + 4x4 transform, the unchanged gvom_ros.py:106-109 path",
+                           "value_ros_f64_tf: float64 host array + 4x4 transform, the unchanged gvom_ros.py:106-109 path; "
+                           "value_async_combine: combine_maps_async() (extension), the next scan traced while the maps "
+                           "of the pending combine are stored to host memory -- same maps, one step later",
         "stage_ms": res["stage_ms"], "host_us": res["host_us"],
         "sum_hit": res["sum_hit"], "sum_total": res["sum_total"], "cells": res["cells"],
         "roofline": roofline_of(alg, stages),

@@ -117,6 +117,13 @@ struct gvom_handle {
     int hs = 0;
     double *slope_x = nullptr, *slope_y = nullptr, *rough = nullptr, *guessed = nullptr;   // [sy][sx]
     hipStream_t own_stream = nullptr;                   // created by the library
+    // asynchronous combine (gvom_combine_begin / _end): k_map2d runs on a second stream, so the next
+    // scan's k_trace / k_encode (instruction-bound) overlap its PCIe-bound stores
+    hipStream_t stream_b = nullptr;
+    hipEvent_t ev_fused = nullptr, ev_mapped = nullptr, ev_done = nullptr;
+    std::mutex combine_mu;                              // one combine call at a time (taken before `mu`)
+    bool pending_combine = false;                       // begun, not ended
+    bool mapped_unjoined = false;                       // ev_mapped recorded; the main stream has not waited on it
     void *out_host = nullptr;                           // pinned, device-mapped staging for the 4 outputs
     char *out_host_dev = nullptr;                       // device view of out_host (zero-copy target)
     uint32_t scan_seq = 0;                              // sequence number of the {seq,count} flag
@@ -272,6 +279,10 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, b
     CK(hipSetDevice(device_id));
     CK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     h->own_stream = h->stream;
+    CK(hipStreamCreateWithFlags(&h->stream_b, hipStreamNonBlocking));
+    CK(hipEventCreateWithFlags(&h->ev_fused, hipEventDisableTiming));
+    CK(hipEventCreateWithFlags(&h->ev_mapped, hipEventDisableTiming));
+    CK(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
     // accumulators are micro-tiled in 4x4 (x,y) patches (gvom_internal.h "ACCUMULATOR LAYOUT")
     // row pitch of the patch rows, padded (GVOM_ACC_PAD lines of 64 B) so that the z levels of one
     // (x, y) patch -- xy*16 bytes apart, a multiple of 4 KiB for xy = 256 -- do not all map to the
@@ -364,6 +375,25 @@ void scan_abort(gvom_handle *h)
 // is re-tagged with a small epoch and every other tag is zeroed, so a stale tile can never collide
 // with a future epoch.  (2^32 epochs = ~3 days at 7.7 kHz.)
 int renumber_epochs(gvom_handle *h);
+
+// host waits for everything the handle has enqueued (both streams)
+hipError_t sync_streams(gvom_handle *h)
+{
+    if (h->mapped_unjoined) {
+        hipError_t e = hipStreamSynchronize(h->stream_b);
+        if (e != hipSuccess) return e;
+        h->mapped_unjoined = false;
+    }
+    return hipStreamSynchronize(h->stream);
+}
+// main stream waits (on the device) for a k_map2d still running on the second stream: it reads what
+// the next fusion writes (fused double buffer, height maps, block counts)
+hipError_t join_map_stream(gvom_handle *h)
+{
+    if (!h->mapped_unjoined) return hipSuccess;
+    h->mapped_unjoined = false;
+    return hipStreamWaitEvent(h->stream, h->ev_mapped, 0);
+}
 
 // Scan kernels up to (not including) the commit.  `dev_pts` is device memory.
 // Waits until the GPU has published sequence number `seq` in the 64-bit host-mapped word `flag` (high
@@ -520,7 +550,7 @@ void scan_commit(gvom_handle *h, bool accept)
 
 int renumber_epochs(gvom_handle *h)
 {
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, sync_streams(h));
     uint32_t next = 0;
     for (size_t k = 0; k < h->slots.size(); ++k) {
         Slot &sl = h->slots[k];
@@ -535,7 +565,7 @@ int renumber_epochs(gvom_handle *h)
         f.epoch = fresh;
     }
     h->epoch = next;
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, sync_streams(h));
     return GVOM_OK;
 }
 
@@ -610,6 +640,7 @@ int fuse_impl(gvom_handle *h)
     if (!last.filled) return GVOM_EMPTY_BUFFER;                        // gvom.py:179-181
     // before any map descriptor below copies an epoch
     if (h->epoch >= 0xFFFFFF00u) { int rc0 = renumber_epochs(h); if (rc0) return rc0; }
+    HIPCHK(h, join_map_stream(h));
     const int nxt = h->has_combined ? 1 - h->cur : 0;
     Fused &F = h->fused[nxt];
     const Fused *prev = (h->has_combined && h->fused[h->cur].valid) ? &h->fused[h->cur] : nullptr;
@@ -692,8 +723,10 @@ int fuse_impl(gvom_handle *h)
 // 2-D maps (k_map2d) from height/inferred of the whole window (all rows must be present).
 // gathered: sharded run -- every row of the interleaved height buffer (heights + owner-computed
 // positive densities) has been all-gathered and this rank computes ALL rows of the outputs.
-int map2d_impl(gvom_handle *h, bool gathered, bool publish, char *out_dev, bool yx, const double *occ = nullptr)
+int map2d_impl(gvom_handle *h, bool gathered, bool publish, char *out_dev, bool yx, const double *occ = nullptr,
+               hipStream_t on = nullptr)
 {
+    const hipStream_t ms = on ? on : h->stream;
     const gvom_params &p = h->prm;
     const Fused &F = h->fused[h->cur];
     Map2dParams P;
@@ -717,13 +750,13 @@ int map2d_impl(gvom_handle *h, bool gathered, bool publish, char *out_dev, bool 
     const size_t n2 = h->cells2d;
     int32_t *o_pos = (int32_t *)out_dev, *o_neg = o_pos + n2, *o_vis = o_neg + n2;
     double *o_rgh = (double *)(o_vis + n2);
-    if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[6], h->stream));
-    HIPCHK(h, gvom_launch_map2d(h->stream, P, F.state, F.tags, (const uint32_t *)F.hit.p,
+    if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[6], ms));
+    HIPCHK(h, gvom_launch_map2d(ms, P, F.state, F.tags, (const uint32_t *)F.hit.p,
                                 (const uint32_t *)F.total.p, h->height, h->inferred, h->slope_x,
                                 h->slope_y, h->rough, h->guessed, o_pos, o_neg, o_rgh, o_vis,
                                 h->blockcounts, h->fuse_blocks,
                                 publish ? (unsigned long long *)(h->counters_host_dev + 2) : nullptr));
-    if (h->profiling) { HIPCHK(h, hipEventRecord(h->ev[7], h->stream)); h->ev_map = true; }
+    if (h->profiling) { HIPCHK(h, hipEventRecord(h->ev[7], ms)); h->ev_map = true; }
     h->maps_valid = true;
     return GVOM_OK;
 }
@@ -764,9 +797,31 @@ void collect_stage_ms(gvom_handle *h)
     (void)hipGetLastError();               // never leave a sticky error behind for the launchers
 }
 
+// Waits for the combine's kernels with the handle mutex RELEASED (a second thread -- the ROS node's
+// cloud callback -- can hand the next scan over meanwhile: its kernels queue up behind k_map2d and the
+// GPU does not idle between the steps); other combine calls are held off by combine_mu / pending_combine.
+int finish_combine(gvom_handle *h, std::unique_lock<std::mutex> &lk)
+{
+    HIPCHK(h, hipEventRecord(h->ev_done, h->stream));
+    h->pending_combine = true;
+    lk.unlock();
+    const hipError_t e = hipEventSynchronize(h->ev_done);
+    lk.lock();
+    h->pending_combine = false;
+    HIPCHK(h, e);
+    Fused &F = h->fused[h->cur];
+    unsigned long long c;
+    memcpy(&c, h->counters_host + 2, 8);
+    F.count = (int64_t)c;
+    h->combined_cell_count = F.count;
+    collect_stage_ms(h);
+    return GVOM_OK;
+}
+
+// the split (sharded) combine calls: plain wait under the handle mutex
 int finish_combine(gvom_handle *h)
 {
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, sync_streams(h));
     Fused &F = h->fused[h->cur];
     unsigned long long c;
     memcpy(&c, h->counters_host + 2, 8);
@@ -797,6 +852,7 @@ VIS void gvom_destroy(gvom_t *h)
 {
     if (!h) return;
     hipSetDevice(h->device);
+    if (h->stream_b) hipStreamSynchronize(h->stream_b);
     if (h->stream) hipStreamSynchronize(h->stream);
     auto fb = [](Buf &b) { if (b.p) hipFree(b.p); b.p = nullptr; b.bytes = 0; };
     hipFree(h->hit); hipFree(h->total); hipFree(h->mh);
@@ -813,6 +869,10 @@ VIS void gvom_destroy(gvom_t *h)
     hipFree(h->rough); hipFree(h->guessed);
     if (h->out_host) hipHostFree(h->out_host);
     for (auto &e : h->ev) if (e) hipEventDestroy(e);
+    if (h->ev_fused) hipEventDestroy(h->ev_fused);
+    if (h->ev_mapped) hipEventDestroy(h->ev_mapped);
+    if (h->ev_done) hipEventDestroy(h->ev_done);
+    if (h->stream_b) hipStreamDestroy(h->stream_b);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     delete h;
 }
@@ -958,7 +1018,9 @@ VIS int gvom_combine_maps(gvom_t *h, double origin_world[3], int32_t *positive, 
                           double *roughness, int32_t *visibility)
 {
     if (!h || h->sharded) return GVOM_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::lock_guard<std::mutex> ck(h->combine_mu);
+    std::unique_lock<std::mutex> lk(h->mu);
+    if (h->pending_combine) { h->err = "a combine begun with gvom_combine_begin has not been ended"; return GVOM_ERR_INVALID; }
     HIPCHK(h, hipSetDevice(h->device));
     double t0 = now_ns();
     int rc = fuse_impl(h);
@@ -967,7 +1029,7 @@ VIS int gvom_combine_maps(gvom_t *h, double origin_world[3], int32_t *positive, 
     const size_t n2 = h->cells2d;
     char *stage = (char *)h->out_host;
     HT(h, 2, t0);                                        // combine: launches
-    if ((rc = finish_combine(h))) return rc;
+    if ((rc = finish_combine(h, lk))) return rc;
     HT(h, 3, t0);                                        // combine: wait
     if (positive) memcpy(positive, stage, n2 * 4);
     if (negative) memcpy(negative, stage + n2 * 4, n2 * 4);
@@ -1006,7 +1068,7 @@ VIS int gvom_output_buffer_free(gvom_t *h, void *host_ptr)
     if (!h || !host_ptr) return GVOM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, sync_streams(h));
     HIPCHK(h, hipHostFree(host_ptr));
     return GVOM_OK;
 }
@@ -1014,7 +1076,9 @@ VIS int gvom_output_buffer_free(gvom_t *h, void *host_ptr)
 VIS int gvom_combine_maps_into(gvom_t *h, double origin_world[3], void *pinned_out)
 {
     if (!h || !pinned_out || h->sharded) return GVOM_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::lock_guard<std::mutex> ck(h->combine_mu);
+    std::unique_lock<std::mutex> lk(h->mu);
+    if (h->pending_combine) { h->err = "a combine begun with gvom_combine_begin has not been ended"; return GVOM_ERR_INVALID; }
     HIPCHK(h, hipSetDevice(h->device));
     double t0 = now_ns();
     int rc = fuse_impl(h);
@@ -1023,7 +1087,7 @@ VIS int gvom_combine_maps_into(gvom_t *h, double origin_world[3], void *pinned_o
     HIPCHK(h, hipHostGetDevicePointer((void **)&dev, pinned_out, 0));
     if ((rc = map2d_impl(h, false, true, dev, true))) return rc;
     HT(h, 2, t0);
-    if ((rc = finish_combine(h))) return rc;
+    if ((rc = finish_combine(h, lk))) return rc;
     HT(h, 3, t0);
     if (origin_world) {
         const Fused &F = h->fused[h->cur];
@@ -1043,7 +1107,9 @@ VIS int gvom_combine_occupancy_into(gvom_t *h, double origin_world[3], void *pin
                                     double density_threshold, double min_roughness, double max_roughness)
 {
     if (!h || !pinned_out || h->sharded) return GVOM_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::lock_guard<std::mutex> ck(h->combine_mu);
+    std::unique_lock<std::mutex> lk(h->mu);
+    if (h->pending_combine) { h->err = "a combine begun with gvom_combine_begin has not been ended"; return GVOM_ERR_INVALID; }
     HIPCHK(h, hipSetDevice(h->device));
     double t0 = now_ns();
     int rc = fuse_impl(h);
@@ -1053,10 +1119,64 @@ VIS int gvom_combine_occupancy_into(gvom_t *h, double origin_world[3], void *pin
     const double occ[3] = {density_threshold, min_roughness, max_roughness};
     if ((rc = map2d_impl(h, false, true, dev, true, occ))) return rc;
     HT(h, 2, t0);
-    if ((rc = finish_combine(h))) return rc;
+    if ((rc = finish_combine(h, lk))) return rc;
     HT(h, 3, t0);
     if (origin_world) {
         const Fused &F = h->fused[h->cur];
+        origin_world[0] = (double)F.origin[0] * h->prm.xy_resolution;
+        origin_world[1] = (double)F.origin[1] * h->prm.xy_resolution;
+        origin_world[2] = (double)F.origin[2] * h->prm.z_resolution;
+    }
+    return GVOM_OK;
+}
+
+// ---- asynchronous combine --------------------------------------------------------------------
+// gvom_combine_begin = gvom_combine_maps_into / gvom_combine_occupancy_into (occ != NULL: its three
+// thresholds) without the wait: the fusion is enqueued on the handle's stream, k_map2d on a second
+// stream behind it.  The caller may hand the next scan to gvom_process_pointcloud* right away: its
+// k_trace / k_encode run WHILE k_map2d stores the maps over PCIe (the next fusion waits for it on the
+// device).  gvom_combine_end waits for the maps (handle mutex released while it waits) and completes
+// the call; `pinned_out` must not be read before it returns.  One combine may be pending at a time.
+VIS int gvom_combine_begin(gvom_t *h, void *pinned_out, const double *occ)
+{
+    if (!h || !pinned_out || h->sharded) return GVOM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (h->pending_combine) { h->err = "a combine begun with gvom_combine_begin has not been ended"; return GVOM_ERR_INVALID; }
+    HIPCHK(h, hipSetDevice(h->device));
+    double t0 = now_ns();
+    int rc = fuse_impl(h);
+    if (rc) return rc;
+    char *dev = nullptr;
+    HIPCHK(h, hipHostGetDevicePointer((void **)&dev, pinned_out, 0));
+    HIPCHK(h, hipEventRecord(h->ev_fused, h->stream));
+    HIPCHK(h, hipStreamWaitEvent(h->stream_b, h->ev_fused, 0));
+    if ((rc = map2d_impl(h, false, true, dev, true, occ, h->stream_b))) return rc;
+    HIPCHK(h, hipEventRecord(h->ev_mapped, h->stream_b));
+    h->mapped_unjoined = true;
+    h->pending_combine = true;
+    HT(h, 2, t0);
+    return GVOM_OK;
+}
+
+VIS int gvom_combine_end(gvom_t *h, double origin_world[3])
+{
+    if (!h) return GVOM_ERR_INVALID;
+    std::unique_lock<std::mutex> lk(h->mu);
+    if (!h->pending_combine) { h->err = "gvom_combine_end without gvom_combine_begin"; return GVOM_ERR_INVALID; }
+    HIPCHK(h, hipSetDevice(h->device));
+    double t0 = now_ns();
+    lk.unlock();                                           // process_pointcloud may run meanwhile
+    const hipError_t e = hipEventSynchronize(h->ev_mapped);
+    lk.lock();
+    HIPCHK(h, e);
+    h->pending_combine = false;
+    Fused &F = h->fused[h->cur];
+    unsigned long long c;
+    memcpy(&c, h->counters_host + 2, 8);
+    F.count = (int64_t)c;
+    h->combined_cell_count = F.count;
+    HT(h, 3, t0);
+    if (origin_world) {
         origin_world[0] = (double)F.origin[0] * h->prm.xy_resolution;
         origin_world[1] = (double)F.origin[1] * h->prm.xy_resolution;
         origin_world[2] = (double)F.origin[2] * h->prm.z_resolution;
@@ -1118,7 +1238,7 @@ VIS int gvom_sync(gvom_t *h)
     if (!h) return GVOM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, sync_streams(h));
     collect_stage_ms(h);
     return GVOM_OK;
 }
@@ -1210,7 +1330,7 @@ VIS int gvom_read_dense(gvom_t *h, int which, int32_t *state, int32_t *hit, int3
     hipError_t e = gvom_launch_read_dense(h->stream, h->prm.xy_size, h->prm.z_size, om, h->sy_lo, h->sy_hi,
                                           tg, ep, st, ch, ct, cm,
                                           tmp, tmp + V, tmp + 2 * V, (float *)(tmp + 3 * V), nullptr);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) e = sync_streams(h);
     if (e == hipSuccess && state) e = hipMemcpy(state, tmp, V * 4, hipMemcpyDeviceToHost);
     if (e == hipSuccess && hit) e = hipMemcpy(hit, tmp + V, V * 4, hipMemcpyDeviceToHost);
     if (e == hipSuccess && total) e = hipMemcpy(total, tmp + 2 * V, V * 4, hipMemcpyDeviceToHost);
@@ -1254,7 +1374,7 @@ VIS int gvom_read_rows(gvom_t *h, int which, int32_t *rows_dense)
                  (int)floor_mod(org[2], h->prm.z_size)};
     hipError_t e = gvom_launch_read_dense(h->stream, h->prm.xy_size, h->prm.z_size, om, h->sy_lo, h->sy_hi, tg, ep, st,
                                           nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, tmp);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) e = sync_streams(h);
     if (e == hipSuccess) e = hipMemcpy(rows_dense, tmp, V * 4, hipMemcpyDeviceToHost);
     hipFree(tmp);
     HIPCHK(h, e);
@@ -1285,7 +1405,7 @@ VIS int gvom_gather_metrics(gvom_t *h, int which, const int32_t *rows, int64_t n
     HIPCHK(h, hipMalloc((void **)&tmp, (size_t)n * 4 + (size_t)n * 10 * esz));
     hipError_t e = hipMemcpy(tmp + (size_t)n * 10 * esz, rows, (size_t)n * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = gvom_launch_gather_rows10(h->stream, f64, src, (const int32_t *)(tmp + (size_t)n * 10 * esz), n, tmp);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) e = sync_streams(h);
     if (e == hipSuccess) e = hipMemcpy(out, tmp, (size_t)n * 10 * esz, hipMemcpyDeviceToHost);
     hipFree(tmp);
     HIPCHK(h, e);
@@ -1305,7 +1425,7 @@ VIS int gvom_read_map2d(gvom_t *h, int which2d, double *out)
     HIPCHK(h, hipMalloc((void **)&tmp, h->cells2d * 8));
     hipError_t e = gvom_launch_unwrap_f64(h->stream, h->prm.xy_size, (int)floor_mod(F.origin[0], h->prm.xy_size),
                                           (int)floor_mod(F.origin[1], h->prm.xy_size), src, stride, tmp);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) e = sync_streams(h);
     if (e == hipSuccess) e = hipMemcpy(out, tmp, h->cells2d * 8, hipMemcpyDeviceToHost);
     hipFree(tmp);
     HIPCHK(h, e);
@@ -1348,7 +1468,7 @@ static int debug_maps(gvom_t *h, float *out7, float *out3)
                                             h->prm.xy_resolution, h->prm.z_resolution, h->height, h->hs, h->rough,
                                             h->slope_x, h->slope_y, out7 ? tmp : nullptr, h->guessed,
                                             out3 ? tmp : nullptr);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) e = sync_streams(h);
     if (e == hipSuccess) e = hipMemcpy(out7 ? out7 : out3, tmp, n2 * (out7 ? 7 : 3) * 4, hipMemcpyDeviceToHost);
     hipFree(tmp);
     HIPCHK(h, e);
@@ -1391,7 +1511,7 @@ VIS int gvom_debug_voxel_eigen(gvom_t *h, float *out, float *eigen, int64_t max_
                                     (const float *)F.metrics.p, tmp, tmp_e, max_rows,
                                     (unsigned long long *)(h->counters + 12));
     unsigned long long cnt = 0;
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) e = sync_streams(h);
     if (e == hipSuccess) e = hipMemcpy(&cnt, h->counters + 12, 8, hipMemcpyDeviceToHost);
     const int64_t nrows = (int64_t)cnt < max_rows ? (int64_t)cnt : max_rows;
     if (e == hipSuccess && nrows > 0) e = hipMemcpy(out, tmp, (size_t)nrows * 32, hipMemcpyDeviceToHost);
@@ -1440,7 +1560,7 @@ VIS int gvom_last_stage_ms(gvom_t *h, float ms[GVOM_N_STAGES])
     std::lock_guard<std::mutex> lk(h->mu);
     if (h->ev_scan || h->ev_fuse || h->ev_map) {
         HIPCHK(h, hipSetDevice(h->device));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, sync_streams(h));
         collect_stage_ms(h);
     }
     for (int k = 0; k < GVOM_N_STAGES; ++k) ms[k] = h->stage_ms[k];

@@ -1080,6 +1080,12 @@ __global__ __launch_bounds__(1024) void k_fuse(const FuseParams P, const FuseDes
 // saturating packed adds; the previous fused map through its 32-bit states, loaded alongside and
 // folded last.  A saturated sum marks a CANDIDATE: occupied in some slot, or more than 65534 passes
 // (the sensor's own voxel); the per-voxel path below settles which from the 32-bit states.
+#ifndef FUSE_NG
+#define FUSE_NG 4
+#endif
+#ifndef FUSE_TW
+#define FUSE_TW 4
+#endif
 template <int SPR, bool MEM>
 __global__ __launch_bounds__(1024) void k_fuse4(const FuseParams P, const FuseDescs KD,
                                                 const MapDesc *__restrict__ descs_mem,
@@ -1131,12 +1137,13 @@ __global__ __launch_bounds__(1024) void k_fuse4(const FuseParams P, const FuseDe
         const int zl = (cc_l * P.nz + w) * P.zc + k_l;      // chunks are dealt round-robin to the waves (see below)
         const bool valid_l = cc_l < P.cpw && k_l < P.zc && zl < P.zs;
         const uint32_t tl = tbase + (uint32_t)wrap_add(valid_l ? zl : 0, P.om[2], P.zs) * P.nseg;
-        for (int s0 = 0; s0 < nsrc; s0 += 4) {
-            uint32_t tv[4];
+        constexpr int TW = SPR == 2 ? 4 : FUSE_TW;
+        for (int s0 = 0; s0 < nsrc; s0 += TW) {
+            uint32_t tv[TW];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) tv[j] = ((gptr_u32)descs[min(s0 + j, nsrc - 1)].tags)[tl];
+            for (int j = 0; j < TW; ++j) tv[j] = ((gptr_u32)descs[min(s0 + j, nsrc - 1)].tags)[tl];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < TW; ++j) {
                 const unsigned long long m = GVOM_DBG(P, 4) ? 0ull : __ballot(valid_l && tv[j] == descs[min(s0 + j, nsrc - 1)].epoch);
                 if (lane == 0 && s0 + j < nsrc) s_live[w][s0 + j] = m;
             }
@@ -1275,7 +1282,7 @@ __global__ __launch_bounds__(1024) void k_fuse4(const FuseParams P, const FuseDe
                 uint32_t hh = 0, tt = 0, mm = 0x3f800000u;
                 bool slot_occ = false;                                        // occupied in some ring slot
                 int cnt = -1, stp = -1;                                        // exact free count of the slots; the previous map's state
-                constexpr int NG = 4;
+                constexpr int NG = SPR == 2 ? 4 : FUSE_NG;
                 for (int s0 = 0; s0 < nsrc; s0 += NG) {
                     int st[NG];
                     bool ok[NG];

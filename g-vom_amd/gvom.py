@@ -120,6 +120,8 @@ ABI = [
     ("gvom_read_dense", _I, [_P, _I, _P, _P, _P, _P, _P, ctypes.POINTER(_I64)]),
     ("gvom_read_map2d", _I, [_P, _I, _P]),
     ("gvom_last_stage_ms", _I, [_P, ctypes.POINTER(ctypes.c_float * N_STAGES)]),
+    ("gvom_combine_begin", _I, [_P, _P, _P]),
+    ("gvom_combine_end", _I, [_P, _P]),
     ("gvom_set_profiling", _I, [_P, _I]),
     ("gvom_host_timing", _I, [_P, ctypes.POINTER(ctypes.c_double * 8)]),
     ("gvom_set_tuning", _I, [_P, ctypes.c_char_p, _I]),
@@ -238,6 +240,29 @@ def transform_from_translation_rotation(translation, rotation):
     t = np.identity(4)
     t[:3, 3] = translation[:3]
     return np.dot(t, r)
+
+
+class _PendingMaps(object):
+    """A combine begun with Gvom.combine_maps_async(); result() completes it (once)."""
+
+    def __init__(self, owner, holder):
+        self._owner, self._holder, self._out, self._done = owner, holder, None, holder is None
+
+    def result(self):
+        if not self._done:
+            g = self._owner
+            xy = g.xy_size
+            n2 = xy * xy
+            origin = np.zeros(3, np.float64)
+            g._check(g._lib.gvom_combine_end(g._h, _ptr(origin)))
+            raw = np.asarray(self._holder)
+            self._out = (origin,
+                         np.ndarray((xy, xy), np.int32, raw, 0, (4, 4 * xy)),
+                         np.ndarray((xy, xy), np.int32, raw, 4 * n2, (4, 4 * xy)),
+                         np.ndarray((xy, xy), np.float64, raw, 12 * n2, (8, 8 * xy)),
+                         np.ndarray((xy, xy), np.int32, raw, 8 * n2, (4, 4 * xy)))
+            self._done, self._holder = True, None
+        return self._out
 
 
 class Gvom(object):
@@ -411,6 +436,26 @@ class Gvom(object):
             print("[WARNING] The map buffer is empty, nothing will happen!")
             return None
         return out
+
+    def combine_maps_async(self):
+        """combine_maps() split in two (an extension; the reference's call is synchronous): enqueues the
+        combine and returns a handle at once; `.result()` waits and returns what combine_maps() returns.
+        Hand the next scan to process_pointcloud*() in between: its ray tracing runs on the GPU while the
+        maps of this combine are written to host memory.  One combine may be pending at a time."""
+        xy = self.xy_size
+        n2 = xy * xy
+        if self._out_pool.free:
+            ptr = self._out_pool.free.pop()
+        else:
+            p = ctypes.c_void_p()
+            self._check(self._lib.gvom_output_buffer_alloc(self._h, ctypes.byref(p)))
+            ptr = p.value
+        holder = _PinnedOutput(self._out_pool, ptr, n2 * 20)
+        rc = self._check(self._lib.gvom_combine_begin(self._h, ctypes.c_void_p(ptr), None))
+        if rc == GVOM_EMPTY_BUFFER:
+            print("[WARNING] The map buffer is empty, nothing will happen!")
+            return _PendingMaps(self, None)
+        return _PendingMaps(self, holder)
 
     def combine_maps_occupancy(self, density_threshold=50, min_roughness=-10, max_roughness=0):
         """combine_maps() fused with the post-processing the ROS node applies to its result

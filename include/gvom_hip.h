@@ -152,6 +152,18 @@ int gvom_combine_maps_into(gvom_t *h, double origin_world[3], void *pinned_out);
 int gvom_combine_occupancy_into(gvom_t *h, double origin_world[3], void *pinned_out,
                                 double density_threshold, double min_roughness, double max_roughness);
 
+/* Asynchronous combine (an extension: the reference's combine_maps, gvom.py:177-354, is synchronous).
+ * gvom_combine_begin enqueues what gvom_combine_maps_into (occ == NULL) or gvom_combine_occupancy_into
+ * (occ = {density_threshold, min_roughness, max_roughness}) computes and returns without waiting;
+ * gvom_combine_end waits for the maps and completes the call (the fused cell count, origin_world).
+ * Between the two the caller may hand the NEXT scan to gvom_process_pointcloud*: its kernels run while
+ * the maps of this combine are stored to host memory (k_map2d runs on a second stream; the next fusion
+ * waits for it on the device).  `pinned_out` must not be read before gvom_combine_end has returned.
+ * One combine may be pending per handle; the synchronous combine entry points return GVOM_ERR_INVALID
+ * while one is.  Results are those of the synchronous calls. */
+int gvom_combine_begin(gvom_t *h, void *pinned_out, const double *occ);
+int gvom_combine_end(gvom_t *h, double origin_world[3]);
+
 /* --- one map sharded over the GPUs of a node (one rank = one process = one GPU) -------------------
  * No counterpart in the reference (it has no multi-GPU path); semantics = SURVEY 8(e):
  * the rays are data-parallel, the per-voxel accumulators (hit / total: int32 sum, min-height: f32 min)

@@ -132,6 +132,87 @@ def test_tile_epoch_renumbering_before_the_counter_wraps(gvom_mod, site):
             assert np.array_equal(np.asarray(wd[j]), gd[j]), (k, j)
 
 
+def test_asynchronous_combine_overlapped_with_the_next_scan(gvom_mod):
+    """combine_maps_async(): the next scan is processed while the maps of the pending combine are still
+    being computed / stored (k_map2d on the second stream).  Every result equals the synchronous
+    mapper's, over a moving window with ring wrap; misuse is refused."""
+    params = (0.4, 0.2, 64, 32, 3, 0.5, 0.5, 0.5, 0.3, 2.0, 4.0, 1.0, 1, 1)
+    rng = np.random.default_rng(11)
+    a, b = gvom_mod.Gvom(*params), gvom_mod.Gvom(*params)
+    assert b.combine_maps_async().result() is None                 # empty ring
+    pending, want = None, None
+    for k in range(10):
+        ego = (0.45 * k, -0.3 * k, 0.04 * k)
+        pc = np.stack([rng.uniform(-11, 11, 20000) + ego[0], rng.uniform(-11, 11, 20000) + ego[1],
+                       rng.normal(-0.8, 0.4, 20000)], 1).astype(np.float32)
+        a.process_pointcloud(pc, ego)
+        b.process_pointcloud(pc, ego)                              # runs while combine k-1 is pending
+        if pending is not None:
+            got = pending.result()
+            assert pending.result() is got                         # idempotent
+            for i in range(5):
+                assert np.array_equal(got[i], want[i]), (k, i)
+        want = a.combine_maps()
+        pending = b.combine_maps_async()
+        with pytest.raises(Exception):
+            b.combine_maps()                                       # one combine at a time
+        with pytest.raises(Exception):
+            b.combine_maps_async()
+    got = pending.result()
+    for i in range(5):
+        assert np.array_equal(got[i], want[i])
+    assert b.combined_cell_count_cpu == a.combined_cell_count_cpu
+    ad, bd = a.read_dense(gvom_mod.GVOM_WHICH_FUSED), b.read_dense(gvom_mod.GVOM_WHICH_FUSED)
+    for j in range(4):
+        assert np.array_equal(ad[j], bd[j])
+    # after the pending combine is ended the synchronous call works again
+    assert b.combine_maps() is not None
+
+
+def test_scans_from_a_second_thread_while_a_combine_waits(gvom_mod):
+    """The ROS node calls process_pointcloud and combine_maps from two callback threads
+    (gvom_ros.py:44-51).  combine_maps waits for its maps with the handle released, so scans keep being
+    accepted; no call is lost, nothing deadlocks, and once both threads are done the map is the one a
+    sequential run of the same scans gives (the fusion only depends on the scans in the ring)."""
+    import threading
+    params = (0.4, 0.2, 64, 32, 3, 0.5, 0.5, 0.5, 0.3, 2.0, 4.0, 1.0, 1, 1)
+    rng = np.random.default_rng(12)
+    scans = []
+    for k in range(40):
+        ego = (0.1 * k, 0.0, 0.0)
+        scans.append((np.stack([rng.uniform(-11, 11, 20000) + ego[0], rng.uniform(-11, 11, 20000),
+                                rng.normal(-0.8, 0.4, 20000)], 1).astype(np.float32), ego))
+    g, ref = gvom_mod.Gvom(*params), gvom_mod.Gvom(*params)
+    combines, errors = [0], []
+
+    def scanner():
+        try:
+            for pc, ego in scans:
+                g.process_pointcloud(pc, ego)
+        except Exception as exc:                                      # pragma: no cover
+            errors.append(exc)
+
+    def combiner():
+        try:
+            while t1.is_alive():
+                if g.combine_maps() is not None:
+                    combines[0] += 1
+        except Exception as exc:                                      # pragma: no cover
+            errors.append(exc)
+
+    t1 = threading.Thread(target=scanner); t2 = threading.Thread(target=combiner)
+    t1.start(); t2.start(); t1.join(60); t2.join(60)
+    assert not t1.is_alive() and not t2.is_alive() and not errors, errors
+    assert combines[0] > 0
+    for pc, ego in scans:
+        ref.process_pointcloud(pc, ego)
+    # the previous fused map enters a combine (gvom.py:972-997), so only ring contents are compared
+    for slot in range(params[4]):
+        a, b = g.read_dense(slot), ref.read_dense(slot)
+        for j in range(4):
+            assert np.array_equal(a[j], b[j]), (slot, j)
+
+
 def test_returned_arrays_outlive_the_mapper(gvom_mod):
     """combine_maps' arrays are views of a pinned buffer: they stay valid after the Gvom is gone, and the
     buffer is released when the last of them is collected (no leak per orphaned result)."""
