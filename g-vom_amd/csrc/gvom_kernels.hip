@@ -1080,12 +1080,10 @@ __global__ __launch_bounds__(1024) void k_fuse(const FuseParams P, const FuseDes
 // saturating packed adds; the previous fused map through its 32-bit states, loaded alongside and
 // folded last.  A saturated sum marks a CANDIDATE: occupied in some slot, or more than 65534 passes
 // (the sensor's own voxel); the per-voxel path below settles which from the 32-bit states.
-#ifndef FUSE_NG
-#define FUSE_NG 4
-#endif
-#ifndef FUSE_TW
-#define FUSE_TW 4
-#endif
+// sources per round trip of the tag phase / of the per-voxel path for rings longer than 2 (measured on
+// c3 / m256b8: 12 / 12 -> 36.6 / 39.9 us, 4 / 4 -> 39.7 / 43.8)
+#define FUSE_NG 12
+#define FUSE_TW 12
 template <int SPR, bool MEM>
 __global__ __launch_bounds__(1024) void k_fuse4(const FuseParams P, const FuseDescs KD,
                                                 const MapDesc *__restrict__ descs_mem,
