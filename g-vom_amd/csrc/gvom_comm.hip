@@ -110,6 +110,9 @@ extern "C" {
 // name: the same string on every rank of the communicator and unique to it on the node (e.g.
 // "gvom_<master port>"); rank 0 creates /dev/shm/<name>, the others wait for it.  device: the HIP
 // device this rank's handle lives on.  world == 1 is allowed (collectives degenerate to copies).
+// device < 0: HOST-ONLY communicator -- the shared-memory rendezvous and gvom_comm_exchange_host /
+// gvom_comm_barrier without RCCL or any HIP call (the CPU tests exercise the multi-process rendezvous
+// with it); the device collectives return GVOM_ERR_INVALID on it.
 VIS int gvom_comm_create(int rank, int world, int device, const char *name, gvom_comm_t **out)
 {
     if (!out || !name || world < 1 || world > GVOM_COMM_MAX_RANKS || rank < 0 || rank >= world) return GVOM_ERR_INVALID;
@@ -123,8 +126,11 @@ VIS int gvom_comm_create(int rank, int world, int device, const char *name, gvom
         delete c;
         return code;
     };
-    if (!c->rccl.load(c->err)) return fail(c->err, GVOM_ERR_NO_DEVICE);
-    if (hipSetDevice(device) != hipSuccess) return fail("hipSetDevice failed", GVOM_ERR_NO_DEVICE);
+    const bool host_only = device < 0;
+    if (!host_only) {
+        if (!c->rccl.load(c->err)) return fail(c->err, GVOM_ERR_NO_DEVICE);
+        if (hipSetDevice(device) != hipSuccess) return fail("hipSetDevice failed", GVOM_ERR_NO_DEVICE);
+    }
     if (rank == 0) {
         shm_unlink(c->shm_name.c_str());                               // a stale segment of a crashed run
         int fd = shm_open(c->shm_name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
@@ -136,7 +142,7 @@ VIS int gvom_comm_create(int rank, int world, int device, const char *name, gvom
         memset((void *)c->seg, 0, sizeof(Segment));
         c->seg->world = (uint32_t)world;
         c->seg->created_s = wall_s();
-        if (c->rccl.GetUniqueId(&c->seg->id) != ncclSuccess) return fail("ncclGetUniqueId failed", GVOM_ERR_HIP);
+        if (!host_only && c->rccl.GetUniqueId(&c->seg->id) != ncclSuccess) return fail("ncclGetUniqueId failed", GVOM_ERR_HIP);
         c->seg->id_ready.store(1, std::memory_order_release);
         c->seg->magic.store(0x47564f4du, std::memory_order_release);
     } else {
@@ -167,10 +173,12 @@ VIS int gvom_comm_create(int rank, int world, int device, const char *name, gvom
         }
         if (c->seg->world != (uint32_t)world) return fail("world size differs from rank 0's", GVOM_ERR_INVALID);
     }
-    ncclUniqueId id;
-    memcpy(&id, &c->seg->id, sizeof id);
-    ncclResult_t r = c->rccl.CommInitRank(&c->nccl, world, id, rank);
-    if (r != ncclSuccess) return fail(std::string("ncclCommInitRank failed: ") + c->rccl.GetErrorString(r), GVOM_ERR_HIP);
+    if (!host_only) {
+        ncclUniqueId id;
+        memcpy(&id, &c->seg->id, sizeof id);
+        ncclResult_t r = c->rccl.CommInitRank(&c->nccl, world, id, rank);
+        if (r != ncclSuccess) return fail(std::string("ncclCommInitRank failed: ") + c->rccl.GetErrorString(r), GVOM_ERR_HIP);
+    }
     // the name can go once everybody is attached (the mapping stays valid)
     if (c->seg->attached.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint32_t)world) shm_unlink(c->shm_name.c_str());
     *out = c;
@@ -226,6 +234,7 @@ VIS int gvom_comm_exchange_scan(gvom_comm_t *c, gvom_t *h, const int64_t *send_q
 {
     if (!c || !h || !send_quads || !send_eps || !recv_quads || !recv_eps) return GVOM_ERR_INVALID;
     if (c->world == 1) return GVOM_OK;
+    if (!c->nccl) { c->err = "host-only communicator: no device collectives"; return GVOM_ERR_INVALID; }
     if (hipSetDevice(c->device) != hipSuccess) { c->err = "hipSetDevice failed"; return GVOM_ERR_HIP; }
     hipStream_t st = (hipStream_t)gvom_stream(h);
     NCCLCHK(c, c->rccl.GroupStart());
@@ -262,6 +271,7 @@ VIS int gvom_comm_exchange_scan(gvom_comm_t *c, gvom_t *h, const int64_t *send_q
 VIS int gvom_comm_allgather_rows(gvom_comm_t *c, gvom_t *h)
 {
     if (!c || !h) return GVOM_ERR_INVALID;
+    if (!c->nccl) { c->err = "host-only communicator: no device collectives"; return GVOM_ERR_INVALID; }
     void *ptr = nullptr;
     int64_t bytes = 0, row = 0;
     int rc = gvom_device_buffer(h, GVOM_BUF_HEIGHT_MAPS, &ptr, &bytes, &row);

@@ -307,5 +307,11 @@ class ShardedGvom(object):
 
 def rendezvous_name():
     """Name of the shared-memory rendezvous for the job this process belongs to: launchers set
-    MASTER_PORT (torchrun and bench.py do), which is unique to a job on one node."""
-    return "gvom_%s_%s" % (os.environ.get("MASTER_PORT", "29500"), os.environ.get("GVOM_JOB_NONCE", "0"))
+    MASTER_PORT (torchrun and bench.py do), which is unique to a job on one node; GVOM_JOB_NONCE (bench.py
+    sets it) or, under torchrun, the agent's pid keep two jobs on one port apart."""
+    nonce = os.environ.get("GVOM_JOB_NONCE")
+    if nonce is None:
+        # torchrun's workers are children of one agent process: its pid tells this job from an earlier one
+        # on the same port whose segment a crash has left behind
+        nonce = "t%d" % os.getppid() if "TORCHELASTIC_RUN_ID" in os.environ else "0"
+    return "gvom_%s_%s" % (os.environ.get("MASTER_PORT", "29500"), nonce)

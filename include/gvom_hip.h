@@ -209,7 +209,9 @@ int gvom_combine_map2d_into(gvom_t *h, double origin_world[3], void *pinned_out)
  * name: the same string on every rank and unique to this communicator on the node (rank 0 creates
  * /dev/shm/<name> for the ncclUniqueId and the small host-side exchanges).  gvom_comm_exchange_host:
  * all[r*k + j] = rank r's mine[j] (k <= 160).  gvom_comm_exchange_scan / gvom_comm_allgather_rows run
- * on the handle's stream and do not synchronise. */
+ * on the handle's stream and do not synchronise.  device < 0: host-only communicator (rendezvous +
+ * gvom_comm_exchange_host / gvom_comm_barrier, no RCCL and no HIP call; the device collectives return
+ * GVOM_ERR_INVALID) -- the CPU tests run the multi-process rendezvous with it. */
 typedef struct gvom_comm gvom_comm_t;
 int  gvom_comm_create(int rank, int world, int device, const char *name, gvom_comm_t **out);
 void gvom_comm_destroy(gvom_comm_t *c);
