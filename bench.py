@@ -296,13 +296,15 @@ def run_config(hip, name, steps, warmup, poses, full):
     return out, (alg, stages, params, scans)
 
 
-def roofline_of(alg, stages):
+def roofline_of(alg, stages, profiled=True):
+    """profiled: the committed counter passes (profiles/) were taken on this workload (m256); for the
+    other configs the counter-derived fields are null rather than another workload's numbers."""
     kern = {"trace": "k_trace", "encode": "k_encode", "fuse": "k_fuse4", "map2d": "k_map2d"}
     ms = {s: v["median"] for s, v in stages.items()}
     dom = max(ms, key=lambda s: ms[s])
     achieved = alg[dom] / (ms[dom] * 1e-3) / 1e9
-    traf = pmc_traffic(kern[dom])
-    sq, sq_src = sq_counters(kern[dom])
+    traf = pmc_traffic(kern[dom]) if profiled else None
+    sq, sq_src = sq_counters(kern[dom]) if profiled else (None, None)
     valu = None
     if sq and sq.get("SQ_INSTS_VALU"):
         bound_us = sq["SQ_INSTS_VALU"] / VALU_ISSUE_RATE * 1e6
@@ -316,7 +318,7 @@ def roofline_of(alg, stages):
     # V-sized streams that the tile tags no longer perform
     stage_gbs = {}
     for s, kname in kern.items():
-        t = pmc_traffic(kname)
+        t = pmc_traffic(kname) if profiled else None
         if t and ms.get(s):
             stage_gbs[s] = t["bytes_per_launch"] / (ms[s] * 1e-3) / 1e9
     req = (traf or {}).get("atomic_requests_per_launch")
@@ -364,7 +366,7 @@ def run_single(args):
                            "of the pending combine are stored to host memory -- same maps, one step later",
         "stage_ms": res["stage_ms"], "host_us": res["host_us"],
         "sum_hit": res["sum_hit"], "sum_total": res["sum_total"], "cells": res["cells"],
-        "roofline": roofline_of(alg, stages),
+        "roofline": roofline_of(alg, stages, profiled=(name == "m256")),
     }
     if not args.no_extra and name == "m256":
         out["configs"] = {}

@@ -264,6 +264,14 @@ class _PendingMaps(object):
             self._done, self._holder = True, None
         return self._out
 
+    def __del__(self):
+        # a handle dropped without result(): end the combine so that the mapper accepts the next one
+        try:
+            if not self._done and self._owner._h:
+                self._owner._lib.gvom_combine_end(self._owner._h, None)
+        except Exception:
+            pass
+
 
 class Gvom(object):
     """A class to convert lidar pointclouds into a cost map (reference gvom.py:12-27)."""

@@ -167,6 +167,10 @@ def test_asynchronous_combine_overlapped_with_the_next_scan(gvom_mod):
         assert np.array_equal(ad[j], bd[j])
     # after the pending combine is ended the synchronous call works again
     assert b.combine_maps() is not None
+    # ... and a handle dropped without result() ends its combine
+    dropped = b.combine_maps_async()
+    del dropped
+    assert b.combine_maps() is not None
 
 
 def test_scans_from_a_second_thread_while_a_combine_waits(gvom_mod):
