@@ -38,7 +38,7 @@ struct Slot {                                  // one scan in sparse form
     uint16_t *code16 = nullptr;                // [V] 16-bit codes of the same voxels (xy % 4 == 0 grids), read by k_fuse4
     uint32_t *tags = nullptr;                  // [ntiles] tile epochs (live iff == epoch)
     uint32_t epoch = 0;
-    Buf chit, ctotal, cminh;                   // compact rows
+    Buf crows;                                 // compact rows, uint4 each: {hit, total, min-height bits, 0}
     Buf metrics, base, rowvox;                 // optional statistics: double[rows][10] x2 (metrics; own-voxel moments), row -> voxel
     int64_t origin[3] = {0, 0, 0};
     int64_t count = 0;
@@ -51,7 +51,7 @@ struct Fused {
     int32_t *state = nullptr;
     uint32_t *tags = nullptr;
     uint32_t epoch = 0;
-    Buf hit, total, minh;
+    Buf rows;                                  // compact rows, uint4 each (as a slot's)
     Buf metrics;                               // optional statistics: float[rows][10]
     int64_t origin[3] = {0, 0, 0};
     int64_t count = 0;                         // rows on THIS rank
@@ -438,9 +438,7 @@ int scan_launch(gvom_handle *h, std::unique_lock<std::mutex> &lk, const void *de
     const size_t esz = dtype == GVOM_DTYPE_F32 ? 4 : 8;
     // compact rows are indexed by return (the row of an occupied voxel = the index of one of its returns)
     const size_t cap = std::max<size_t>(1, (size_t)n);
-    if ((rc = ensure(h, st.chit, cap * 4))) return rc;
-    if ((rc = ensure(h, st.ctotal, cap * 4))) return rc;
-    if ((rc = ensure(h, st.cminh, cap * 4))) return rc;
+    if ((rc = ensure(h, st.crows, cap * 16))) return rc;
     if (h->stats && ((rc = ensure(h, h->world_pts, (size_t)n * 3 * esz)) || (rc = ensure(h, st.metrics, cap * 80)) ||
                      (rc = ensure(h, st.base, cap * 80)) || (rc = ensure(h, st.rowvox, cap * 4)))) return rc;
     double t0 = now_ns();
@@ -492,8 +490,8 @@ int scan_launch(gvom_handle *h, std::unique_lock<std::mutex> &lk, const void *de
         h->pending_n = n;
         return GVOM_OK;
     }
-    le = gvom_launch_encode(h->stream, P, h->hit, h->total, h->mh, st.state, st.code16, (uint32_t *)st.chit.p,
-                            (uint32_t *)st.ctotal.p, (uint32_t *)st.cminh.p, st.tags, h->counters,
+    le = gvom_launch_encode(h->stream, P, h->hit, h->total, h->mh, st.state, st.code16, (uint4 *)st.crows.p,
+                            st.tags, h->counters,
                             (unsigned long long *)h->counters_host_dev, seq, h->resident_blocks);
     if (le != hipSuccess) { scan_abort(h); HIPCHK(h, le); }
     if (h->profiling) { HIPCHK(h, hipEventRecord(h->ev[2], h->stream)); h->ev_scan = true; }
@@ -656,8 +654,7 @@ int fuse_impl(gvom_handle *h)
         const Slot &s = h->slots[h->ring[i]];
         if (!s.filled) continue;
         MapDesc &d = h->descs_host[ns++];
-        d.state = s.state; d.hit = (const uint32_t *)s.chit.p; d.total = (const uint32_t *)s.ctotal.p;
-        d.minh = (const uint32_t *)s.cminh.p;
+        d.state = s.state; d.rows = (const uint4 *)s.crows.p;
         d.d[0] = clamp_delta(F.origin[0] - s.origin[0], p.xy_size);
         d.d[1] = clamp_delta(F.origin[1] - s.origin[1], p.xy_size);
         d.d[2] = clamp_delta(F.origin[2] - s.origin[2], p.z_size);
@@ -668,8 +665,7 @@ int fuse_impl(gvom_handle *h)
     P.has_prev = prev ? 1 : 0;
     if (prev) {
         MapDesc &d = h->descs_host[ns];
-        d.state = prev->state; d.hit = (const uint32_t *)prev->hit.p;
-        d.total = (const uint32_t *)prev->total.p; d.minh = (const uint32_t *)prev->minh.p;
+        d.state = prev->state; d.rows = (const uint4 *)prev->rows.p;
         d.d[0] = clamp_delta(F.origin[0] - prev->origin[0], p.xy_size);
         d.d[1] = clamp_delta(F.origin[1] - prev->origin[1], p.xy_size);
         d.d[2] = clamp_delta(F.origin[2] - prev->origin[2], p.z_size);
@@ -687,9 +683,7 @@ int fuse_impl(gvom_handle *h)
     const size_t row_cap = (size_t)h->fuse_blocks * P.nz * 64 * P.zc * P.cpw;
     if (row_cap >= 2147483648ull) { h->err = "fused row space exceeds 31 bits"; return GVOM_ERR_CAPACITY; }
     int rc;
-    if ((rc = ensure(h, F.hit, row_cap * 4))) return rc;
-    if ((rc = ensure(h, F.total, row_cap * 4))) return rc;
-    if ((rc = ensure(h, F.minh, row_cap * 4))) return rc;
+    if ((rc = ensure(h, F.rows, row_cap * 16))) return rc;
     if (h->stats && (rc = ensure(h, F.metrics, row_cap * 40))) return rc;
     for (int k = 0; k < 3; ++k) { P.origin[k] = (double)F.origin[k]; P.ego[k] = h->ego[k]; }
     P.xy_res = p.xy_resolution; P.z_res = p.z_resolution;
@@ -706,8 +700,8 @@ int fuse_impl(gvom_handle *h)
         descs_mem = h->descs_dev;
     }
     if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[4], h->stream));
-    HIPCHK(h, gvom_launch_fuse(h->stream, P, KD, descs_mem, F.state, (uint32_t *)F.hit.p,
-                               (uint32_t *)F.total.p, (uint32_t *)F.minh.p, F.tags, h->blockcounts,
+    HIPCHK(h, gvom_launch_fuse(h->stream, P, KD, descs_mem, F.state, (uint4 *)F.rows.p,
+                               F.tags, h->blockcounts,
                                h->height, h->inferred));
     if (h->profiling) { HIPCHK(h, hipEventRecord(h->ev[5], h->stream)); h->ev_fuse = true; }
     if (h->stats)
@@ -751,8 +745,8 @@ int map2d_impl(gvom_handle *h, bool gathered, bool publish, char *out_dev, bool 
     int32_t *o_pos = (int32_t *)out_dev, *o_neg = o_pos + n2, *o_vis = o_neg + n2;
     double *o_rgh = (double *)(o_vis + n2);
     if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[6], ms));
-    HIPCHK(h, gvom_launch_map2d(ms, P, F.state, F.tags, (const uint32_t *)F.hit.p,
-                                (const uint32_t *)F.total.p, h->height, h->inferred, h->slope_x,
+    HIPCHK(h, gvom_launch_map2d(ms, P, F.state, F.tags, (const uint4 *)F.rows.p,
+                                h->height, h->inferred, h->slope_x,
                                 h->slope_y, h->rough, h->guessed, o_pos, o_neg, o_rgh, o_vis,
                                 h->blockcounts, h->fuse_blocks,
                                 publish ? (unsigned long long *)(h->counters_host_dev + 2) : nullptr));
@@ -776,8 +770,8 @@ int posdens_impl(gvom_handle *h)
     P.pos_thr = p.positive_obstacle_threshold; P.robot_height = p.robot_height;
     P.nseg = h->nseg; P.hs = h->hs; P.epoch = F.epoch;
     // its first workgroup also publishes the fused cell count (k_fuse has completed by then)
-    HIPCHK(h, gvom_launch_posdens(h->stream, P, F.state, F.tags, (const uint32_t *)F.hit.p,
-                                  (const uint32_t *)F.total.p, h->hmaps, h->blockcounts, h->fuse_blocks,
+    HIPCHK(h, gvom_launch_posdens(h->stream, P, F.state, F.tags, (const uint4 *)F.rows.p,
+                                  h->hmaps, h->blockcounts, h->fuse_blocks,
                                   (unsigned long long *)(h->counters_host_dev + 2),
                                   (unsigned long long *)(h->counters + 10)));
     return GVOM_OK;
@@ -859,8 +853,8 @@ VIS void gvom_destroy(gvom_t *h)
     hipFree(h->x_send_ids); hipFree(h->x_send_pay); hipFree(h->x_recv_ids); hipFree(h->x_recv_pay);
     hipFree(h->x_qcnt); hipFree(h->x_ecnt); fb(h->x_send_eps); fb(h->x_recv_eps);
     if (h->x_host) hipHostFree(h->x_host);
-    for (auto &s : h->slots) { hipFree(s.state); hipFree(s.code16); hipFree(s.tags); fb(s.chit); fb(s.ctotal); fb(s.cminh); fb(s.metrics); fb(s.base); fb(s.rowvox); }
-    for (auto &f : h->fused) { hipFree(f.state); hipFree(f.tags); fb(f.hit); fb(f.total); fb(f.minh); fb(f.metrics); }
+    for (auto &s : h->slots) { hipFree(s.state); hipFree(s.code16); hipFree(s.tags); fb(s.crows); fb(s.metrics); fb(s.base); fb(s.rowvox); }
+    for (auto &f : h->fused) { hipFree(f.state); hipFree(f.tags); fb(f.rows); fb(f.metrics); }
     fb(h->in_pts); fb(h->world_pts);
     hipFree(h->counters); if (h->counters_host) hipHostFree(h->counters_host);
     hipFree(h->descs_dev); if (h->descs_host) hipHostFree(h->descs_host);
@@ -989,7 +983,7 @@ VIS int gvom_shard_scan_merge(gvom_t *h, const int64_t *recv_quads, const int64_
     // (at least one row: k_fuse redirects the loads of unoccupied voxels to row 0 of every source)
     const size_t cap = std::max<size_t>(1, (size_t)h->pending_n + (size_t)tot_eps);
     int rc;
-    if ((rc = ensure(h, st.chit, cap * 4)) || (rc = ensure(h, st.ctotal, cap * 4)) || (rc = ensure(h, st.cminh, cap * 4))) return rc;
+    if ((rc = ensure(h, st.crows, cap * 16))) return rc;
     double t0 = now_ns();
     {   // everything received, whatever the source, in one launch each (quads, endpoints)
         ShardUnpack X;
@@ -1003,8 +997,8 @@ VIS int gvom_shard_scan_merge(gvom_t *h, const int64_t *recv_quads, const int64_
         if (le != hipSuccess) { scan_abort(h); HIPCHK(h, le); }
     }
     const uint32_t seq = ++h->scan_seq;
-    hipError_t le = gvom_launch_encode(h->stream, P, h->hit, h->total, h->mh, st.state, st.code16, (uint32_t *)st.chit.p,
-                                       (uint32_t *)st.ctotal.p, (uint32_t *)st.cminh.p, st.tags, h->counters,
+    hipError_t le = gvom_launch_encode(h->stream, P, h->hit, h->total, h->mh, st.state, st.code16, (uint4 *)st.crows.p,
+                                       st.tags, h->counters,
                                        (unsigned long long *)h->counters_host_dev, seq, h->resident_blocks);
     if (le != hipSuccess) { scan_abort(h); HIPCHK(h, le); }
     if (h->profiling) { HIPCHK(h, hipEventRecord(h->ev[2], h->stream)); h->ev_scan = true; }
@@ -1309,18 +1303,16 @@ VIS int gvom_read_dense(gvom_t *h, int which, int32_t *state, int32_t *hit, int3
     if (!h) return GVOM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->device));
-    const int32_t *st; const uint32_t *ch, *ct, *cm, *tg; uint32_t ep; const int64_t *org; int64_t cnt;
+    const int32_t *st; const uint4 *cr; const uint32_t *tg; uint32_t ep; const int64_t *org; int64_t cnt;
     if (which == GVOM_WHICH_FUSED) {
         if (!h->has_combined) return GVOM_NO_DATA;
         const Fused &F = h->fused[h->cur];
-        st = F.state; ch = (const uint32_t *)F.hit.p; ct = (const uint32_t *)F.total.p;
-        cm = (const uint32_t *)F.minh.p; org = F.origin; cnt = F.count; tg = F.tags; ep = F.epoch;
+        st = F.state; cr = (const uint4 *)F.rows.p; org = F.origin; cnt = F.count; tg = F.tags; ep = F.epoch;
     } else {
         if (which < 0 || which >= h->prm.buffer_size) return GVOM_ERR_INVALID;
         const Slot &s = h->slots[h->ring[which]];
         if (!s.filled) return GVOM_NO_DATA;
-        st = s.state; ch = (const uint32_t *)s.chit.p; ct = (const uint32_t *)s.ctotal.p;
-        cm = (const uint32_t *)s.cminh.p; org = s.origin; cnt = s.count; tg = s.tags; ep = s.epoch;
+        st = s.state; cr = (const uint4 *)s.crows.p; org = s.origin; cnt = s.count; tg = s.tags; ep = s.epoch;
     }
     const size_t V = h->V;
     int32_t *tmp = nullptr;
@@ -1328,7 +1320,7 @@ VIS int gvom_read_dense(gvom_t *h, int which, int32_t *state, int32_t *hit, int3
     int om[3] = {(int)floor_mod(org[0], h->prm.xy_size), (int)floor_mod(org[1], h->prm.xy_size),
                  (int)floor_mod(org[2], h->prm.z_size)};
     hipError_t e = gvom_launch_read_dense(h->stream, h->prm.xy_size, h->prm.z_size, om, h->sy_lo, h->sy_hi,
-                                          tg, ep, st, ch, ct, cm,
+                                          tg, ep, st, cr,
                                           tmp, tmp + V, tmp + 2 * V, (float *)(tmp + 3 * V), nullptr);
     if (e == hipSuccess) e = sync_streams(h);
     if (e == hipSuccess && state) e = hipMemcpy(state, tmp, V * 4, hipMemcpyDeviceToHost);
@@ -1373,7 +1365,7 @@ VIS int gvom_read_rows(gvom_t *h, int which, int32_t *rows_dense)
     int om[3] = {(int)floor_mod(org[0], h->prm.xy_size), (int)floor_mod(org[1], h->prm.xy_size),
                  (int)floor_mod(org[2], h->prm.z_size)};
     hipError_t e = gvom_launch_read_dense(h->stream, h->prm.xy_size, h->prm.z_size, om, h->sy_lo, h->sy_hi, tg, ep, st,
-                                          nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, tmp);
+                                          nullptr, nullptr, nullptr, nullptr, nullptr, tmp);
     if (e == hipSuccess) e = sync_streams(h);
     if (e == hipSuccess) e = hipMemcpy(rows_dense, tmp, V * 4, hipMemcpyDeviceToHost);
     hipFree(tmp);
@@ -1507,7 +1499,7 @@ VIS int gvom_debug_voxel_eigen(gvom_t *h, float *out, float *eigen, int64_t max_
     hipError_t e = hipMemsetAsync(h->counters + 12, 0, 8, h->stream);
     if (e == hipSuccess)
         e = gvom_launch_voxel_cloud(h->stream, P, (double)F.origin[0], (double)F.origin[1], (double)F.origin[2],
-                                    F.state, F.tags, (const uint32_t *)F.hit.p, (const uint32_t *)F.total.p,
+                                    F.state, F.tags, (const uint4 *)F.rows.p,
                                     (const float *)F.metrics.p, tmp, tmp_e, max_rows,
                                     (unsigned long long *)(h->counters + 12));
     unsigned long long cnt = 0;

@@ -89,9 +89,7 @@ struct ShardUnpack { uint32_t q_off[GVOM_MAX_SLOTS + 1]; };    // q_off[s] = fir
 
 struct MapDesc {          // one source map of the fusion (ring slot or previous fused map)
     const int32_t  *state;
-    const uint32_t *hit;
-    const uint32_t *total;
-    const uint32_t *minh;   // float bits
+    const uint4 *rows;      // compact rows, 16 bytes each: {hit, total, min-height (float bits), 0} -- one line access per row
     int d[3];               // fused origin - this map's origin (window shift), clamped
     uint32_t epoch;         // tile (T) of this map is live iff tags[T] == epoch
     const uint32_t *tags;
@@ -152,13 +150,13 @@ hipError_t gvom_launch_unpack(hipStream_t s, const ScanParams &P, const ShardUnp
                               const void *pay_all, uint32_t my_quads, uint32_t ne, const void *eps, long row_base,
                               uint32_t *hit, uint32_t *total, uint32_t *mh, int32_t *state, uint32_t *tags);
 hipError_t gvom_launch_encode(hipStream_t s, const ScanParams &P, uint32_t *hit, uint32_t *total, uint32_t *mh,
-                              int32_t *state, uint16_t *code16, uint32_t *chit, uint32_t *ctotal, uint32_t *cminh, const uint32_t *tags,
+                              int32_t *state, uint16_t *code16, uint4 *crows, const uint32_t *tags,
                               uint32_t *counters, unsigned long long *host_flag, uint32_t seq, unsigned resident_blocks);
 hipError_t gvom_launch_fuse(hipStream_t s, const FuseParams &P, const FuseDescs &KD,
-                            const MapDesc *descs_dev, int32_t *fstate, uint32_t *fhit, uint32_t *ftotal, uint32_t *fminh,
+                            const MapDesc *descs_dev, int32_t *fstate, uint4 *frows,
                             uint32_t *ftags, uint32_t *blockcounts, double *height, double *inferred);
 hipError_t gvom_launch_map2d(hipStream_t s, const Map2dParams &P, const int32_t *fstate, const uint32_t *ftags,
-                             const uint32_t *fhit, const uint32_t *ftotal, const double *height,
+                             const uint4 *frows, const double *height,
                              const double *inferred, double *slope_x, double *slope_y,
                              double *rough, double *guessed, int32_t *out_pos, int32_t *out_neg,
                              double *out_rough, int32_t *out_vis, const uint32_t *blockcounts,
@@ -170,20 +168,20 @@ hipError_t gvom_launch_stats(hipStream_t s, const ScanParams &P, int dtype, cons
 hipError_t gvom_launch_fuse_stats(hipStream_t s, const FuseParams &P, const FuseDescs &KD, const MapDesc *descs_dev,
                                   const int32_t *fstate, const uint32_t *ftags, float *fmetrics);
 hipError_t gvom_launch_voxel_cloud(hipStream_t s, const Map2dParams &P, double o0, double o1, double o2,
-                                   const int32_t *fstate, const uint32_t *ftags, const uint32_t *fhit,
-                                   const uint32_t *ftotal, const float *fmetrics, float *out, float *eig, int64_t max_rows,
+                                   const int32_t *fstate, const uint32_t *ftags, const uint4 *frows,
+                                   const float *fmetrics, float *out, float *eig, int64_t max_rows,
                                    unsigned long long *row_counter);
 hipError_t gvom_launch_gather_rows10(hipStream_t s, int is_f64, const void *src, const int32_t *rows, int64_t n, void *out);
 hipError_t gvom_launch_retag(hipStream_t s, uint32_t *tags, size_t n, uint32_t old_epoch, uint32_t new_epoch);
 // test hooks / debug accessors
 hipError_t gvom_launch_read_dense(hipStream_t s, int xy, int zs, const int om[3], int sy_lo, int sy_hi,
-                                  const uint32_t *tags, uint32_t epoch, const int32_t *state, const uint32_t *chit,
-                                  const uint32_t *ctotal, const uint32_t *cminh, int32_t *o_state,
+                                  const uint32_t *tags, uint32_t epoch, const int32_t *state, const uint4 *crows,
+                                  int32_t *o_state,
                                   int32_t *o_hit, int32_t *o_total, float *o_minh, int32_t *o_row);
 // storage order [sy][sx] -> reference order [x][y] (window coordinates)
 hipError_t gvom_launch_unwrap_f64(hipStream_t s, int xy, int om0, int om1, const double *in, int in_stride, double *out_xy);
 hipError_t gvom_launch_posdens(hipStream_t s, const Map2dParams &P, const int32_t *fstate,
-                               const uint32_t *ftags, const uint32_t *fhit, const uint32_t *ftotal,
+                               const uint32_t *ftags, const uint4 *frows,
                                double *hmaps, const uint32_t *blockcounts, int nblocks,
                                unsigned long long *host_counter, unsigned long long *dev_counter);
 hipError_t gvom_launch_debug_height(hipStream_t s, int xy, int om0, int om1, const double origin[3], double xy_res,

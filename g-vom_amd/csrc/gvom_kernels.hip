@@ -32,6 +32,8 @@ typedef const __attribute__((address_space(1))) uint32_t *gptr_u32;
 typedef const __attribute__((address_space(1))) uint16_t *gptr_u16;
 typedef uint32_t v2u __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(1))) v2u *gptr_u2;
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) v4u *gptr_v4u;
 // The fusion kernels index their source descriptors with wave-uniform values.  Through a pointer that
 // may be kernel-argument or global memory (one generic pointer) every field read was a FLAT vector
 // load + readfirstlane and a round trip of its own ahead of the load it feeds; as constant-address-space
@@ -662,7 +664,7 @@ __global__ __launch_bounds__(256) void k_unpack_eps(const ScanParams P, uint32_t
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_encode(const ScanParams P, uint32_t t_begin, uint32_t t_end,
                                                 uint32_t *hit, uint32_t *total, uint32_t *mh, int32_t *state,
-                                                uint16_t *code16, uint32_t *chit, uint32_t *ctotal, uint32_t *cminh,
+                                                uint16_t *code16, uint4 *crows,
                                                 const uint32_t *__restrict__ tags, uint32_t epoch,
                                                 uint32_t *counters, unsigned long long *host_flag,
                                                 uint32_t seq)
@@ -724,8 +726,7 @@ __global__ __launch_bounds__(256) void k_encode(const ScanParams P, uint32_t t_b
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     if (h[i] > 0 && sx0 + i < (uint32_t)xy) {
-                        chit[rows[i]] = h[i]; ctotal[rows[i]] = t[i];
-                        cminh[rows[i]] = 0x3f800000u - m[i];          // min-height (gvom.py:1014-1015, 1329)
+                        crows[rows[i]] = make_uint4(h[i], t[i], 0x3f800000u - m[i], 0u);   // min-height (gvom.py:1014-1015, 1329)
                         st[i] = rows[i];
                     }
                 }
@@ -772,8 +773,8 @@ __global__ __launch_bounds__(256) void k_encode(const ScanParams P, uint32_t t_b
 template <bool ZC16, bool MEM>
 __global__ __launch_bounds__(1024) void k_fuse(const FuseParams P, const FuseDescs KD,
                                                const MapDesc *__restrict__ descs_mem,
-                                               int32_t *fstate, uint32_t *fhit, uint32_t *ftotal,
-                                               uint32_t *fminh, uint32_t *ftags, uint32_t *blockcounts,
+                                               int32_t *fstate, uint4 *frows,
+                                               uint32_t *ftags, uint32_t *blockcounts,
                                                double *height, double *inferred)
 {
     __shared__ uint32_t s_cnt[16];
@@ -854,14 +855,13 @@ __global__ __launch_bounds__(1024) void k_fuse(const FuseParams P, const FuseDes
                 descs[s].tags[tbase + (L - colbase) / P.xy * P.nseg] == descs[s].epoch) {   // live tile
                 const int st = descs[s].state[L];
                 if (st >= 0) {                                            // gvom.py:841,910-912
-                    h += descs[s].hit[st];
-                    t += descs[s].total[st];
-                    m = min(m, descs[s].minh[st]);
+                    const uint4 rv = descs[s].rows[st];
+                    h += rv.x; t += rv.y; m = min(m, rv.z);
                 }
             }
         }
         fstate[L] = (int32_t)row;
-        fhit[row] = h; ftotal[row] = t; fminh[row] = m;
+        frows[row] = make_uint4(h, t, m, 0u);
         if (z == zocc) hocc = m;
     };
 
@@ -953,7 +953,7 @@ __global__ __launch_bounds__(1024) void k_fuse(const FuseParams P, const FuseDes
             for (int j = 0; j < 4; ++j) { hh[j] = 0; tt[j] = 0; mm[j] = 0x3f800000u; }    // gvom.py:222-228
             for (int s = 0; s < nsrc; ++s) {
                 const gptr_i32 sp = (gptr_i32)descs[s].state;
-                const gptr_u32 hp = (gptr_u32)descs[s].hit, tp = (gptr_u32)descs[s].total, mp = (gptr_u32)descs[s].minh;
+                const gptr_v4u rp = (gptr_v4u)descs[s].rows;
                 const uint32_t live = ((uint32_t)(s_live[w][s] >> (16 * cc)) >> kg) & 0xfu;
                 const int dz = descs[s].d[2];
                 const bool okS = (okmask >> s) & 1ull;
@@ -972,7 +972,8 @@ __global__ __launch_bounds__(1024) void k_fuse(const FuseParams P, const FuseDes
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const uint32_t r = st[j] >= 0 ? (uint32_t)st[j] : 0u;
-                    gh[j] = hp[r]; gt[j] = tp[r]; gm[j] = mp[r];
+                    const v4u rv = rp[r];
+                    gh[j] = rv.x; gt[j] = rv.y; gm[j] = rv.z;
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -988,7 +989,7 @@ __global__ __launch_bounds__(1024) void k_fuse(const FuseParams P, const FuseDes
                     const int sz = wrap_add(z, P.om[2], P.zs);
                     const uint32_t row = rbase + running + (uint32_t)__popcll(b & lanemask_lt());
                     fstate[colbase + (uint32_t)sz * P.xy] = (int32_t)row;
-                    fhit[row] = hh[j]; ftotal[row] = tt[j]; fminh[row] = mm[j];
+                    frows[row] = make_uint4(hh[j], tt[j], mm[j], 0u);
                     if (z == zocc) hocc = mm[j];
                 }
                 running += (uint32_t)__popcll(b);
@@ -1087,8 +1088,8 @@ __global__ __launch_bounds__(1024) void k_fuse(const FuseParams P, const FuseDes
 template <int SPR, bool MEM>
 __global__ __launch_bounds__(1024) void k_fuse4(const FuseParams P, const FuseDescs KD,
                                                 const MapDesc *__restrict__ descs_mem,
-                                                int32_t *fstate, uint32_t *fhit, uint32_t *ftotal,
-                                                uint32_t *fminh, uint32_t *ftags, uint32_t *blockcounts,
+                                                int32_t *fstate, uint4 *frows,
+                                                uint32_t *ftags, uint32_t *blockcounts,
                                                 double *height, double *inferred)
 {
     __shared__ uint32_t s_cnt[16];
@@ -1298,7 +1299,8 @@ __global__ __launch_bounds__(1024) void k_fuse4(const FuseParams P, const FuseDe
                         const int sI = min(s0 + u, nsrc - 1);
                         if (!ok[u]) st[u] = -1;
                         const uint32_t r = st[u] >= 0 ? (uint32_t)st[u] : 0u;
-                        gh[u] = ((gptr_u32)descs[sI].hit)[r]; gt[u] = ((gptr_u32)descs[sI].total)[r]; gm[u] = ((gptr_u32)descs[sI].minh)[r];
+                        const v4u rv = ((gptr_v4u)descs[sI].rows)[r];           // one 16-byte row: hit, total, min-height
+                        gh[u] = rv.x; gt[u] = rv.y; gm[u] = rv.z;
                     }
 #pragma unroll
                     for (int u = 0; u < NG; ++u) {
@@ -1315,7 +1317,7 @@ __global__ __launch_bounds__(1024) void k_fuse4(const FuseParams P, const FuseDe
                 if (occupied) {
                     const uint32_t row = rbase + running + (uint32_t)__popcll(ob & lanemask_lt());
                     fstate[off] = (int32_t)row;
-                    fhit[row] = hh; ftotal[row] = tt; fminh[row] = mm;
+                    frows[row] = make_uint4(hh, tt, mm, 0u);
                     atomicMin(&s_zh[w][col], ((unsigned long long)(uint32_t)zv << 32) | mm);   // lowest occupied level wins
                 } else if (on) {
                     fstate[off] = cnt + (stp < -1 ? stp + 1 : 0);                                 // gvom.py:996
@@ -1439,8 +1441,7 @@ __device__ __forceinline__ void st_sys(V *p, V v)
 template <bool GATHERED_POS, bool YX>
 __global__ __launch_bounds__(512) void k_map2d(const Map2dParams P, const int32_t *__restrict__ fstate,
                                                const uint32_t *__restrict__ ftags,
-                                               const uint32_t *__restrict__ fhit,
-                                               const uint32_t *__restrict__ ftotal,
+                                               const uint4 *__restrict__ frows,
                                                const double *__restrict__ height,
                                                const double *__restrict__ inferred,
                                                double *slope_x, double *slope_y, double *rough,
@@ -1640,7 +1641,8 @@ __global__ __launch_bounds__(512) void k_map2d(const Map2dParams P, const int32_
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const uint32_t r = row[k] >= 0 ? (uint32_t)row[k] : 0u;
-                    hc[k] = fhit[r]; tc[k] = ftotal[r];
+                    const uint2 ht = *reinterpret_cast<const uint2 *>(frows + r);
+                    hc[k] = ht.x; tc[k] = ht.y;
                 }
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
@@ -1951,8 +1953,7 @@ __global__ __launch_bounds__(256) void k_fuse_stats(const FuseParams P, const Fu
 __global__ __launch_bounds__(256) void k_voxel_cloud(const Map2dParams P, double o0, double o1, double o2,
                                                      const int32_t *__restrict__ fstate,
                                                      const uint32_t *__restrict__ ftags,
-                                                     const uint32_t *__restrict__ fhit,
-                                                     const uint32_t *__restrict__ ftotal,
+                                                     const uint4 *__restrict__ frows,
                                                      const float *__restrict__ fmetrics, float *out, float *eig,
                                                      long max_rows, unsigned long long *row_counter)
 {
@@ -2004,7 +2005,7 @@ __global__ __launch_bounds__(256) void k_voxel_cloud(const Map2dParams P, double
         }
         const int x = wrap_sub(sx, P.om[0], P.xy), y = wrap_sub(sy, P.om[1], P.xy), z = wrap_sub(sz, P.om[2], P.zs);
         float *o = out + pos * 8;
-        const uint32_t hc = fhit[row], tc = ftotal[row];
+        const uint32_t hc = frows[row].x, tc = frows[row].y;
         o[0] = (float)(((double)x + o0) * P.xy_res);
         o[1] = (float)(((double)y + o1) * P.xy_res);
         o[2] = (float)(((double)z + o2) * P.z_res);
@@ -2050,15 +2051,15 @@ hipError_t gvom_launch_fuse_stats(hipStream_t s, const FuseParams &P, const Fuse
 }
 
 hipError_t gvom_launch_voxel_cloud(hipStream_t s, const Map2dParams &P, double o0, double o1, double o2,
-                                   const int32_t *fstate, const uint32_t *ftags, const uint32_t *fhit,
-                                   const uint32_t *ftotal, const float *fmetrics, float *out, float *eig, int64_t max_rows,
+                                   const int32_t *fstate, const uint32_t *ftags, const uint4 *frows,
+                                   const float *fmetrics, float *out, float *eig, int64_t max_rows,
                                    unsigned long long *row_counter)
 {
     const uint32_t ntiles = (uint32_t)(P.y_hi - P.y_lo) * P.zs * P.nseg;
     if (ntiles == 0) return hipSuccess;
     unsigned blocks = (ntiles + 3) / 4;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(k_voxel_cloud, dim3(blocks), dim3(256), 0, s, P, o0, o1, o2, fstate, ftags, fhit, ftotal,
+    hipLaunchKernelGGL(k_voxel_cloud, dim3(blocks), dim3(256), 0, s, P, o0, o1, o2, fstate, ftags, frows,
                        fmetrics, out, eig, (long)max_rows, row_counter);
     return hipGetLastError();
 }
@@ -2069,8 +2070,7 @@ hipError_t gvom_launch_voxel_cloud(hipStream_t s, const Map2dParams &P, double o
 // storage order + compact rows -> dense arrays in the reference's x + y*xy + z*xy*xy order
 __global__ void k_read_dense(int xy, int zs, int om0, int om1, int om2, int sy_lo, int sy_hi,
                              const uint32_t *__restrict__ tags, uint32_t epoch,
-                             const int32_t *__restrict__ state, const uint32_t *__restrict__ chit,
-                             const uint32_t *__restrict__ ctotal, const uint32_t *__restrict__ cminh,
+                             const int32_t *__restrict__ state, const uint4 *__restrict__ crows,
                              int32_t *o_state, int32_t *o_hit, int32_t *o_total, float *o_minh, int32_t *o_row)
 {
     const size_t V = (size_t)xy * xy * zs;
@@ -2084,8 +2084,9 @@ __global__ void k_read_dense(int xy, int zs, int om0, int om1, int om2, int sy_l
             st = state[((size_t)sy * zs + sz) * xy + sx];
         if (o_row) { o_row[idx] = st >= 0 ? st : -1; continue; }     // compact row of every occupied voxel
         if (st >= 0) {
-            o_state[idx] = 0; o_hit[idx] = (int32_t)chit[st]; o_total[idx] = (int32_t)ctotal[st];
-            o_minh[idx] = __uint_as_float(cminh[st]);
+            const uint4 rv = crows[st];
+            o_state[idx] = 0; o_hit[idx] = (int32_t)rv.x; o_total[idx] = (int32_t)rv.y;
+            o_minh[idx] = __uint_as_float(rv.z);
         } else {
             o_state[idx] = st; o_hit[idx] = 0; o_total[idx] = 0; o_minh[idx] = 1.0f;
         }
@@ -2105,8 +2106,7 @@ __global__ void k_unwrap(int xy, int om0, int om1, const E *__restrict__ in, int
 // stored as the third row of the interleaved height buffer so that it travels with the heights.
 __global__ __launch_bounds__(256) void k_posdens(const Map2dParams P, const int32_t *__restrict__ fstate,
                                                  const uint32_t *__restrict__ ftags,
-                                                 const uint32_t *__restrict__ fhit,
-                                                 const uint32_t *__restrict__ ftotal, double *hmaps,
+                                                 const uint4 *__restrict__ frows, double *hmaps,
                                                  const uint32_t *blockcounts, int nblocks,
                                                  unsigned long long *host_counter, unsigned long long *dev_counter)
 {
@@ -2149,7 +2149,8 @@ __global__ __launch_bounds__(256) void k_posdens(const Map2dParams P, const int3
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const uint32_t r = row[k] >= 0 ? (uint32_t)row[k] : 0u;
-                hc[k] = fhit[r]; tc[k] = ftotal[r];
+                const uint2 ht = *reinterpret_cast<const uint2 *>(frows + r);
+                hc[k] = ht.x; tc[k] = ht.y;
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k)
@@ -2232,7 +2233,7 @@ hipError_t gvom_launch_unpack(hipStream_t s, const ScanParams &P, const ShardUnp
 }
 
 hipError_t gvom_launch_encode(hipStream_t s, const ScanParams &P, uint32_t *hit, uint32_t *total, uint32_t *mh,
-                              int32_t *state, uint16_t *code16, uint32_t *chit, uint32_t *ctotal, uint32_t *cminh, const uint32_t *tags,
+                              int32_t *state, uint16_t *code16, uint4 *crows, const uint32_t *tags,
                               uint32_t *counters, unsigned long long *host_flag, uint32_t seq, unsigned resident_blocks)
 {
     // units = quads (4 rows x 64 sx at one sz) that intersect the slab; one wave handles 2 quads per
@@ -2246,7 +2247,7 @@ hipError_t gvom_launch_encode(hipStream_t s, const ScanParams &P, uint32_t *hit,
     if (enc_blocks > enc_cap) enc_blocks = enc_cap;
     if (enc_blocks < 1) enc_blocks = 1;
     hipLaunchKernelGGL(k_encode, dim3(enc_blocks), dim3(256), 0, s, P, t_begin, t_end, hit, total, mh, state,
-                       code16, chit, ctotal, cminh, tags, P.epoch, counters, host_flag, seq);
+                       code16, crows, tags, P.epoch, counters, host_flag, seq);
     return hipGetLastError();
 }
 
@@ -2264,14 +2265,14 @@ hipError_t gvom_launch_retag(hipStream_t s, uint32_t *tags, size_t n, uint32_t o
 }
 
 hipError_t gvom_launch_fuse(hipStream_t s, const FuseParams &P, const FuseDescs &KD,
-                            const MapDesc *descs_dev, int32_t *fstate, uint32_t *fhit,
-                            uint32_t *ftotal, uint32_t *fminh, uint32_t *ftags, uint32_t *blockcounts,
+                            const MapDesc *descs_dev, int32_t *fstate, uint4 *frows,
+                            uint32_t *ftags, uint32_t *blockcounts,
                             double *height, double *inferred)
 {
     const dim3 grid((P.xy + 63) / 64, P.sy_hi - P.sy_lo);
     if (grid.y == 0) return hipSuccess;
-#define FUSE_LAUNCH(...) hipLaunchKernelGGL((__VA_ARGS__), grid, dim3(64 * P.nz), 0, s, P, KD, descs_dev, fstate, fhit, \
-                                          ftotal, fminh, ftags, blockcounts, height, inferred)
+#define FUSE_LAUNCH(...) hipLaunchKernelGGL((__VA_ARGS__), grid, dim3(64 * P.nz), 0, s, P, KD, descs_dev, fstate, frows, \
+                                          ftags, blockcounts, height, inferred)
     const bool mem = descs_dev != nullptr;
     if (P.zc == 16 && (P.xy & 3) == 0 && !GVOM_DBG(P, 8)) {
         if (P.nslots <= 2) { if (mem) FUSE_LAUNCH(k_fuse4<2, true>); else FUSE_LAUNCH(k_fuse4<2, false>); }
@@ -2286,7 +2287,7 @@ hipError_t gvom_launch_fuse(hipStream_t s, const FuseParams &P, const FuseDescs 
 }
 
 hipError_t gvom_launch_map2d(hipStream_t s, const Map2dParams &P, const int32_t *fstate,
-                             const uint32_t *ftags, const uint32_t *fhit, const uint32_t *ftotal, const double *height,
+                             const uint32_t *ftags, const uint4 *frows, const double *height,
                              const double *inferred, double *slope_x, double *slope_y,
                              double *rough, double *guessed, int32_t *out_pos, int32_t *out_neg,
                              double *out_rough, int32_t *out_vis, const uint32_t *blockcounts,
@@ -2296,7 +2297,7 @@ hipError_t gvom_launch_map2d(hipStream_t s, const Map2dParams &P, const int32_t 
     const int tx = P.out_yx ? 32 : 8, ty = P.out_yx ? 8 : 32;
     const dim3 grid((P.xy + tx - 1) / tx, (P.xy + ty - 1) / ty);
 #define MAP2D_LAUNCH(G, Y)                                                                              \
-    hipLaunchKernelGGL((k_map2d<G, Y>), grid, dim3(512), 0, s, P, fstate, ftags, fhit, ftotal, height, \
+    hipLaunchKernelGGL((k_map2d<G, Y>), grid, dim3(512), 0, s, P, fstate, ftags, frows, height, \
                        inferred, slope_x, slope_y, rough, guessed, out_pos, out_neg, out_rough, out_vis, \
                        blockcounts, nblocks, host_counter)
     if (P.gathered_pos) { if (P.out_yx) MAP2D_LAUNCH(true, true); else MAP2D_LAUNCH(true, false); }
@@ -2306,13 +2307,13 @@ hipError_t gvom_launch_map2d(hipStream_t s, const Map2dParams &P, const int32_t 
 }
 
 hipError_t gvom_launch_read_dense(hipStream_t s, int xy, int zs, const int om[3], int sy_lo, int sy_hi,
-                                  const uint32_t *tags, uint32_t epoch, const int32_t *state, const uint32_t *chit,
-                                  const uint32_t *ctotal, const uint32_t *cminh, int32_t *o_state,
+                                  const uint32_t *tags, uint32_t epoch, const int32_t *state, const uint4 *crows,
+                                  int32_t *o_state,
                                   int32_t *o_hit, int32_t *o_total, float *o_minh, int32_t *o_row)
 {
     hipLaunchKernelGGL(k_read_dense, dim3(2048), dim3(256), 0, s, xy, zs, om[0], om[1], om[2], sy_lo, sy_hi,
                        tags, epoch, state,
-                       chit, ctotal, cminh, o_state, o_hit, o_total, o_minh, o_row);
+                       crows, o_state, o_hit, o_total, o_minh, o_row);
     return hipGetLastError();
 }
 
@@ -2343,7 +2344,7 @@ hipError_t gvom_launch_unwrap_f64(hipStream_t s, int xy, int om0, int om1, const
 }
 
 hipError_t gvom_launch_posdens(hipStream_t s, const Map2dParams &P, const int32_t *fstate,
-                               const uint32_t *ftags, const uint32_t *fhit, const uint32_t *ftotal,
+                               const uint32_t *ftags, const uint4 *frows,
                                double *hmaps, const uint32_t *blockcounts, int nblocks,
                                unsigned long long *host_counter, unsigned long long *dev_counter)
 {
@@ -2352,7 +2353,7 @@ hipError_t gvom_launch_posdens(hipStream_t s, const Map2dParams &P, const int32_
         return hipGetLastError();
     }
     hipLaunchKernelGGL(k_posdens, dim3((P.xy + 63) / 64, (P.y_hi - P.y_lo + 3) / 4), dim3(64, 4), 0, s, P,
-                       fstate, ftags, fhit, ftotal, hmaps, blockcounts, nblocks, host_counter, dev_counter);
+                       fstate, ftags, frows, hmaps, blockcounts, nblocks, host_counter, dev_counter);
     return hipGetLastError();
 }
 
