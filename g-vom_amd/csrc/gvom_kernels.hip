@@ -183,17 +183,13 @@ __device__ __forceinline__ bool window_voxel(const ScanParams &P, float px, floa
     wx = (uint32_t)cvt_floor_i32(px) - (uint32_t)(int)P.origin[0];
     wy = (uint32_t)cvt_floor_i32(py) - (uint32_t)(int)P.origin[1];
     wz = (uint32_t)cvt_floor_i32(pz) - (uint32_t)(int)P.origin[2];
-    return max(wx, wy) < (uint32_t)P.xy && wz < (uint32_t)P.zs;
+    // ONE compare for the three axes (its result is the lane mask the step body needs, no boolean to
+    // re-materialise): z is padded up to the xy bound with a saturating add ("negative" differences are
+    // huge unsigned values and stay huge).  Requires z_size <= xy_size: callers take the literal form for
+    // grids taller than wide.
+    const uint32_t uxy = (uint32_t)P.xy;
+    return max(max(wx, wy), __builtin_elementwise_add_sat(wz, uxy - (uint32_t)P.zs)) < uxy;
 }
-// one position, either form: literal when a coordinate is within 2^-21 of zero
-template <bool BIG>
-__device__ __forceinline__ bool window_voxel_auto(const ScanParams &P, float px, float py, float pz,
-                                                  uint32_t &wx, uint32_t &wy, uint32_t &wz)
-{
-    if (BIG || fminf(fminf(fabsf(px), fabsf(py)), fabsf(pz)) < 0x1p-21f) return window_voxel<true>(P, px, py, pz, wx, wy, wz);
-    return window_voxel<false>(P, px, py, pz, wx, wy, wz);
-}
-
 // Number of DDA steps the reference's length test lets a ray take (gvom.py:1127,1149):
 //   length_0 = 0, length_j = fl(length_{j-1} + step_len) in f64; step j runs iff length_{j-1} < lim,
 // i.e. n = the smallest j with length_j >= lim (0 if lim <= 0), capped at `cap` + 1 (callers only need
@@ -338,17 +334,18 @@ __device__ __forceinline__ void walk_steps(const ScanParams &P, int lane, uint32
     glb_u32 *const total1 = (glb_u32 *)total;
     uint32_t memo = LC_EMPTY; int memo_slot = 0;
     bool dirty = false;
-    for (int left = steps; left > 0 && lanes(active) != 0ull; --left) {
+    // A ray that has ended is parked at x = +inf: it never falls into the window again, so "takes part in
+    // this step" is the window test alone -- no per-lane flag carried around the loop.
+    px = active ? px : INFINITY;
+    for (int left = steps; left > 0; --left) {
         ++j;
         // every lane computes (a finished ray's lanes produce values nobody uses): no divergent
         // region around the arithmetic
         px += incx; py += incy; pz += incz;
         uint32_t wx, wy, wz;                                              // window voxel
-        const bool inw = window_voxel<LIT>(P, px, py, pz, wx, wy, wz);
-        const bool commit = active & inw;
-        active = commit & (j < cnt);                                      // gvom.py:1127 (length test), 1135-1144 (left the grid)
+        const bool commit = window_voxel<LIT>(P, px, py, pz, wx, wy, wz);
         const unsigned long long cmask = lanes(commit);
-        if (cmask == 0ull) break;                                         // wave-uniform: no lane is active any more
+        if (cmask == 0ull) { px = INFINITY; break; }                      // wave-uniform: every ray of the bundle has ended
         dirty = true;
         uint32_t sx, sy, sz;                                              // toroidal storage coordinates
         if (P2) { sx = (wx + om0) & (uxy - 1u); sy = (wy + om1) & (uxy - 1u); sz = (wz + om2) & (uzs - 1u); }
@@ -357,10 +354,11 @@ __device__ __forceinline__ void walk_steps(const ScanParams &P, int lane, uint32
         // merge runs of equal voxel indices among neighbouring lanes
         const uint32_t key = commit ? Ls : (0xFFFFFF00u | (uint32_t)lane);
         const uint32_t leftk = (uint32_t)__builtin_amdgcn_update_dpp((int)~key, (int)key, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-        const bool head = commit & (leftk != key);
-        const unsigned long long hm = lanes(head);
-        // a run ends in front of the next head or of the next lane without a step
-        const unsigned long long ends = (hm | ~cmask) >> 1;
+        const bool differs = leftk != key;
+        const unsigned long long hm = lanes(differs) & cmask;             // heads of runs (mask arithmetic on the scalar unit)
+        const bool head = commit & differs;
+        // a run ends in front of the next head or of the next lane without a step -- or with the wave
+        const unsigned long long ends = ((hm | ~cmask) >> 1) | (1ull << 63);
         if (head && !GVOM_DBG(P, 16)) {
             // memo: the (line, row-in-line) this lane added to last; a miss looks the line up
             // (or inserts it) and stamps the voxel's tile tag
@@ -375,8 +373,7 @@ __device__ __forceinline__ void walk_steps(const ScanParams &P, int lane, uint32
                 if (!GVOM_DBG(P, 2)) tags[mad24s(mad24s(sy, uzs, sz), unseg, sx >> 6)] = P.epoch;
             }
             // (independent of the look-up: issued while the LDS compare-and-swap is in flight)
-            const unsigned long long after = ends >> lane;
-            const uint32_t run = after ? (uint32_t)__ffsll((long long)after) : (uint32_t)(64 - lane);   // lanes in my run
+            const uint32_t run = (uint32_t)__ffsll((long long)(ends >> lane));   // lanes in my run
             int slot = memo_slot;
             if (miss) {
                 slot = (was == LC_EMPTY || was == line) ? (int)hh : -1;
@@ -385,7 +382,10 @@ __device__ __forceinline__ void walk_steps(const ScanParams &P, int lane, uint32
             if (slot >= 0) __hip_atomic_fetch_add(&cnt3[slot * 16 + (int)(Ls & 15u)], run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             else __hip_atomic_fetch_add(&total1[Ls], run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // table congested: direct add
         }
+        // gvom.py:1127 (length test), 1135-1144 (left the grid): the ray ends after this step
+        px = (commit & (j < cnt)) ? px : INFINITY;
     }
+    active = px < INFINITY;
     if (dirty) lc_flush(P, lck, lcc, total, lane);
 }
 
@@ -406,8 +406,8 @@ __device__ __forceinline__ void walk_item(const ScanParams &P, int lane, uint32_
         // the loop -- to about p + run * inc; the margin is far above the rounding of that estimate, which
         // is below run * ulp(run) wherever the hull is near zero; NaN estimates compare false: such a
         // lane is inactive or leaves the grid at once)
-        bool lit = BIG;
-        if (!BIG) {
+        bool lit = BIG || P.zs > P.xy;                       // (the integer window test assumes z_size <= xy_size)
+        if (!lit) {
             const float fs = (float)min((uint32_t)run, cnt - j);              // steps this ray can still take here (active lanes: cnt > j)
             const float ax = px + incx, ay = py + incy, az = pz + incz;
             const float qx = px + fs * incx, qy = py + fs * incy, qz = pz + fs * incz;
@@ -426,7 +426,7 @@ __device__ __forceinline__ void walk_item(const ScanParams &P, int lane, uint32_
 }
 
 // ------------------------------------------------------------------------------------------
-// k_trace.  Grid (ceil(N/256), nsegs + 1): row P.ep_row holds the endpoint
+// k_trace.  Grid (ceil(N/512), nsegs + 1), 8 waves per workgroup: row P.ep_row holds the endpoint
 // blocks (endpoint_update), every other row one STEP SEGMENT of the rays: a wave sets its 64 rays up
 // (ray_setup, ray_steps), replays the steps of the earlier segments -- three f32 additions per step,
 // the reference's exact accumulation, no lookup, no memory traffic -- and runs the step body for its
@@ -434,14 +434,14 @@ __device__ __forceinline__ void walk_item(const ScanParams &P, int lane, uint32_
 // so "the ray has already ended before step k" is decided by the state AT step k alone, given that
 // step 1 lies inside the grid, which every wave checks.
 // ------------------------------------------------------------------------------------------
-template <typename T, bool BIG>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_trace(
+template <typename T, bool BIG, int WPB>
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_trace(
     const ScanParams P, const ShardExchange X, const T *__restrict__ in, long stride, long n, T *__restrict__ world,
     uint32_t *hit, uint32_t *total, uint32_t *mh, int32_t *state, uint32_t *tags, uint32_t *counters, double *stat_sums,
     double *stat_base, uint32_t *stat_rowvox)
 {
     const int lane = threadIdx.x & (WAVE - 1);
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long i = (long)blockIdx.x * (64 * WPB) + threadIdx.x;
     const bool live = i < n;
     T x = 0, y = 0, z = 0;
     if (live) load_return(P, in, stride, i, x, y, z);
@@ -502,8 +502,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const bool active = j0 < cnt && !GVOM_DBG(P, 8);
     if (lanes(active) == 0ull) return;                   // wave-uniform: every ray of the bundle ends earlier
     for (uint32_t k = j0; k > 0; --k) { px += R.incx; py += R.incy; pz += R.incz; }   // replay (exact accumulation)
-    __shared__ __attribute__((aligned(16))) uint32_t s_keys[4 * 64];
-    __shared__ uint32_t s_cnt[4 * 1024];
+    __shared__ __attribute__((aligned(16))) uint32_t s_keys[WPB * 64];
+    __shared__ uint32_t s_cnt[WPB * 1024];
     uint32_t *lck = s_keys + (threadIdx.x >> 6) * 64;
     uint32_t *lcc = s_cnt + (threadIdx.x >> 6) * 1024;
     LC_ST(&lck[lane], LC_EMPTY);
@@ -2196,14 +2196,14 @@ hipError_t gvom_launch_trace(hipStream_t s, const ScanParams &P, const ShardExch
                              uint32_t *counters, double *stat_sums, double *stat_base,
                              uint32_t *stat_rowvox)
 {
-    const unsigned blocks = (unsigned)((n + 255) / 256);
-    if (blocks == 0) return hipSuccess;
-#define TRACE_LAUNCH(TT, BB)                                                                             \
-    hipLaunchKernelGGL((k_trace<TT, BB>), dim3(blocks, (unsigned)P.nsegs + (P.ep_row >= 0 ? 1u : 0u)), dim3(256), 0, s, P, X, (const TT *)pts, \
+    if (n <= 0) return hipSuccess;
+#define TRACE_LAUNCH(TT, BB, WW)                                                                             \
+    hipLaunchKernelGGL((k_trace<TT, BB, WW>), dim3((unsigned)((n + 64 * WW - 1) / (64 * WW)), (unsigned)P.nsegs + (P.ep_row >= 0 ? 1u : 0u)), dim3(64 * WW), 0, s, P, X, (const TT *)pts, \
                        (long)stride_elems, (long)n, (TT *)world, hit, total, mh, state, tags, counters,     \
                        stat_sums, stat_base, stat_rowvox)
-    if (dtype == 0) { if (big_origin) TRACE_LAUNCH(float, true); else TRACE_LAUNCH(float, false); }
-    else { if (big_origin) TRACE_LAUNCH(double, true); else TRACE_LAUNCH(double, false); }
+    // 8 waves per workgroup (measured on m256: 1 / 2 / 4 / 8 / 16 waves -> 47.4 / 44.6 / 41.7 / 40.5 / 42.8 us)
+    if (dtype == 0) { if (big_origin) TRACE_LAUNCH(float, true, 8); else TRACE_LAUNCH(float, false, 8); }
+    else { if (big_origin) TRACE_LAUNCH(double, true, 8); else TRACE_LAUNCH(double, false, 8); }
 #undef TRACE_LAUNCH
     return hipGetLastError();
 }
