@@ -332,8 +332,9 @@ __device__ __forceinline__ void walk_steps(const ScanParams &P, int lane, uint32
     lds_u32 *const keys3 = (lds_u32 *)lck;
     lds_u32 *const cnt3 = (lds_u32 *)lcc;
     glb_u32 *const total1 = (glb_u32 *)total;
-    uint32_t memo = LC_EMPTY; int memo_slot = 0;
+    uint32_t memo = LC_EMPTY;
     bool dirty = false;
+    const bool is32 = lane == 32;                                         // (loop-invariant lane mask)
     // A ray that has ended is parked at x = +inf: it never falls into the window again, so "takes part in
     // this step" is the window test alone -- no per-lane flag carried around the loop.
     px = active ? px : INFINITY;
@@ -354,11 +355,12 @@ __device__ __forceinline__ void walk_steps(const ScanParams &P, int lane, uint32
         // merge runs of equal voxel indices among neighbouring lanes
         const uint32_t key = commit ? Ls : (0xFFFFFF00u | (uint32_t)lane);
         const uint32_t leftk = (uint32_t)__builtin_amdgcn_update_dpp((int)~key, (int)key, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+        // (a run also ends at the half-wave boundary: its length is then found in the low word of a shifted mask)
         const bool differs = leftk != key;
-        const unsigned long long hm = lanes(differs) & cmask;             // heads of runs (mask arithmetic on the scalar unit)
-        const bool head = commit & differs;
-        // a run ends in front of the next head or of the next lane without a step -- or with the wave
-        const unsigned long long ends = ((hm | ~cmask) >> 1) | (1ull << 63);
+        const unsigned long long hm = (lanes(differs) | (1ull << 32)) & cmask;   // heads of runs (mask arithmetic on the scalar unit)
+        const bool head = commit & (differs | is32);
+        // a run ends in front of the next head or of the next lane without a step -- or with the half-wave
+        const unsigned long long ends = ((hm | ~cmask) >> 1) | (1ull << 63) | (1ull << 31);
         if (head && !GVOM_DBG(P, 16)) {
             // memo: the (line, row-in-line) this lane added to last; a miss looks the line up
             // (or inserts it) and stamps the voxel's tile tag
@@ -373,13 +375,12 @@ __device__ __forceinline__ void walk_steps(const ScanParams &P, int lane, uint32
                 if (!GVOM_DBG(P, 2)) tags[mad24s(mad24s(sy, uzs, sz), unseg, sx >> 6)] = P.epoch;
             }
             // (independent of the look-up: issued while the LDS compare-and-swap is in flight)
-            const uint32_t run = (uint32_t)__ffsll((long long)(ends >> lane));   // lanes in my run
-            int slot = memo_slot;
-            if (miss) {
-                slot = (was == LC_EMPTY || was == line) ? (int)hh : -1;
-                if (slot >= 0) { memo = lrow; memo_slot = slot; }
-            }
-            if (slot >= 0) __hip_atomic_fetch_add(&cnt3[slot * 16 + (int)(Ls & 15u)], run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t run = 1u + (uint32_t)__builtin_ctz((uint32_t)(ends >> lane));   // lanes in my run (<= 32: see `ends`; never 0)
+            // the slot is a function of the voxel (a memo hit means: same line, still in its slot -- slots are
+            // only released by the flush); a miss whose slot holds another line adds directly
+            const bool ok = (was == LC_EMPTY) | (was == line);
+            memo = ok ? lrow : memo;
+            if (ok) __hip_atomic_fetch_add(&cnt3[hh * 16u + (Ls & 15u)], run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             else __hip_atomic_fetch_add(&total1[Ls], run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // table congested: direct add
         }
         // gvom.py:1127 (length test), 1135-1144 (left the grid): the ray ends after this step
