@@ -20,6 +20,7 @@
 #include <fcntl.h>
 #include <immintrin.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <sys/mman.h>
@@ -89,7 +90,9 @@ struct gvom_comm {
     Segment *seg = nullptr;
     std::string shm_name, err;
     uint64_t calls = 0;                        // host exchanges so far
-    double timeout_s = 60.0;
+    // rendezvous / host-exchange patience: the ranks of a job start seconds to minutes apart on a cold box
+    // (first import of the interpreter's packages); GVOM_COMM_TIMEOUT_S overrides
+    double timeout_s = 600.0;
 };
 
 namespace {
@@ -120,6 +123,7 @@ VIS int gvom_comm_create(int rank, int world, int device, const char *name, gvom
     gvom_comm *c = new gvom_comm();
     c->rank = rank; c->world = world; c->device = device;
     c->shm_name = std::string("/") + name;
+    if (const char *t = getenv("GVOM_COMM_TIMEOUT_S")) { const double v = atof(t); if (v > 0.0) c->timeout_s = v; }
     auto fail = [&](const std::string &why, int code) {
         fprintf(stderr, "gvom_comm_create(rank %d of %d): %s\n", rank, world, why.c_str());
         if (c->seg) munmap(c->seg, sizeof(Segment));
