@@ -1162,8 +1162,8 @@ VIS int gvom_combine_end(gvom_t *h, double origin_world[3])
     lk.unlock();                                           // process_pointcloud may run meanwhile
     const hipError_t e = hipEventSynchronize(h->ev_mapped);
     lk.lock();
+    h->pending_combine = false;                            // (also on failure: the handle must not stay blocked)
     HIPCHK(h, e);
-    h->pending_combine = false;
     Fused &F = h->fused[h->cur];
     unsigned long long c;
     memcpy(&c, h->counters_host + 2, 8);
