@@ -216,7 +216,9 @@ void fill_scan_params(const gvom_handle *h, const int64_t origin[3], const doubl
         if (nsegs > 9) nsegs = 9;
         if (nsegs > maxsteps / 8) nsegs = maxsteps / 8 > 0 ? maxsteps / 8 : 1;
         P.nsegs = nsegs;
-        P.lc_period = h->tune_period > 0 ? h->tune_period : 16;
+        // flush period (final step body; c4: 8 / 12 / 16 / 24 / 32 -> 552 / 537 / 545 / 608 / 638 us, c5 12 / 16: 2438 / 2460,
+        // m256 and c3: 12 = 16)
+        P.lc_period = h->tune_period > 0 ? h->tune_period : (n_points > 3 * 131072 ? 12 : 16);
         if (P.lc_period > 32) P.lc_period = 32;          // the line cache is direct-mapped with 64 entries
         P.ep_row = h->tune_ep_row >= -1 ? h->tune_ep_row : 0;  // endpoint blocks first: their atomics retire under the walk (-1: inside segment 0's waves)
         if (P.ep_row > P.nsegs) P.ep_row = P.nsegs;

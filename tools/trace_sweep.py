@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Sweeps the result-neutral trace knobs (gvom_set_tuning: chunk, ep_row) on one config and prints the
 HIP-event stage times (median over sampled steps) and the step time per setting.
-Usage: tools/trace_sweep.py [config] [steps]"""
+Usage: tools/trace_sweep.py [config] [steps] [segs,...] [periods,...]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "g-vom_amd")]
@@ -14,7 +14,8 @@ hip = bench.Hip(); hip.set_device(0)
 params, scans = synth.config_inputs(name, n_scans=4)
 dev = [(hip.to_device(pc), pc.shape[0], pc.dtype, ego, tf) for (pc, ego, tf) in scans]
 g = gvom.Gvom(*params)
-settings = [("segs", int(v), 16) for v in (sys.argv[3].split(",") if len(sys.argv) > 3 else "2,3,4,5,6".split(","))]
+periods = [int(v) for v in (sys.argv[4].split(",") if len(sys.argv) > 4 else ["16"])]
+settings = [("segs", int(v), p_) for v in (sys.argv[3].split(",") if len(sys.argv) > 3 else "2,3,4,5,6".split(",")) for p_ in periods]
 for kind, chunk, ep in settings:
     g.set_tuning("segs", chunk); g.set_tuning("period", ep)
     for k in range(30):
