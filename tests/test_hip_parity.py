@@ -785,6 +785,35 @@ def test_tall_grids_use_the_generic_fusion_kernel(gvom_mod, grid):
     assert compare_records(got, want, float_tol=1e-5) > 20
 
 
+@pytest.mark.parametrize("grid", [(32, 16, 20), (30, 12, 24), (16, 300, 18), (32, 16, 40)])
+def test_long_rings_read_their_descriptors_from_memory(gvom_mod, grid):
+    """More than 17 fusion sources (ring slots + previous map) no longer fit the kernel arguments: the
+    descriptors then come from device memory (the MEM instantiations of k_fuse4 / k_fuse).  The ring fills
+    beyond 17 slots, wraps (the 40-slot one does not) and the window moves; xy % 4 != 0 and a tall grid take
+    the generic kernels."""
+    xy, zs, buf = grid
+    params = (0.4, 0.2 if zs < 100 else 0.05, xy, zs, buf, 0.5, 0.5, 0.5, 0.3, 2.0, 2.0, 1.0, 1, 1)
+    rng = np.random.default_rng(xy * 1000 + buf)
+    g, w = gvom_mod.Gvom(*params), oracle.OracleGvom(*params)
+    n_scans = 26
+    for k in range(n_scans):
+        ego = (0.25 * k, -0.15 * k, 0.02 * k)
+        n = 1500
+        pc = np.stack([rng.uniform(-0.2 * xy, 0.2 * xy, n) + ego[0], rng.uniform(-0.2 * xy, 0.2 * xy, n) + ego[1],
+                       rng.normal(-0.5, 0.3, n) + ego[2]], axis=1).astype(np.float32)
+        g.process_pointcloud(pc, ego); w.process_pointcloud(pc.copy(), ego)
+        if k >= 16 or k % 5 == 0:
+            a, b = g.combine_maps(), w.combine_maps()
+            for i in (0, 1, 2, 4):
+                assert np.array_equal(a[i], b[i]), (k, i)
+            assert np.allclose(a[3], b[3], rtol=0, atol=1e-5)
+            assert g.combined_cell_count_cpu == w.combined_cell_count_cpu, k
+    gd = g.read_dense(gvom_mod.GVOM_WHICH_FUSED)
+    wd = scenarios.dense_from_compact(w.combined_index_map, w.combined_hit_count, w.combined_total_count, w.combined_min_height)
+    for j in range(4):
+        assert np.array_equal(np.asarray(wd[j]), gd[j]), j
+
+
 def test_cuda_f32_sqrt_flag(gvom_mod):
     """GVOM_FLAG_CUDA_F32_SQRT: real Numba-CUDA types math.sqrt(float32) as float32
     (gvom.py:1109-1114); the simulator -- and therefore the fixtures and the default -- takes the float64
