@@ -243,10 +243,12 @@ def transform_from_translation_rotation(translation, rotation):
 
 
 class _PendingMaps(object):
-    """A combine begun with Gvom.combine_maps_async(); result() completes it (once)."""
+    """A combine begun with Gvom.combine_maps_async() / combine_maps_occupancy_async(); result() completes
+    it (once)."""
 
-    def __init__(self, owner, holder):
+    def __init__(self, owner, holder, occupancy=False):
         self._owner, self._holder, self._out, self._done = owner, holder, None, holder is None
+        self._occupancy = occupancy
 
     def result(self):
         if not self._done:
@@ -256,11 +258,14 @@ class _PendingMaps(object):
             origin = np.zeros(3, np.float64)
             g._check(g._lib.gvom_combine_end(g._h, _ptr(origin)))
             raw = np.asarray(self._holder)
-            self._out = (origin,
-                         np.ndarray((xy, xy), np.int32, raw, 0, (4, 4 * xy)),
-                         np.ndarray((xy, xy), np.int32, raw, 4 * n2, (4, 4 * xy)),
-                         np.ndarray((xy, xy), np.float64, raw, 12 * n2, (8, 8 * xy)),
-                         np.ndarray((xy, xy), np.int32, raw, 8 * n2, (4, 4 * xy)))
+            if self._occupancy:
+                self._out = (origin,) + tuple(raw[k * n2:(k + 1) * n2].view(np.int8) for k in range(5))
+            else:
+                self._out = (origin,
+                             np.ndarray((xy, xy), np.int32, raw, 0, (4, 4 * xy)),
+                             np.ndarray((xy, xy), np.int32, raw, 4 * n2, (4, 4 * xy)),
+                             np.ndarray((xy, xy), np.float64, raw, 12 * n2, (8, 8 * xy)),
+                             np.ndarray((xy, xy), np.int32, raw, 8 * n2, (4, 4 * xy)))
             self._done, self._holder = True, None
         return self._out
 
@@ -464,6 +469,23 @@ class Gvom(object):
             print("[WARNING] The map buffer is empty, nothing will happen!")
             return _PendingMaps(self, None)
         return _PendingMaps(self, holder)
+
+    def combine_maps_occupancy_async(self, density_threshold=50, min_roughness=-10, max_roughness=0):
+        """combine_maps_occupancy() split like combine_maps_async(): `.result()` returns its tuple."""
+        n2 = self.xy_size * self.xy_size
+        if self._out_pool.free:
+            ptr = self._out_pool.free.pop()
+        else:
+            p = ctypes.c_void_p()
+            self._check(self._lib.gvom_output_buffer_alloc(self._h, ctypes.byref(p)))
+            ptr = p.value
+        holder = _PinnedOutput(self._out_pool, ptr, n2 * 20)
+        occ = (ctypes.c_double * 3)(float(density_threshold), float(min_roughness), float(max_roughness))
+        rc = self._check(self._lib.gvom_combine_begin(self._h, ctypes.c_void_p(ptr), occ))
+        if rc == GVOM_EMPTY_BUFFER:
+            print("[WARNING] The map buffer is empty, nothing will happen!")
+            return _PendingMaps(self, None)
+        return _PendingMaps(self, holder, occupancy=True)
 
     def combine_maps_occupancy(self, density_threshold=50, min_roughness=-10, max_roughness=0):
         """combine_maps() fused with the post-processing the ROS node applies to its result

@@ -171,6 +171,13 @@ def test_asynchronous_combine_overlapped_with_the_next_scan(gvom_mod):
     dropped = b.combine_maps_async()
     del dropped
     assert b.combine_maps() is not None
+    # the occupancy form (int8 grids): asynchronous == synchronous
+    for _ in range(3):
+        a.combine_maps()                                           # b has combined three times more (the previous map enters a combine)
+    want_occ = a.combine_maps_occupancy(40, -8, 0)
+    got_occ = b.combine_maps_occupancy_async(40, -8, 0).result()
+    for i in range(6):
+        assert np.array_equal(got_occ[i], want_occ[i]), i
 
 
 def test_scans_from_a_second_thread_while_a_combine_waits(gvom_mod):
