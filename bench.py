@@ -280,6 +280,18 @@ def run_config(hip, name, steps, warmup, poses, full):
     pend[0].result()
     out["value_async_combine"] = n_pts * steps / _median(b5) / 1e6
     out["ms_per_step_async_combine"] = _median(b5) / steps * 1e3
+
+    def step_async_occ(k):                             # the same with the int8 occupancy grids (5 B/cell over PCIe)
+        d, n, dt, ego, tf = dev[k % len(dev)]
+        g.process_pointcloud_device(d.value, n, dt, ego, tf)
+        maps = pend[0].result() if pend[0] is not None else None
+        pend[0] = g.combine_maps_occupancy_async()
+        return maps
+
+    pend[0] = None
+    b6, k = timed_blocks(step_async_occ, k, steps, 0.2)
+    pend[0].result()
+    out["value_async_occupancy_api"] = n_pts * steps / _median(b6) / 1e6
     out["host_us"] = g.host_timing()
     # exact integer accounting for the roofline (algorithmic bytes), AFTER the timed regions:
     # the dense read-back allocates and frees 16*V bytes
@@ -360,6 +372,7 @@ def run_single(args):
         "value_host_f32": res["value_host_f32"], "value_ros_f64_tf": res["value_ros_f64_tf"],
         "value_occupancy_api": res["value_occupancy_api"],
         "value_async_combine": res["value_async_combine"], "ms_per_step_async_combine": res["ms_per_step_async_combine"],
+        "value_async_occupancy_api": res["value_async_occupancy_api"],
         "value_semantics": "value: cloud resident in HBM (driver contract); value_host_f32: host numpy in (gvom.py:110); "
                            "value_ros_f64_tf: float64 host array + 4x4 transform, the unchanged gvom_ros.py:106-109 path; "
                            "value_async_combine: combine_maps_async() (extension), the next scan traced while the maps "
