@@ -68,6 +68,11 @@ class Hip(object):
     def set_device(self, d):
         self.chk(self.rt.hipSetDevice(d), "hipSetDevice")
 
+    def device_count(self):
+        n = ctypes.c_int(0)
+        self.chk(self.rt.hipGetDeviceCount(ctypes.byref(n)), "hipGetDeviceCount")
+        return n.value
+
     def to_device(self, arr):
         p = ctypes.c_void_p()
         self.chk(self.rt.hipMalloc(ctypes.byref(p), arr.nbytes), "hipMalloc")

@@ -22,8 +22,13 @@ def run(args):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
-    affinity = bench.pin_to_gpu_numa(local_rank)      # each rank next to its own GPU
     hip = bench.Hip()
+    ndev = hip.device_count()
+    if ndev < 1:
+        raise RuntimeError("rank %d sees no HIP device" % rank)
+    if local_rank >= ndev:                            # a launcher that shows every rank only its own GPU
+        local_rank = local_rank % ndev
+    affinity = bench.pin_to_gpu_numa(local_rank)      # each rank next to its own GPU
     hip.set_device(local_rank)
     name = args.config if args.config in ("m256", "c2", "c3", "m256b8") else "m256"
     params, beams, desc = synth.CONFIGS[name]
