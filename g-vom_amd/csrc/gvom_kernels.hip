@@ -663,7 +663,8 @@ __global__ __launch_bounds__(256) void k_unpack_eps(const ScanParams P, uint32_t
 // Min-height arrives as a third dense accumulator (1.0f's bits minus the value's bits, atomicMax:
 // zero between scans like the other two), read only where a voxel is occupied.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_encode(const ScanParams P, uint32_t t_begin, uint32_t t_end,
+template <int ENC_T>
+__global__ __launch_bounds__(ENC_T) void k_encode(const ScanParams P, uint32_t t_begin, uint32_t t_end,
                                                 uint32_t *hit, uint32_t *total, uint32_t *mh, int32_t *state,
                                                 uint16_t *code16, uint4 *crows,
                                                 const uint32_t *__restrict__ tags, uint32_t epoch,
@@ -2238,17 +2239,25 @@ hipError_t gvom_launch_encode(hipStream_t s, const ScanParams &P, uint32_t *hit,
                               uint32_t *counters, unsigned long long *host_flag, uint32_t seq, unsigned resident_blocks)
 {
     // units = quads (4 rows x 64 sx at one sz) that intersect the slab; one wave handles 2 quads per
-    // iteration, 4 waves per block
+    // iteration
     const uint32_t q_lo = (uint32_t)P.sy_lo >> 2, q_hi = ((uint32_t)P.sy_hi + 3) >> 2;
     const uint32_t t_begin = q_lo * P.zs * P.nseg, t_end = q_hi * P.zs * P.nseg;
     const uint32_t ntiles = t_end - t_begin;
-    unsigned enc_blocks = (ntiles + 7) / 8;
+    // workgroup size (every wave handles 2 quads per iteration either way).  Measured, 64 / 128 / 256 / 512 / 1024
+    // threads: 256^3 (65 k quads) 18.8 / 18.8 / 21.2 / 21.0 / 30.1 us, c4 (131 k quads) 60 / 69 / 80 / 94 / 83, c5
+    // (524 k quads) 127 / 126 / 100: one-wave workgroups up to 262 k quads, four-wave ones above
+    const unsigned T = ntiles <= 262144u ? 64u : 256u;
+    unsigned enc_blocks = (ntiles + (T / 32) - 1) / (T / 32);
     // at most four resident rounds (measured on 256^3 / 2048 resident blocks: 4096 -> 20.0 us, 8192 -> 18.8 us)
-    const unsigned enc_cap = resident_blocks > 0 ? 4u * resident_blocks : 8192u;
+    const unsigned enc_cap = (resident_blocks > 0 ? 4u * resident_blocks : 8192u) * 256u / T;
     if (enc_blocks > enc_cap) enc_blocks = enc_cap;
     if (enc_blocks < 1) enc_blocks = 1;
-    hipLaunchKernelGGL(k_encode, dim3(enc_blocks), dim3(256), 0, s, P, t_begin, t_end, hit, total, mh, state,
-                       code16, crows, tags, P.epoch, counters, host_flag, seq);
+    if (T == 64u)
+        hipLaunchKernelGGL(k_encode<64>, dim3(enc_blocks), dim3(64), 0, s, P, t_begin, t_end, hit, total, mh, state,
+                           code16, crows, tags, P.epoch, counters, host_flag, seq);
+    else
+        hipLaunchKernelGGL(k_encode<256>, dim3(enc_blocks), dim3(256), 0, s, P, t_begin, t_end, hit, total, mh, state,
+                           code16, crows, tags, P.epoch, counters, host_flag, seq);
     return hipGetLastError();
 }
 
