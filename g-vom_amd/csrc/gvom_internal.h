@@ -152,6 +152,7 @@ hipError_t gvom_launch_unpack(hipStream_t s, const ScanParams &P, const ShardUnp
 hipError_t gvom_launch_encode(hipStream_t s, const ScanParams &P, uint32_t *hit, uint32_t *total, uint32_t *mh,
                               int32_t *state, uint16_t *code16, uint4 *crows, const uint32_t *tags,
                               uint32_t *counters, unsigned long long *host_flag, uint32_t seq, unsigned resident_blocks);
+hipError_t gvom_launch_publish_seq(hipStream_t s, unsigned long long *host_flag, uint32_t seq);
 hipError_t gvom_launch_fuse(hipStream_t s, const FuseParams &P, const FuseDescs &KD,
                             const MapDesc *descs_dev, int32_t *fstate, uint4 *frows,
                             uint32_t *ftags, uint32_t *blockcounts, double *height, double *inferred);

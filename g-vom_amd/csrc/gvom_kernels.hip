@@ -2261,6 +2261,18 @@ hipError_t gvom_launch_encode(hipStream_t s, const ScanParams &P, uint32_t *hit,
     return hipGetLastError();
 }
 
+// one store of `seq` into host-mapped memory: launched behind the last kernel of a call, it tells the
+// spinning host that everything before it on the stream has completed (lower latency than an event wait)
+__global__ void k_publish_seq(unsigned long long *host_flag, uint32_t seq)
+{
+    __hip_atomic_store(host_flag, (unsigned long long)seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+hipError_t gvom_launch_publish_seq(hipStream_t s, unsigned long long *host_flag, uint32_t seq)
+{
+    hipLaunchKernelGGL(k_publish_seq, dim3(1), dim3(1), 0, s, host_flag, seq);
+    return hipGetLastError();
+}
+
 // epoch renumbering (gvom_capi.hip renumber_epochs): live tiles get the map's new epoch, all others 0
 __global__ void k_retag(uint32_t *tags, size_t n, uint32_t old_epoch, uint32_t new_epoch)
 {
