@@ -124,6 +124,7 @@ struct gvom_handle {
     std::mutex combine_mu;                              // one combine call at a time (taken before `mu`)
     bool pending_combine = false;                       // begun, not ended
     uint32_t combine_seq = 0;                           // completion flag of the synchronous combine (counters_host + 4)
+    double last_wait_ns[2] = {0.0, 0.0};                // how long the scan / the combine waited last time (wait_published)
     bool mapped_unjoined = false;                       // ev_mapped recorded; the main stream has not waited on it
     void *out_host = nullptr;                           // pinned, device-mapped staging for the 4 outputs
     char *out_host_dev = nullptr;                       // device view of out_host (zero-copy target)
@@ -401,14 +402,17 @@ hipError_t join_map_stream(gvom_handle *h)
 // Scan kernels up to (not including) the commit.  `dev_pts` is device memory.
 // Waits until the GPU has published sequence number `seq` in the 64-bit host-mapped word `flag` (high
 // half, or the whole word).  `lk` (the handle mutex) is RELEASED while waiting, so combine_maps from
-// another thread is not locked out for the length of a trace; a long wait (c5: milliseconds) stops
-// spinning and yields the core.
+// another thread is not locked out for the length of a trace.  A wait that took long the last time (c5:
+// milliseconds) first SLEEPS most of that time away and spins only over the end: the core is free meanwhile
+// and the wake-up still comes within microseconds (a sleep has a granularity of ~60 us; spinning with short
+// sleeps in between overshot a 250 us wait by 30 us).  `last_ns`: this wait's duration the previous time.
 bool wait_published(gvom_handle *h, std::unique_lock<std::mutex> &lk, volatile unsigned long long *flag, uint32_t seq,
-                    bool high_half)
+                    bool high_half, double *last_ns)
 {
     auto done = [&]() { return (uint32_t)(high_half ? (*flag >> 32) : *flag) == seq; };
     lk.unlock();
     const double start = now_ns();
+    if (last_ns && *last_ns > 4.0e5 && !done()) usleep((useconds_t)((*last_ns - 2.0e5) * 1e-3));   // all but the last ~200 us
     unsigned spins = 0;
     bool ok = true;
     while (!done()) {
@@ -416,9 +420,10 @@ bool wait_published(gvom_handle *h, std::unique_lock<std::mutex> &lk, volatile u
         if ((++spins & 0x3ff) == 0) {
             const double waited = now_ns() - start;
             if (waited > 2.0e9) { ok = false; break; }                // device trouble: the caller falls back
-            if (waited > 2.0e5) usleep(20);                           // beyond 200 us: yield instead of burning the core
+            if (waited > 2.0e7) usleep(50);                           // far beyond anything expected: stop burning the core
         }
     }
+    if (last_ns) *last_ns = now_ns() - start;
     lk.lock();
     return ok;
 }
@@ -475,7 +480,7 @@ int scan_launch(gvom_handle *h, std::unique_lock<std::mutex> &lk, const void *de
                               h->counters, h->x_host_dev, seq);
         if (le != hipSuccess) { scan_abort(h); HIPCHK(h, le); }
         volatile unsigned long long *flag = (volatile unsigned long long *)(h->x_host + 2 * h->world + 1);
-        if (!wait_published(h, lk, flag, seq, false)) {
+        if (!wait_published(h, lk, flag, seq, false, &h->last_wait_ns[0])) {
             hipError_t se = hipStreamSynchronize(h->stream);
             if (se != hipSuccess || (uint32_t)*flag != seq) {
                 scan_abort(h);
@@ -509,7 +514,7 @@ int scan_launch(gvom_handle *h, std::unique_lock<std::mutex> &lk, const void *de
     // with this handle is stream-ordered behind it.
     {
         volatile unsigned long long *flag = (volatile unsigned long long *)h->counters_host;
-        if (!wait_published(h, lk, flag, seq, true)) {
+        if (!wait_published(h, lk, flag, seq, true, &h->last_wait_ns[0])) {
             hipError_t se = hipStreamSynchronize(h->stream);
             if (se != hipSuccess || (uint32_t)(*flag >> 32) != seq) {
                 scan_abort(h);
@@ -806,7 +811,7 @@ int finish_combine(gvom_handle *h, std::unique_lock<std::mutex> &lk)
     HIPCHK(h, hipEventRecord(h->ev_done, h->stream));
     h->pending_combine = true;
     hipError_t e = hipSuccess;
-    if (!wait_published(h, lk, (volatile unsigned long long *)(h->counters_host + 4), seq, false)) {
+    if (!wait_published(h, lk, (volatile unsigned long long *)(h->counters_host + 4), seq, false, &h->last_wait_ns[1])) {
         lk.unlock();
         e = hipEventSynchronize(h->ev_done);
         lk.lock();
