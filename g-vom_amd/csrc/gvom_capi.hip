@@ -403,7 +403,7 @@ hipError_t join_map_stream(gvom_handle *h)
 // Waits until the GPU has published sequence number `seq` in the 64-bit host-mapped word `flag` (high
 // half, or the whole word).  `lk` (the handle mutex) is RELEASED while waiting, so combine_maps from
 // another thread is not locked out for the length of a trace.  A wait that took long the last time (c5:
-// milliseconds) first SLEEPS most of that time away and spins only over the end: the core is free meanwhile
+// milliseconds) first SLEEPS four fifths of that time away and spins only over the rest: the core is free meanwhile
 // and the wake-up still comes within microseconds (a sleep has a granularity of ~60 us; spinning with short
 // sleeps in between overshot a 250 us wait by 30 us).  `last_ns`: this wait's duration the previous time.
 bool wait_published(gvom_handle *h, std::unique_lock<std::mutex> &lk, volatile unsigned long long *flag, uint32_t seq,
@@ -412,7 +412,7 @@ bool wait_published(gvom_handle *h, std::unique_lock<std::mutex> &lk, volatile u
     auto done = [&]() { return (uint32_t)(high_half ? (*flag >> 32) : *flag) == seq; };
     lk.unlock();
     const double start = now_ns();
-    if (last_ns && *last_ns > 4.0e5 && !done()) usleep((useconds_t)((*last_ns - 2.0e5) * 1e-3));   // all but the last ~200 us
+    if (last_ns && *last_ns > 4.0e5 && !done()) usleep((useconds_t)(*last_ns * 0.8e-3));   // four fifths of it (a sleep may run 100 us over)
     unsigned spins = 0;
     bool ok = true;
     while (!done()) {
