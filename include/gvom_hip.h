@@ -160,7 +160,8 @@ int gvom_combine_occupancy_into(gvom_t *h, double origin_world[3], void *pinned_
  * the maps of this combine are stored to host memory (k_map2d runs on a second stream; the next fusion
  * waits for it on the device).  `pinned_out` must not be read before gvom_combine_end has returned.
  * One combine may be pending per handle; the synchronous combine entry points return GVOM_ERR_INVALID
- * while one is.  Results are those of the synchronous calls. */
+ * while one is (and gvom_combine_begin does while another thread waits inside a synchronous combine;
+ * synchronous combines of several threads simply queue up).  Results are those of the synchronous calls. */
 int gvom_combine_begin(gvom_t *h, void *pinned_out, const double *occ);
 int gvom_combine_end(gvom_t *h, double origin_world[3]);
 
