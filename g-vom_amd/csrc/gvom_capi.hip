@@ -283,7 +283,12 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, b
     CK(hipSetDevice(device_id));
     CK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     h->own_stream = h->stream;
-    CK(hipStreamCreateWithFlags(&h->stream_b, hipStreamNonBlocking));
+    {   // the second stream's kernels (fusion, k_map2d: latency- and PCIe-bound, few waves) go ahead of the
+        // instruction-bound k_trace they overlap with in an asynchronous combine
+        int lo = 0, hi = 0;
+        CK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        CK(hipStreamCreateWithPriority(&h->stream_b, hipStreamNonBlocking, hi));
+    }
     CK(hipEventCreateWithFlags(&h->ev_fused, hipEventDisableTiming));
     CK(hipEventCreateWithFlags(&h->ev_mapped, hipEventDisableTiming));
     CK(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
@@ -638,15 +643,17 @@ int choose_nz(int zs, int *zc, int *cpw)
     return (nchunks + *cpw - 1) / *cpw;
 }
 
-// fusion + column reductions (k_fuse) into fused[1 - cur]
-int fuse_impl(gvom_handle *h)
+// fusion + column reductions (k_fuse) into fused[1 - cur]; `on`: the stream (nullptr: the main one; the second
+// stream for an asynchronous combine, where it is ordered behind the previous k_map2d by itself)
+int fuse_impl(gvom_handle *h, hipStream_t on = nullptr)
 {
+    const hipStream_t fs = on ? on : h->stream;
     const gvom_params &p = h->prm;
     const Slot &last = h->slots[h->ring[h->last_buffer_index]];
     if (!last.filled) return GVOM_EMPTY_BUFFER;                        // gvom.py:179-181
     // before any map descriptor below copies an epoch
     if (h->epoch >= 0xFFFFFF00u) { int rc0 = renumber_epochs(h); if (rc0) return rc0; }
-    HIPCHK(h, join_map_stream(h));
+    if (!on) HIPCHK(h, join_map_stream(h));
     const int nxt = h->has_combined ? 1 - h->cur : 0;
     Fused &F = h->fused[nxt];
     const Fused *prev = (h->has_combined && h->fused[h->cur].valid) ? &h->fused[h->cur] : nullptr;
@@ -704,16 +711,16 @@ int fuse_impl(gvom_handle *h)
         memcpy(KD.d, h->descs_host, sizeof(MapDesc) * nsrc);
     } else {
         HIPCHK(h, hipMemcpyAsync(h->descs_dev, h->descs_host, sizeof(MapDesc) * nsrc,
-                                 hipMemcpyHostToDevice, h->stream));
+                                 hipMemcpyHostToDevice, fs));
         descs_mem = h->descs_dev;
     }
-    if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[4], h->stream));
-    HIPCHK(h, gvom_launch_fuse(h->stream, P, KD, descs_mem, F.state, (uint4 *)F.rows.p,
+    if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[4], fs));
+    HIPCHK(h, gvom_launch_fuse(fs, P, KD, descs_mem, F.state, (uint4 *)F.rows.p,
                                F.tags, h->blockcounts,
                                h->height, h->inferred));
-    if (h->profiling) { HIPCHK(h, hipEventRecord(h->ev[5], h->stream)); h->ev_fuse = true; }
+    if (h->profiling) { HIPCHK(h, hipEventRecord(h->ev[5], fs)); h->ev_fuse = true; }
     if (h->stats)
-        HIPCHK(h, gvom_launch_fuse_stats(h->stream, P, KD, descs_mem, F.state, F.tags, (float *)F.metrics.p));
+        HIPCHK(h, gvom_launch_fuse_stats(fs, P, KD, descs_mem, F.state, F.tags, (float *)F.metrics.p));
     F.valid = true;
     h->cur = nxt;
     h->has_combined = true;
@@ -1153,12 +1160,25 @@ VIS int gvom_combine_begin(gvom_t *h, void *pinned_out, const double *occ)
     if (h->pending_combine) { h->err = "a combine begun with gvom_combine_begin has not been ended"; return GVOM_ERR_INVALID; }
     HIPCHK(h, hipSetDevice(h->device));
     double t0 = now_ns();
-    int rc = fuse_impl(h);
-    if (rc) return rc;
+    // k_map2d goes to the second stream, and with a ring of three or more filled slots the fusion too (behind
+    // the scan's k_encode on the main stream): the next scan's k_trace / k_encode overlap them -- they touch the
+    // accumulators and the spare slot only.  (Measured, pipelined use, fusion on the main / the second stream:
+    // m256 86.5 / 88.8 us per step, c4 680 / 692, but c3 137 / 115, m256b8 119 / 102: a long fusion is worth it.)
+    int filled = 0;
+    for (int i = 0; i < h->prm.buffer_size; ++i) filled += h->slots[h->ring[i]].filled ? 1 : 0;
+    const bool fuse_on_b = filled >= 3;
+    int rc;
+    if (fuse_on_b) {
+        HIPCHK(h, hipEventRecord(h->ev_fused, h->stream));
+        HIPCHK(h, hipStreamWaitEvent(h->stream_b, h->ev_fused, 0));
+        if ((rc = fuse_impl(h, h->stream_b))) return rc;
+    } else {
+        if ((rc = fuse_impl(h))) return rc;
+        HIPCHK(h, hipEventRecord(h->ev_fused, h->stream));
+        HIPCHK(h, hipStreamWaitEvent(h->stream_b, h->ev_fused, 0));
+    }
     char *dev = nullptr;
     HIPCHK(h, hipHostGetDevicePointer((void **)&dev, pinned_out, 0));
-    HIPCHK(h, hipEventRecord(h->ev_fused, h->stream));
-    HIPCHK(h, hipStreamWaitEvent(h->stream_b, h->ev_fused, 0));
     if ((rc = map2d_impl(h, false, true, dev, true, occ, h->stream_b))) return rc;
     HIPCHK(h, hipEventRecord(h->ev_mapped, h->stream_b));
     h->mapped_unjoined = true;
