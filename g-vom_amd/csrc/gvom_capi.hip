@@ -408,7 +408,7 @@ hipError_t join_map_stream(gvom_handle *h)
 // Waits until the GPU has published sequence number `seq` in the 64-bit host-mapped word `flag` (high
 // half, or the whole word).  `lk` (the handle mutex) is RELEASED while waiting, so combine_maps from
 // another thread is not locked out for the length of a trace.  A wait that took long the last time (c5:
-// milliseconds) first SLEEPS four fifths of that time away and spins only over the rest: the core is free meanwhile
+// milliseconds) first SLEEPS most of that time away (all but a fifth, at least 250 us) and spins over the rest: the core is free meanwhile
 // and the wake-up still comes within microseconds (a sleep has a granularity of ~60 us; spinning with short
 // sleeps in between overshot a 250 us wait by 30 us).  `last_ns`: this wait's duration the previous time.
 bool wait_published(gvom_handle *h, std::unique_lock<std::mutex> &lk, volatile unsigned long long *flag, uint32_t seq,
@@ -417,7 +417,17 @@ bool wait_published(gvom_handle *h, std::unique_lock<std::mutex> &lk, volatile u
     auto done = [&]() { return (uint32_t)(high_half ? (*flag >> 32) : *flag) == seq; };
     lk.unlock();
     const double start = now_ns();
-    if (last_ns && *last_ns > 4.0e5 && !done()) usleep((useconds_t)(*last_ns * 0.8e-3));   // four fifths of it (a sleep may run 100 us over)
+    bool slept = false;
+    if (last_ns && *last_ns > 6.0e5 && !done()) {
+        // all but the last fifth, at least 250 us (a sleep may run 100 us over and more)
+        const double margin = *last_ns * 0.2 > 2.5e5 ? *last_ns * 0.2 : 2.5e5;
+        usleep((useconds_t)((*last_ns - margin) * 1e-3));
+        slept = true;
+    }
+    // the estimate follows only what has been OBSERVED: completion seen while spinning gives the true duration;
+    // a flag already set after the sleep means the sleep was too long -- halve it (an outlier, e.g. a first
+    // call that allocated, cannot keep every later wait long); never more than 20 ms
+    const bool overslept = slept && done();
     unsigned spins = 0;
     bool ok = true;
     while (!done()) {
@@ -428,7 +438,10 @@ bool wait_published(gvom_handle *h, std::unique_lock<std::mutex> &lk, volatile u
             if (waited > 2.0e7) usleep(50);                           // far beyond anything expected: stop burning the core
         }
     }
-    if (last_ns) *last_ns = now_ns() - start;
+    if (last_ns) {
+        const double est = overslept ? *last_ns * 0.5 : now_ns() - start;
+        *last_ns = est < 2.0e7 ? est : 2.0e7;
+    }
     lk.lock();
     return ok;
 }
