@@ -42,3 +42,27 @@ def test_self_spawned_ranks_fail_loudly_without_gpus():
     assert p.returncode != 0
     assert b"rank exit codes" in p.stderr
     assert not [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_json_line_with_the_contract_keys():
+    """`python bench.py` (short run): ONE JSON line on stdout with the keys the driver reads, the roofline of the
+    dominant kernel measured live, and the CPU baseline of the same workload."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "10", "--no-extra",
+                        "--cpu-budget", "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 40 and d["warmup"] == 10 and d["higher_is_better"] is True
+    assert d["unit"] == "M points/s" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - d["config"]["points_per_scan"] / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and 0 < r["frac"] < 1 and r["peak"] == 8000.0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
+    assert d["value"] > 50 * c["value"]
