@@ -66,3 +66,21 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
     assert d["value"] > 50 * c["value"]
+
+
+@pytest.mark.gpu
+def test_sharded_bench_leg_with_one_rank():
+    """The N > 1 leg of bench.py (one process per GPU, RCCL bound by libgvom_hip.so, shared-memory rendezvous) run
+    with ONE rank -- what a one-GPU box allows: the same code path the driver's scaling run takes, JSON contract
+    included."""
+    env = dict(os.environ, GVOM_BENCH_FORCE_SHARDED="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "40", "--warmup", "10",
+                        "--no-cpu"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["steps"] == 40 and d["value"] > 100
+    assert "sharded" in d["config"]["workload"] and d["config"]["points_per_gpu"] == d["config"]["points_per_step"]
