@@ -213,14 +213,17 @@ void fill_scan_params(const gvom_handle *h, const int64_t origin[3], const doubl
     // points: 5 segments 43.6 us, 6: 44.1, 7: 43.8, 4: 46.4; flush period 16: -0.4 us against 12.)
     {
         const int maxsteps = (p.xy_size > p.z_size ? p.xy_size : p.z_size) / 2 + 2;
-        int nsegs = n_points > 3 * 131072 ? 3 : 5;
+        // "plenty of returns": more 64-ray bundles than three quarters of the device's resident wave slots
+        // (MI355X: 256 CUs x 32 waves -> 393,216 returns)
+        const bool many = n_points / 64 > 3 * (int64_t)h->resident_blocks;
+        int nsegs = many ? 3 : 5;
         if (h->tune_segs > 0) nsegs = h->tune_segs;
         if (nsegs > 9) nsegs = 9;
         if (nsegs > maxsteps / 8) nsegs = maxsteps / 8 > 0 ? maxsteps / 8 : 1;
         P.nsegs = nsegs;
         // flush period (final step body; c4: 8 / 12 / 16 / 24 / 32 -> 552 / 537 / 545 / 608 / 638 us, c5 12 / 16: 2438 / 2460,
         // m256 and c3: 12 = 16)
-        P.lc_period = h->tune_period > 0 ? h->tune_period : (n_points > 3 * 131072 ? 12 : 16);
+        P.lc_period = h->tune_period > 0 ? h->tune_period : (many ? 12 : 16);
         if (P.lc_period > 32) P.lc_period = 32;          // the line cache is direct-mapped with 64 entries
         P.ep_row = h->tune_ep_row >= -1 ? h->tune_ep_row : 0;  // endpoint blocks first: their atomics retire under the walk (-1: inside segment 0's waves)
         if (P.ep_row > P.nsegs) P.ep_row = P.nsegs;
