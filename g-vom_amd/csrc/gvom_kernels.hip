@@ -47,6 +47,13 @@ __device__ __forceinline__ uint32_t pk_add_sat_u16(uint32_t a, uint32_t b) {    
     const us2 r = __builtin_elementwise_add_sat(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b));
     return __builtin_bit_cast(uint32_t, r);
 }
+// Free (ray-pass) counts live in the state as -count - 1 and the fused map carries its predecessor's along
+// (gvom.py:996): in a voxel every ray passes -- the sensor's own -- the sum reaches 2^31 after ~1000 combines of a
+// 262 k-point, 8-slot ring, and an int32 that wraps turns into a non-negative value, which every reader takes for
+// a ROW INDEX (the reference's int32 wraps the same way and then indexes out of bounds).  Here the count stops at
+// 2^30: it stays a free count for ever; results are the reference's wherever it has not overflowed itself.
+#define GVOM_FREE_FLOOR (-(1 << 30))
+__device__ __forceinline__ int add_free(int c, int st_plus_1) { return max(c + max(st_plus_1, GVOM_FREE_FLOOR), GVOM_FREE_FLOOR); }
 __device__ __forceinline__ int wrap_add(int a, int b, int n) { int s = a + b; return s >= n ? s - n : s; }
 __device__ __forceinline__ int wrap_sub(int a, int b, int n) { int s = a - b; return s < 0 ? s + n : s; }
 // accumulator (hit/total) index of storage voxel (sx, sy, sz): 4x4 (x,y) patches per 64-B line
@@ -882,14 +889,14 @@ __global__ __launch_bounds__(1024) void k_fuse(const FuseParams P, const FuseDes
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
                     if (st[k] >= 0) occbits |= 1u << k;                                   // gvom.py:963
-                    else if (st[k] < -1 && !((occbits >> k) & 1u)) c[k] += st[k] + 1;     // gvom.py:967
+                    else if (st[k] < -1 && !((occbits >> k) & 1u)) c[k] = add_free(c[k], st[k] + 1);   // gvom.py:967
                 }
             } else {
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
                     if (!((occbits >> k) & 1u)) {
                         if (st[k] >= 0 && c[k] >= -11) occbits |= 1u << k;                // gvom.py:992
-                        else if (st[k] < -1) c[k] += st[k] + 1;                           // gvom.py:996
+                        else if (st[k] < -1) c[k] = add_free(c[k], st[k] + 1);             // gvom.py:996
                     }
                 }
             }
@@ -1009,7 +1016,7 @@ __global__ __launch_bounds__(1024) void k_fuse(const FuseParams P, const FuseDes
                 if (((okmask >> s) & 1ull) && zz >= 0 && zz < P.zs && descs[s].tags[T] == descs[s].epoch) {
                     const int st = descs[s].state[L];
                     if (st >= 0) occ = true;                              // gvom.py:963
-                    else if (st < -1 && !occ) c += st + 1;                // gvom.py:967
+                    else if (st < -1 && !occ) c = add_free(c, st + 1);    // gvom.py:967
                 }
             }
             if (P.has_prev) {
@@ -1019,7 +1026,7 @@ __global__ __launch_bounds__(1024) void k_fuse(const FuseParams P, const FuseDes
                     descs[s].tags[T] == descs[s].epoch) {
                     const int p = descs[s].state[L];
                     if (p >= 0 && c >= -11) occ = true;                   // gvom.py:992
-                    else if (p < -1) c += p + 1;                          // gvom.py:996
+                    else if (p < -1) c = add_free(c, p + 1);              // gvom.py:996
                 }
             }
             occ = occ && col_ok;
@@ -1184,10 +1191,10 @@ __global__ __launch_bounds__(1024) void k_fuse4(const FuseParams P, const FuseDe
                     const int k = 4 * j + i;
                     if (!is_prev) {
                         if (st >= 0) occbits |= 1u << k;                                  // gvom.py:963
-                        else if (st < -1 && !((occbits >> k) & 1u)) c[k] += st + 1;       // gvom.py:967
+                        else if (st < -1 && !((occbits >> k) & 1u)) c[k] = add_free(c[k], st + 1);   // gvom.py:967
                     } else if (!((occbits >> k) & 1u)) {
                         if (st >= 0 && c[k] >= -11) occbits |= 1u << k;                   // gvom.py:992
-                        else if (st < -1) c[k] += st + 1;                                 // gvom.py:996
+                        else if (st < -1) c[k] = add_free(c[k], st + 1);                  // gvom.py:996
                     }
                 }
             }
@@ -1309,7 +1316,7 @@ __global__ __launch_bounds__(1024) void k_fuse4(const FuseParams P, const FuseDe
                         if (st[u] >= 0) { hh += gh[u]; tt += gt[u]; mm = min(mm, gm[u]); }          // gvom.py:910-912
                         if (s0 + u < P.nslots) {
                             if (st[u] >= 0) slot_occ = true;                                      // gvom.py:963
-                            else if (st[u] < -1) cnt += st[u] + 1;                                // gvom.py:967
+                            else if (st[u] < -1) cnt = add_free(cnt, st[u] + 1);                  // gvom.py:967
                         } else if (s0 + u == P.nslots) stp = st[u];
                     }
                 }
@@ -1322,7 +1329,7 @@ __global__ __launch_bounds__(1024) void k_fuse4(const FuseParams P, const FuseDe
                     frows[row] = make_uint4(hh, tt, mm, 0u);
                     atomicMin(&s_zh[w][col], ((unsigned long long)(uint32_t)zv << 32) | mm);   // lowest occupied level wins
                 } else if (on) {
-                    fstate[off] = cnt + (stp < -1 ? stp + 1 : 0);                                 // gvom.py:996
+                    fstate[off] = stp < -1 ? add_free(cnt, stp + 1) : cnt;                        // gvom.py:996
                     atomicMin(&s_zf[w][col], (uint32_t)zv);                                       // gvom.py:551
                 }
                 running += (uint32_t)__popcll(ob);

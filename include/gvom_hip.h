@@ -125,6 +125,8 @@ int gvom_process_pointcloud2(gvom_t *h, const void *data, int64_t n_points, int6
 /* --- Gvom.combine_maps (gvom.py:177-354) --------------------------------------------------
  * Caller-allocated xy_size*xy_size outputs (any of them may be NULL to skip its copy).
  * Returns GVOM_OK or GVOM_EMPTY_BUFFER. */
+/* Note on very long runs: the fused map carries its predecessor's free (ray-pass) counts along (gvom.py:996); they
+ * are held as -count - 1 in int32 states and stop at 2^30 here (the reference's wrap into the row-index range). */
 int gvom_combine_maps(gvom_t *h, double origin_world[3], int32_t *positive, int32_t *negative,
                       double *roughness, int32_t *visibility);
 

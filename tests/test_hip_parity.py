@@ -224,6 +224,40 @@ def test_scans_from_a_second_thread_while_a_combine_waits(gvom_mod):
             assert np.array_equal(a[j], b[j]), (slot, j)
 
 
+@pytest.mark.parametrize("grid", [(64, 32), (30, 20)])
+def test_free_counts_stop_before_they_wrap_into_row_indices(gvom_mod, grid):
+    """The voxels next to the sensor are passed by a good part of all rays, and the fused map carries its
+    predecessor's free counts along (gvom.py:996): ~25,000 passes per combine reach 2^31 within 90,000 combines
+    (c3's 262 k-point scans in a ring of 8: within ~1000).  An int32 that wraps becomes a
+    non-negative state, i.e. a row index, for every reader (the reference's does, and then indexes out of
+    bounds).  Here the count stops at 2^30: the voxel stays free, the maps stay what they were, nothing faults.
+    (Both fusion kernels: xy % 4 == 0 and not.)"""
+    xy, zs = grid
+    params = (0.4, 0.2, xy, zs, 1, 0.5, 0.5, 0.5, 0.3, 2.0, 4.0, 1.0, 1, 1)
+    rng = np.random.default_rng(3)
+    n = 200000
+    d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1)[:, None]
+    pc = (d * rng.uniform(2.0, 0.19 * xy, (n, 1)) * np.array([1, 1, 0.15])).astype(np.float32)
+    g = gvom_mod.Gvom(*params)
+    g.process_pointcloud(pc, (0.0, 0.0, 0.0))
+    for k in range(200):
+        out = g.combine_maps()
+    early = [m.copy() for m in out]                                   # (the previous map's carry-over has settled by now)
+    for k in range(100000):                                           # the busiest voxels: ~25 k x 100,000 = 2.5e9 > 2^31
+        out = g.combine_maps()
+    state = g.read_dense(gvom_mod.GVOM_WHICH_FUSED)[0]
+    assert state.min() == -(1 << 30)                                   # the busiest voxels sit on the floor ...
+    busy = state == -(1 << 30)
+    assert 0 < busy.sum() < 64
+    # ... and every voxel that was free after two combines still is (no count turned into a row)
+    g2 = gvom_mod.Gvom(*params)
+    g2.process_pointcloud(pc, (0.0, 0.0, 0.0)); g2.combine_maps(); g2.combine_maps()
+    s2 = g2.read_dense(gvom_mod.GVOM_WHICH_FUSED)[0]
+    assert np.array_equal(state >= 0, s2 >= 0) and np.array_equal(state == -1, s2 == -1)
+    for i in (1, 2, 4):
+        assert np.array_equal(out[i], early[i]), i
+
+
 def test_returned_arrays_outlive_the_mapper(gvom_mod):
     """combine_maps' arrays are views of a pinned buffer: they stay valid after the Gvom is gone, and the
     buffer is released when the last of them is collected (no leak per orphaned result)."""
