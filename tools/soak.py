@@ -21,6 +21,8 @@ st = g.read_dense(gvom.GVOM_WHICH_FUSED)
 print("%s: %d steps, %.1f us/step; fused state min %d, hit max %d, total max %d" % (
     name, steps, (time.perf_counter() - t0) / steps * 1e6, st[0].min(), st[1].max(), st[2].max()), flush=True)
 del g
+if cmp_steps <= 0:
+    sys.exit(0)
 small = (0.2, 0.2, 128, 64, 4) + synth.REF_TAIL
 a, b = gvom.Gvom(*small), gvom.Gvom(*small)
 rng = np.random.default_rng(5); pend = None; want = None; bad = 0
