@@ -16,7 +16,7 @@ dev = [(hip.to_device(pc), pc.shape[0], pc.dtype, ego, tf) for (pc, ego, tf) in 
 g = gvom.Gvom(*params)
 t0 = time.perf_counter()
 for k in range(steps):
-    d, n, dt, ego, tf = dev[k % 8]; g.process_pointcloud_device(d.value, n, dt, ego, tf); out = g.combine_maps()
+    d, n, dt, ego, tf = dev[k % len(dev)]; g.process_pointcloud_device(d.value, n, dt, ego, tf); out = g.combine_maps()
 st = g.read_dense(gvom.GVOM_WHICH_FUSED)
 print("%s: %d steps, %.1f us/step; fused state min %d, hit max %d, total max %d" % (
     name, steps, (time.perf_counter() - t0) / steps * 1e6, st[0].min(), st[1].max(), st[2].max()), flush=True)
