@@ -258,6 +258,23 @@ def test_free_counts_stop_before_they_wrap_into_row_indices(gvom_mod, grid):
         assert np.array_equal(out[i], early[i]), i
 
 
+def test_huge_jumps_of_the_window(gvom_mod):
+    """The ego jumps by tens of kilometres and to 3e8 m (window origin beyond 2^30 voxels: the literal float64
+    voxel lookup) and back, with a ring of 3 and float64 clouds: every slot of the ring falls out of the window and
+    comes back; everything equals the oracle."""
+    params = (0.4, 0.2, 32, 16, 3, 0.5, 0.5, 0.5, 0.3, 2.0, 4.0, 1.0, 1, 1)
+    rng = np.random.default_rng(9)
+    egos = [(0, 0, 0), (0.5, 0.2, 0.0), (5e4, -3e4, 10.0), (5e4 + 0.3, -3e4, 10.0), (3.2e8, 1.1e8, -50.0),
+            (3.2e8 + 0.4, 1.1e8, -50.0), (-7.7e8, 2.0e8, 0.0), (0, 0, 0), (0.3, 0, 0)]
+    steps = []
+    for ego in egos:
+        pc = np.stack([rng.uniform(-5, 5, 4000) + ego[0], rng.uniform(-5, 5, 4000) + ego[1],
+                       rng.normal(-0.8, 0.3, 4000) + ego[2]], 1)
+        steps += [("scan", pc, ego, None), ("combine",)]
+    got, want = _run_both(gvom_mod, params, steps)
+    assert compare_records(got, want, float_tol=1e-5) > 100
+
+
 def test_returned_arrays_outlive_the_mapper(gvom_mod):
     """combine_maps' arrays are views of a pinned buffer: they stay valid after the Gvom is gone, and the
     buffer is released when the last of them is collected (no leak per orphaned result)."""
