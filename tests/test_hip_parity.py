@@ -258,6 +258,20 @@ def test_free_counts_stop_before_they_wrap_into_row_indices(gvom_mod, grid):
         assert np.array_equal(out[i], early[i]), i
 
 
+def test_cloud_sizes_swing_by_orders_of_magnitude(gvom_mod):
+    """5 ... 300,000 returns from scan to scan (float32 and float64, host arrays): the grow-only buffers are
+    re-allocated while earlier scans sit in the ring; an empty cloud in between; everything equals the oracle."""
+    params = (0.4, 0.2, 64, 32, 4, 0.5, 0.5, 0.5, 0.3, 2.0, 4.0, 1.0, 1, 1)
+    rng = np.random.default_rng(21)
+    steps = []
+    for k, n in enumerate([100, 50000, 5, 0, 300000, 17, 120000, 1, 64, 65, 4096, 250000]):
+        ego = (0.3 * k, -0.1 * k, 0.0)
+        pc = np.stack([rng.uniform(-11, 11, n) + ego[0], rng.uniform(-11, 11, n) + ego[1], rng.normal(-0.8, 0.4, n)], 1)
+        steps += [("scan", pc.astype(np.float32 if k % 3 else np.float64), ego, None), ("combine",)]
+    got, want = _run_both(gvom_mod, params, steps, record_debug=False)
+    assert compare_records(got, want, float_tol=1e-5) > 50
+
+
 def test_huge_jumps_of_the_window(gvom_mod):
     """The ego jumps by tens of kilometres and to 3e8 m (window origin beyond 2^30 voxels: the literal float64
     voxel lookup) and back, with a ring of 3 and float64 clouds: every slot of the ring falls out of the window and
