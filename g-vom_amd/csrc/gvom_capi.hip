@@ -126,6 +126,13 @@ struct gvom_handle {
     uint32_t combine_seq = 0;                           // completion flag of the synchronous combine (counters_host + 4)
     double last_wait_ns[2] = {0.0, 0.0};                // how long the scan / the combine waited last time (wait_published)
     bool mapped_unjoined = false;                       // ev_mapped recorded; the main stream has not waited on it
+    // a fusion enqueued on the second stream (asynchronous combine, rings of >= 3 filled slots) READS the ring slots
+    // it was given; the main stream must not overwrite one of them (the second scan after the begin does: the
+    // oldest slot becomes the staging slot) nor read the fused map it writes before it has finished
+    hipEvent_t ev_fuse_b = nullptr;
+    bool fuse_b_unjoined = false;                       // ev_fuse_b recorded; the main stream has not waited on it
+    uint64_t fuse_b_slots = 0;                          // bit k: slots[k] is a source of that fusion
+    bool scan_inflight = false;                         // a scan's kernels are enqueued and it is not committed yet (scan_mu held)
     void *out_host = nullptr;                           // pinned, device-mapped staging for the 4 outputs
     char *out_host_dev = nullptr;                       // device view of out_host (zero-copy target)
     uint32_t scan_seq = 0;                              // sequence number of the {seq,count} flag
@@ -136,6 +143,8 @@ struct gvom_handle {
     int in_off[3] = {0, 1, 2};                          // element offsets of x, y, z in the cloud being scanned
     bool in_f32 = false;                                // float32 records widened to a float64 computation (PointCloud2 ingest)
 
+    Buf tl;                                             // diagnostic build: k_trace's timeline of the last scan (GVOM_TRACE_TIMELINE)
+    int tl_grid[2] = {0, 0};
     double host_ns[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // host-side phase timing (GVOM_HOST_TIMING)
     long host_calls = 0;
     bool host_timing = false;
@@ -295,6 +304,7 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, b
     CK(hipEventCreateWithFlags(&h->ev_fused, hipEventDisableTiming));
     CK(hipEventCreateWithFlags(&h->ev_mapped, hipEventDisableTiming));
     CK(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
+    CK(hipEventCreateWithFlags(&h->ev_fuse_b, hipEventDisableTiming));
     // accumulators are micro-tiled in 4x4 (x,y) patches (gvom_internal.h "ACCUMULATOR LAYOUT")
     // row pitch of the patch rows, padded (GVOM_ACC_PAD lines of 64 B) so that the z levels of one
     // (x, y) patch -- xy*16 bytes apart, a multiple of 4 KiB for xy = 256 -- do not all map to the
@@ -344,7 +354,9 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, b
     double **maps[4] = {&h->slope_x, &h->slope_y, &h->rough, &h->guessed};
     for (auto m : maps) CK(hipMalloc((void **)m, h->cells2d * 8));
 
-    CK(hipHostMalloc(&h->out_host, h->cells2d * 20, hipHostMallocMapped));
+    // coherent: gvom_combine_maps learns of completion from a flag a later kernel stores (finish_combine), not from a
+    // stream synchronisation; k_map2d's stores to non-coherent host memory would only be guaranteed visible after one
+    CK(hipHostMalloc(&h->out_host, h->cells2d * 20, hipHostMallocMapped | hipHostMallocCoherent));
     CK(hipHostGetDevicePointer((void **)&h->out_host_dev, h->out_host, 0));
     if (sharded) {
         // rank exchange regions (DESIGN.md "Multi-GPU"): a quad = 4 storage rows x 64 sx at one sz
@@ -381,6 +393,7 @@ void scan_abort(gvom_handle *h)
     (void)hipStreamSynchronize(h->stream);
     (void)hipGetLastError();
     h->pending = false;
+    h->scan_inflight = false;
 }
 
 // Tile epochs are 32-bit and only grow (two per step).  Before the counter can wrap, every live map
@@ -391,12 +404,21 @@ int renumber_epochs(gvom_handle *h);
 // host waits for everything the handle has enqueued (both streams)
 hipError_t sync_streams(gvom_handle *h)
 {
-    if (h->mapped_unjoined) {
+    if (h->mapped_unjoined || h->fuse_b_unjoined) {
         hipError_t e = hipStreamSynchronize(h->stream_b);
         if (e != hipSuccess) return e;
         h->mapped_unjoined = false;
+        h->fuse_b_unjoined = false;
     }
     return hipStreamSynchronize(h->stream);
+}
+// main stream waits (on the device) for a fusion still running on the second stream: before it overwrites a
+// ring slot that fusion reads, or reads the fused map it writes
+hipError_t join_fuse_stream(gvom_handle *h)
+{
+    if (!h->fuse_b_unjoined) return hipSuccess;
+    h->fuse_b_unjoined = false;
+    return hipStreamWaitEvent(h->stream, h->ev_fuse_b, 0);
 }
 // main stream waits (on the device) for a k_map2d still running on the second stream: it reads what
 // the next fusion writes (fused double buffer, height maps, block counts)
@@ -404,7 +426,15 @@ hipError_t join_map_stream(gvom_handle *h)
 {
     if (!h->mapped_unjoined) return hipSuccess;
     h->mapped_unjoined = false;
+    h->fuse_b_unjoined = false;                            // (k_map2d runs behind that fusion on the same stream)
     return hipStreamWaitEvent(h->stream, h->ev_mapped, 0);
+}
+
+// the read hooks launch on the main stream and read what an asynchronous combine's kernels write on the second
+hipError_t join_second_stream(gvom_handle *h)
+{
+    hipError_t e = join_map_stream(h);
+    return e != hipSuccess ? e : join_fuse_stream(h);
 }
 
 // Scan kernels up to (not including) the commit.  `dev_pts` is device memory.
@@ -462,8 +492,12 @@ int scan_launch(gvom_handle *h, std::unique_lock<std::mutex> &lk, const void *de
     ScanParams P;
     fill_scan_params(h, origin, tf, P, n);
     Slot &st = h->slots[h->staging];
+    // the staging slot may still be a SOURCE of a fusion running on the second stream (asynchronous combine: the
+    // second scan after gvom_combine_begin writes the slot the ring has just evicted)
+    if (h->fuse_b_unjoined && ((h->fuse_b_slots >> h->staging) & 1ull)) HIPCHK(h, join_fuse_stream(h));
     st.epoch = ++h->epoch;                                 // tiles stamped by this scan
     P.epoch = st.epoch;
+    h->scan_inflight = true;
     const size_t esz = dtype == GVOM_DTYPE_F32 ? 4 : 8;
     // compact rows are indexed by return (the row of an occupied voxel = the index of one of its returns)
     const size_t cap = std::max<size_t>(1, (size_t)n);
@@ -486,6 +520,16 @@ int scan_launch(gvom_handle *h, std::unique_lock<std::mutex> &lk, const void *de
         h->x_ep_cap = n > 0 ? n : 1;
         X.ep_send = (uint2 *)h->x_send_eps.p; X.ep_cnt = h->x_ecnt; X.ep_cap = (long)h->x_ep_cap;
     }
+    P.tl = nullptr;
+#ifdef GVOM_DIAG
+    if (gvom_diag_env("GVOM_TRACE_TIMELINE") && n > 0) {
+        h->tl_grid[0] = (int)((n + 511) / 512); h->tl_grid[1] = P.nsegs + (P.ep_row >= 0 ? 1 : 0);
+        const size_t bytes = (size_t)h->tl_grid[0] * h->tl_grid[1] * 8 * 32;
+        if ((rc = ensure(h, h->tl, bytes))) return rc;
+        HIPCHK(h, hipMemsetAsync(h->tl.p, 0, bytes, h->stream));
+        P.tl = (unsigned long long *)h->tl.p;
+    }
+#endif
     hipError_t le = gvom_launch_trace(h->stream, P, X, dtype, big, dev_pts, stride_elems, n,
                                       h->stats ? h->world_pts.p : nullptr, h->hit, h->total, h->mh, st.state,
                                       st.tags, h->counters, h->stats ? (double *)st.metrics.p : nullptr,
@@ -562,6 +606,7 @@ int scan_launch(gvom_handle *h, std::unique_lock<std::mutex> &lk, const void *de
 
 void scan_commit(gvom_handle *h, bool accept)
 {
+    h->scan_inflight = false;
     if (!h->pending) return;
     h->pending = false;
     if (!accept) return;                                   // gvom.py:148-150: ring untouched
@@ -581,9 +626,14 @@ int renumber_epochs(gvom_handle *h)
     uint32_t next = 0;
     for (size_t k = 0; k < h->slots.size(); ++k) {
         Slot &sl = h->slots[k];
-        const uint32_t fresh = sl.filled ? ++next : 0u;  // the staging slot's tiles are dead
+        // the staging slot's tiles are dead -- unless a scan is in flight in it (a combine thread can get here while
+        // the scan's thread waits for k_trace with the handle mutex released, or between the two halves of a sharded
+        // scan): its kernels have completed (sync above), its tiles keep a live epoch and the commit finds it intact
+        const bool inflight = (int)k == h->staging && (h->scan_inflight || h->pending);
+        const uint32_t fresh = (sl.filled || inflight) ? ++next : 0u;
         HIPCHK(h, gvom_launch_retag(h->stream, sl.tags, h->ntiles, sl.epoch, fresh));
         sl.epoch = fresh;
+        if (inflight) h->pending_P.epoch = fresh;         // gvom_shard_scan_merge's kernels stamp / test this epoch
     }
     for (int k = 0; k < 2; ++k) {
         Fused &f = h->fused[k];
@@ -623,6 +673,9 @@ int process_impl(gvom_handle *h, const void *xyz, bool on_device, int64_t n, int
     for (int k = 0; k < 3; ++k) h->in_off[k] = off_bytes ? (int)(off_bytes[k] / (int64_t)esz) : k;
     h->in_f32 = widen_f32;
     h->ego[0] = ego[0]; h->ego[1] = ego[1]; h->ego[2] = ego[2];       // gvom.py:102-104
+    // a sharded scan whose second half never came (the exchange failed between gvom_shard_scan_local and
+    // gvom_shard_scan_merge): k_trace's additions to this rank's rows were never encoded or zeroed
+    if (h->pending && h->sharded) scan_abort(h);
     h->pending = false;
     if (h->sharded && !defer) { h->err = "a sharded handle scans through gvom_shard_scan_local / gvom_shard_scan_merge"; return GVOM_ERR_INVALID; }
     if (n == 0 && !defer) return GVOM_EMPTY_CLOUD;                     // gvom.py:107-109 (a rank's share of a sharded scan may be empty)
@@ -893,7 +946,7 @@ VIS void gvom_destroy(gvom_t *h)
     if (h->x_host) hipHostFree(h->x_host);
     for (auto &s : h->slots) { hipFree(s.state); hipFree(s.code16); hipFree(s.tags); fb(s.crows); fb(s.metrics); fb(s.base); fb(s.rowvox); }
     for (auto &f : h->fused) { hipFree(f.state); hipFree(f.tags); fb(f.rows); fb(f.metrics); }
-    fb(h->in_pts); fb(h->world_pts);
+    fb(h->in_pts); fb(h->world_pts); fb(h->tl);
     hipFree(h->counters); if (h->counters_host) hipHostFree(h->counters_host);
     hipFree(h->descs_dev); if (h->descs_host) hipHostFree(h->descs_host);
     hipFree(h->blockcounts);
@@ -904,6 +957,7 @@ VIS void gvom_destroy(gvom_t *h)
     if (h->ev_fused) hipEventDestroy(h->ev_fused);
     if (h->ev_mapped) hipEventDestroy(h->ev_mapped);
     if (h->ev_done) hipEventDestroy(h->ev_done);
+    if (h->ev_fuse_b) hipEventDestroy(h->ev_fuse_b);
     if (h->stream_b) hipStreamDestroy(h->stream_b);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     delete h;
@@ -1188,6 +1242,11 @@ VIS int gvom_combine_begin(gvom_t *h, void *pinned_out, const double *occ)
         HIPCHK(h, hipEventRecord(h->ev_fused, h->stream));
         HIPCHK(h, hipStreamWaitEvent(h->stream_b, h->ev_fused, 0));
         if ((rc = fuse_impl(h, h->stream_b))) return rc;
+        HIPCHK(h, hipEventRecord(h->ev_fuse_b, h->stream_b));
+        h->fuse_b_unjoined = true;
+        h->fuse_b_slots = 0;
+        for (int i = 0; i < h->prm.buffer_size; ++i)
+            if (h->slots[h->ring[i]].filled) h->fuse_b_slots |= 1ull << h->ring[i];
     } else {
         if ((rc = fuse_impl(h))) return rc;
         HIPCHK(h, hipEventRecord(h->ev_fused, h->stream));
@@ -1216,6 +1275,7 @@ VIS int gvom_combine_end(gvom_t *h, double origin_world[3])
     const hipError_t e = hipEventSynchronize(h->ev_mapped);
     lk.lock();
     h->pending_combine = false;                            // (also on failure: the handle must not stay blocked)
+    h->fuse_b_unjoined = false;                            // k_map2d has completed, and the fusion in front of it
     HIPCHK(h, e);
     Fused &F = h->fused[h->cur];
     unsigned long long c;
@@ -1372,7 +1432,8 @@ VIS int gvom_read_dense(gvom_t *h, int which, int32_t *state, int32_t *hit, int3
     HIPCHK(h, hipMalloc((void **)&tmp, V * 16));
     int om[3] = {(int)floor_mod(org[0], h->prm.xy_size), (int)floor_mod(org[1], h->prm.xy_size),
                  (int)floor_mod(org[2], h->prm.z_size)};
-    hipError_t e = gvom_launch_read_dense(h->stream, h->prm.xy_size, h->prm.z_size, om, h->sy_lo, h->sy_hi,
+    hipError_t e = join_second_stream(h);
+    if (e == hipSuccess) e = gvom_launch_read_dense(h->stream, h->prm.xy_size, h->prm.z_size, om, h->sy_lo, h->sy_hi,
                                           tg, ep, st, cr,
                                           tmp, tmp + V, tmp + 2 * V, (float *)(tmp + 3 * V), nullptr);
     if (e == hipSuccess) e = sync_streams(h);
@@ -1417,7 +1478,8 @@ VIS int gvom_read_rows(gvom_t *h, int which, int32_t *rows_dense)
     HIPCHK(h, hipMalloc((void **)&tmp, V * 4));
     int om[3] = {(int)floor_mod(org[0], h->prm.xy_size), (int)floor_mod(org[1], h->prm.xy_size),
                  (int)floor_mod(org[2], h->prm.z_size)};
-    hipError_t e = gvom_launch_read_dense(h->stream, h->prm.xy_size, h->prm.z_size, om, h->sy_lo, h->sy_hi, tg, ep, st,
+    hipError_t e = join_second_stream(h);
+    if (e == hipSuccess) e = gvom_launch_read_dense(h->stream, h->prm.xy_size, h->prm.z_size, om, h->sy_lo, h->sy_hi, tg, ep, st,
                                           nullptr, nullptr, nullptr, nullptr, nullptr, tmp);
     if (e == hipSuccess) e = sync_streams(h);
     if (e == hipSuccess) e = hipMemcpy(rows_dense, tmp, V * 4, hipMemcpyDeviceToHost);
@@ -1448,7 +1510,8 @@ VIS int gvom_gather_metrics(gvom_t *h, int which, const int32_t *rows, int64_t n
     const size_t esz = f64 ? 8 : 4;
     char *tmp = nullptr;
     HIPCHK(h, hipMalloc((void **)&tmp, (size_t)n * 4 + (size_t)n * 10 * esz));
-    hipError_t e = hipMemcpy(tmp + (size_t)n * 10 * esz, rows, (size_t)n * 4, hipMemcpyHostToDevice);
+    hipError_t e = join_second_stream(h);
+    if (e == hipSuccess) e = hipMemcpy(tmp + (size_t)n * 10 * esz, rows, (size_t)n * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = gvom_launch_gather_rows10(h->stream, f64, src, (const int32_t *)(tmp + (size_t)n * 10 * esz), n, tmp);
     if (e == hipSuccess) e = sync_streams(h);
     if (e == hipSuccess) e = hipMemcpy(out, tmp, (size_t)n * 10 * esz, hipMemcpyDeviceToHost);
@@ -1468,7 +1531,8 @@ VIS int gvom_read_map2d(gvom_t *h, int which2d, double *out)
     const Fused &F = h->fused[h->cur];
     double *tmp = nullptr;
     HIPCHK(h, hipMalloc((void **)&tmp, h->cells2d * 8));
-    hipError_t e = gvom_launch_unwrap_f64(h->stream, h->prm.xy_size, (int)floor_mod(F.origin[0], h->prm.xy_size),
+    hipError_t e = join_second_stream(h);
+    if (e == hipSuccess) e = gvom_launch_unwrap_f64(h->stream, h->prm.xy_size, (int)floor_mod(F.origin[0], h->prm.xy_size),
                                           (int)floor_mod(F.origin[1], h->prm.xy_size), src, stride, tmp);
     if (e == hipSuccess) e = sync_streams(h);
     if (e == hipSuccess) e = hipMemcpy(out, tmp, h->cells2d * 8, hipMemcpyDeviceToHost);
@@ -1508,7 +1572,8 @@ static int debug_maps(gvom_t *h, float *out7, float *out3)
     float *tmp = nullptr;
     HIPCHK(h, hipMalloc((void **)&tmp, n2 * 7 * 4));
     double org[3] = {(double)F.origin[0], (double)F.origin[1], (double)F.origin[2]};
-    hipError_t e = gvom_launch_debug_height(h->stream, h->prm.xy_size, (int)floor_mod(F.origin[0], h->prm.xy_size),
+    hipError_t e = join_second_stream(h);
+    if (e == hipSuccess) e = gvom_launch_debug_height(h->stream, h->prm.xy_size, (int)floor_mod(F.origin[0], h->prm.xy_size),
                                             (int)floor_mod(F.origin[1], h->prm.xy_size), org,
                                             h->prm.xy_resolution, h->prm.z_resolution, h->height, h->hs, h->rough,
                                             h->slope_x, h->slope_y, out7 ? tmp : nullptr, h->guessed,
@@ -1549,7 +1614,8 @@ VIS int gvom_debug_voxel_eigen(gvom_t *h, float *out, float *eigen, int64_t max_
     const size_t mr = (size_t)(max_rows > 0 ? max_rows : 1);
     HIPCHK(h, hipMalloc((void **)&tmp, mr * 44));         // 8 + 3 floats per row
     float *tmp_e = eigen ? tmp + mr * 8 : nullptr;
-    hipError_t e = hipMemsetAsync(h->counters + 12, 0, 8, h->stream);
+    hipError_t e = join_second_stream(h);
+    if (e == hipSuccess) e = hipMemsetAsync(h->counters + 12, 0, 8, h->stream);
     if (e == hipSuccess)
         e = gvom_launch_voxel_cloud(h->stream, P, (double)F.origin[0], (double)F.origin[1], (double)F.origin[2],
                                     F.state, F.tags, (const uint4 *)F.rows.p,
@@ -1665,5 +1731,23 @@ VIS int gvom_backend_info(char *buf, size_t len)
 }
 
 VIS int gvom_abi_version(void) { return GVOM_ABI_VERSION; }
+
+#ifdef GVOM_DIAG
+// diagnostic library only (not part of include/gvom_hip.h): k_trace's per-wave timeline of the last scan,
+// 4 uint64 per wave {start, set-up done (0: the wave left before it walked), end, HW_ID | XCC_ID << 32} in
+// dispatch order [row][workgroup][wave]; grid[0] workgroups per row, grid[1] rows (tools/trace_timeline.py)
+VIS int gvom_diag_timeline(gvom_t *h, unsigned long long *out, int64_t max_words, int grid[2])
+{
+    if (!h || !out || !grid) return GVOM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, sync_streams(h));
+    grid[0] = h->tl_grid[0]; grid[1] = h->tl_grid[1];
+    const int64_t words = (int64_t)grid[0] * grid[1] * 8 * 4;
+    if (!h->tl.p || words <= 0) return GVOM_NO_DATA;
+    HIPCHK(h, hipMemcpy(out, h->tl.p, (size_t)(words < max_words ? words : max_words) * 8, hipMemcpyDeviceToHost));
+    return GVOM_OK;
+}
+#endif
 
 }  // extern "C"

@@ -17,7 +17,9 @@
 
 #include <atomic>
 #include <dlfcn.h>
+#include <errno.h>
 #include <fcntl.h>
+#include <signal.h>
 #include <immintrin.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -74,12 +76,42 @@ struct Segment {                               // the shared-memory rendezvous o
     std::atomic<uint32_t> id_ready;
     std::atomic<uint32_t> attached;
     double created_s;                          // CLOCK_REALTIME at creation: a segment left behind by a crashed run is not joined
+    int64_t creator_pid;                       // rank 0's process and its start time (/proc/<pid>/stat field 22): a joiner only
+    uint64_t creator_start;                    // attaches to a segment whose creator is ALIVE -- a crashed job's is not
     ncclUniqueId id;
     Slot slots[2][GVOM_COMM_MAX_RANKS];
 };
 
 inline double now_s() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + t.tv_nsec * 1e-9; }
 inline double wall_s() { timespec t; clock_gettime(CLOCK_REALTIME, &t); return t.tv_sec + t.tv_nsec * 1e-9; }
+
+// start time of a process in clock ticks since boot (0: unknown / no such process); with the pid it names one
+// process for the lifetime of the machine, whatever pid reuse does
+uint64_t proc_start_time(int64_t pid)
+{
+    char path[64], buf[1024];
+    snprintf(path, sizeof path, "/proc/%lld/stat", (long long)pid);
+    FILE *f = fopen(path, "r");
+    if (!f) return 0;
+    const size_t n = fread(buf, 1, sizeof buf - 1, f);
+    fclose(f);
+    buf[n] = 0;
+    const char *p = strrchr(buf, ')');                 // the command name may contain spaces and parentheses
+    if (!p) return 0;
+    int field = 2;                                     // p points at the end of field 2
+    for (++p; *p; ++p) {
+        if (*p == ' ') { if (++field == 22) return strtoull(p + 1, nullptr, 10); }
+    }
+    return 0;
+}
+bool creator_alive(const Segment *sg)
+{
+    const int64_t pid = sg->creator_pid;
+    if (pid <= 0) return false;
+    if (kill((pid_t)pid, 0) != 0 && errno != EPERM) return false;
+    const uint64_t st = proc_start_time(pid);
+    return st == 0 || sg->creator_start == 0 || st == sg->creator_start;    // (no /proc: the pid test alone)
+}
 
 }  // namespace
 
@@ -124,9 +156,11 @@ VIS int gvom_comm_create(int rank, int world, int device, const char *name, gvom
     c->rank = rank; c->world = world; c->device = device;
     c->shm_name = std::string("/") + name;
     if (const char *t = getenv("GVOM_COMM_TIMEOUT_S")) { const double v = atof(t); if (v > 0.0) c->timeout_s = v; }
+    bool created = false;                                              // rank 0: the name exists and is ours
     auto fail = [&](const std::string &why, int code) {
         fprintf(stderr, "gvom_comm_create(rank %d of %d): %s\n", rank, world, why.c_str());
         if (c->seg) munmap(c->seg, sizeof(Segment));
+        if (created) shm_unlink(c->shm_name.c_str());                  // never leave a segment behind for a later run to join
         delete c;
         return code;
     };
@@ -138,6 +172,7 @@ VIS int gvom_comm_create(int rank, int world, int device, const char *name, gvom
     if (rank == 0) {
         shm_unlink(c->shm_name.c_str());                               // a stale segment of a crashed run
         int fd = shm_open(c->shm_name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+        created = fd >= 0;
         if (fd < 0 || ftruncate(fd, sizeof(Segment)) != 0) { if (fd >= 0) close(fd); return fail("cannot create the shared-memory rendezvous", GVOM_ERR_HIP); }
         void *m = mmap(nullptr, sizeof(Segment), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
         close(fd);
@@ -146,11 +181,15 @@ VIS int gvom_comm_create(int rank, int world, int device, const char *name, gvom
         memset((void *)c->seg, 0, sizeof(Segment));
         c->seg->world = (uint32_t)world;
         c->seg->created_s = wall_s();
+        c->seg->creator_pid = (int64_t)getpid();
+        c->seg->creator_start = proc_start_time((int64_t)getpid());
         if (!host_only && c->rccl.GetUniqueId(&c->seg->id) != ncclSuccess) return fail("ncclGetUniqueId failed", GVOM_ERR_HIP);
         c->seg->id_ready.store(1, std::memory_order_release);
         c->seg->magic.store(0x47564f4du, std::memory_order_release);
     } else {
-        // join the segment rank 0 has created for THIS run: complete (magic), fresh, same world size
+        // join the segment rank 0 has created for THIS run: complete (magic), fresh, same world size, created by a
+        // process that is still alive (a job that crashed minutes ago leaves a complete, fresh-looking segment behind:
+        // its ncclUniqueId would hang ncclCommInitRank), and still the one the name refers to once accepted
         const double deadline = now_s() + c->timeout_s;
         while (true) {
             int fd = shm_open(c->shm_name.c_str(), O_RDWR, 0600);
@@ -163,10 +202,20 @@ VIS int gvom_comm_create(int rank, int world, int device, const char *name, gvom
                     while (sg->magic.load(std::memory_order_acquire) != 0x47564f4du && now_s() < t_end) usleep(100);
                     const double age = wall_s() - sg->created_s;
                     if (sg->magic.load(std::memory_order_acquire) == 0x47564f4du && sg->id_ready.load(std::memory_order_acquire) == 1u &&
-                        age > -5.0 && age < c->timeout_s + 60.0 && sg->attached.load(std::memory_order_acquire) < (uint32_t)world) {
-                        close(fd);
-                        c->seg = sg;
-                        break;
+                        age > -5.0 && age < c->timeout_s + 60.0 && sg->attached.load(std::memory_order_acquire) < (uint32_t)world &&
+                        creator_alive(sg)) {
+                        // rank 0 of this run may have replaced the segment between our open and now
+                        struct stat nb;
+                        const int fd2 = shm_open(c->shm_name.c_str(), O_RDWR, 0600);
+                        const bool same = fd2 >= 0 && fstat(fd2, &nb) == 0 && nb.st_ino == sb.st_ino && nb.st_dev == sb.st_dev;
+                        // (name gone: the last rank to attach has unlinked it -- only possible for the live segment)
+                        const bool gone = fd2 < 0 && errno == ENOENT;
+                        if (fd2 >= 0) close(fd2);
+                        if (same || gone) {
+                            close(fd);
+                            c->seg = sg;
+                            break;
+                        }
                     }
                     munmap(m, sizeof(Segment));
                 }
@@ -214,9 +263,17 @@ VIS int gvom_comm_exchange_host(gvom_comm_t *c, const int64_t *mine, int k, int6
     const double deadline = now_s() + c->timeout_s;
     for (int r = 0; r < c->world; ++r) {
         unsigned spins = 0;
+        double slow_since = 0.0;
         while (slots[r].seq.load(std::memory_order_acquire) != call) {
             _mm_pause();
-            if ((++spins & 0xffff) == 0 && now_s() > deadline) { c->err = "host exchange timed out (a rank is missing)"; return GVOM_ERR_HIP; }
+            if ((++spins & 0xfff) == 0) {
+                // a peer that is milliseconds late is minutes late as likely as not (it died, or it is still importing):
+                // stop burning the core
+                const double t = now_s();
+                if (slow_since == 0.0) slow_since = t;
+                if (t > deadline) { c->err = "host exchange timed out (a rank is missing)"; return GVOM_ERR_HIP; }
+                if (t - slow_since > 5e-3) usleep(t - slow_since > 1.0 ? 1000 : 50);
+            }
         }
         memcpy(all + (size_t)r * k, slots[r].values, (size_t)k * 8);
     }
@@ -242,31 +299,33 @@ VIS int gvom_comm_exchange_scan(gvom_comm_t *c, gvom_t *h, const int64_t *send_q
     if (hipSetDevice(c->device) != hipSuccess) { c->err = "hipSetDevice failed"; return GVOM_ERR_HIP; }
     hipStream_t st = (hipStream_t)gvom_stream(h);
     NCCLCHK(c, c->rccl.GroupStart());
+    // (inside the group every failure path must still close it: an open group stays with the thread)
+    int rc = GVOM_OK;
+    auto xfer = [&](bool send, int which, int p, size_t bytes) {
+        if (rc != GVOM_OK || bytes == 0) return;
+        void *ptr = nullptr;
+        int64_t cap = 0;
+        if (gvom_shard_buffer(h, which, p, &ptr, &cap) || (int64_t)bytes > cap) {
+            c->err = "exchange region missing or smaller than the announced count";
+            rc = GVOM_ERR_INVALID;
+            return;
+        }
+        const ncclResult_t r = send ? c->rccl.Send(ptr, bytes, ncclUint8, p, c->nccl, st) : c->rccl.Recv(ptr, bytes, ncclUint8, p, c->nccl, st);
+        if (r != ncclSuccess) { c->err = std::string(send ? "ncclSend" : "ncclRecv") + " failed: " + c->rccl.GetErrorString(r); rc = GVOM_ERR_HIP; }
+    };
     for (int p = 0; p < c->world; ++p) {
         if (p == c->rank) continue;
-        void *ptr = nullptr;
-        if (send_quads[p] > 0) {
-            if (gvom_shard_buffer(h, GVOM_XBUF_SEND_IDS, p, &ptr, nullptr)) return GVOM_ERR_INVALID;
-            NCCLCHK(c, c->rccl.Send(ptr, (size_t)send_quads[p] * 4, ncclUint8, p, c->nccl, st));
-            if (gvom_shard_buffer(h, GVOM_XBUF_SEND_QUADS, p, &ptr, nullptr)) return GVOM_ERR_INVALID;
-            NCCLCHK(c, c->rccl.Send(ptr, (size_t)send_quads[p] * 1024, ncclUint8, p, c->nccl, st));
-        }
-        if (send_eps[p] > 0) {
-            if (gvom_shard_buffer(h, GVOM_XBUF_SEND_EPS, p, &ptr, nullptr)) return GVOM_ERR_INVALID;
-            NCCLCHK(c, c->rccl.Send(ptr, (size_t)send_eps[p] * 8, ncclUint8, p, c->nccl, st));
-        }
-        if (recv_quads[p] > 0) {
-            if (gvom_shard_buffer(h, GVOM_XBUF_RECV_IDS, p, &ptr, nullptr)) return GVOM_ERR_INVALID;
-            NCCLCHK(c, c->rccl.Recv(ptr, (size_t)recv_quads[p] * 4, ncclUint8, p, c->nccl, st));
-            if (gvom_shard_buffer(h, GVOM_XBUF_RECV_QUADS, p, &ptr, nullptr)) return GVOM_ERR_INVALID;
-            NCCLCHK(c, c->rccl.Recv(ptr, (size_t)recv_quads[p] * 1024, ncclUint8, p, c->nccl, st));
-        }
-        if (recv_eps[p] > 0) {
-            if (gvom_shard_buffer(h, GVOM_XBUF_RECV_EPS, p, &ptr, nullptr)) return GVOM_ERR_INVALID;
-            NCCLCHK(c, c->rccl.Recv(ptr, (size_t)recv_eps[p] * 8, ncclUint8, p, c->nccl, st));
-        }
+        if (send_quads[p] < 0 || send_eps[p] < 0 || recv_quads[p] < 0 || recv_eps[p] < 0) { c->err = "negative count"; rc = GVOM_ERR_INVALID; break; }
+        xfer(true, GVOM_XBUF_SEND_IDS, p, (size_t)send_quads[p] * 4);
+        xfer(true, GVOM_XBUF_SEND_QUADS, p, (size_t)send_quads[p] * 1024);
+        xfer(true, GVOM_XBUF_SEND_EPS, p, (size_t)send_eps[p] * 8);
+        xfer(false, GVOM_XBUF_RECV_IDS, p, (size_t)recv_quads[p] * 4);
+        xfer(false, GVOM_XBUF_RECV_QUADS, p, (size_t)recv_quads[p] * 1024);
+        xfer(false, GVOM_XBUF_RECV_EPS, p, (size_t)recv_eps[p] * 8);
     }
-    NCCLCHK(c, c->rccl.GroupEnd());
+    const ncclResult_t ge = c->rccl.GroupEnd();
+    if (rc != GVOM_OK) return rc;
+    if (ge != ncclSuccess) { c->err = std::string("ncclGroupEnd failed: ") + c->rccl.GetErrorString(ge); return GVOM_ERR_HIP; }
     return GVOM_OK;
 }
 

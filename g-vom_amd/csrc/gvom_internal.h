@@ -74,6 +74,7 @@ struct ScanParams {
                           //    as ros_numpy hands the reference a float64 array (stride and offsets in 4-byte units)
     int    shard_world, shard_rank, shard_rows;   // ranks of a sharded map (1, 0, xy when unsharded): rank r owns storage rows [r*shard_rows, (r+1)*shard_rows)
     int    dbg;           // diagnostic build only
+    unsigned long long *tl;   // diagnostic build only (GVOM_TRACE_TIMELINE): 4 words per wave {start, set-up done, end, hardware id}
 };
 
 // rank exchange, k_trace side: endpoints in another rank's rows are appended to that rank's send list

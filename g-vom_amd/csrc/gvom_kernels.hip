@@ -433,6 +433,18 @@ __device__ __forceinline__ void walk_item(const ScanParams &P, int lane, uint32_
     }
 }
 
+// Diagnostic build only (GVOM_TRACE_TIMELINE): every wave of k_trace leaves {start, set-up done, end} times (100 MHz
+// s_memrealtime ticks) and where it ran (HW_ID: wave / SIMD / CU / SE; XCC_ID) -- tools/trace_timeline.py turns them
+// into the kernel's timeline: when each dispatch row starts, how full the chip is, where the tail is.
+#ifdef GVOM_DIAG
+#define TL_MARK(P, widx, k) do { if ((P).tl && (threadIdx.x & 63) == 0) (P).tl[(size_t)(widx) * 4 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define TL_WHERE(P, widx) do { if ((P).tl && (threadIdx.x & 63) == 0) (P).tl[(size_t)(widx) * 4 + 3] = \
+    (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); } while (0)
+#else
+#define TL_MARK(P, widx, k) do { } while (0)
+#define TL_WHERE(P, widx) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------
 // k_trace.  Grid (ceil(N/512), nsegs + 1), 8 waves per workgroup: row P.ep_row holds the endpoint
 // blocks (endpoint_update), every other row one STEP SEGMENT of the rays: a wave sets its 64 rays up
@@ -451,6 +463,9 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(8, 8))
     const int lane = threadIdx.x & (WAVE - 1);
     const long i = (long)blockIdx.x * (64 * WPB) + threadIdx.x;
     const bool live = i < n;
+    const size_t widx = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * WPB + (threadIdx.x >> 6);   // (timeline only)
+    (void)widx;
+    TL_MARK(P, widx, 0); TL_WHERE(P, widx);
     T x = 0, y = 0, z = 0;
     if (live) load_return(P, in, stride, i, x, y, z);
     const T d2 = (x * x + y * y) + z * z;
@@ -482,7 +497,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(8, 8))
             }
         }
         endpoint_commit(P, lane, i, mine, E.L, E.A, E.mbits, hit, total, mh, state, tags, stat_sums, stat_base, stat_rowvox);
-        if (P.ep_row >= 0) return;
+        if (P.ep_row >= 0) { TL_MARK(P, widx, 2); return; }
     }
     const int seg = P.ep_row >= 0 ? (int)blockIdx.y - ((int)blockIdx.y > P.ep_row ? 1 : 0) : (int)blockIdx.y;
     const uint32_t j0 = (uint32_t)P.seg_start[seg];
@@ -497,7 +512,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(8, 8))
         const float r = sqrtf((ux * ux + uy * uy) + uz * uz);
         const float mag = ((fabsf(ax) + fabsf(ay)) + fabsf(az)) + ((fabsf(ux) + fabsf(uy)) + fabsf(uz));
         const bool dead = !pass || (r + (r * 1e-5f + mag * 4e-6f) <= (float)j0 + 0.9f);
-        if (lanes(!dead) == 0ull) return;                                // wave-uniform
+        if (lanes(!dead) == 0ull) { TL_MARK(P, widx, 2); return; }       // wave-uniform
     }
     const RaySetup R = ray_setup<T>(P, x, y, z);
     float px = P.pt0[0], py = P.pt0[1], pz = P.pt0[2];
@@ -508,7 +523,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(8, 8))
     }
     const uint32_t cnt = run ? ray_steps(R.lim, R.step_len, R.inv_step, 0x7ffffff0u) : 0u;     // steps the length test allows
     const bool active = j0 < cnt && !GVOM_DBG(P, 8);
-    if (lanes(active) == 0ull) return;                   // wave-uniform: every ray of the bundle ends earlier
+    if (lanes(active) == 0ull) { TL_MARK(P, widx, 2); return; }   // wave-uniform: every ray of the bundle ends earlier
     for (uint32_t k = j0; k > 0; --k) { px += R.incx; py += R.incy; pz += R.incz; }   // replay (exact accumulation)
     __shared__ __attribute__((aligned(16))) uint32_t s_keys[WPB * 64];
     __shared__ uint32_t s_cnt[WPB * 1024];
@@ -518,7 +533,9 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(8, 8))
 #pragma unroll
     for (int q = 0; q < 16; ++q) LC_ST(&lcc[q * 64 + lane], 0u);
     const int steps = seg == P.nsegs - 1 ? 0x3fffffff : P.seg_start[seg + 1] - (int)j0;
+    TL_MARK(P, widx, 1);
     walk_item<BIG>(P, lane, j0, cnt, px, py, pz, R.incx, R.incy, R.incz, active, steps, P.lc_period, lck, lcc, total, tags);
+    TL_MARK(P, widx, 2);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -170,8 +170,14 @@ class RcclComm(object):
 
 class ThreadFabric(object):
     """Shared state of `world` ThreadComm objects: the ranks are threads of one process that share
-    one GPU (ctypes drops the GIL around library calls).  Device data moves with hipMemcpy between
-    the handles' own exchange regions -- the same regions, counts and order as the RCCL path."""
+    one GPU (ctypes drops the GIL around library calls).  Device data moves between the handles' own
+    exchange regions -- the same regions, counts and order as the RCCL path -- and with the RCCL path's
+    ORDERING: every copy is enqueued on the RECEIVING handle's stream (gvom_stream), as ncclRecv /
+    ncclAllGather are, so the kernels that consume the data are stream-ordered behind it.
+    (Round 2 used hipMemcpy on the null stream: a device-to-device hipMemcpy may return before the copy
+    has run, and the handles' streams are hipStreamNonBlocking, i.e. NOT ordered against the null
+    stream -- k_unpack_* / k_map2d could start before their input had arrived.  That was the
+    run-to-run difference of VERDICT r2 item 1; tools/repro_shard_race.py shows both behaviours.)"""
 
     def __init__(self, world):
         self.world = world
@@ -179,7 +185,8 @@ class ThreadFabric(object):
         self.slots = [None] * world
         self.backends = [None] * world
         self.rt = ctypes.CDLL("libamdhip64.so")
-        self.rt.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        self.rt.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+        self.rt.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
 
     def comm(self, rank):
         return ThreadComm(self, rank)
@@ -199,9 +206,20 @@ class ThreadComm(object):
     def barrier(self):
         self.f.barrier.wait()
 
-    def _copy(self, dst, src, nbytes):
-        if nbytes and self.f.rt.hipMemcpy(ctypes.c_void_p(dst), ctypes.c_void_p(src), nbytes, 3) != 0:
-            raise RuntimeError("hipMemcpy (device to device) failed")
+    def _stream(self, backend):
+        return ctypes.c_void_p(backend.lib.gvom_stream(backend.h))
+
+    def _copy(self, backend, dst, src, nbytes):
+        """device -> device on the receiving handle's stream (3 = hipMemcpyDeviceToDevice)"""
+        if nbytes and self.f.rt.hipMemcpyAsync(ctypes.c_void_p(dst), ctypes.c_void_p(src), nbytes, 3,
+                                               self._stream(backend)) != 0:
+            raise RuntimeError("hipMemcpyAsync (device to device) failed")
+
+    def _drain(self, backend):
+        # the senders may overwrite their regions once the second barrier has been passed: my pulls must
+        # have READ them by then (RCCL: the sender's next kernel is ordered behind its own ncclSend)
+        if self.f.rt.hipStreamSynchronize(self._stream(backend)) != 0:
+            raise RuntimeError("hipStreamSynchronize failed")
 
     def exchange_scan(self, backend, send_q, send_e, recv_q, recv_e):
         f = self.f
@@ -216,21 +234,23 @@ class ThreadComm(object):
                                               (XBUF_SEND_QUADS, XBUF_RECV_QUADS, recv_q[s], 1024),
                                               (XBUF_SEND_EPS, XBUF_RECV_EPS, recv_e[s], 8)):
                 if n:
-                    self._copy(backend.buffer(which_r, s)[0], src.buffer(which_s, self.rank)[0], n * unit)
+                    self._copy(backend, backend.buffer(which_r, s)[0], src.buffer(which_s, self.rank)[0], n * unit)
+        self._drain(backend)
         f.barrier.wait()                                 # nobody repacks before everyone has pulled
 
     def allgather_rows(self, backend):
         f = self.f
         f.backends[self.rank] = backend
-        backend.sync()
+        backend.sync()                                   # my rows are complete
         f.barrier.wait()
         ptr, nbytes = backend.height_rows()
         share = nbytes // self.world
         for s in range(self.world):
             if s != self.rank:
                 sp, _ = f.backends[s].height_rows()
-                self._copy(ptr + s * share, sp + s * share, share)
-        f.barrier.wait()
+                self._copy(backend, ptr + s * share, sp + s * share, share)
+        self._drain(backend)
+        f.barrier.wait()                                 # nobody's next fusion rewrites its rows before everyone has pulled
 
 
 class ShardedGvom(object):
@@ -306,12 +326,12 @@ class ShardedGvom(object):
 
 
 def rendezvous_name():
-    """Name of the shared-memory rendezvous for the job this process belongs to: launchers set
-    MASTER_PORT (torchrun and bench.py do), which is unique to a job on one node; GVOM_JOB_NONCE (bench.py
-    sets it) or, under torchrun, the agent's pid keep two jobs on one port apart."""
+    """Name of the shared-memory rendezvous for the job this process belongs to.  MASTER_PORT (torchrun and
+    bench.py set it) tells jobs on one node apart; the nonce tells this job from an EARLIER one on the same
+    port: GVOM_JOB_NONCE if the launcher sets it (bench.py does), else the parent process -- the ranks of one
+    job on one node are children of one launcher (torchrun's agent, mpirun's orted, slurmstepd), whose pid
+    changes from job to job.  (The library additionally refuses a segment whose creator is no longer alive.)"""
     nonce = os.environ.get("GVOM_JOB_NONCE")
     if nonce is None:
-        # torchrun's workers are children of one agent process: its pid tells this job from an earlier one
-        # on the same port whose segment a crash has left behind
-        nonce = "t%d" % os.getppid() if "TORCHELASTIC_RUN_ID" in os.environ else "0"
+        nonce = "p%d" % os.getppid()
     return "gvom_%s_%s" % (os.environ.get("MASTER_PORT", "29500"), nonce)

@@ -23,6 +23,20 @@ def owned_rows_mask(origin_y, xy, r, W):
     return (sy >= r * rows) & (sy < (r + 1) * rows)
 
 
+def _where(k, a, b, origin_world, params, W, rank):
+    """which returned array differs, in how many cells, and which ranks OWN the storage rows of those cells
+    (an all-gather that arrived late shows up as whole foreign slabs; a kernel race as scattered cells)"""
+    name = ("origin", "positive", "negative", "roughness", "visibility")[k]
+    if a.shape != b.shape or a.ndim != 2:
+        return "%s on rank %d" % (name, rank)
+    xy = params[2]
+    bad = np.argwhere(~((a == b) | ((a != a) & (b != b))))
+    oy = int(round(origin_world[1] / params[0]))
+    owners = sorted(set((((bad[:, 1] + oy) % xy) // (xy // W)).tolist()))
+    return "%s on rank %d: %d cells, window rows y %d..%d, owner ranks %s" % (
+        name, rank, bad.shape[0], bad[:, 1].min(), bad[:, 1].max(), owners)
+
+
 def shares_of(pc, W, rng):
     """ragged split of a cloud: random cut points, so shares differ in length and may be empty"""
     n = pc.shape[0]
@@ -86,8 +100,8 @@ def check_case(seed):
                 assert (out is None) == (wt[1] is None), "combine presence"
                 if out is None:
                     continue
-                for a, b in zip(out, wt[1]):
-                    assert a.dtype == b.dtype and np.array_equal(a, b), "returned maps"
+                for k, (a, b) in enumerate(zip(out, wt[1])):
+                    assert a.dtype == b.dtype and np.array_equal(a, b), "returned maps: " + _where(k, a, b, wt[1][0], params, W, r)
                 assert sh.combined_cell_count_cpu == wt[3], "cell count"
                 got = sh.b.g.read_dense(gvom.GVOM_WHICH_FUSED)
                 m = np.broadcast_to(owned_rows_mask(got[4][1], xy, r, W)[None, :, None], (zs, xy, xy)).reshape(-1)
@@ -110,7 +124,7 @@ if __name__ == "__main__":
             with contextlib.redirect_stdout(io.StringIO()):
                 check_case(seed)
         except AssertionError as e:
-            bad.append((seed, (2, 4, 8)[seed % 3], str(e)[:80]))
+            bad.append((seed, (2, 4, 8)[seed % 3], str(e)[:200]))
     print("checked %d seeds, %d failures" % (count, len(bad)))
     for b in bad[:20]:
         print("  seed %d world %d: %s" % b)

@@ -1,6 +1,6 @@
 """Runs `world` ranks of g-vom_amd/gvom_sharded.ShardedGvom as THREADS of this process on ONE GPU
-(gvom_sharded.ThreadComm: the handles' own exchange regions, moved with hipMemcpy in the order and
-sizes of the RCCL path).  Used by the GPU tests: real pack / unpack / slab kernels, real split
+(gvom_sharded.ThreadComm: the handles' own exchange regions, moved with hipMemcpyAsync on the receiving handle's stream, in the order,
+sizes and stream ordering of the RCCL path).  Used by the GPU tests: real pack / unpack / slab kernels, real split
 C-ABI entry points, SPMD orchestration -- only the wire is not xGMI."""
 import threading
 

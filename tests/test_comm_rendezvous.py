@@ -54,3 +54,39 @@ def test_a_segment_left_behind_by_a_crashed_job_is_not_joined():
     finally:
         if os.path.exists(path):
             os.unlink(path)
+
+
+def test_a_fresh_segment_of_a_job_that_crashed_minutes_ago_is_not_joined():
+    """a job that crashed half a minute ago leaves a complete, fresh-looking segment behind (magic,
+    id ready, fewer ranks attached than the world, young): ranks that start before rank 0 must not take its
+    stale ncclUniqueId.  The segment names its creator (pid + start time); a creator that is no longer alive
+    disqualifies it, and the ranks wait for the one rank 0 of THIS run creates."""
+    name = "gvom_test_crashed_%d" % os.getpid()
+    path = "/dev/shm/" + name
+    dead = subprocess.Popen([sys.executable, "-c", "pass"])
+    dead.wait()
+    with open(path, "wb") as f:      # magic, world, id_ready, attached (1 < 3), created_s (30 s ago), creator pid + start time
+        f.write(struct.pack("<IIIIdqQ", 0x47564F4D, 3, 1, 1, time.time() - 30.0, dead.pid, 12345))
+        f.write(b"\0" * (1 << 20))
+    try:
+        outs = _run(3, name, 200, delay_ms=400)
+        for r, (rc, out) in enumerate(outs):
+            assert rc == 0 and ("ok %d" % r) in out, (r, rc, out)
+    finally:
+        if os.path.exists(path):
+            os.unlink(path)
+
+
+def test_rank_zero_removes_its_segment_when_creation_fails():
+    """a failed gvom_comm_create on rank 0 must not leave /dev/shm/<name> behind for a later run to join
+    (here: the device does not exist, so hipSetDevice / the RCCL load fails after nothing or before the segment;
+    either way no file may remain)"""
+    import ctypes
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "g-vom_amd"))
+    import gvom
+    lib = gvom.load_library()
+    name = "gvom_test_fail_%d" % os.getpid()
+    c = ctypes.c_void_p()
+    rc = lib.gvom_comm_create(0, 2, 4096, name.encode(), ctypes.byref(c))
+    assert rc != 0 and not c
+    assert not os.path.exists("/dev/shm/" + name)

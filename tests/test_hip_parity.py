@@ -180,6 +180,48 @@ def test_asynchronous_combine_overlapped_with_the_next_scan(gvom_mod):
         assert np.array_equal(got_occ[i], want_occ[i]), i
 
 
+def test_asynchronous_combine_with_several_scans_before_its_end(gvom_mod):
+    """with three or more filled slots the asynchronous combine runs its FUSION on the second stream
+    too.  The first scan after combine_maps_async() goes into the spare slot, but its commit makes the ring's
+    oldest slot -- a source of the fusion in flight -- the next spare one, and the SECOND scan writes it.  A long
+    ring (40 slots of a 256 x 256 x 64 grid: a fusion of several hundred microseconds) and tiny clouds (a scan
+    of a few tens) make that overlap certain; the main stream must wait for the fusion before it touches the
+    slot, and the read hooks before they read the fused map.  Everything equals the synchronous mapper's."""
+    params = (0.2, 0.2, 256, 64, 40, 0.5, 0.5, 0.5, 0.3, 2.0, 4.0, 1.0, 1, 1)
+    rng = np.random.default_rng(21)
+
+    def cloud(k, n):
+        ego = (0.21 * k, -0.13 * k, 0.01 * k)
+        return np.stack([rng.uniform(-20, 20, n) + ego[0], rng.uniform(-20, 20, n) + ego[1],
+                         rng.normal(-0.9, 0.5, n)], 1).astype(np.float32), ego
+    a, b = gvom_mod.Gvom(*params), gvom_mod.Gvom(*params)
+    k = 0
+    for _ in range(42):                                              # fill the ring and wrap once: big clouds
+        pc, ego = cloud(k, 30000); k += 1
+        a.process_pointcloud(pc, ego); b.process_pointcloud(pc, ego)
+    for rnd in range(6):
+        want = a.combine_maps()
+        pending = b.combine_maps_async()
+        if rnd == 3:                                                 # a read hook while the fusion is in flight
+            ad, bd = a.read_dense(gvom_mod.GVOM_WHICH_FUSED), b.read_dense(gvom_mod.GVOM_WHICH_FUSED)
+            for j in range(4):
+                assert np.array_equal(ad[j], bd[j]), ("fused map read during the combine", j)
+        for _ in range(3 + rnd % 2):                                 # several tiny scans before the combine is ended
+            pc, ego = cloud(k, 300); k += 1
+            a.process_pointcloud(pc, ego); b.process_pointcloud(pc, ego)
+        got = pending.result()
+        for i in range(5):
+            assert np.array_equal(got[i], want[i]), (rnd, i)
+        assert a.combined_cell_count_cpu == b.combined_cell_count_cpu
+    ad, bd = a.read_dense(gvom_mod.GVOM_WHICH_FUSED), b.read_dense(gvom_mod.GVOM_WHICH_FUSED)
+    for j in range(4):
+        assert np.array_equal(ad[j], bd[j]), j
+    for slot in (0, 17, 39):
+        ad, bd = a.read_dense(slot), b.read_dense(slot)
+        for j in range(4):
+            assert np.array_equal(ad[j], bd[j]), (slot, j)
+
+
 def test_scans_from_a_second_thread_while_a_combine_waits(gvom_mod):
     """The ROS node calls process_pointcloud and combine_maps from two callback threads
     (gvom_ros.py:44-51).  combine_maps waits for its maps with the handle released, so scans keep being

@@ -51,6 +51,7 @@ for W in worlds:
                     cp(b.buffer(4, s)[0], bs[s].buffer(1, me)[0], rq[s] * 1024)
                     cp(b.buffer(5, s)[0], bs[s].buffer(2, me)[0], re[s] * 8)
             recv.append((rq, re))
+        assert rt.hipDeviceSynchronize() == 0          # (null-stream copies: the handles' streams are not ordered against them)
         for me, b in enumerate(bs):
             b.scan_merge(recv[me][0], recv[me][1], True)
             b.sync()
