@@ -60,6 +60,10 @@ class Hip(object):
         self.rt.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
         self.rt.hipFree.argtypes = [ctypes.c_void_p]
         self.rt.hipSetDevice.argtypes = [ctypes.c_int]
+        self.rt.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+        self.rt.hipEventRecord.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        self.rt.hipEventSynchronize.argtypes = [ctypes.c_void_p]
+        self.rt.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
 
     def chk(self, rc, what):
         if rc != 0:
@@ -72,6 +76,21 @@ class Hip(object):
         n = ctypes.c_int(0)
         self.chk(self.rt.hipGetDeviceCount(ctypes.byref(n)), "hipGetDeviceCount")
         return n.value
+
+    def event_create(self):
+        e = ctypes.c_void_p()
+        self.chk(self.rt.hipEventCreate(ctypes.byref(e)), "hipEventCreate")
+        return e
+
+    def event_record(self, ev, stream):
+        self.chk(self.rt.hipEventRecord(ev, ctypes.c_void_p(stream)), "hipEventRecord")
+
+    def event_elapsed_ms(self, a, b):
+        """(both events must have completed: the caller has synchronised their stream)"""
+        ms = ctypes.c_float(0.0)
+        self.chk(self.rt.hipEventSynchronize(b), "hipEventSynchronize")
+        self.chk(self.rt.hipEventElapsedTime(ctypes.byref(ms), a, b), "hipEventElapsedTime")
+        return float(ms.value)
 
     def to_device(self, arr):
         p = ctypes.c_void_p()
@@ -399,6 +418,23 @@ def run_single(args):
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: this process starts the N ranks (one per GPU) and
     relays rank 0's JSON line.  It makes NO HIP call itself."""
+    import bench_sharded
+    try:
+        bench_sharded.workload(args.config, args.gpus)     # an unknown config / rank count is refused before anything starts
+    except ValueError as e:
+        sys.stderr.write("bench.py: %s\n" % e)
+        sys.exit(2)
+    # the device count comes from a CHILD process (this one never makes a HIP call)
+    probe = subprocess.run([sys.executable, "-c", "import ctypes; rt = ctypes.CDLL('libamdhip64.so'); n = ctypes.c_int(0); "
+                            "rc = rt.hipGetDeviceCount(ctypes.byref(n)); print(n.value if rc == 0 else 0)"],
+                           capture_output=True, text=True)
+    try:
+        ndev = int(probe.stdout.strip().splitlines()[-1])
+    except Exception:
+        ndev = 0
+    if ndev < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d, but %d HIP device(s) are visible\n" % (args.gpus, ndev))
+        sys.exit(2)
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     procs = []
     for r in range(args.gpus):
@@ -408,14 +444,15 @@ def spawn_ranks(args):
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     out0, _ = procs[0].communicate()
     rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    lines = [ln for ln in out0.decode().splitlines() if ln.startswith("{")]
+    if lines:
+        print(lines[-1])                                   # (also when the verdict inside it is "not equal": exit code 3)
     if any(rcs):
         sys.stderr.write("bench.py: rank exit codes %s\n" % rcs)
-        sys.exit(1)
-    lines = [ln for ln in out0.decode().splitlines() if ln.startswith("{")]
+        sys.exit(3 if rcs[0] == 3 else 1)
     if not lines:
         sys.stderr.write("bench.py: rank 0 printed no JSON line\n")
         sys.exit(1)
-    print(lines[-1])
 
 
 def main():
@@ -450,6 +487,9 @@ def main():
     else:
         out = run_single(args)
     print(json.dumps(out))
+    if out.get("sharded_equals_unsharded") is False:       # the sharded map differed from the unsharded one: the numbers above belong to wrong maps
+        sys.stdout.flush()
+        sys.exit(3)
 
 
 if __name__ == "__main__":

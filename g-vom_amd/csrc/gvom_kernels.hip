@@ -438,11 +438,12 @@ __device__ __forceinline__ void walk_item(const ScanParams &P, int lane, uint32_
 // into the kernel's timeline: when each dispatch row starts, how full the chip is, where the tail is.
 #ifdef GVOM_DIAG
 #define TL_MARK(P, widx, k) do { if ((P).tl && (threadIdx.x & 63) == 0) (P).tl[(size_t)(widx) * 4 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#define TL_WHERE(P, widx) do { if ((P).tl && (threadIdx.x & 63) == 0) (P).tl[(size_t)(widx) * 4 + 3] = \
-    (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); } while (0)
+#define TL_WHERE(P, widx, pos) do { if ((P).tl && (threadIdx.x & 63) == 0) (P).tl[(size_t)(widx) * 4 + 3] = \
+    (unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffffu) | ((unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u) << 32) | \
+    ((unsigned long long)(pos) << 40); } while (0)
 #else
 #define TL_MARK(P, widx, k) do { } while (0)
-#define TL_WHERE(P, widx) do { } while (0)
+#define TL_WHERE(P, widx, pos) do { } while (0)
 #endif
 
 // ------------------------------------------------------------------------------------------
@@ -454,24 +455,23 @@ __device__ __forceinline__ void walk_item(const ScanParams &P, int lane, uint32_
 // so "the ray has already ended before step k" is decided by the state AT step k alone, given that
 // step 1 lies inside the grid, which every wave checks.
 // ------------------------------------------------------------------------------------------
-template <typename T, bool BIG, int WPB>
-__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_trace(
-    const ScanParams P, const ShardExchange X, const T *__restrict__ in, long stride, long n, T *__restrict__ world,
-    uint32_t *hit, uint32_t *total, uint32_t *mh, int32_t *state, uint32_t *tags, uint32_t *counters, double *stat_sums,
-    double *stat_base, uint32_t *stat_rowvox)
+// One (dispatch row, 64-ray bundle) item of the trace: the endpoint work of the bundle (row == P.ep_row) or one step
+// segment of its rays.  lck / lcc: the wave's line cache, clean on entry and on exit.
+template <typename T, bool BIG>
+__device__ __forceinline__ void trace_item(const ScanParams &P, const ShardExchange &X, const T *__restrict__ in, long stride, long n,
+                                           T *__restrict__ world, uint32_t *hit, uint32_t *total, uint32_t *mh, int32_t *state,
+                                           uint32_t *tags, uint32_t *counters, double *stat_sums, double *stat_base,
+                                           uint32_t *stat_rowvox, int row, long bundle, int lane, uint32_t *lck, uint32_t *lcc,
+                                           size_t widx)
 {
-    const int lane = threadIdx.x & (WAVE - 1);
-    const long i = (long)blockIdx.x * (64 * WPB) + threadIdx.x;
+    const long i = bundle * 64 + lane;
     const bool live = i < n;
-    const size_t widx = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * WPB + (threadIdx.x >> 6);   // (timeline only)
-    (void)widx;
-    TL_MARK(P, widx, 0); TL_WHERE(P, widx);
     T x = 0, y = 0, z = 0;
     if (live) load_return(P, in, stride, i, x, y, z);
     const T d2 = (x * x + y * y) + z * z;
     const bool pass = live && !((double)d2 < P.min_d2);
-    // endpoint work: in the blocks of grid row P.ep_row, or (P.ep_row < 0) in the waves of segment 0
-    const bool ep_here = P.ep_row >= 0 ? (int)blockIdx.y == P.ep_row : blockIdx.y == 0;
+    // endpoint work: in the items of row P.ep_row, or (P.ep_row < 0) in the waves of segment 0
+    const bool ep_here = P.ep_row >= 0 ? row == P.ep_row : row == 0;
     if (ep_here) {
         if (live && world) { world[3 * i + 0] = x; world[3 * i + 1] = y; world[3 * i + 2] = z; }   // statistics only
         const Endpoint E = endpoint_of<T>(P, pass, x, y, z);
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(8, 8))
         endpoint_commit(P, lane, i, mine, E.L, E.A, E.mbits, hit, total, mh, state, tags, stat_sums, stat_base, stat_rowvox);
         if (P.ep_row >= 0) { TL_MARK(P, widx, 2); return; }
     }
-    const int seg = P.ep_row >= 0 ? (int)blockIdx.y - ((int)blockIdx.y > P.ep_row ? 1 : 0) : (int)blockIdx.y;
+    const int seg = P.ep_row >= 0 ? row - (row > P.ep_row ? 1 : 0) : row;
     const uint32_t j0 = (uint32_t)P.seg_start[seg];
     // ---- later segments: leave before the f64 set-up when no ray of the wave can still be running ----
     // After j0 steps `length` is >= j0 * (1 - 2^-22) (every step adds |1 / sd| with |sd| <= 1 + 2^-23),
@@ -525,17 +525,96 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(8, 8))
     const bool active = j0 < cnt && !GVOM_DBG(P, 8);
     if (lanes(active) == 0ull) { TL_MARK(P, widx, 2); return; }   // wave-uniform: every ray of the bundle ends earlier
     for (uint32_t k = j0; k > 0; --k) { px += R.incx; py += R.incy; pz += R.incz; }   // replay (exact accumulation)
+    const int steps = seg == P.nsegs - 1 ? 0x3fffffff : P.seg_start[seg + 1] - (int)j0;
+    if (P.act && lane == 0) P.act[widx] = 1;             // this wave walks: the next scan's dispatch order is planned from it
+    TL_MARK(P, widx, 1);
+    walk_item<BIG>(P, lane, j0, cnt, px, py, pz, R.incx, R.incy, R.incz, active, steps, P.lc_period, lck, lcc, total, tags);
+    TL_MARK(P, widx, 2);
+}
+
+// k_trace: grid (ceil(N/512), nsegs + 1), 8 waves per workgroup, one (row, bundle) item per wave.
+// DISPATCH ORDER.  The dispatcher fills the chip with the first 1024 workgroups -- 4 per CU, ids g and g + 256 on the
+// same CU -- and hands out the rest as workgroups retire, wherever a slot happens to free up.  In natural order
+// (row-major) a CU gets the endpoint, segment-0, -1 and -2 workgroups of THE SAME 512 rays: three walking workgroups
+// if those rays are long, one if they are short, and the late segments land on top of whatever is there
+// (tools/trace_timeline.py: 1 to 5 walking workgroups per CU, mean 3.3; SIMDs finish between 24 and 38 us).
+// P.perm (built by the PREVIOUS scan's k_encode from which waves walked then, see plan_dispatch) maps the dispatch
+// position to the workgroup to run: walking workgroups first, heaviest first, so that they are dealt round the CUs
+// like cards and every CU gets 3 or 4; endpoint workgroups next, dead ones last.  It is a permutation whatever the
+// previous scan looked like, so it only ever affects speed; nullptr = natural order.
+template <typename T, bool BIG, int WPB>
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_trace(
+    const ScanParams P, const ShardExchange X, const T *__restrict__ in, long stride, long n, T *__restrict__ world,
+    uint32_t *hit, uint32_t *total, uint32_t *mh, int32_t *state, uint32_t *tags, uint32_t *counters, double *stat_sums,
+    double *stat_base, uint32_t *stat_rowvox)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+    uint32_t wg = blockIdx.y * gridDim.x + blockIdx.x;
+    const uint32_t pos = wg;
+    (void)pos;
+    if (P.perm) wg = P.perm[wg];
+    const int row = (int)(wg / gridDim.x);
+    const uint32_t blk = wg - (uint32_t)row * gridDim.x;
+    const long bundle = (long)blk * WPB + (threadIdx.x >> 6);
+    const size_t widx = (size_t)wg * WPB + (threadIdx.x >> 6);          // = (row, bundle): activity flags, timeline
+    TL_MARK(P, widx, 0); TL_WHERE(P, widx, pos);
     __shared__ __attribute__((aligned(16))) uint32_t s_keys[WPB * 64];
     __shared__ uint32_t s_cnt[WPB * 1024];
     uint32_t *lck = s_keys + (threadIdx.x >> 6) * 64;
     uint32_t *lcc = s_cnt + (threadIdx.x >> 6) * 1024;
-    LC_ST(&lck[lane], LC_EMPTY);
+    if (row != P.ep_row) {                               // (endpoint blocks never touch the line cache)
+        LC_ST(&lck[lane], LC_EMPTY);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) LC_ST(&lcc[q * 64 + lane], 0u);
-    const int steps = seg == P.nsegs - 1 ? 0x3fffffff : P.seg_start[seg + 1] - (int)j0;
-    TL_MARK(P, widx, 1);
-    walk_item<BIG>(P, lane, j0, cnt, px, py, pz, R.incx, R.incy, R.incz, active, steps, P.lc_period, lck, lcc, total, tags);
-    TL_MARK(P, widx, 2);
+        for (int q = 0; q < 16; ++q) LC_ST(&lcc[q * 64 + lane], 0u);
+    }
+    trace_item<T, BIG>(P, X, in, stride, n, world, hit, total, mh, state, tags, counters, stat_sums, stat_base, stat_rowvox,
+                       row, bundle, lane, lck, lcc, widx);
+}
+
+// plan_dispatch (one wave, inside k_encode's extra workgroup): the order in which the NEXT scan's k_trace runs its
+// workgroups, from the activity flags this scan's k_trace left (act[workgroup * 8 + wave] = 1: the wave walked).
+// A counting sort, stable within a class (neighbouring workgroups stay neighbours): classes = walking waves 8 .. 1,
+// the last segment's workgroups (a shorter segment) behind the others of the same count; then the endpoint
+// workgroups; then the dead ones.  Clears the flags it has read.
+__device__ __forceinline__ void plan_dispatch(const ScanParams &P, int lane)
+{
+    const uint32_t G = (uint32_t)P.plan_wgs, gx = (uint32_t)P.plan_gx;
+    constexpr int NK = 18;
+    auto key_of = [&](uint32_t g, bool ok) -> int {
+        if (!ok) return NK;
+        const int row = (int)(g / gx);
+        if (row == P.ep_row) return 16;
+        const uint2 f = *reinterpret_cast<const uint2 *>(P.act + (size_t)g * 8);
+        const int wv = __popc(f.x & 0x01010101u) + __popc(f.y & 0x01010101u);
+        return wv == 0 ? 17 : (8 - wv) * 2 + (row == P.plan_last_row ? 1 : 0);
+    };
+    uint32_t start[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) start[k] = 0;
+    for (uint32_t g0 = 0; g0 < G; g0 += 64) {                        // pass 1: class sizes
+        const int key = key_of(g0 + lane, g0 + lane < G);
+#pragma unroll
+        for (int k = 0; k < NK; ++k) start[k] += (uint32_t)__popcll(lanes(key == k));
+    }
+    uint32_t run = 0;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) { const uint32_t c = start[k]; start[k] = run; run += c; }
+    for (uint32_t g0 = 0; g0 < G; g0 += 64) {                        // pass 2: stable placement
+        const uint32_t g = g0 + lane;
+        const bool ok = g < G;
+        const int key = key_of(g, ok);
+        uint32_t pos = 0;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const unsigned long long m = lanes(key == k);
+            if (key == k) pos = start[k] + (uint32_t)__popcll(m & lanemask_lt());
+            start[k] += (uint32_t)__popcll(m);
+        }
+        if (ok) {
+            P.perm_out[pos] = g;
+            *reinterpret_cast<uint2 *>(P.act + (size_t)g * 8) = make_uint2(0u, 0u);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -696,6 +775,10 @@ __global__ __launch_bounds__(ENC_T) void k_encode(const ScanParams P, uint32_t t
                                                 uint32_t seq)
 {
     const int xy = P.xy, nseg = P.nseg;
+    if (P.plan_wgs > 0 && blockIdx.x == gridDim.x - 1) {  // the extra workgroup: plans the next scan's k_trace dispatch order
+        if (threadIdx.x < WAVE) plan_dispatch(P, (int)threadIdx.x);
+        return;
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         // k_trace has completed.  Publish {seq, any-in-grid} as ONE 8-byte system-scope store to
         // host-mapped memory (the host spins on it and returns to its caller while this kernel
@@ -711,7 +794,7 @@ __global__ __launch_bounds__(ENC_T) void k_encode(const ScanParams P, uint32_t t
     // a 4x4 patch line) and one 16-byte store of state.
     const int lane = threadIdx.x & (WAVE - 1);
     const uint32_t wid = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    const uint32_t nw = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t nw = ((gridDim.x - (P.plan_wgs > 0 ? 1u : 0u)) * blockDim.x) >> 6;
     const int p4 = lane >> 2, r = lane & 3;
     const bool vec_state = (xy & 3) == 0;                // 16-byte aligned state rows
     for (uint32_t u0 = t_begin + wid * 2; u0 < t_end; u0 += nw * 2) {
@@ -2276,6 +2359,7 @@ hipError_t gvom_launch_encode(hipStream_t s, const ScanParams &P, uint32_t *hit,
     const unsigned enc_cap = (resident_blocks > 0 ? 4u * resident_blocks : 8192u) * 256u / T;
     if (enc_blocks > enc_cap) enc_blocks = enc_cap;
     if (enc_blocks < 1) enc_blocks = 1;
+    if (P.plan_wgs > 0) ++enc_blocks;                    // + the workgroup that plans the next scan's dispatch order
     if (T == 64u)
         hipLaunchKernelGGL(k_encode<64>, dim3(enc_blocks), dim3(64), 0, s, P, t_begin, t_end, hit, total, mh, state,
                            code16, crows, tags, P.epoch, counters, host_flag, seq);

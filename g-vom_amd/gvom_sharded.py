@@ -277,6 +277,7 @@ class ShardedGvom(object):
         self.ego_position = [0, 0, 0]
         self._cells_dirty = False
         self._cell_count = None
+        self.last_exchange_bytes = (0, 0)        # (sent, received) by this rank in the last scan's exchange
 
     @property
     def combined_cell_count_cpu(self):
@@ -305,6 +306,7 @@ class ShardedGvom(object):
         self.b.recv_reserve(recv_e)
         sq = [send_q[d] if d != me else 0 for d in range(W)]
         se = [send_e[d] if d != me else 0 for d in range(W)]
+        self.last_exchange_bytes = (1028 * sum(sq) + 8 * sum(se), 1028 * sum(recv_q) + 8 * sum(recv_e))
         self.comm.exchange_scan(self.b, sq, se, recv_q, recv_e)      # the scan's only device exchange
         self.b.scan_merge(recv_q, recv_e, accept)
         if me == 0:

@@ -118,8 +118,9 @@ CONFIGS = {
     "m256": ((0.2, 0.2, 256, 256, 1) + REF_TAIL, 64, "256x256x256 @0.2 m (metric grid), OS1-64 131,072-pt scan, buffer=1"),
     "m256b8": ((0.2, 0.2, 256, 256, 8) + REF_TAIL, 64, "256x256x256 @0.2 m (metric grid), OS1-64 scan, buffer=8"),
     # the multi-GPU configs of BASELINE.json, also runnable on ONE GPU (sensors = 128-beam scans interleaved in azimuth)
-    "c4": ((0.2, 0.2, 512, 128, 1) + REF_TAIL, 128, "512x512x128 @0.2 m, 4 x OS1-128 = 1,048,576-pt cloud, buffer=1"),
-    "c5": ((0.2, 0.2, 1024, 128, 1) + REF_TAIL, 128, "1024x1024x128 @0.2 m, 16 x OS1-128 = 4,194,304-pt cloud per tick, buffer=1"),
+    # (buffer sizes as BASELINE.md section 3 states them: c4 buffer=4, c5 buffer=8)
+    "c4": ((0.2, 0.2, 512, 128, 4) + REF_TAIL, 128, "512x512x128 @0.2 m, 4 x OS1-128 = 1,048,576-pt cloud, buffer=4"),
+    "c5": ((0.2, 0.2, 1024, 128, 8) + REF_TAIL, 128, "1024x1024x128 @0.2 m, 16 x OS1-128 = 4,194,304-pt cloud per tick, buffer=8"),
 }
 SENSORS = {"c4": 4, "c5": 16}
 

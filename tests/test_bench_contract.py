@@ -28,20 +28,52 @@ def test_roofline_object_has_the_contract_keys():
     assert rp["traffic"] and rp["valu"] and rp["valu"]["insts_per_launch"] > 1e6
 
 
-def test_self_spawned_ranks_fail_loudly_without_gpus():
-    """`python bench.py --gpus 2` without a launcher: the parent (which makes no HIP call) starts two ranks with
-    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set; without a GPU they raise, and the parent reports the exit codes
-    and exits non-zero -- it neither hangs nor prints a JSON line."""
-    if os.path.exists("/dev/kfd"):
-        pytest.skip("a GPU driver is present: the ranks would run")
-    env = dict(os.environ, GVOM_COMM_TIMEOUT_S="20")
+def _bench(argv, env_extra=None, timeout=300):
+    env = dict(os.environ, GVOM_COMM_TIMEOUT_S="20", **(env_extra or {}))
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
-                        "--no-cpu"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
-    assert p.returncode != 0
-    assert b"rank exit codes" in p.stderr
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, timeout=timeout)
+
+
+def test_more_ranks_than_devices_is_refused_before_anything_is_spawned():
+    """`python bench.py --gpus 2` without a launcher on a box with fewer than 2 GPUs (here: none): the parent --
+    which makes no HIP call itself, the device count comes from a child process -- refuses with a clear message and
+    a non-zero exit code; it neither starts ranks that would hang in the rendezvous nor prints a JSON line."""
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("a GPU driver is present")
+    p = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu"])
+    assert p.returncode == 2
+    assert b"HIP device(s) are visible" in p.stderr
     assert not [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+
+
+@pytest.mark.parametrize("argv", [["--gpus", "3", "--config", "c4"], ["--gpus", "8", "--config", "c4"],
+                                  ["--gpus", "3", "--config", "c5"], ["--gpus", "3", "--config", "m256"],
+                                  ["--gpus", "2", "--config", "c1"]])
+def test_sharded_workloads_that_do_not_exist_are_refused(argv):
+    """`--gpus 4 --config c4` used to bench m256 silently.  c4 splits its 4 sensors over 1 / 2 / 4 ranks,
+    c5 its 16 over 1 / 2 / 4 / 8 / 16; xy_size must be a multiple of 4 x ranks; c1 has no sharded form."""
+    p = _bench(argv + ["--steps", "1", "--warmup", "0", "--no-cpu"])
+    assert p.returncode == 2, p.stderr.decode()[-500:]
+    assert not [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+
+
+def test_sharded_workload_table():
+    import bench_sharded
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "g-vom_amd"))
+    import synth
+    params, beams, per_rank, desc = bench_sharded.workload("c4", 4)
+    assert params[2:5] == (512, 128, 4) and beams == 128 and per_rank == 1          # BASELINE.md: 512^2 x 128, buffer 4
+    params, beams, per_rank, desc = bench_sharded.workload("c5", 8)
+    assert params[2:5] == (1024, 128, 8) and per_rank == 2                          # 8 ranks x 524,288 returns
+    assert bench_sharded.workload("m256", 8)[2] == 1
+    # the ranks' shares, concatenated in rank order, are the cloud of synth.config_inputs (what the unsharded mapper gets)
+    want = synth.config_inputs("c4", n_scans=2)[1][1]
+    got = [bench_sharded.make_share("c4", r, 2, 1) for r in range(2)]
+    assert got[0][0].shape[0] == 2 * 262144 and got[0][1] == want[1]
+    assert np.array_equal(np.concatenate([g[0] for g in got], 0), want[0])
 
 
 @pytest.mark.gpu
@@ -84,3 +116,22 @@ def test_sharded_bench_leg_with_one_rank():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["steps"] == 40 and d["value"] > 100
     assert "sharded" in d["config"]["workload"] and d["config"]["points_per_gpu"] == d["config"]["points_per_step"]
+    # the line carries its own correctness verdict, rank 0's k_trace roofline and the exchange figures
+    assert d["sharded_equals_unsharded"] is True and d["verify"]["differing_cells"] == 0 and d["verify"]["steps"] == 3
+    r = d["roofline"]
+    assert r["kernel"] == "k_trace" and 0 < r["frac"] < 1 and r["algorithmic_bytes_per_launch"] > 1e7
+    assert len(d["exchange"]["per_rank"]) == 1 and d["exchange"]["per_rank"][0]["sent_bytes"] == 0
+
+
+@pytest.mark.gpu
+def test_sharded_bench_leg_runs_baseline_config_c4():
+    """BASELINE.json config 4 (512 x 512 x 128, buffer 4, the 1,048,576-point cloud) through the sharded leg with the
+    one rank a one-GPU box allows -- the workload is c4's, not a silent substitute, and the line says the sharded
+    maps equal the unsharded ones."""
+    p = _bench(["--gpus", "1", "--config", "c4", "--steps", "10", "--warmup", "6", "--no-cpu"],
+               {"GVOM_BENCH_FORCE_SHARDED": "1"}, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    d = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    assert d["config"]["name"] == "c4" and d["config"]["grid"] == [512, 512, 128] and d["config"]["buffer_size"] == 4
+    assert d["config"]["points_per_step"] == 1048576
+    assert d["sharded_equals_unsharded"] is True and d["verify"]["steps"] == 6

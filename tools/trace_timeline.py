@@ -72,3 +72,27 @@ lastend = np.zeros(int(key.max()) + 1)
 np.maximum.at(lastend, key, E)
 le = lastend[lastend > 0]
 print("last wave end per SIMD: 10%% %.1f / median %.1f / 90%% %.1f / max %.1f us" % tuple(np.percentile(le, [10, 50, 90, 100])))
+
+# where the dispatcher puts the workgroups: linear workgroup id -> (XCC, SE, CU); do ids g and g + 256 share a CU?
+wg_hw = w[:, :, 3].reshape(gy * gx, 8)[:, 0]
+nwg = gy * gx
+order = np.argsort((wg_hw >> 40) & 0xffffff, kind="stable")      # logical workgroup ids in DISPATCH order
+wg_hw = wg_hw[order]
+wg_cu = (((wg_hw >> 32) & 15) * 8 + ((wg_hw >> 13) & 7)) * 16 + ((wg_hw >> 8) & 15)
+wg_xcc = (wg_hw >> 32) & 15
+first = min(nwg, 1024)
+print("first %d workgroups: XCC == id %% 8 for %d of them; distinct CUs %d; workgroups per CU min %d / max %d"
+      % (first, int((wg_xcc[:first] == np.arange(first) % 8).sum()), len(set(wg_cu[:first].tolist())),
+         np.bincount(np.unique(wg_cu[:first], return_inverse=True)[1]).min(), np.bincount(np.unique(wg_cu[:first], return_inverse=True)[1]).max()))
+for d in (8, 64, 128, 256, 512):
+    if nwg > d:
+        k = min(first, nwg - d)
+        print("  ids g and g + %d on the same CU: %d of %d" % (d, int((wg_cu[:k] == wg_cu[d:d + k]).sum()), k))
+print("  CU of workgroups 0..31:", [int(c) for c in wg_cu[:32]])
+print("  CU of workgroups 256..287:", [int(c) for c in wg_cu[256:288]])
+# alive workgroups per CU (a workgroup is alive if any of its waves walks)
+alive_wg = (w[:, :, 1].reshape(gy * gx, 8) > 0).any(1)[order]
+print("walking workgroups among the first 1024 dispatched: %d of %d" % (int(alive_wg[:1024].sum()), int(alive_wg.sum())))
+cus, inv = np.unique(wg_cu, return_inverse=True)
+per_cu = np.bincount(inv, weights=alive_wg.astype(float))
+print("walking workgroups per CU: min %d / median %d / max %d of %d CUs" % (per_cu.min(), np.median(per_cu), per_cu.max(), cus.size))
