@@ -77,11 +77,6 @@ struct gvom_handle {
     uint32_t *hit = nullptr, *total = nullptr, *mh = nullptr;   // dense accumulators (hit, ray passes, min-height), zero between scans
     size_t acc_elems = 0;
     int tune_segs = 0, tune_ep_row = -2, tune_period = 0; // gvom_set_tuning (0 / -2: automatic)
-    int tune_plan = -1;                                   // k_trace's planned dispatch order (-1: automatic = on, 0: natural order)
-    // k_trace's dispatch order, planned by the previous scan's k_encode (gvom_kernels.hip: k_trace, plan_dispatch)
-    Buf plan_perm, plan_act;
-    int plan_gx = 0, plan_rows = 0, plan_ep = -9;        // launch shape the stored order was planned for
-    bool plan_ready = false;                              // plan_perm holds an order for that shape
     // rank exchange of a sharded map (world > 1): send / receive regions, indexed by peer rank
     uint32_t *x_send_ids = nullptr, *x_recv_ids = nullptr;     // quad ids: [Q] by owner / [world][myQ] by source
     void *x_send_pay = nullptr, *x_recv_pay = nullptr;         // 1 KiB per quad, same indexing
@@ -241,7 +236,6 @@ void fill_scan_params(const gvom_handle *h, const int64_t origin[3], const doubl
         if (P.lc_period > 32) P.lc_period = 32;          // the line cache is direct-mapped with 64 entries
         P.ep_row = h->tune_ep_row >= -1 ? h->tune_ep_row : 0;  // endpoint blocks first: their atomics retire under the walk (-1: inside segment 0's waves)
         if (P.ep_row > P.nsegs) P.ep_row = P.nsegs;
-        P.perm = nullptr; P.act = nullptr; P.perm_out = nullptr; P.plan_wgs = 0; P.plan_gx = 0; P.plan_last_row = 0;
         P.f32_sqrt = h->f32_sqrt ? 1 : 0;
         P.dbg = gvom_diag_env("GVOM_TRACE_DEBUG");
         const double w_last = nsegs <= 3 ? 0.35 : 0.6;
@@ -396,8 +390,6 @@ void scan_abort(gvom_handle *h)
     (void)hipMemsetAsync(h->total, 0, h->acc_elems * 4, h->stream);
     (void)hipMemsetAsync(h->mh, 0, h->acc_elems * 4, h->stream);
     (void)hipMemsetAsync(h->counters, 0, GVOM_CNT_WORDS * 4, h->stream);
-    if (h->plan_act.p) (void)hipMemsetAsync(h->plan_act.p, 0, h->plan_act.bytes, h->stream);
-    h->plan_ready = false;
     (void)hipStreamSynchronize(h->stream);
     (void)hipGetLastError();
     h->pending = false;
@@ -528,33 +520,12 @@ int scan_launch(gvom_handle *h, std::unique_lock<std::mutex> &lk, const void *de
         h->x_ep_cap = n > 0 ? n : 1;
         X.ep_send = (uint2 *)h->x_send_eps.p; X.ep_cnt = h->x_ecnt; X.ep_cap = (long)h->x_ep_cap;
     }
-    if (n > 0) {   // dispatch order of k_trace: use the order the previous scan planned (same launch shape), plan the next
-        const int gx = (int)((n + 511) / 512), rows = P.nsegs + (P.ep_row >= 0 ? 1 : 0);
-        const size_t G = (size_t)gx * rows;
-        if (h->plan_perm.bytes < G * 4 || h->plan_act.bytes < G * 8) {
-            if ((rc = ensure(h, h->plan_perm, G * 4)) || (rc = ensure(h, h->plan_act, G * 8))) return rc;
-            HIPCHK(h, hipMemsetAsync(h->plan_act.p, 0, h->plan_act.bytes, h->stream));
-            h->plan_ready = false;
-        }
-        const bool same = h->plan_ready && h->plan_gx == gx && h->plan_rows == rows && h->plan_ep == P.ep_row;
-        if (!same && h->plan_ready) {                      // flags of another launch shape: start over
-            HIPCHK(h, hipMemsetAsync(h->plan_act.p, 0, h->plan_act.bytes, h->stream));
-            h->plan_ready = false;
-        }
-        const bool use = h->tune_plan != 0;
-        P.perm = (use && same) ? (const uint32_t *)h->plan_perm.p : nullptr;
-        P.act = use ? (unsigned char *)h->plan_act.p : nullptr;
-        P.perm_out = (uint32_t *)h->plan_perm.p;
-        P.plan_wgs = use ? (int)G : 0; P.plan_gx = gx;
-        P.plan_last_row = (P.nsegs - 1) + ((P.ep_row >= 0 && P.ep_row <= P.nsegs - 1) ? 1 : 0);
-        h->plan_gx = gx; h->plan_rows = rows; h->plan_ep = P.ep_row;
-        h->plan_ready = false;                             // (true again once this scan's k_encode has been enqueued)
-    }
-    P.tl = nullptr;
+    P.tl = nullptr; P.tl_words = 0;
 #ifdef GVOM_DIAG
     if (gvom_diag_env("GVOM_TRACE_TIMELINE") && n > 0) {
         h->tl_grid[0] = (int)((n + 511) / 512); h->tl_grid[1] = P.nsegs + (P.ep_row >= 0 ? 1 : 0);
-        const size_t bytes = (size_t)h->tl_grid[0] * h->tl_grid[1] * 8 * 32;
+        const size_t bytes = (size_t)h->tl_grid[0] * h->tl_grid[1] * 8 * 32 + 64;
+        P.tl_words = (long)h->tl_grid[0] * h->tl_grid[1] * 8 * 4;
         if ((rc = ensure(h, h->tl, bytes))) return rc;
         HIPCHK(h, hipMemsetAsync(h->tl.p, 0, bytes, h->stream));
         P.tl = (unsigned long long *)h->tl.p;
@@ -597,7 +568,6 @@ int scan_launch(gvom_handle *h, std::unique_lock<std::mutex> &lk, const void *de
                             st.tags, h->counters,
                             (unsigned long long *)h->counters_host_dev, seq, h->resident_blocks);
     if (le != hipSuccess) { scan_abort(h); HIPCHK(h, le); }
-    h->plan_ready = P.plan_wgs > 0;
     if (h->profiling) { HIPCHK(h, hipEventRecord(h->ev[2], h->stream)); h->ev_scan = true; }
     if (h->stats) {                                      // optional per-voxel statistics
         HIPCHK(h, gvom_launch_stats(h->stream, P, dtype, h->world_pts.p, n, st.state, st.tags,
@@ -977,7 +947,7 @@ VIS void gvom_destroy(gvom_t *h)
     if (h->x_host) hipHostFree(h->x_host);
     for (auto &s : h->slots) { hipFree(s.state); hipFree(s.code16); hipFree(s.tags); fb(s.crows); fb(s.metrics); fb(s.base); fb(s.rowvox); }
     for (auto &f : h->fused) { hipFree(f.state); hipFree(f.tags); fb(f.rows); fb(f.metrics); }
-    fb(h->in_pts); fb(h->world_pts); fb(h->tl); fb(h->plan_perm); fb(h->plan_act);
+    fb(h->in_pts); fb(h->world_pts); fb(h->tl);
     hipFree(h->counters); if (h->counters_host) hipHostFree(h->counters_host);
     hipFree(h->descs_dev); if (h->descs_host) hipHostFree(h->descs_host);
     hipFree(h->blockcounts);
@@ -1124,7 +1094,6 @@ VIS int gvom_shard_scan_merge(gvom_t *h, const int64_t *recv_quads, const int64_
                                        st.tags, h->counters,
                                        (unsigned long long *)h->counters_host_dev, seq, h->resident_blocks);
     if (le != hipSuccess) { scan_abort(h); HIPCHK(h, le); }
-    h->plan_ready = P.plan_wgs > 0;
     if (h->profiling) { HIPCHK(h, hipEventRecord(h->ev[2], h->stream)); h->ev_scan = true; }
     HT(h, 0, t0);
     // (no host wait: everything the caller can do next with this handle is stream-ordered behind k_encode)
@@ -1730,7 +1699,7 @@ VIS int gvom_set_tuning(gvom_t *h, const char *name, int value)
     if (!strcmp(name, "segs")) h->tune_segs = value;
     else if (!strcmp(name, "ep_row")) h->tune_ep_row = value;
     else if (!strcmp(name, "period")) h->tune_period = value;
-    else if (!strcmp(name, "plan")) h->tune_plan = value;
+
     else if (!strcmp(name, "epoch_bias")) h->epoch += (uint32_t)value;   // test hook: advances the tile-epoch counter (towards its wrap)
     else return GVOM_ERR_INVALID;
     return GVOM_OK;
@@ -1776,8 +1745,8 @@ VIS int gvom_diag_timeline(gvom_t *h, unsigned long long *out, int64_t max_words
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, sync_streams(h));
     grid[0] = h->tl_grid[0]; grid[1] = h->tl_grid[1];
-    const int64_t words = (int64_t)grid[0] * grid[1] * 8 * 4;
-    if (!h->tl.p || words <= 0) return GVOM_NO_DATA;
+    const int64_t words = (int64_t)grid[0] * grid[1] * 8 * 4 + 8;      // + 8 summary words (steps by lookup mode)
+    if (!h->tl.p || words <= 8) return GVOM_NO_DATA;
     HIPCHK(h, hipMemcpy(out, h->tl.p, (size_t)(words < max_words ? words : max_words) * 8, hipMemcpyDeviceToHost));
     return GVOM_OK;
 }

@@ -66,13 +66,6 @@ struct ScanParams {
     int    seg_start[10];
     int    ep_row;        // k_trace: blockIdx.y of the endpoint blocks (the other rows are the segments, ascending)
     int    lc_period;     // k_trace: flush the wave's line cache every lc_period committing steps
-    // k_trace's dispatch order (see k_trace / plan_dispatch): perm[dispatch position] = workgroup (row * gridDim.x + block)
-    // or nullptr (natural order); act[workgroup * 8 + wave] = 1 where a wave walks; k_encode's extra workgroup turns
-    // the flags into the NEXT scan's order (perm_out) and clears them.  plan_wgs = 0: no planning.
-    const uint32_t *perm;
-    unsigned char *act;
-    uint32_t *perm_out;
-    int    plan_wgs, plan_gx, plan_last_row;
     int    f32_sqrt;      // GVOM_FLAG_CUDA_F32_SQRT: ray_length = sqrtf(f32 sum) (real Numba-CUDA typing, gvom.py:1109)
     int    sxq;           // accumulator layout: 4x4 (x,y) patches per row of patches = ceil(xy/4) + padding
     uint32_t epoch;       // this scan's tile epoch
@@ -81,6 +74,7 @@ struct ScanParams {
                           //    as ros_numpy hands the reference a float64 array (stride and offsets in 4-byte units)
     int    shard_world, shard_rank, shard_rows;   // ranks of a sharded map (1, 0, xy when unsharded): rank r owns storage rows [r*shard_rows, (r+1)*shard_rows)
     int    dbg;           // diagnostic build only
+    long   tl_words;      // diagnostic build only: words of per-wave records in tl; 8 summary words follow
     unsigned long long *tl;   // diagnostic build only (GVOM_TRACE_TIMELINE): 4 words per wave {start, set-up done, end, hardware id}
 };
 

@@ -43,6 +43,7 @@ typedef int v4i __attribute__((ext_vector_type(4)));                       // 16
 typedef const __attribute__((address_space(1))) v4i *gptr_v4i;
 
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+typedef float v2f __attribute__((ext_vector_type(2)));                      // packed f32 pair (v_pk_add_f32)
 __device__ __forceinline__ uint32_t pk_add_sat_u16(uint32_t a, uint32_t b) {     // v_pk_add_u16 ... clamp
     const us2 r = __builtin_elementwise_add_sat(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b));
     return __builtin_bit_cast(uint32_t, r);
@@ -323,14 +324,20 @@ __device__ __forceinline__ RaySetup ray_setup(const ScanParams &P, T x, T y, T z
 
 // ------------------------------------------------------------------------------------------
 // walk_steps: at most `steps` lock-step DDA steps of a 64-ray bundle, total += 1 per step
-// (gvom.py:1119-1150).  The step body is straight-line: ray state in natural (x,y,z) order, voxel
-// lookup in 32-bit integers (window_voxel), left neighbour's key by a DPP wave shift; lanes stepping
-// into the same voxel as their left neighbour are merged (2 ballots + run length) and the merged adds
-// go into the wave-private LDS line cache (lc_flush), flushed every `period` committing steps with
-// one memory-side request per line; tile tags stamped on cache misses only.
+// (gvom.py:1119-1150).  The step body is straight-line: ray state in natural (x,y,z) order (x and y as
+// one packed f32 add), the step counter on the scalar unit, voxel lookup in 32-bit integers, left
+// neighbour's key by a DPP wave shift; lanes stepping into the same voxel as their left neighbour are
+// merged (run heads and run lengths by mask arithmetic on the scalar unit, the head mask goes straight into
+// EXEC) and the merged adds go into the wave-private LDS line cache (lc_flush), flushed every `period`
+// committing steps with one memory-side request per line; tile tags stamped on cache misses only.
+// LIT: the reference's literal f64 lookup instead of the integer one (window_voxel).
+// (Round 3 also built a third form without the window test for the steps a ray provably spends inside the window:
+// 6 of 55 vector instructions fewer per step on three quarters of the steps, bit-exact, and not a microsecond faster
+// -- like the other reductions of this round it showed that the kernel is not bound by its instruction count;
+// DESIGN.md section 4.)
 // ------------------------------------------------------------------------------------------
 template <bool LIT, bool P2>
-__device__ __forceinline__ void walk_steps(const ScanParams &P, int lane, uint32_t &j, uint32_t cnt, float &px, float &py, float &pz,
+__device__ __forceinline__ void walk_steps(const ScanParams &P, int lane, uint32_t &j, uint32_t cnt, float &px_, float &py_, float &pz,
                                            float incx, float incy, float incz, bool &active, int steps,
                                            uint32_t *lck, uint32_t *lcc, uint32_t *total, uint32_t *tags)
 {
@@ -341,37 +348,42 @@ __device__ __forceinline__ void walk_steps(const ScanParams &P, int lane, uint32
     glb_u32 *const total1 = (glb_u32 *)total;
     uint32_t memo = LC_EMPTY;
     bool dirty = false;
-    const bool is32 = lane == 32;                                         // (loop-invariant lane mask)
+    uint32_t ju = (uint32_t)__builtin_amdgcn_readfirstlane((int)j);      // the step counter is the same in every lane
     // A ray that has ended is parked at x = +inf: it never falls into the window again, so "takes part in
     // this step" is the window test alone -- no per-lane flag carried around the loop.
-    px = active ? px : INFINITY;
-    for (int left = steps; left > 0; --left) {
-        ++j;
+    v2f pxy = {active ? px_ : INFINITY, py_};
+    const v2f incxy = {incx, incy};
+    // left neighbour's key: lane 0 has none and keeps this value, which no accumulator index equals
+    uint32_t leftk = 0xFFFFFFFFu;
+    int left = steps;
+    unsigned long long cmask;
+    // (one back edge: the loop runs while steps are left and some ray of the bundle still takes part; the bookkeeping
+    // below is all a step with no participant does)
+    do {
+        ++ju;
         // every lane computes (a finished ray's lanes produce values nobody uses): no divergent
         // region around the arithmetic
-        px += incx; py += incy; pz += incz;
-        uint32_t wx, wy, wz;                                              // window voxel
-        const bool commit = window_voxel<LIT>(P, px, py, pz, wx, wy, wz);
-        const unsigned long long cmask = lanes(commit);
-        if (cmask == 0ull) { px = INFINITY; break; }                      // wave-uniform: every ray of the bundle has ended
-        dirty = true;
+        pxy += incxy; pz += incz;
         uint32_t sx, sy, sz;                                              // toroidal storage coordinates
+        uint32_t wx, wy, wz;                                              // window voxel
+        const bool commit = window_voxel<LIT>(P, pxy.x, pxy.y, pz, wx, wy, wz);
         if (P2) { sx = (wx + om0) & (uxy - 1u); sy = (wy + om1) & (uxy - 1u); sz = (wz + om2) & (uzs - 1u); }
         else { sx = min(wx + om0, wx + om0 - uxy); sy = min(wy + om1, wy + om1 - uxy); sz = min(wz + om2, wz + om2 - uzs); }
-        const uint32_t Ls = acc_idx24(sx, sy, sz, uzs, usxq);
-        // merge runs of equal voxel indices among neighbouring lanes
-        const uint32_t key = commit ? Ls : (0xFFFFFF00u | (uint32_t)lane);
-        const uint32_t leftk = (uint32_t)__builtin_amdgcn_update_dpp((int)~key, (int)key, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-        // (a run also ends at the half-wave boundary: its length is then found in the low word of a shifted mask)
-        const bool differs = leftk != key;
-        const unsigned long long hm = (lanes(differs) | (1ull << 32)) & cmask;   // heads of runs (mask arithmetic on the scalar unit)
-        const bool head = commit & (differs | is32);
+        cmask = lanes(commit);
+        const uint32_t line = mad24s(mad24s(sy >> 2, uzs, sz), usxq, sx >> 2);   // accumulator line (acc_idx24)
+        const uint32_t low4 = ((sy & 3u) << 2) | (sx & 3u);
+        const uint32_t Ls = (line << 4) | low4;
+        // merge runs of equal voxel indices among neighbouring lanes.  Lanes that do not take part hold
+        // arbitrary indices: a run also starts where the left neighbour does not take part, and at lane 32
+        // (its length is then found in the low word of a shifted mask)
+        leftk = (uint32_t)__builtin_amdgcn_update_dpp((int)leftk, (int)Ls, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+        const unsigned long long hm = (lanes(leftk != Ls) | ~(cmask << 1) | (1ull << 32)) & cmask;   // heads of runs
         // a run ends in front of the next head or of the next lane without a step -- or with the half-wave
         const unsigned long long ends = ((hm | ~cmask) >> 1) | (1ull << 63) | (1ull << 31);
-        if (head && !GVOM_DBG(P, 16)) {
+        if (__builtin_amdgcn_inverse_ballot_w64(hm) && !GVOM_DBG(P, 16)) {
             // memo: the (line, row-in-line) this lane added to last; a miss looks the line up
             // (or inserts it) and stamps the voxel's tile tag
-            const uint32_t line = Ls >> 4, lrow = Ls >> 2;
+            const uint32_t lrow = Ls >> 2;
             const bool miss = lrow != memo;
             // direct-mapped: 4 x 4 patches x 4 z levels around wherever the bundle is
             const uint32_t hh = ((sz & 3u) << 4) | (((sy >> 2) & 3u) << 2) | ((sx >> 2) & 3u);
@@ -387,13 +399,21 @@ __device__ __forceinline__ void walk_steps(const ScanParams &P, int lane, uint32
             // only released by the flush); a miss whose slot holds another line adds directly
             const bool ok = (was == LC_EMPTY) | (was == line);
             memo = ok ? lrow : memo;
-            if (ok) __hip_atomic_fetch_add(&cnt3[hh * 16u + (Ls & 15u)], run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            else __hip_atomic_fetch_add(&total1[Ls], run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // table congested: direct add
+            // one LDS add for every head: a lane whose slot is taken adds into the spare entry behind the table (never
+            // read) and makes its global add in a branch the wave takes only when some lane needs it
+            if (!GVOM_DBG(P, 128))
+            __hip_atomic_fetch_add(&cnt3[ok ? hh * 16u + low4 : 1024u], run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (lanes(!ok) != 0ull) {
+                if (!ok) __hip_atomic_fetch_add(&total1[Ls], run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // table congested: direct add
+            }
         }
         // gvom.py:1127 (length test), 1135-1144 (left the grid): the ray ends after this step
-        px = (commit & (j < cnt)) ? px : INFINITY;
-    }
-    active = px < INFINITY;
+        pxy.x = (commit & (ju < cnt)) ? pxy.x : INFINITY;
+        dirty = dirty | (cmask != 0ull);
+    } while (--left > 0 && cmask != 0ull);
+    j = ju;
+    px_ = pxy.x; py_ = pxy.y;
+    active = pxy.x < INFINITY;
     if (dirty) lc_flush(P, lck, lcc, total, lane);
 }
 
@@ -524,24 +544,25 @@ __device__ __forceinline__ void trace_item(const ScanParams &P, const ShardExcha
     const uint32_t cnt = run ? ray_steps(R.lim, R.step_len, R.inv_step, 0x7ffffff0u) : 0u;     // steps the length test allows
     const bool active = j0 < cnt && !GVOM_DBG(P, 8);
     if (lanes(active) == 0ull) { TL_MARK(P, widx, 2); return; }   // wave-uniform: every ray of the bundle ends earlier
-    for (uint32_t k = j0; k > 0; --k) { px += R.incx; py += R.incy; pz += R.incz; }   // replay (exact accumulation)
+    {   // replay (the reference's exact f32 accumulation; x and y as one packed add)
+        v2f pxy = {px, py};
+        const v2f incxy = {R.incx, R.incy};
+        for (uint32_t k = j0; k > 0; --k) { pxy += incxy; pz += R.incz; }
+        px = pxy.x; py = pxy.y;
+    }
     const int steps = seg == P.nsegs - 1 ? 0x3fffffff : P.seg_start[seg + 1] - (int)j0;
-    if (P.act && lane == 0) P.act[widx] = 1;             // this wave walks: the next scan's dispatch order is planned from it
     TL_MARK(P, widx, 1);
     walk_item<BIG>(P, lane, j0, cnt, px, py, pz, R.incx, R.incy, R.incz, active, steps, P.lc_period, lck, lcc, total, tags);
     TL_MARK(P, widx, 2);
 }
 
 // k_trace: grid (ceil(N/512), nsegs + 1), 8 waves per workgroup, one (row, bundle) item per wave.
-// DISPATCH ORDER.  The dispatcher fills the chip with the first 1024 workgroups -- 4 per CU, ids g and g + 256 on the
-// same CU -- and hands out the rest as workgroups retire, wherever a slot happens to free up.  In natural order
-// (row-major) a CU gets the endpoint, segment-0, -1 and -2 workgroups of THE SAME 512 rays: three walking workgroups
-// if those rays are long, one if they are short, and the late segments land on top of whatever is there
-// (tools/trace_timeline.py: 1 to 5 walking workgroups per CU, mean 3.3; SIMDs finish between 24 and 38 us).
-// P.perm (built by the PREVIOUS scan's k_encode from which waves walked then, see plan_dispatch) maps the dispatch
-// position to the workgroup to run: walking workgroups first, heaviest first, so that they are dealt round the CUs
-// like cards and every CU gets 3 or 4; endpoint workgroups next, dead ones last.  It is a permutation whatever the
-// previous scan looked like, so it only ever affects speed; nullptr = natural order.
+// (Round 3 measured three other ways of handing out the items, each with per-wave timelines -- profiles/r3_timeline_*:
+// a work queue drawn from one atomic counter (same-address atomics retire at ~90 per us: 256 us), workgroups whose
+// waves take bundles from all over the cloud (half of every workgroup's waves die at once and its LDS keeps the slots
+// from being reused: +11 %, c4 +28 %), and a dispatch order planned from the previous scan so that every CU gets 3 or 4
+// walking workgroups instead of 1 to 5 (no gain: all walking waves are resident from t = 0 either way and the kernel
+// runs at the VALU issue rate).)
 template <typename T, bool BIG, int WPB>
 __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_trace(
     const ScanParams P, const ShardExchange X, const T *__restrict__ in, long stride, long n, T *__restrict__ world,
@@ -549,19 +570,14 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(8, 8))
     double *stat_base, uint32_t *stat_rowvox)
 {
     const int lane = threadIdx.x & (WAVE - 1);
-    uint32_t wg = blockIdx.y * gridDim.x + blockIdx.x;
-    const uint32_t pos = wg;
-    (void)pos;
-    if (P.perm) wg = P.perm[wg];
-    const int row = (int)(wg / gridDim.x);
-    const uint32_t blk = wg - (uint32_t)row * gridDim.x;
-    const long bundle = (long)blk * WPB + (threadIdx.x >> 6);
-    const size_t widx = (size_t)wg * WPB + (threadIdx.x >> 6);          // = (row, bundle): activity flags, timeline
-    TL_MARK(P, widx, 0); TL_WHERE(P, widx, pos);
+    const int row = (int)blockIdx.y;
+    const long bundle = (long)blockIdx.x * WPB + (threadIdx.x >> 6);
+    const size_t widx = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * WPB + (threadIdx.x >> 6);   // (timeline only)
+    TL_MARK(P, widx, 0); TL_WHERE(P, widx, blockIdx.y * gridDim.x + blockIdx.x);
     __shared__ __attribute__((aligned(16))) uint32_t s_keys[WPB * 64];
-    __shared__ uint32_t s_cnt[WPB * 1024];
+    __shared__ uint32_t s_cnt[WPB * 1040];                 // 64 entries x 16 counters + a spare word per wave (walk_steps)
     uint32_t *lck = s_keys + (threadIdx.x >> 6) * 64;
-    uint32_t *lcc = s_cnt + (threadIdx.x >> 6) * 1024;
+    uint32_t *lcc = s_cnt + (threadIdx.x >> 6) * 1040;
     if (row != P.ep_row) {                               // (endpoint blocks never touch the line cache)
         LC_ST(&lck[lane], LC_EMPTY);
 #pragma unroll
@@ -569,52 +585,6 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(8, 8))
     }
     trace_item<T, BIG>(P, X, in, stride, n, world, hit, total, mh, state, tags, counters, stat_sums, stat_base, stat_rowvox,
                        row, bundle, lane, lck, lcc, widx);
-}
-
-// plan_dispatch (one wave, inside k_encode's extra workgroup): the order in which the NEXT scan's k_trace runs its
-// workgroups, from the activity flags this scan's k_trace left (act[workgroup * 8 + wave] = 1: the wave walked).
-// A counting sort, stable within a class (neighbouring workgroups stay neighbours): classes = walking waves 8 .. 1,
-// the last segment's workgroups (a shorter segment) behind the others of the same count; then the endpoint
-// workgroups; then the dead ones.  Clears the flags it has read.
-__device__ __forceinline__ void plan_dispatch(const ScanParams &P, int lane)
-{
-    const uint32_t G = (uint32_t)P.plan_wgs, gx = (uint32_t)P.plan_gx;
-    constexpr int NK = 18;
-    auto key_of = [&](uint32_t g, bool ok) -> int {
-        if (!ok) return NK;
-        const int row = (int)(g / gx);
-        if (row == P.ep_row) return 16;
-        const uint2 f = *reinterpret_cast<const uint2 *>(P.act + (size_t)g * 8);
-        const int wv = __popc(f.x & 0x01010101u) + __popc(f.y & 0x01010101u);
-        return wv == 0 ? 17 : (8 - wv) * 2 + (row == P.plan_last_row ? 1 : 0);
-    };
-    uint32_t start[NK];
-#pragma unroll
-    for (int k = 0; k < NK; ++k) start[k] = 0;
-    for (uint32_t g0 = 0; g0 < G; g0 += 64) {                        // pass 1: class sizes
-        const int key = key_of(g0 + lane, g0 + lane < G);
-#pragma unroll
-        for (int k = 0; k < NK; ++k) start[k] += (uint32_t)__popcll(lanes(key == k));
-    }
-    uint32_t run = 0;
-#pragma unroll
-    for (int k = 0; k < NK; ++k) { const uint32_t c = start[k]; start[k] = run; run += c; }
-    for (uint32_t g0 = 0; g0 < G; g0 += 64) {                        // pass 2: stable placement
-        const uint32_t g = g0 + lane;
-        const bool ok = g < G;
-        const int key = key_of(g, ok);
-        uint32_t pos = 0;
-#pragma unroll
-        for (int k = 0; k < NK; ++k) {
-            const unsigned long long m = lanes(key == k);
-            if (key == k) pos = start[k] + (uint32_t)__popcll(m & lanemask_lt());
-            start[k] += (uint32_t)__popcll(m);
-        }
-        if (ok) {
-            P.perm_out[pos] = g;
-            *reinterpret_cast<uint2 *>(P.act + (size_t)g * 8) = make_uint2(0u, 0u);
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -775,10 +745,6 @@ __global__ __launch_bounds__(ENC_T) void k_encode(const ScanParams P, uint32_t t
                                                 uint32_t seq)
 {
     const int xy = P.xy, nseg = P.nseg;
-    if (P.plan_wgs > 0 && blockIdx.x == gridDim.x - 1) {  // the extra workgroup: plans the next scan's k_trace dispatch order
-        if (threadIdx.x < WAVE) plan_dispatch(P, (int)threadIdx.x);
-        return;
-    }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         // k_trace has completed.  Publish {seq, any-in-grid} as ONE 8-byte system-scope store to
         // host-mapped memory (the host spins on it and returns to its caller while this kernel
@@ -794,7 +760,7 @@ __global__ __launch_bounds__(ENC_T) void k_encode(const ScanParams P, uint32_t t
     // a 4x4 patch line) and one 16-byte store of state.
     const int lane = threadIdx.x & (WAVE - 1);
     const uint32_t wid = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    const uint32_t nw = ((gridDim.x - (P.plan_wgs > 0 ? 1u : 0u)) * blockDim.x) >> 6;
+    const uint32_t nw = (gridDim.x * blockDim.x) >> 6;
     const int p4 = lane >> 2, r = lane & 3;
     const bool vec_state = (xy & 3) == 0;                // 16-byte aligned state rows
     for (uint32_t u0 = t_begin + wid * 2; u0 < t_end; u0 += nw * 2) {
@@ -2359,7 +2325,6 @@ hipError_t gvom_launch_encode(hipStream_t s, const ScanParams &P, uint32_t *hit,
     const unsigned enc_cap = (resident_blocks > 0 ? 4u * resident_blocks : 8192u) * 256u / T;
     if (enc_blocks > enc_cap) enc_blocks = enc_cap;
     if (enc_blocks < 1) enc_blocks = 1;
-    if (P.plan_wgs > 0) ++enc_blocks;                    // + the workgroup that plans the next scan's dispatch order
     if (T == 64u)
         hipLaunchKernelGGL(k_encode<64>, dim3(enc_blocks), dim3(64), 0, s, P, t_begin, t_end, hit, total, mh, state,
                            code16, crows, tags, P.epoch, counters, host_flag, seq);

@@ -37,6 +37,9 @@ rc = lib.gvom_diag_timeline(g._h, buf.ctypes.data_as(ctypes.c_void_p), buf.size,
 assert rc == 0, rc
 gx, gy = grid[0], grid[1]
 w = buf[:gx * gy * 8 * 4].reshape(gy, gx * 8, 4).astype(np.int64)
+modes = buf[gx * gy * 8 * 4:gx * gy * 8 * 4 + 3]
+print("run steps by lookup mode (upper bounds: a run may end early): integer + window test %d, literal f64 %d, integer without window test %d"
+      % (modes[0], modes[1], modes[2]))
 started = w[:, :, 0] > 0
 t0 = w[:, :, 0][started].min()
 us = lambda t: (t - t0) / 100.0
