@@ -138,8 +138,13 @@ def cpu_baseline(params, scans, budget_s=20.0):
     out = {}
     # (beyond ~32 threads the scattered int32 atomics of the DDA, 10 M per scan, mostly onto the voxels near
     # the sensor, cost more than the extra threads bring: 128 threads measured SLOWER than one)
-    for key, all_cores, share in (("one", False, 0.6), ("all", True, 0.4)):
-        threads = oracle.use_all_cores(all_cores, threads=min(cores, 32) if all_cores else None)
+    # one thread, then the OpenMP build at 16 and at 32 threads (tools/cpu_thread_sweep.py, profiles/r3_cpu_thread_sweep.txt:
+    # 8 / 16 / 32 / 64 / 128 threads -> 1.58 / 2.36 / 1.80 / 1.08 / 0.58 M points/s on the 128-core box): the better one is reported
+    sweep = {}
+    for key, threads_req, share in (("one", None, 0.6), ("t16", 16, 0.2), ("t32", 32, 0.2)):
+        if threads_req and threads_req > cores and key != "t16":
+            continue
+        threads = oracle.use_all_cores(threads_req is not None, threads=min(cores, threads_req) if threads_req else None)
         g = oracle.OracleGvom(*params)
         pts = steps = 0
         t0 = time.perf_counter()
@@ -153,11 +158,17 @@ def cpu_baseline(params, scans, budget_s=20.0):
             if el > budget_s * share and steps >= 3:
                 break
         out[key] = (pts / el / 1e6, steps, el, threads)
+        if threads_req:
+            sweep[str(threads)] = pts / el / 1e6
+    out["all"] = max((out[k] for k in ("t16", "t32") if k in out), key=lambda r: r[0])
     oracle.use_all_cores(False)
     v1, s1, e1, _ = out["one"]
     vn, sn, en, tn = out["all"]
     return {"value": v1, "unit": "M points/s", "cores": 1, "kind": "port",
             "value_all_cores": vn, "cores_all": tn, "host_cores_available": cores,
+            "cores_all_note": "%d OpenMP threads = the better of 16 and 32 in this run (%s M points/s); the full sweep "
+                              "8 / 16 / 32 / 64 / 128 threads is profiles/r3_cpu_thread_sweep.txt: beyond 16-32 the scattered atomics "
+                              "near the sensor cost more than the threads bring -- this is NOT all cores" % (tn, json.dumps(sweep)),
             "sample": "%d whole steps (scan+combine) of the same workload in %.1f s on one thread, %d steps in %.1f s "
                       "on %d OpenMP threads; oracle/gvom_oracle.c" % (s1, e1, sn, en, tn),
             "ms_per_step": e1 / s1 * 1e3, "ms_per_step_all_cores": en / sn * 1e3}
@@ -279,6 +290,7 @@ def run_config(hip, name, steps, warmup, poses, full):
 
     b3, k = timed_blocks(step_ros, k, steps, 0.2)
     out["value_ros_f64_tf"] = n_pts * steps / _median(b3) / 1e6
+    out.update(ros_two_threads(g, scans64, n_pts))
 
     # combine_maps_occupancy (combine + the ROS node's post-processing on the GPU, 5 B/cell over PCIe)
     def step_occ(k):
@@ -330,6 +342,67 @@ def run_config(hip, name, steps, warmup, poses, full):
     out.update({"sum_hit": stats["sum_hit"], "sum_total": stats["sum_total"], "cells": stats["cells"]})
     del g
     return out, (alg, stages, params, scans)
+
+
+def ros_two_threads(g, scans64, n_pts, min_s=0.6):
+    """The node's real calling pattern (gvom_ros.py:61-62, 82-115): a lidar thread hands float64 clouds + a 4x4 transform
+    to process_pointcloud while a timer thread calls combine_maps on the same mapper, both as fast as they can.  The
+    upload of scan k + 1 and its trace overlap the maps of combine k (ctypes drops the GIL around the library calls)."""
+    import threading
+    stop = threading.Event()
+    n = {"scans": 0, "maps": 0}
+    err = []
+
+    def lidar():
+        k = 0
+        try:
+            while not stop.is_set():
+                pc, ego, tf = scans64[k % len(scans64)]
+                g.process_pointcloud(pc, ego, tf)
+                k += 1
+                n["scans"] = k
+        except Exception as e:                          # pragma: no cover
+            err.append(e)
+
+    def timer():
+        try:
+            while not stop.is_set():
+                if g.combine_maps() is not None:
+                    n["maps"] += 1
+        except Exception as e:                          # pragma: no cover
+            err.append(e)
+
+    ts = [threading.Thread(target=lidar), threading.Thread(target=timer)]
+    for t in ts:
+        t.start()
+    time.sleep(0.15)                                    # warm-up
+    s0, m0, t0 = n["scans"], n["maps"], time.perf_counter()
+    time.sleep(min_s)
+    s1, m1, t1 = n["scans"], n["maps"], time.perf_counter()
+    stop.set()
+    for t in ts:
+        t.join(30)
+    if err:
+        raise err[0]
+    return {"value_ros_two_threads": (s1 - s0) * n_pts / (t1 - t0) / 1e6, "scans_per_s_ros_two_threads": (s1 - s0) / (t1 - t0),
+            "maps_per_s_ros_two_threads": (m1 - m0) / (t1 - t0)}
+
+
+def step_roofline(alg, res, profiled):
+    """The whole step against the HBM peak, both ways SURVEY 8(d) asks for: the ALGORITHMIC bytes of the reference's data
+    model, (B_scan + B_comb) / (t_scan + t_comb) -- V-sized clears and per-source V-sized reads included, which this
+    implementation does not perform (tile epochs) -- and the bytes the counters measured, per step."""
+    t = res["ms_per_step"] * 1e-3
+    a = sum(alg.values())
+    meas = None
+    if profiled:
+        parts = [pmc_traffic(k) for k in ("k_trace", "k_encode", "k_fuse4", "k_map2d")]
+        if all(parts):
+            meas = sum(p["bytes_per_launch"] for p in parts)
+    return {"algorithmic_bytes": a, "frac_algorithmic": a / t / 1e9 / HBM_PEAK_GBS,
+            "measured_bytes": meas, "frac_measured": (meas / t / 1e9 / HBM_PEAK_GBS) if meas else None,
+            "note": "per step (1 scan + 1 combine) over ms_per_step; algorithmic = N*P + 4*(sum_hit + sum_total) + 4*N_in + 20*V "
+                    "+ 4*V*(S+L) + 8*V + 68*xy^2 (SURVEY 8d); measured = PMC HBM bytes of the four kernels (profiles/)"}
 
 
 def roofline_of(alg, stages, profiled=True):
@@ -398,13 +471,18 @@ def run_single(args):
         "value_async_combine": res["value_async_combine"], "ms_per_step_async_combine": res["ms_per_step_async_combine"],
         "value_async_occupancy_api": res["value_async_occupancy_api"],
         "value_semantics": "value: cloud resident in HBM (driver contract); value_host_f32: host numpy in (gvom.py:110); "
-                           "value_ros_f64_tf: float64 host array + 4x4 transform, the unchanged gvom_ros.py:106-109 path; "
+                           "value_ros_f64_tf: float64 host array + 4x4 transform, the unchanged gvom_ros.py:106-109 path, one thread; "
+                           "value_ros_two_threads: the same inputs from a lidar thread while a timer thread calls combine_maps "
+                           "(the node's two callbacks, gvom_ros.py:61-62, 113-115), both free-running; "
                            "value_async_combine: combine_maps_async() (extension), the next scan traced while the maps "
                            "of the pending combine are stored to host memory -- same maps, one step later",
         "stage_ms": res["stage_ms"], "host_us": res["host_us"],
         "sum_hit": res["sum_hit"], "sum_total": res["sum_total"], "cells": res["cells"],
         "roofline": roofline_of(alg, stages, profiled=(name == "m256")),
     }
+    out["roofline"]["step"] = step_roofline(alg, res, profiled=(name == "m256"))
+    for key in ("value_ros_two_threads", "scans_per_s_ros_two_threads", "maps_per_s_ros_two_threads"):
+        out[key] = res[key]
     if not args.no_extra and name == "m256":
         out["configs"] = {}
         for other, poses in (("c2", 8), ("c3", 8), ("m256b8", 8)):

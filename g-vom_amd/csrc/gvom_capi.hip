@@ -120,6 +120,11 @@ struct gvom_handle {
     // asynchronous combine (gvom_combine_begin / _end): k_map2d runs on a second stream, so the next
     // scan's k_trace / k_encode (instruction-bound) overlap its PCIe-bound stores
     hipStream_t stream_b = nullptr;
+    // host clouds go up on a stream of their own when the main stream is busy (the ROS node's two threads: the cloud
+    // callback hands scan k + 1 over while the timer thread's combine k is still running): the copy engine moves the
+    // cloud while k_fuse / k_map2d run, and k_trace waits for it on the device
+    hipStream_t stream_up = nullptr;
+    hipEvent_t ev_up = nullptr;
     hipEvent_t ev_fused = nullptr, ev_mapped = nullptr, ev_done = nullptr;
     std::mutex combine_mu;                              // one combine call at a time (taken before `mu`)
     bool pending_combine = false;                       // begun, not ended
@@ -305,6 +310,8 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, b
     CK(hipEventCreateWithFlags(&h->ev_mapped, hipEventDisableTiming));
     CK(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
     CK(hipEventCreateWithFlags(&h->ev_fuse_b, hipEventDisableTiming));
+    CK(hipStreamCreateWithFlags(&h->stream_up, hipStreamNonBlocking));
+    CK(hipEventCreateWithFlags(&h->ev_up, hipEventDisableTiming));
     // accumulators are micro-tiled in 4x4 (x,y) patches (gvom_internal.h "ACCUMULATOR LAYOUT")
     // row pitch of the patch rows, padded (GVOM_ACC_PAD lines of 64 B) so that the z levels of one
     // (x, y) patch -- xy*16 bytes apart, a multiple of 4 KiB for xy = 256 -- do not all map to the
@@ -684,8 +691,20 @@ int process_impl(gvom_handle *h, const void *xyz, bool on_device, int64_t n, int
     if (!on_device && n > 0) {
         int rc = ensure(h, h->in_pts, (size_t)n * row_stride_bytes);
         if (rc) return rc;
-        HIPCHK(h, hipMemcpyAsync(h->in_pts.p, xyz, (size_t)(n - 1) * row_stride_bytes + (size_t)last_field + esz,
-                                 hipMemcpyHostToDevice, h->stream));
+        const size_t up_bytes = (size_t)(n - 1) * row_stride_bytes + (size_t)last_field + esz;
+        // in_pts is free: the previous scan's k_trace (its only reader) had completed when that call returned
+        if (hipStreamQuery(h->stream) == hipErrorNotReady) {
+            // the main stream still has work queued (a combine from another thread, the previous k_encode): upload beside it
+            lk.unlock();                                  // a pageable source is staged by the calling thread: not under the handle mutex
+            const hipError_t ue = hipMemcpyAsync(h->in_pts.p, xyz, up_bytes, hipMemcpyHostToDevice, h->stream_up);
+            lk.lock();
+            HIPCHK(h, ue);
+            HIPCHK(h, hipEventRecord(h->ev_up, h->stream_up));
+            HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_up, 0));
+        } else {
+            (void)hipGetLastError();
+            HIPCHK(h, hipMemcpyAsync(h->in_pts.p, xyz, up_bytes, hipMemcpyHostToDevice, h->stream));
+        }
         dev = h->in_pts.p;
     }
     int rc = scan_launch(h, lk, dev, n, row_stride_bytes / (int64_t)esz, dtype, tf, defer);
@@ -959,6 +978,8 @@ VIS void gvom_destroy(gvom_t *h)
     if (h->ev_mapped) hipEventDestroy(h->ev_mapped);
     if (h->ev_done) hipEventDestroy(h->ev_done);
     if (h->ev_fuse_b) hipEventDestroy(h->ev_fuse_b);
+    if (h->ev_up) hipEventDestroy(h->ev_up);
+    if (h->stream_up) { hipStreamSynchronize(h->stream_up); hipStreamDestroy(h->stream_up); }
     if (h->stream_b) hipStreamDestroy(h->stream_b);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     delete h;

@@ -17,8 +17,9 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libgvom_oracle.so")
-_OMP_PATH = os.path.join(_HERE, "libgvom_oracle_omp.so")       # the same source on all host cores (-fopenmp -DORC_OMP)
+# (GVOM_ORACLE_LIBRARY / GVOM_ORACLE_OMP_LIBRARY: the sanitizer builds of `make -C oracle san`, tests/test_sanitizers.py)
+_LIB_PATH = os.environ.get("GVOM_ORACLE_LIBRARY", os.path.join(_HERE, "libgvom_oracle.so"))
+_OMP_PATH = os.environ.get("GVOM_ORACLE_OMP_LIBRARY", os.path.join(_HERE, "libgvom_oracle_omp.so"))   # the same source on all host cores (-fopenmp -DORC_OMP)
 
 _c = ctypes
 _i64, _f64 = _c.c_int64, _c.c_double
@@ -29,6 +30,8 @@ def build(force=False):
     """Compile the oracle with gcc (oracle/Makefile)."""
     src = os.path.join(_HERE, "gvom_oracle.c")
     for path in (_LIB_PATH, _OMP_PATH):
+        if os.path.dirname(os.path.abspath(path)) != _HERE:
+            continue                                   # a sanitizer build handed in through the environment: built by its own recipe
         if force or not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
             subprocess.check_call(["make", "-C", _HERE, "-B", os.path.basename(path)], stdout=subprocess.DEVNULL)
     return _LIB_PATH

@@ -56,11 +56,12 @@ def test_sharded_map_equals_single_handle_over_a_moving_window(world):
         assert run_ranks(world, params, body) == [True] * world
 
 
-@pytest.mark.parametrize("cfg,worlds,scans,buffer", [("c2", "4,8", "3", "1"), ("c4", "4", "2", "1")])
+@pytest.mark.parametrize("cfg,worlds,scans,buffer", [("c2", "4,8", "3", "1"), ("c4", "4", "6", "4")])
 def test_sharded_map_at_full_size(cfg, worlds, scans, buffer):
     """tests/fuzz/shard_big.py: the weak-scaling clouds of the bench on the c2 grid (4 and 8 ranks x
-    131,072 returns) and BASELINE c4 (512 x 512 x 128, 4 ranks x 262,144 returns): slots, fused map and
-    returned maps of every rank equal the unsharded handle's."""
+    131,072 returns) and BASELINE c4 at its own settings (512 x 512 x 128, buffer 4, 4 ranks x 262,144 returns, six
+    scans of a moving window: the ring wraps and evicts): slots, fused map and returned maps of every rank equal the
+    unsharded handle's."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", "shard_big.py"), cfg, worlds, scans, buffer],
                          capture_output=True, text=True, timeout=1200)
     assert out.returncode == 0, (out.stdout + out.stderr)[-2000:]

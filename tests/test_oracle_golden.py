@@ -66,3 +66,28 @@ def test_warning_strings_and_return_types(capsys):
     assert np.count_nonzero(out[1]) == 207 and np.count_nonzero(out[2]) == 0
     assert out[4].sum() == 250
     assert out[3].min() == pytest.approx(-7.333893209065674, abs=1e-9)
+
+
+ROS_SHORT = ("hard", "soft", "certainty", "negative", "roughness")
+
+
+def test_ros_postprocessing_matches_the_reference_node():
+    """SURVEY 8f rank 3, pinned by the reference itself: tests/golden/ros_f3.npz holds what the
+    UNMODIFIED VoxelMapper.cb_timer (reference gvom_ros.py:113-165, imported with stand-ins for the ROS packages:
+    tests/golden/make_ros_golden.py) published for recorded combine_maps() tuples -- the reference's own outputs of
+    F3 / F4 / F5 and one tuple that walks the value ranges -- under the node's default parameters and under a
+    second set (density 12.5, roughness -6 .. 1.5).  oracle.ros_occupancy_grids must reproduce every int8 array."""
+    rec = np.load(os.path.join(G, "ros_f3.npz"))
+    n = 0
+    for p in rec["param_sets"]:
+        thr = (float(rec[p + "_density_threshold"]), float(rec[p + "_min_roughness"]), float(rec[p + "_max_roughness"]))
+        for tag in rec["tags"]:
+            tup = tuple(rec["in_%s_%s" % (tag, f)] for f in ("origin_world", "positive", "negative", "roughness", "visibility"))
+            got = oracle.ros_occupancy_grids(tup, *thr)
+            for short, g in zip(ROS_SHORT, got):
+                w = rec["%s_%s_%s" % (p, tag, short)]
+                assert g.dtype == np.int8 and np.array_equal(g, w), (p, tag, short, int(np.sum(g != w)))
+                n += 1
+            assert np.array_equal(rec["%s_%s_all_certainty" % (p, tag)], got[2])          # gvom_ros.py:152-153: one array, two topics
+            assert np.array_equal(rec["%s_%s_origin_xy" % (p, tag)], tup[0][:2])          # gvom_ros.py:137-138
+    assert n == 2 * 7 * 5
