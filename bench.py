@@ -442,6 +442,32 @@ def roofline_of(alg, stages, profiled=True):
             "measured_hbm_GBs_per_stage": stage_gbs}
 
 
+def run_with_statistics(hip, name, steps, warmup, poses):
+    """The same steps with the reference's per-voxel statistics switched on (gvom.py:1172-1299, 858-909: mean / covariance
+    of every occupied voxel's 27-neighbourhood, merged over the ring -- what process_pointcloud and combine_maps ALSO do
+    in the reference, feeding only make_debug_voxel_map).  Device-resident cloud, synchronous API."""
+    import gvom
+    import synth
+    params, scans = synth.config_inputs(name, n_scans=max(1, poses))
+    g = gvom.Gvom(*params, device=0, voxel_statistics=True)
+    dev = [(hip.to_device(pc), pc.shape[0], pc.dtype, ego, tf) for (pc, ego, tf) in scans]
+
+    def step(k):
+        d, n, dt, ego, tf = dev[k % len(dev)]
+        g.process_pointcloud_device(d.value, n, dt, ego, tf)
+        return g.combine_maps()
+
+    for k in range(warmup):
+        step(k)
+    blocks, k = timed_blocks(step, warmup, steps, 0.3)
+    med = _median(blocks)
+    cloud = g.make_debug_voxel_map()
+    out = {"value": scans[0][0].shape[0] * steps / med / 1e6, "ms_per_step": med / steps * 1e3,
+           "debug_voxel_rows": int(cloud.shape[0]) if cloud is not None else None}
+    del g
+    return out
+
+
 def run_single(args):
     import synth
     affinity = pin_to_gpu_numa(0)
@@ -483,6 +509,12 @@ def run_single(args):
     out["roofline"]["step"] = step_roofline(alg, res, profiled=(name == "m256"))
     for key in ("value_ros_two_threads", "scans_per_s_ros_two_threads", "maps_per_s_ros_two_threads"):
         out[key] = res[key]
+    if not args.no_extra:
+        st = run_with_statistics(hip, name, min(steps, 200), min(args.warmup, 40), poses)
+        out["value_with_statistics"] = st["value"]
+        out["statistics"] = dict(st, extra_ms_per_step=st["ms_per_step"] - res["ms_per_step"],
+                                 note="voxel_statistics=True (GVOM_VOXEL_STATISTICS=1): the per-voxel mean / covariance path "
+                                      "of the reference, off by default here because it is not on the north-star path")
     if not args.no_extra and name == "m256":
         out["configs"] = {}
         for other, poses in (("c2", 8), ("c3", 8), ("m256b8", 8)):

@@ -93,7 +93,7 @@ struct gvom_handle {
     std::vector<int> ring;                              // ring position -> slots index
     int staging = 0;
     int buffer_index = 0, last_buffer_index = 0;
-    Buf in_pts, world_pts;
+    Buf in_pts, world_pts[2];                           // world_pts: the returns as k_trace stored them for k_stats, alternating per scan
     uint32_t *counters = nullptr;                       // device: [0] scan rows, [2..3] fuse rows (u64)
     uint32_t *counters_host = nullptr;                  // pinned, device-mapped: kernels publish counts here
     uint32_t *counters_host_dev = nullptr;              // device view of counters_host
@@ -125,6 +125,20 @@ struct gvom_handle {
     // cloud while k_fuse / k_map2d run, and k_trace waits for it on the device
     hipStream_t stream_up = nullptr;
     hipEvent_t ev_up = nullptr;
+    // per-voxel statistics (opt-in) run on a stream of their own: k_stats / k_stats_gather beside the combine's fusion,
+    // k_fuse_stats beside k_map2d's PCIe-bound stores.  ev_enc_s / ev_fz_s: main (or fusion) stream -> statistics
+    // stream; ev_sdone: everything enqueued on the statistics stream so far (the next k_trace rewrites what it reads);
+    // ev_fsdone: the last k_fuse_stats (the next fusion rewrites the fused buffer it reads as "previous")
+    hipStream_t stream_s = nullptr;
+    hipEvent_t ev_enc_s = nullptr, ev_fz_s = nullptr, ev_sdone = nullptr, ev_fsdone = nullptr;
+    // ev_before[k & 1]: the statistics stream's work enqueued BEFORE scan k's own -- all that can still read what scan
+    // k + 1 rewrites (the slot it stages into left the ring at commit k; its buffer of stored returns was scan k - 1's):
+    // scan k + 1 waits for that, not for scan k's statistics, which run beside it
+    hipEvent_t ev_before[2] = {nullptr, nullptr};
+    bool before_valid[2] = {false, false};
+    uint32_t stats_scan = 0;                             // scans with statistics so far (parity selects the buffers above)
+    bool stats_prev_committed = true;                    // a rejected scan leaves its slot as the staging slot: the next scan rewrites it
+    bool s_pending = false, fs_pending = false;          // recorded and not known to have completed
     hipEvent_t ev_fused = nullptr, ev_mapped = nullptr, ev_done = nullptr;
     std::mutex combine_mu;                              // one combine call at a time (taken before `mu`)
     bool pending_combine = false;                       // begun, not ended
@@ -311,6 +325,9 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, b
     CK(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
     CK(hipEventCreateWithFlags(&h->ev_fuse_b, hipEventDisableTiming));
     CK(hipStreamCreateWithFlags(&h->stream_up, hipStreamNonBlocking));
+    CK(hipStreamCreateWithFlags(&h->stream_s, hipStreamNonBlocking));
+    for (hipEvent_t *e : {&h->ev_enc_s, &h->ev_fz_s, &h->ev_sdone, &h->ev_fsdone, &h->ev_before[0], &h->ev_before[1]})
+        CK(hipEventCreateWithFlags(e, hipEventDisableTiming));
     CK(hipEventCreateWithFlags(&h->ev_up, hipEventDisableTiming));
     // accumulators are micro-tiled in 4x4 (x,y) patches (gvom_internal.h "ACCUMULATOR LAYOUT")
     // row pitch of the patch rows, padded (GVOM_ACC_PAD lines of 64 B) so that the z levels of one
@@ -397,6 +414,9 @@ void scan_abort(gvom_handle *h)
     (void)hipMemsetAsync(h->total, 0, h->acc_elems * 4, h->stream);
     (void)hipMemsetAsync(h->mh, 0, h->acc_elems * 4, h->stream);
     (void)hipMemsetAsync(h->counters, 0, GVOM_CNT_WORDS * 4, h->stream);
+    if (h->stream_s) (void)hipStreamSynchronize(h->stream_s);
+    h->s_pending = h->fs_pending = false;
+    h->before_valid[0] = h->before_valid[1] = false;
     (void)hipStreamSynchronize(h->stream);
     (void)hipGetLastError();
     h->pending = false;
@@ -416,6 +436,12 @@ hipError_t sync_streams(gvom_handle *h)
         if (e != hipSuccess) return e;
         h->mapped_unjoined = false;
         h->fuse_b_unjoined = false;
+    }
+    if (h->s_pending || h->fs_pending) {
+        hipError_t e = hipStreamSynchronize(h->stream_s);
+        if (e != hipSuccess) return e;
+        h->s_pending = h->fs_pending = false;
+        h->before_valid[0] = h->before_valid[1] = false;
     }
     return hipStreamSynchronize(h->stream);
 }
@@ -441,7 +467,9 @@ hipError_t join_map_stream(gvom_handle *h)
 hipError_t join_second_stream(gvom_handle *h)
 {
     hipError_t e = join_map_stream(h);
-    return e != hipSuccess ? e : join_fuse_stream(h);
+    if (e == hipSuccess) e = join_fuse_stream(h);
+    if (e == hipSuccess && h->s_pending) e = hipStreamWaitEvent(h->stream, h->ev_sdone, 0);   // the statistics stream's work
+    return e;
 }
 
 // Scan kernels up to (not including) the commit.  `dev_pts` is device memory.
@@ -509,8 +537,9 @@ int scan_launch(gvom_handle *h, std::unique_lock<std::mutex> &lk, const void *de
     // compact rows are indexed by return (the row of an occupied voxel = the index of one of its returns)
     const size_t cap = std::max<size_t>(1, (size_t)n);
     if ((rc = ensure(h, st.crows, cap * 16))) return rc;
-    if (h->stats && ((rc = ensure(h, h->world_pts, (size_t)n * 3 * esz)) || (rc = ensure(h, st.metrics, cap * 80)) ||
-                     (rc = ensure(h, st.base, cap * 80)) || (rc = ensure(h, st.rowvox, cap * 4)))) return rc;
+    Buf &wpts = h->world_pts[h->stats_scan & 1u];
+    if (h->stats && ((rc = ensure(h, wpts, (size_t)n * 3 * esz)) || (rc = ensure(h, st.metrics, cap * 80)) ||
+                     (rc = ensure(h, st.base, cap * 8 * GVOM_BASE_PITCH)) || (rc = ensure(h, st.rowvox, cap * 4)))) return rc;
     double t0 = now_ns();
     const uint32_t seq = ++h->scan_seq;
     if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
@@ -519,7 +548,14 @@ int scan_launch(gvom_handle *h, std::unique_lock<std::mutex> &lk, const void *de
     bool big = false;
     for (int k = 0; k < 3; ++k)
         if (origin[k] >= (1ll << 30) || origin[k] <= -(1ll << 30)) big = true;
-    if (h->stats) HIPCHK(h, hipMemsetAsync(st.rowvox.p, 0xFF, cap * 4, h->stream));   // no row claimed yet
+    if (h->stats) {
+        // what the statistics stream may still be reading of the things this scan rewrites (see ev_before): the
+        // previous scan's own statistics are NOT among them and keep running beside this scan's trace
+        const uint32_t prev_par = (h->stats_scan + 1u) & 1u;
+        if (!h->stats_prev_committed && h->s_pending) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_sdone, 0));
+        else if (h->before_valid[prev_par]) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_before[prev_par], 0));
+        HIPCHK(h, hipMemsetAsync(st.rowvox.p, 0xFF, cap * 4, h->stream));   // no row claimed yet
+    }
     ShardExchange X;
     X.ep_send = nullptr; X.ep_cnt = nullptr; X.ep_cap = 0;
     if (h->sharded) {
@@ -539,7 +575,7 @@ int scan_launch(gvom_handle *h, std::unique_lock<std::mutex> &lk, const void *de
     }
 #endif
     hipError_t le = gvom_launch_trace(h->stream, P, X, dtype, big, dev_pts, stride_elems, n,
-                                      h->stats ? h->world_pts.p : nullptr, h->hit, h->total, h->mh, st.state,
+                                      h->stats ? wpts.p : nullptr, h->hit, h->total, h->mh, st.state,
                                       st.tags, h->counters, h->stats ? (double *)st.metrics.p : nullptr,
                                       h->stats ? (double *)st.base.p : nullptr,
                                       h->stats ? (uint32_t *)st.rowvox.p : nullptr);
@@ -576,10 +612,18 @@ int scan_launch(gvom_handle *h, std::unique_lock<std::mutex> &lk, const void *de
                             (unsigned long long *)h->counters_host_dev, seq, h->resident_blocks);
     if (le != hipSuccess) { scan_abort(h); HIPCHK(h, le); }
     if (h->profiling) { HIPCHK(h, hipEventRecord(h->ev[2], h->stream)); h->ev_scan = true; }
-    if (h->stats) {                                      // optional per-voxel statistics
-        HIPCHK(h, gvom_launch_stats(h->stream, P, dtype, h->world_pts.p, n, st.state, st.tags,
+    if (h->stats) {                                      // optional per-voxel statistics, beside whatever follows
+        const uint32_t par = h->stats_scan & 1u;
+        HIPCHK(h, hipEventRecord(h->ev_before[par], h->stream_s));   // the statistics stream's work up to here
+        h->before_valid[par] = true;
+        ++h->stats_scan;
+        HIPCHK(h, hipEventRecord(h->ev_enc_s, h->stream));
+        HIPCHK(h, hipStreamWaitEvent(h->stream_s, h->ev_enc_s, 0));
+        HIPCHK(h, gvom_launch_stats(h->stream_s, P, dtype, wpts.p, n, st.state, st.tags,
                                     p.xy_eigen_dist, p.z_eigen_dist, (double *)st.base.p, (double *)st.metrics.p,
                                     (const uint32_t *)st.rowvox.p));
+        HIPCHK(h, hipEventRecord(h->ev_sdone, h->stream_s));
+        h->s_pending = true;
     }
     HT(h, 0, t0);                                        // scan: launches
     // Wait only for k_trace: k_encode's first thread publishes {seq, any-in-grid} to host-mapped
@@ -617,6 +661,7 @@ void scan_commit(gvom_handle *h, bool accept)
     h->scan_inflight = false;
     if (!h->pending) return;
     h->pending = false;
+    h->stats_prev_committed = accept;
     if (!accept) return;                                   // gvom.py:148-150: ring untouched
     const int b = h->buffer_index;                         // gvom.py:163-175
     const int old = h->ring[b];
@@ -794,6 +839,9 @@ int fuse_impl(gvom_handle *h, hipStream_t on = nullptr)
     P.radius2 = p.robot_radius * p.robot_radius;
     P.ground_to_lidar_height = p.ground_to_lidar_height;
     const int nsrc = ns + (prev ? 1 : 0);
+    // the previous k_fuse_stats reads (as its "previous map") the fused buffer this fusion writes, and the descriptor
+    // table this call refills
+    if (h->stats && h->fs_pending) HIPCHK(h, hipStreamWaitEvent(fs, h->ev_fsdone, 0));
     FuseDescs KD;
     const MapDesc *descs_mem = nullptr;
     if (nsrc <= GVOM_KARG_DESCS) {
@@ -808,8 +856,14 @@ int fuse_impl(gvom_handle *h, hipStream_t on = nullptr)
                                F.tags, h->blockcounts,
                                h->height, h->inferred));
     if (h->profiling) { HIPCHK(h, hipEventRecord(h->ev[5], fs)); h->ev_fuse = true; }
-    if (h->stats)
-        HIPCHK(h, gvom_launch_fuse_stats(fs, P, KD, descs_mem, F.state, F.tags, (float *)F.metrics.p));
+    if (h->stats) {                                      // beside k_map2d, behind this fusion and the scans' statistics
+        HIPCHK(h, hipEventRecord(h->ev_fz_s, fs));
+        HIPCHK(h, hipStreamWaitEvent(h->stream_s, h->ev_fz_s, 0));
+        HIPCHK(h, gvom_launch_fuse_stats(h->stream_s, P, KD, descs_mem, F.state, F.tags, (float *)F.metrics.p));
+        HIPCHK(h, hipEventRecord(h->ev_fsdone, h->stream_s));
+        HIPCHK(h, hipEventRecord(h->ev_sdone, h->stream_s));
+        h->s_pending = h->fs_pending = true;
+    }
     F.valid = true;
     h->cur = nxt;
     h->has_combined = true;
@@ -966,7 +1020,7 @@ VIS void gvom_destroy(gvom_t *h)
     if (h->x_host) hipHostFree(h->x_host);
     for (auto &s : h->slots) { hipFree(s.state); hipFree(s.code16); hipFree(s.tags); fb(s.crows); fb(s.metrics); fb(s.base); fb(s.rowvox); }
     for (auto &f : h->fused) { hipFree(f.state); hipFree(f.tags); fb(f.rows); fb(f.metrics); }
-    fb(h->in_pts); fb(h->world_pts); fb(h->tl);
+    fb(h->in_pts); fb(h->world_pts[0]); fb(h->world_pts[1]); fb(h->tl);
     hipFree(h->counters); if (h->counters_host) hipHostFree(h->counters_host);
     hipFree(h->descs_dev); if (h->descs_host) hipHostFree(h->descs_host);
     hipFree(h->blockcounts);
@@ -980,6 +1034,8 @@ VIS void gvom_destroy(gvom_t *h)
     if (h->ev_fuse_b) hipEventDestroy(h->ev_fuse_b);
     if (h->ev_up) hipEventDestroy(h->ev_up);
     if (h->stream_up) { hipStreamSynchronize(h->stream_up); hipStreamDestroy(h->stream_up); }
+    if (h->stream_s) { hipStreamSynchronize(h->stream_s); hipStreamDestroy(h->stream_s); }
+    for (hipEvent_t e : {h->ev_enc_s, h->ev_fz_s, h->ev_sdone, h->ev_fsdone, h->ev_before[0], h->ev_before[1]}) if (e) hipEventDestroy(e);
     if (h->stream_b) hipStreamDestroy(h->stream_b);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     delete h;

@@ -86,6 +86,7 @@ struct ShardExchange {
 };
 
 #define GVOM_PACK_CHUNK 64     // quads per k_pack workgroup
+#define GVOM_BASE_PITCH 16     // doubles per row of a scan's own-voxel moments (10 used): one 128-byte block per row
 // rank exchange, owner side: received quads of all source ranks are unpacked by one launch
 struct ShardUnpack { uint32_t q_off[GVOM_MAX_SLOTS + 1]; };    // q_off[s] = first quad (wave) of source s, q_off[world] = total
 

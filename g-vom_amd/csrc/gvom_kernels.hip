@@ -272,7 +272,7 @@ __device__ __forceinline__ void endpoint_commit(const ScanParams &P, int lane, l
         // voxel: the last store wins, every candidate is a valid, unique row.
         state[L] = (int32_t)row;
         if (stat_sums) {                            // optional statistics: zeroed metrics (gvom.py:1011-1012)
-            for (int m = 0; m < 10; ++m) { stat_sums[(size_t)row * 10 + m] = 0.0; stat_base[(size_t)row * 10 + m] = 0.0; }
+            for (int m = 0; m < 10; ++m) { stat_sums[(size_t)row * 10 + m] = 0.0; stat_base[(size_t)row * GVOM_BASE_PITCH + m] = 0.0; }
             stat_rowvox[row] = L;                   // row -> voxel, for the per-row neighbour gather
         }
     }
@@ -1834,122 +1834,163 @@ __global__ __launch_bounds__(256) void k_stats(const ScanParams P, const T *__re
                                                const uint32_t *__restrict__ tags, int xy_e, int z_e,
                                                double *base, double *sums, int direct_only)
 {
+    // own-voxel moments of a wave's 64 returns, staged for the transposed adds below
+    __shared__ double s_m[4][64][10];
+    __shared__ int32_t s_row[4][64];
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const T x = world[3 * i + 0], y = world[3 * i + 1], z = world[3 * i + 2];
-    const T d2 = (x * x + y * y) + z * z;
-    if ((double)d2 < P.min_d2) return;
-    const double ax = (double)x / P.xy_res - P.origin[0];
-    const double ay = (double)y / P.xy_res - P.origin[1];
-    const double az = (double)z / P.z_res - P.origin[2];
-    const double bx = floor(ax), by = floor(ay), bz = floor(az);
-    if (!(fabs(bx) < 1e9) || !(fabs(by) < 1e9) || !(fabs(bz) < 1e9)) return;
-    const int xb = (int)bx, yb = (int)by, zb = (int)bz;
-    const bool base_in = xb >= 0 && xb < P.xy && yb >= 0 && yb < P.xy && zb >= 0 && zb < P.zs;
-    if (base_in && !direct_only) {
-        const int sx = wrap_add(xb, P.om[0], P.xy), sy = wrap_add(yb, P.om[1], P.xy), sz = wrap_add(zb, P.om[2], P.zs);
-        const int32_t row = state[((uint32_t)sy * P.zs + sz) * P.xy + sx];      // >= 0: this voxel has a hit
-        if (row < 0) return;
-        const double lx = ax - bx, ly = ay - by, lz = az - bz;
-        double *m = base + (size_t)row * 10;
-        unsafeAtomicAdd(m + 0, lx); unsafeAtomicAdd(m + 1, ly); unsafeAtomicAdd(m + 2, lz);
-        unsafeAtomicAdd(m + 3, lx * lx); unsafeAtomicAdd(m + 4, lx * ly); unsafeAtomicAdd(m + 5, lx * lz);
-        unsafeAtomicAdd(m + 6, ly * ly); unsafeAtomicAdd(m + 7, ly * lz); unsafeAtomicAdd(m + 8, lz * lz);
-        unsafeAtomicAdd(m + 9, 1.0);
-        return;
+    int32_t own = -1;
+    double mom[10];
+    if (i < n) {
+        const T x = world[3 * i + 0], y = world[3 * i + 1], z = world[3 * i + 2];
+        const T d2 = (x * x + y * y) + z * z;
+        const double ax = (double)x / P.xy_res - P.origin[0];
+        const double ay = (double)y / P.xy_res - P.origin[1];
+        const double az = (double)z / P.z_res - P.origin[2];
+        const double bx = floor(ax), by = floor(ay), bz = floor(az);
+        if (!((double)d2 < P.min_d2) && fabs(bx) < 1e9 && fabs(by) < 1e9 && fabs(bz) < 1e9) {
+            const int xb = (int)bx, yb = (int)by, zb = (int)bz;
+            const bool base_in = xb >= 0 && xb < P.xy && yb >= 0 && yb < P.xy && zb >= 0 && zb < P.zs;
+            if (base_in && !direct_only) {
+                const int sx = wrap_add(xb, P.om[0], P.xy), sy = wrap_add(yb, P.om[1], P.xy), sz = wrap_add(zb, P.om[2], P.zs);
+                own = state[((uint32_t)sy * P.zs + sz) * P.xy + sx];      // >= 0: this voxel has a hit
+                const double lx = ax - bx, ly = ay - by, lz = az - bz;
+                mom[0] = lx; mom[1] = ly; mom[2] = lz;
+                mom[3] = lx * lx; mom[4] = lx * ly; mom[5] = lx * lz; mom[6] = ly * ly; mom[7] = ly * lz; mom[8] = lz * lz;
+                mom[9] = 1.0;
+            } else {
+                for (int xi = xb - xy_e; xi <= xb + xy_e; ++xi) {
+                    if (xi < 0 || xi >= P.xy) continue;
+                    for (int yi = yb - xy_e; yi <= yb + xy_e; ++yi) {
+                        if (yi < 0 || yi >= P.xy) continue;
+                        const int sy = wrap_add(yi, P.om[1], P.xy);
+                        if (sy < P.sy_lo || sy >= P.sy_hi) continue;
+                        const int sx = wrap_add(xi, P.om[0], P.xy);
+                        for (int zi = zb - z_e; zi <= zb + z_e; ++zi) {
+                            if (zi < 0 || zi >= P.zs) continue;
+                            const int sz = wrap_add(zi, P.om[2], P.zs);
+                            const uint32_t rz = (uint32_t)sy * P.zs + sz;
+                            if (tags[rz * P.nseg + (sx >> 6)] != P.epoch) continue;      // untouched tile
+                            const int32_t row = state[rz * P.xy + sx];
+                            if (row < 0) continue;
+                            const double lx = ax - (double)xi, ly = ay - (double)yi, lz = az - (double)zi;
+                            double *m = sums + (size_t)row * 10;
+                            unsafeAtomicAdd(m + 0, lx); unsafeAtomicAdd(m + 1, ly); unsafeAtomicAdd(m + 2, lz);
+                            unsafeAtomicAdd(m + 3, lx * lx); unsafeAtomicAdd(m + 4, lx * ly); unsafeAtomicAdd(m + 5, lx * lz);
+                            unsafeAtomicAdd(m + 6, ly * ly); unsafeAtomicAdd(m + 7, ly * lz); unsafeAtomicAdd(m + 8, lz * lz);
+                            unsafeAtomicAdd(m + 9, 1.0);
+                        }
+                    }
+                }
+            }
+        }
     }
-    for (int xi = xb - xy_e; xi <= xb + xy_e; ++xi) {
-        if (xi < 0 || xi >= P.xy) continue;
-        for (int yi = yb - xy_e; yi <= yb + xy_e; ++yi) {
-            if (yi < 0 || yi >= P.xy) continue;
-            const int sy = wrap_add(yi, P.om[1], P.xy);
-            if (sy < P.sy_lo || sy >= P.sy_hi) continue;
-            const int sx = wrap_add(xi, P.om[0], P.xy);
-            for (int zi = zb - z_e; zi <= zb + z_e; ++zi) {
-                if (zi < 0 || zi >= P.zs) continue;
-                const int sz = wrap_add(zi, P.om[2], P.zs);
-                const uint32_t rz = (uint32_t)sy * P.zs + sz;
-                if (tags[rz * P.nseg + (sx >> 6)] != P.epoch) continue;      // untouched tile
-                const int32_t row = state[rz * P.xy + sx];
-                if (row < 0) continue;
-                const double lx = ax - (double)xi, ly = ay - (double)yi, lz = az - (double)zi;
-                double *m = sums + (size_t)row * 10;
-                unsafeAtomicAdd(m + 0, lx); unsafeAtomicAdd(m + 1, ly); unsafeAtomicAdd(m + 2, lz);
-                unsafeAtomicAdd(m + 3, lx * lx); unsafeAtomicAdd(m + 4, lx * ly); unsafeAtomicAdd(m + 5, lx * lz);
-                unsafeAtomicAdd(m + 6, ly * ly); unsafeAtomicAdd(m + 7, ly * lz); unsafeAtomicAdd(m + 8, lz * lz);
-                unsafeAtomicAdd(m + 9, 1.0);
+    // The adds are memory-side atomics and run at the REQUEST rate (one per 64-B line an instruction touches): ten
+    // instructions with 64 lanes in 64 different rows are 640-1280 requests per wave.  Transposed -- lane = (return, moment),
+    // six returns per instruction, a row's ten moments in ONE 128-byte block -- they are two requests per return.
+    s_row[wv][lane] = own;
+    if (own >= 0) {
+#pragma unroll
+        for (int k = 0; k < 10; ++k) s_m[wv][lane][k] = mom[k];
+    }
+    __syncthreads();
+    if (lane < 60) {
+        const int c = lane % 10, q = lane / 10;
+#pragma unroll 1
+        for (int it = 0; it < 11; ++it) {
+            const int pnt = it * 6 + q;
+            if (pnt < 64) {
+                const int32_t r = s_row[wv][pnt];
+                if (r >= 0) unsafeAtomicAdd(base + (size_t)r * GVOM_BASE_PITCH + c, s_m[wv][pnt][c]);
             }
         }
     }
 }
 
-// k_stats_gather: ONE WAVE per occupied voxel (= compact row; rowvox[row] is its voxel): the lanes
-// fetch the neighbourhood's voxels in parallel (lane <-> neighbour offset), shift their own-voxel
-// moments by the offset (see k_stats) and a butterfly reduction sums them; lane 0 adds the directly
-// accumulated part and turns the raw moments into the reference's per-scan metrics layout: mean
-// xyz, population covariance xx xy xz yy yz zz (gvom.py:1224-1230, 1289-1299), count.
+// k_stats_gather: half a wave per occupied voxel (= compact row; rowvox[row] is its voxel): a wave looks at GATHER_CPW
+// candidate rows at once (a row is the index of one of the voxel's returns: most candidates are not in use), then takes
+// the used ones two at a time (few candidates per wave: every used row is a chain of dependent round trips, and the
+// kernel's time is the longest chain -- 64 candidates per wave took 91 us, a wave per candidate 40); the lanes of a half fetch the neighbourhood's voxels in parallel (lane <-> neighbour offset), shift
+// their own-voxel moments by the offset (see k_stats) and a butterfly reduction sums them; the half's first lane adds the
+// directly accumulated part and turns the raw moments into the reference's per-scan metrics layout: mean xyz, population
+// covariance xx xy xz yy yz zz (gvom.py:1224-1230, 1289-1299), count.
+#define GATHER_CPW 16
 __global__ __launch_bounds__(256) void k_stats_gather(const ScanParams P, const int32_t *__restrict__ state,
                                                       const uint32_t *__restrict__ tags, int xy_e, int z_e,
                                                       const double *__restrict__ base, double *sums,
                                                       const uint32_t *__restrict__ rowvox,
                                                       uint32_t nrows, int direct_only)
 {
-    const int lane = threadIdx.x & (WAVE - 1);
+    const int lane = threadIdx.x & (WAVE - 1), hl = lane & 31, half = lane >> 5;
     const uint32_t wid = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const uint32_t nw = (gridDim.x * blockDim.x) >> 6;
     const int wx = 2 * xy_e + 1, wz = 2 * z_e + 1, nb = wx * wx * wz;
     // a compact row is the index of one of the voxel's returns (k_trace): row `row` is in use iff the
     // return claimed a voxel (rowvox != ~0, reset per scan) and that voxel's state still names it
-    for (uint32_t row = wid; row < nrows; row += nw) {
-        const uint32_t Lr = rowvox[row];
-        if (Lr == 0xFFFFFFFFu || state[Lr] != (int32_t)row) continue;      // wave-uniform
-        double m[10];
+    for (uint32_t row0 = wid * GATHER_CPW; row0 < nrows; row0 += nw * GATHER_CPW) {
+        const uint32_t cand = row0 + (uint32_t)lane;
+        const uint32_t Lc = (lane < GATHER_CPW && cand < nrows) ? rowvox[cand] : 0xFFFFFFFFu;
+        const bool used = Lc != 0xFFFFFFFFu && state[Lc] == (int32_t)cand;
+        unsigned long long todo = lanes(used);
+        while (todo != 0ull) {                                         // wave-uniform: two used rows per turn
+            const int ka = __ffsll((long long)todo) - 1;
+            todo &= todo - 1ull;
+            int kb = -1;
+            if (todo != 0ull) { kb = __ffsll((long long)todo) - 1; todo &= todo - 1ull; }
+            const int k = half ? kb : ka;
+            const bool have = k >= 0;
+            const uint32_t row = row0 + (uint32_t)(have ? k : ka);
+            const uint32_t Lr = (uint32_t)__shfl((int)Lc, have ? k : ka);
+            double m[10];
 #pragma unroll
-        for (int k = 0; k < 10; ++k) m[k] = 0.0;
-        if (!direct_only) {
-            const uint32_t L = Lr;
-            const int sx = (int)(L % P.xy), sz = (int)((L / P.xy) % P.zs), sy = (int)(L / ((uint32_t)P.xy * P.zs));
-            const int x = wrap_sub(sx, P.om[0], P.xy), y = wrap_sub(sy, P.om[1], P.xy), z = wrap_sub(sz, P.om[2], P.zs);
-            for (int j = lane; j < nb; j += WAVE) {
-                const int dx = j / (wx * wz) - xy_e, dy = (j / wz) % wx - xy_e, dz = j % wz - z_e;
-                const int xn = x + dx, yn = y + dy, zn = z + dz;
-                if (xn < 0 || xn >= P.xy || yn < 0 || yn >= P.xy || zn < 0 || zn >= P.zs) continue;
-                const int sxn = wrap_add(xn, P.om[0], P.xy), syn = wrap_add(yn, P.om[1], P.xy), szn = wrap_add(zn, P.om[2], P.zs);
-                const uint32_t rzn = (uint32_t)syn * P.zs + szn;
-                if (tags[rzn * P.nseg + (sxn >> 6)] != P.epoch) continue;
-                const int32_t rn = state[rzn * P.xy + sxn];
-                if (rn < 0) continue;
-                const double *b = base + (size_t)rn * 10;
-                const double nn = b[9];
-                if (!(nn > 0.0)) continue;
-                // a point of voxel (x+dx, ...) with in-voxel position l sits at l + d relative to THIS voxel
-                const double ddx = (double)dx, ddy = (double)dy, ddz = (double)dz;
-                const double s0 = b[0], s1 = b[1], s2 = b[2];
-                m[0] += s0 + nn * ddx; m[1] += s1 + nn * ddy; m[2] += s2 + nn * ddz;
-                m[3] += b[3] + 2.0 * ddx * s0 + nn * ddx * ddx;
-                m[4] += b[4] + ddx * s1 + ddy * s0 + nn * ddx * ddy;
-                m[5] += b[5] + ddx * s2 + ddz * s0 + nn * ddx * ddz;
-                m[6] += b[6] + 2.0 * ddy * s1 + nn * ddy * ddy;
-                m[7] += b[7] + ddy * s2 + ddz * s1 + nn * ddy * ddz;
-                m[8] += b[8] + 2.0 * ddz * s2 + nn * ddz * ddz;
-                m[9] += nn;
+            for (int q = 0; q < 10; ++q) m[q] = 0.0;
+            if (!direct_only && have) {
+                const uint32_t L = Lr;
+                const int sx = (int)(L % P.xy), sz = (int)((L / P.xy) % P.zs), sy = (int)(L / ((uint32_t)P.xy * P.zs));
+                const int x = wrap_sub(sx, P.om[0], P.xy), y = wrap_sub(sy, P.om[1], P.xy), z = wrap_sub(sz, P.om[2], P.zs);
+                for (int j = hl; j < nb; j += 32) {
+                    const int dx = j / (wx * wz) - xy_e, dy = (j / wz) % wx - xy_e, dz = j % wz - z_e;
+                    const int xn = x + dx, yn = y + dy, zn = z + dz;
+                    if (xn < 0 || xn >= P.xy || yn < 0 || yn >= P.xy || zn < 0 || zn >= P.zs) continue;
+                    const int sxn = wrap_add(xn, P.om[0], P.xy), syn = wrap_add(yn, P.om[1], P.xy), szn = wrap_add(zn, P.om[2], P.zs);
+                    const uint32_t rzn = (uint32_t)syn * P.zs + szn;
+                    const uint32_t tgn = tags[rzn * P.nseg + (sxn >> 6)];
+                    const int32_t rn = state[rzn * P.xy + sxn];          // (issued beside the tag: stale where the tile is dead, and then unused)
+                    if (tgn != P.epoch || rn < 0) continue;
+                    const double *b = base + (size_t)rn * GVOM_BASE_PITCH;
+                    const double nn = b[9];
+                    if (!(nn > 0.0)) continue;
+                    // a point of voxel (x+dx, ...) with in-voxel position l sits at l + d relative to THIS voxel
+                    const double ddx = (double)dx, ddy = (double)dy, ddz = (double)dz;
+                    const double s0 = b[0], s1 = b[1], s2 = b[2];
+                    m[0] += s0 + nn * ddx; m[1] += s1 + nn * ddy; m[2] += s2 + nn * ddz;
+                    m[3] += b[3] + 2.0 * ddx * s0 + nn * ddx * ddx;
+                    m[4] += b[4] + ddx * s1 + ddy * s0 + nn * ddx * ddy;
+                    m[5] += b[5] + ddx * s2 + ddz * s0 + nn * ddx * ddz;
+                    m[6] += b[6] + 2.0 * ddy * s1 + nn * ddy * ddy;
+                    m[7] += b[7] + ddy * s2 + ddz * s1 + nn * ddy * ddz;
+                    m[8] += b[8] + 2.0 * ddz * s2 + nn * ddz * ddz;
+                    m[9] += nn;
+                }
             }
+            if (!direct_only) {
 #pragma unroll
-            for (int k = 0; k < 10; ++k)
+                for (int q = 0; q < 10; ++q)
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) m[k] += __shfl_xor(m[k], o);
+                    for (int o = 16; o > 0; o >>= 1) m[q] += __shfl_xor(m[q], o);      // within the half (xor < 32)
+            }
+            if (hl != 0 || !have) continue;
+            double *o = sums + (size_t)row * 10;
+#pragma unroll
+            for (int q = 0; q < 10; ++q) m[q] += o[q];                       // directly accumulated part
+            const double nn = m[9];
+            if (!(nn > 0.0)) { for (int q = 0; q < 9; ++q) o[q] = 0.0; o[9] = nn; continue; }
+            const double mx = m[0] / nn, my = m[1] / nn, mz = m[2] / nn;
+            o[0] = mx; o[1] = my; o[2] = mz;
+            o[3] = m[3] / nn - mx * mx; o[4] = m[4] / nn - mx * my; o[5] = m[5] / nn - mx * mz;
+            o[6] = m[6] / nn - my * my; o[7] = m[7] / nn - my * mz; o[8] = m[8] / nn - mz * mz;
+            o[9] = nn;
         }
-        if (lane != 0) continue;
-        double *o = sums + (size_t)row * 10;
-#pragma unroll
-        for (int k = 0; k < 10; ++k) m[k] += o[k];                       // directly accumulated part
-        const double nn = m[9];
-        if (!(nn > 0.0)) { for (int k = 0; k < 9; ++k) o[k] = 0.0; o[9] = nn; continue; }
-        const double mx = m[0] / nn, my = m[1] / nn, mz = m[2] / nn;
-        o[0] = mx; o[1] = my; o[2] = mz;
-        o[3] = m[3] / nn - mx * mx; o[4] = m[4] / nn - mx * my; o[5] = m[5] / nn - mx * mz;
-        o[6] = m[6] / nn - my * my; o[7] = m[7] / nn - my * mz; o[8] = m[8] / nn - mz * mz;
-        o[9] = nn;
     }
 }
 
@@ -1985,41 +2026,66 @@ __device__ __forceinline__ void merge_metrics(float (&c)[10], const TO *o)
 
 // k_fuse_stats: the covariance half of gvom.py:821-912 for every occupied voxel of the fused map
 // written by k_fuse: sources in the reference's order (ring slots, then the previous fused map).
+// Occupied voxels are a few per 64-voxel tile (a surface), and the merge is ~300 instructions per source: with a wave
+// per tile 95 % of the lanes idled through it.  A (one-wave) workgroup therefore takes FS_TPW tiles at a time -- their
+// tags in one round trip, their states in a second -- lists their occupied voxels in LDS and merges them with one lane
+// per occupied voxel.  (A 16-wave workgroup with two barriers per 16 tiles took 148 us against 55: the merges of a
+// group waited for its slowest tile, and two such workgroups fill a CU.)
+#define FS_TPW 16
 template <bool MEM>
-__global__ __launch_bounds__(256) void k_fuse_stats(const FuseParams P, const FuseDescs KD,
-                                                    const MapDesc *__restrict__ descs_mem,
-                                                    const int32_t *__restrict__ fstate,
-                                                    const uint32_t *__restrict__ ftags, float *fmetrics)
+__global__ __launch_bounds__(64) void k_fuse_stats(const FuseParams P, const FuseDescs KD,
+                                                   const MapDesc *__restrict__ descs_mem,
+                                                   const int32_t *__restrict__ fstate,
+                                                   const uint32_t *__restrict__ ftags, float *fmetrics)
 {
+    __shared__ uint32_t s_list[64 * FS_TPW];
     const cptr_desc descs = MEM ? (cptr_desc)descs_mem : (cptr_desc)KD.d;
-    const int lane = threadIdx.x & (WAVE - 1);
-    const uint32_t wid = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    const uint32_t nw = (gridDim.x * blockDim.x) >> 6;
+    const int lane = threadIdx.x;
     const uint32_t t0 = (uint32_t)P.sy_lo * P.zs * P.nseg, t1 = (uint32_t)P.sy_hi * P.zs * P.nseg;
     const int nsrc = P.nslots + P.has_prev;
-    for (uint32_t tile = t0 + wid; tile < t1; tile += nw) {
-        if (ftags[tile] != P.epoch) continue;                            // wave-uniform
-        const uint32_t rz = tile / P.nseg;
-        const int sx = (int)(tile % P.nseg) * 64 + lane, sy = (int)(rz / P.zs), sz = (int)(rz % P.zs);
-        if (sx >= P.xy) continue;
-        const uint32_t L = rz * P.xy + sx;
-        const int32_t row = fstate[L];
-        if (row < 0) continue;
-        const int x = wrap_sub(sx, P.om[0], P.xy), y = wrap_sub(sy, P.om[1], P.xy), z = wrap_sub(sz, P.om[2], P.zs);
-        float c[10];
+    for (uint32_t g0 = t0 + blockIdx.x * FS_TPW; g0 < t1; g0 += gridDim.x * FS_TPW) {
+        const uint32_t tg = (lane < FS_TPW && g0 + (uint32_t)lane < t1) ? ftags[g0 + (uint32_t)lane] : ~P.epoch;
+        const uint32_t live = (uint32_t)lanes(tg == P.epoch);          // bit t: tile g0 + t is live
+        if (live == 0u) continue;                                        // wave-uniform
+        int32_t st[FS_TPW];
 #pragma unroll
-        for (int k = 0; k < 10; ++k) c[k] = 0.0f;                        // gvom.py:234-236
-        for (int s = 0; s < nsrc; ++s) {
-            const int xs = x + descs[s].d[0], ys = y + descs[s].d[1], zs_ = z + descs[s].d[2];
-            if (xs < 0 || xs >= P.xy || ys < 0 || ys >= P.xy || zs_ < 0 || zs_ >= P.zs) continue;
-            if (descs[s].tags[tile] != descs[s].epoch) continue;
-            const int st = descs[s].state[L];
-            if (st < 0 || !descs[s].metrics) continue;
-            if (s < P.nslots) merge_metrics<double>(c, (const double *)descs[s].metrics + (size_t)st * 10);
-            else merge_metrics<float>(c, (const float *)descs[s].metrics + (size_t)st * 10);
+        for (int t = 0; t < FS_TPW; ++t) {                               // every live tile's states: independent loads, one round trip
+            const uint32_t tile = g0 + (uint32_t)t;
+            const int sx = (int)(tile % P.nseg) * 64 + lane;
+            st[t] = ((live >> t) & 1u) && sx < P.xy ? fstate[(tile / P.nseg) * P.xy + (uint32_t)sx] : -1;
         }
+        uint32_t count = 0;
 #pragma unroll
-        for (int k = 0; k < 10; ++k) fmetrics[(size_t)row * 10 + k] = c[k];
+        for (int t = 0; t < FS_TPW; ++t) {
+            const unsigned long long m = lanes(st[t] >= 0);
+            const uint32_t tile = g0 + (uint32_t)t;
+            if (st[t] >= 0) s_list[count + (uint32_t)__popcll(m & lanemask_lt())] = (tile / P.nseg) * P.xy + (tile % P.nseg) * 64u + (uint32_t)lane;
+            count += (uint32_t)__popcll(m);
+        }
+        __syncthreads();
+        for (uint32_t e = (uint32_t)lane; e < count; e += 64u) {
+            const uint32_t L = s_list[e];
+            const int32_t row = fstate[L];
+            const uint32_t rz = L / (uint32_t)P.xy;
+            const int sx = (int)(L - rz * (uint32_t)P.xy), sy = (int)(rz / P.zs), sz = (int)(rz % P.zs);
+            const uint32_t tl = rz * P.nseg + ((uint32_t)sx >> 6);
+            const int x = wrap_sub(sx, P.om[0], P.xy), y = wrap_sub(sy, P.om[1], P.xy), z = wrap_sub(sz, P.om[2], P.zs);
+            float c[10];
+#pragma unroll
+            for (int k = 0; k < 10; ++k) c[k] = 0.0f;                        // gvom.py:234-236
+            for (int s = 0; s < nsrc; ++s) {
+                const int xs = x + descs[s].d[0], ys = y + descs[s].d[1], zs_ = z + descs[s].d[2];
+                if (xs < 0 || xs >= P.xy || ys < 0 || ys >= P.xy || zs_ < 0 || zs_ >= P.zs) continue;
+                if (descs[s].tags[tl] != descs[s].epoch) continue;
+                const int st_s = descs[s].state[L];
+                if (st_s < 0 || !descs[s].metrics) continue;
+                if (s < P.nslots) merge_metrics<double>(c, (const double *)descs[s].metrics + (size_t)st_s * 10);
+                else merge_metrics<float>(c, (const float *)descs[s].metrics + (size_t)st_s * 10);
+            }
+#pragma unroll
+            for (int k = 0; k < 10; ++k) fmetrics[(size_t)row * 10 + k] = c[k];
+        }
+        __syncthreads();
     }
 }
 
@@ -2105,8 +2171,8 @@ hipError_t gvom_launch_stats(hipStream_t s, const ScanParams &P, int dtype, cons
         hipLaunchKernelGGL(k_stats<double>, dim3(blocks), dim3(256), 0, s, P, (const double *)world, (long)n, state,
                            tags, xy_e, z_e, base, sums, direct_only);
     if (n > 0) {
-        unsigned gb = (unsigned)((n + 3) / 4);
-        if (gb > 4096) gb = 4096;
+        unsigned gb = (unsigned)((n + 4 * GATHER_CPW - 1) / (4 * GATHER_CPW));   // a wave per GATHER_CPW candidate rows
+        if (gb > 16384) gb = 16384;
         hipLaunchKernelGGL(k_stats_gather, dim3(gb), dim3(256), 0, s, P, state, tags, xy_e, z_e, base, sums, rowvox,
                            (uint32_t)n, direct_only);
     }
@@ -2118,10 +2184,10 @@ hipError_t gvom_launch_fuse_stats(hipStream_t s, const FuseParams &P, const Fuse
 {
     const uint32_t ntiles = (uint32_t)(P.sy_hi - P.sy_lo) * P.zs * P.nseg;
     if (ntiles == 0) return hipSuccess;
-    unsigned blocks = (ntiles + 3) / 4;
-    if (blocks > 8192) blocks = 8192;
-    if (descs_dev) hipLaunchKernelGGL(k_fuse_stats<true>, dim3(blocks), dim3(256), 0, s, P, KD, descs_dev, fstate, ftags, fmetrics);
-    else hipLaunchKernelGGL(k_fuse_stats<false>, dim3(blocks), dim3(256), 0, s, P, KD, descs_dev, fstate, ftags, fmetrics);
+    unsigned blocks = (ntiles + FS_TPW - 1) / FS_TPW;
+    if (blocks > 32768) blocks = 32768;
+    if (descs_dev) hipLaunchKernelGGL(k_fuse_stats<true>, dim3(blocks), dim3(64), 0, s, P, KD, descs_dev, fstate, ftags, fmetrics);
+    else hipLaunchKernelGGL(k_fuse_stats<false>, dim3(blocks), dim3(64), 0, s, P, KD, descs_dev, fstate, ftags, fmetrics);
     return hipGetLastError();
 }
 
