@@ -174,8 +174,19 @@ def cpu_baseline(params, scans, budget_s=20.0):
             "ms_per_step": e1 / s1 * 1e3, "ms_per_step_all_cores": en / sn * 1e3}
 
 
-def _newest_profile(pattern, kernel):
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
+_CONFIG_TAGS = ("c1", "c2", "c3", "c4", "c5", "m256b8")
+
+
+def _newest_profile(pattern, kernel, config="m256"):
+    """newest committed counter summary for `config`: profiles/<tag>_<config>_<kind>.json, or <tag>_<kind>.json for the
+    headline workload m256"""
+    kind = pattern.lstrip("*")                            # "_traffic.json" / "_sq.json"
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True)
+    if config == "m256":
+        files = [f for f in files if not any(os.path.basename(f).endswith("_%s%s" % (c, kind)) for c in _CONFIG_TAGS)]
+    else:
+        files = [f for f in files if os.path.basename(f).endswith("_%s%s" % (config, kind))]
+    for f in files:
         try:
             ks = json.load(open(f))["kernels"]
         except Exception:
@@ -186,20 +197,20 @@ def _newest_profile(pattern, kernel):
     return None, None
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, config="m256"):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*_traffic.json:
     separate FETCH_SIZE / WRITE_SIZE passes, corrected with the factors calibrated on known-byte
     kernels in the same session), newest file first.  None if no profile covers the kernel."""
-    k, src = _newest_profile("*_traffic.json", kernel)
+    k, src = _newest_profile("*_traffic.json", kernel, config)
     if k and k.get("hbm_bytes_corrected"):
         return {"bytes_per_launch": k["hbm_bytes_corrected"], "source": src,
                 "atomic_requests_per_launch": k.get("TCC_EA0_ATOMIC_sum")}
     return None
 
 
-def sq_counters(kernel):
+def sq_counters(kernel, config="m256"):
     """SQ counters per launch of `kernel` from the committed passes (profiles/*_sq.json, tools/pmc_sq.sh)."""
-    k, src = _newest_profile("*_sq.json", kernel)
+    k, src = _newest_profile("*_sq.json", kernel, config)
     return (k, src) if k else (None, None)
 
 
@@ -388,32 +399,32 @@ def ros_two_threads(g, scans64, n_pts, min_s=0.6):
             "maps_per_s_ros_two_threads": (m1 - m0) / (t1 - t0)}
 
 
-def step_roofline(alg, res, profiled):
+def step_roofline(alg, res, config):
     """The whole step against the HBM peak, both ways SURVEY 8(d) asks for: the ALGORITHMIC bytes of the reference's data
     model, (B_scan + B_comb) / (t_scan + t_comb) -- V-sized clears and per-source V-sized reads included, which this
     implementation does not perform (tile epochs) -- and the bytes the counters measured, per step."""
     t = res["ms_per_step"] * 1e-3
     a = sum(alg.values())
     meas = None
-    if profiled:
-        parts = [pmc_traffic(k) for k in ("k_trace", "k_encode", "k_fuse4", "k_map2d")]
-        if all(parts):
-            meas = sum(p["bytes_per_launch"] for p in parts)
+    parts = [pmc_traffic(k, config) for k in ("k_trace", "k_encode", "k_fuse4", "k_map2d")]
+    if all(parts):
+        meas = sum(p["bytes_per_launch"] for p in parts)
     return {"algorithmic_bytes": a, "frac_algorithmic": a / t / 1e9 / HBM_PEAK_GBS,
             "measured_bytes": meas, "frac_measured": (meas / t / 1e9 / HBM_PEAK_GBS) if meas else None,
             "note": "per step (1 scan + 1 combine) over ms_per_step; algorithmic = N*P + 4*(sum_hit + sum_total) + 4*N_in + 20*V "
                     "+ 4*V*(S+L) + 8*V + 68*xy^2 (SURVEY 8d); measured = PMC HBM bytes of the four kernels (profiles/)"}
 
 
-def roofline_of(alg, stages, profiled=True):
-    """profiled: the committed counter passes (profiles/) were taken on this workload (m256); for the
-    other configs the counter-derived fields are null rather than another workload's numbers."""
+def roofline_of(alg, stages, profiled="m256"):
+    """profiled: the config whose committed counter passes (profiles/) apply -- a config without passes of its own gets
+    null counter-derived fields rather than another workload's numbers (False / None: no counters at all)."""
+    config = profiled if isinstance(profiled, str) else ("m256" if profiled else None)
     kern = {"trace": "k_trace", "encode": "k_encode", "fuse": "k_fuse4", "map2d": "k_map2d"}
     ms = {s: v["median"] for s, v in stages.items()}
     dom = max(ms, key=lambda s: ms[s])
     achieved = alg[dom] / (ms[dom] * 1e-3) / 1e9
-    traf = pmc_traffic(kern[dom]) if profiled else None
-    sq, sq_src = sq_counters(kern[dom]) if profiled else (None, None)
+    traf = pmc_traffic(kern[dom], config) if config else None
+    sq, sq_src = sq_counters(kern[dom], config) if config else (None, None)
     valu = None
     if sq and sq.get("SQ_INSTS_VALU"):
         bound_us = sq["SQ_INSTS_VALU"] / VALU_ISSUE_RATE * 1e6
@@ -427,7 +438,7 @@ def roofline_of(alg, stages, profiled=True):
     # V-sized streams that the tile tags no longer perform
     stage_gbs = {}
     for s, kname in kern.items():
-        t = pmc_traffic(kname) if profiled else None
+        t = pmc_traffic(kname, config) if config else None
         if t and ms.get(s):
             stage_gbs[s] = t["bytes_per_launch"] / (ms[s] * 1e-3) / 1e9
     req = (traf or {}).get("atomic_requests_per_launch")
@@ -504,9 +515,9 @@ def run_single(args):
                            "of the pending combine are stored to host memory -- same maps, one step later",
         "stage_ms": res["stage_ms"], "host_us": res["host_us"],
         "sum_hit": res["sum_hit"], "sum_total": res["sum_total"], "cells": res["cells"],
-        "roofline": roofline_of(alg, stages, profiled=(name == "m256")),
+        "roofline": roofline_of(alg, stages, profiled=name),
     }
-    out["roofline"]["step"] = step_roofline(alg, res, profiled=(name == "m256"))
+    out["roofline"]["step"] = step_roofline(alg, res, name)
     for key in ("value_ros_two_threads", "scans_per_s_ros_two_threads", "maps_per_s_ros_two_threads"):
         out[key] = res[key]
     if not args.no_extra:

@@ -83,8 +83,11 @@ struct gvom_handle {
     Buf x_send_eps, x_recv_eps;                                 // endpoints {L, min-height}: [world][ep_cap] / concatenated by source
     int64_t x_ep_cap = 0;
     std::vector<int64_t> x_recv_ep_off;                         // receive offsets (endpoints) by source, [world + 1]
-    uint32_t *x_qcnt = nullptr, *x_ecnt = nullptr;              // device counters, [world * 16] each
-    unsigned long long *x_host = nullptr, *x_host_dev = nullptr;   // pinned, mapped: [2*world + 2]
+    uint32_t *x_qcnt = nullptr, *x_ecnt = nullptr, *x_spcnt = nullptr;   // device counters, [world * 16] each
+    unsigned long long *x_host = nullptr, *x_host_dev = nullptr;   // pinned, mapped: [3*world + 2]
+    Buf x_send_sp, x_recv_sp;                                   // sharded statistics: returns (3 values each) for / from other ranks
+    std::vector<int64_t> x_recv_sp_off;                         // receive offsets (returns) by source, [world + 1]
+    int pending_dtype = 0;                                      // cloud type of the scan between scan_local and scan_merge
     size_t x_Q = 0, x_myQ = 0;
     ScanParams pending_P;                                       // scan parameters between scan_local and scan_merge
     unsigned resident_blocks = 2048;                    // 256-thread workgroups resident on the device (queried)
@@ -202,6 +205,22 @@ int ensure(gvom_handle *h, Buf &b, size_t bytes)
     return GVOM_OK;
 }
 
+// grows a device buffer KEEPING its contents (stream-ordered copy, then a wait: rare)
+int ensure_keep(gvom_handle *h, Buf &b, size_t bytes)
+{
+    if (b.bytes >= bytes) return GVOM_OK;
+    const size_t want = bytes + bytes / 2 + 256;
+    void *np = nullptr;
+    HIPCHK(h, hipMalloc(&np, want));
+    if (b.p) {
+        HIPCHK(h, hipMemcpyAsync(np, b.p, b.bytes, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipFree(b.p));
+    }
+    b.p = np; b.bytes = want;
+    return GVOM_OK;
+}
+
 inline int64_t floor_mod(int64_t a, int64_t n) { int64_t r = a % n; return r < 0 ? r + n : r; }
 
 inline int clamp_delta(int64_t d, int size)
@@ -233,6 +252,7 @@ void fill_scan_params(const gvom_handle *h, const int64_t origin[3], const doubl
     P.nseg = h->nseg;
     P.sxq = h->sxq;
     P.shard_world = h->world; P.shard_rank = h->rank; P.shard_rows = h->world > 1 ? p.xy_size / h->world : p.xy_size;
+    P.stat_e = p.xy_eigen_dist;
     // DDA step segments: the ego sits at the window centre, so a ray takes at most size/2 + 2 steps.
     // Segments exist to fill the chip with waves when a scan has few returns (a 131 k-point scan is 2
     // waves per SIMD); every segment wave repeats the ray set-up and replays the earlier steps, so
@@ -279,8 +299,7 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, b
     if (params->buffer_size >= GVOM_MAX_SLOTS || params->z_size > 1024 || world > GVOM_MAX_SLOTS) return GVOM_ERR_CAPACITY;
     // a sharded map: every rank owns xy/world storage rows, a multiple of 4 (accumulator patches are
     // 4 rows high); per-voxel statistics need every return on the owner and are not exchanged
-    if (sharded && (params->xy_size % (4 * world) != 0 || (params->reserved0 & GVOM_FLAG_VOXEL_STATISTICS)))
-        return GVOM_ERR_INVALID;
+    if (sharded && params->xy_size % (4 * world) != 0) return GVOM_ERR_INVALID;
     const double Vd = (double)params->xy_size * params->xy_size * params->z_size;
     if (Vd >= 2147483648.0) return GVOM_ERR_CAPACITY;
     int ndev = 0;
@@ -292,7 +311,10 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, b
     h->rank = rank; h->world = world; h->sharded = sharded;
     h->stats = (params->reserved0 & GVOM_FLAG_VOXEL_STATISTICS) != 0;
     h->f32_sqrt = (params->reserved0 & GVOM_FLAG_CUDA_F32_SQRT) != 0;
-    if (const char *v = getenv("GVOM_VOXEL_STATISTICS")) h->stats = atoi(v) != 0 && !sharded;
+    if (const char *v = getenv("GVOM_VOXEL_STATISTICS")) h->stats = atoi(v) != 0;
+    // sharded statistics send a return to the ranks that own the first and the last row of its neighbourhood: the
+    // neighbourhood (2 xy_eigen_dist + 1 rows) must not reach over a whole slab
+    if (sharded && h->stats && world > 1 && 2 * params->xy_eigen_dist + 1 > params->xy_size / world) { delete h; return GVOM_ERR_INVALID; }
     if (const char *v = getenv("GVOM_HOST_TIMING")) h->host_timing = atoi(v) != 0;
     const int xy = params->xy_size, zs = params->z_size;
     h->sy_lo = (int)((int64_t)xy * rank / world);
@@ -392,12 +414,15 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, b
         CK(hipMalloc(&h->x_recv_pay, h->x_Q * 1024));
         CK(hipMalloc((void **)&h->x_qcnt, (size_t)world * 64));
         CK(hipMalloc((void **)&h->x_ecnt, (size_t)world * 64));
+        CK(hipMalloc((void **)&h->x_spcnt, (size_t)world * 64));
         CK(hipMemsetAsync(h->x_qcnt, 0, (size_t)world * 64, h->stream));
         CK(hipMemsetAsync(h->x_ecnt, 0, (size_t)world * 64, h->stream));
-        CK(hipHostMalloc((void **)&h->x_host, (size_t)(2 * world + 2) * 8, hipHostMallocMapped | hipHostMallocCoherent));
+        CK(hipMemsetAsync(h->x_spcnt, 0, (size_t)world * 64, h->stream));
+        CK(hipHostMalloc((void **)&h->x_host, (size_t)(3 * world + 2) * 8, hipHostMallocMapped | hipHostMallocCoherent));
         CK(hipHostGetDevicePointer((void **)&h->x_host_dev, h->x_host, 0));
-        memset(h->x_host, 0, (size_t)(2 * world + 2) * 8);
+        memset(h->x_host, 0, (size_t)(3 * world + 2) * 8);
         h->x_recv_ep_off.assign(world + 1, 0);
+        h->x_recv_sp_off.assign(world + 1, 0);
     }
     for (auto &e : h->ev) CK(hipEventCreate(&e));
     CK(hipStreamSynchronize(h->stream));
@@ -472,6 +497,24 @@ hipError_t join_second_stream(gvom_handle *h)
     return e;
 }
 
+// Optional per-voxel statistics of the scan just encoded, on the statistics stream beside whatever
+// follows.  nrows: candidate compact rows; extra / n_extra: returns received from other ranks (sharded map).
+int enqueue_scan_stats(gvom_handle *h, const ScanParams &P, int dtype, Slot &st, int64_t n, int64_t nrows, const void *extra, int64_t n_extra)
+{
+    const uint32_t par = h->stats_scan & 1u;
+    HIPCHK(h, hipEventRecord(h->ev_before[par], h->stream_s));   // the statistics stream's work up to here
+    h->before_valid[par] = true;
+    ++h->stats_scan;
+    HIPCHK(h, hipEventRecord(h->ev_enc_s, h->stream));
+    HIPCHK(h, hipStreamWaitEvent(h->stream_s, h->ev_enc_s, 0));
+    HIPCHK(h, gvom_launch_stats(h->stream_s, P, dtype, h->world_pts[par].p, n, st.state, st.tags,
+                                h->prm.xy_eigen_dist, h->prm.z_eigen_dist, (double *)st.base.p, (double *)st.metrics.p,
+                                (const uint32_t *)st.rowvox.p, nrows, extra, n_extra));
+    HIPCHK(h, hipEventRecord(h->ev_sdone, h->stream_s));
+    h->s_pending = true;
+    return GVOM_OK;
+}
+
 // Scan kernels up to (not including) the commit.  `dev_pts` is device memory.
 // Waits until the GPU has published sequence number `seq` in the 64-bit host-mapped word `flag` (high
 // half, or the whole word).  `lk` (the handle mutex) is RELEASED while waiting, so combine_maps from
@@ -538,8 +581,11 @@ int scan_launch(gvom_handle *h, std::unique_lock<std::mutex> &lk, const void *de
     const size_t cap = std::max<size_t>(1, (size_t)n);
     if ((rc = ensure(h, st.crows, cap * 16))) return rc;
     Buf &wpts = h->world_pts[h->stats_scan & 1u];
-    if (h->stats && ((rc = ensure(h, wpts, (size_t)n * 3 * esz)) || (rc = ensure(h, st.metrics, cap * 80)) ||
-                     (rc = ensure(h, st.base, cap * 8 * GVOM_BASE_PITCH)) || (rc = ensure(h, st.rowvox, cap * 4)))) return rc;
+    // (a sharded map's received endpoints get rows behind the rank's own returns: room for as many again; gvom_shard_scan_merge
+    // grows the arrays, keeping their contents, if more arrive)
+    const size_t scap = h->sharded ? 2 * cap : cap;
+    if (h->stats && ((rc = ensure(h, wpts, (size_t)(n > 0 ? n : 1) * 3 * esz)) || (rc = ensure(h, st.metrics, scap * 80)) ||
+                     (rc = ensure(h, st.base, scap * 8 * GVOM_BASE_PITCH)) || (rc = ensure(h, st.rowvox, scap * 4)))) return rc;
     double t0 = now_ns();
     const uint32_t seq = ++h->scan_seq;
     if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
@@ -554,14 +600,18 @@ int scan_launch(gvom_handle *h, std::unique_lock<std::mutex> &lk, const void *de
         const uint32_t prev_par = (h->stats_scan + 1u) & 1u;
         if (!h->stats_prev_committed && h->s_pending) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_sdone, 0));
         else if (h->before_valid[prev_par]) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_before[prev_par], 0));
-        HIPCHK(h, hipMemsetAsync(st.rowvox.p, 0xFF, cap * 4, h->stream));   // no row claimed yet
+        HIPCHK(h, hipMemsetAsync(st.rowvox.p, 0xFF, st.rowvox.bytes, h->stream));   // no row claimed yet
     }
     ShardExchange X;
-    X.ep_send = nullptr; X.ep_cnt = nullptr; X.ep_cap = 0;
+    X.ep_send = nullptr; X.ep_cnt = nullptr; X.ep_cap = 0; X.sp_send = nullptr; X.sp_cnt = nullptr;
     if (h->sharded) {
         if ((rc = ensure(h, h->x_send_eps, (size_t)h->world * (size_t)(n > 0 ? n : 1) * 8))) return rc;
         h->x_ep_cap = n > 0 ? n : 1;
         X.ep_send = (uint2 *)h->x_send_eps.p; X.ep_cnt = h->x_ecnt; X.ep_cap = (long)h->x_ep_cap;
+        if (h->stats && h->world > 1) {
+            if ((rc = ensure(h, h->x_send_sp, (size_t)h->world * (size_t)h->x_ep_cap * 3 * esz))) return rc;
+            X.sp_send = h->x_send_sp.p; X.sp_cnt = h->x_spcnt;
+        }
     }
     P.tl = nullptr; P.tl_words = 0;
 #ifdef GVOM_DIAG
@@ -585,7 +635,7 @@ int scan_launch(gvom_handle *h, std::unique_lock<std::mutex> &lk, const void *de
         // sharded map: the ray passes in other ranks' rows are packed for their owners; the counts go
         // to host-mapped memory (the caller sizes the exchange with them); k_encode follows in
         // scan_merge, once the other ranks' contributions have been added
-        le = gvom_launch_pack(h->stream, P, h->total, st.tags, h->x_send_ids, h->x_send_pay, h->x_qcnt, h->x_ecnt,
+        le = gvom_launch_pack(h->stream, P, h->total, st.tags, h->x_send_ids, h->x_send_pay, h->x_qcnt, h->x_ecnt, h->x_spcnt,
                               h->counters, h->x_host_dev, seq);
         if (le != hipSuccess) { scan_abort(h); HIPCHK(h, le); }
         volatile unsigned long long *flag = (volatile unsigned long long *)(h->x_host + 2 * h->world + 1);
@@ -599,6 +649,7 @@ int scan_launch(gvom_handle *h, std::unique_lock<std::mutex> &lk, const void *de
         }
         h->pending_any = h->x_host[2 * h->world] != 0;
         h->pending_P = P;
+        h->pending_dtype = dtype;
         st.count = -1;
         st.origin[0] = origin[0]; st.origin[1] = origin[1]; st.origin[2] = origin[2];
         st.stats_valid = false;
@@ -612,19 +663,7 @@ int scan_launch(gvom_handle *h, std::unique_lock<std::mutex> &lk, const void *de
                             (unsigned long long *)h->counters_host_dev, seq, h->resident_blocks);
     if (le != hipSuccess) { scan_abort(h); HIPCHK(h, le); }
     if (h->profiling) { HIPCHK(h, hipEventRecord(h->ev[2], h->stream)); h->ev_scan = true; }
-    if (h->stats) {                                      // optional per-voxel statistics, beside whatever follows
-        const uint32_t par = h->stats_scan & 1u;
-        HIPCHK(h, hipEventRecord(h->ev_before[par], h->stream_s));   // the statistics stream's work up to here
-        h->before_valid[par] = true;
-        ++h->stats_scan;
-        HIPCHK(h, hipEventRecord(h->ev_enc_s, h->stream));
-        HIPCHK(h, hipStreamWaitEvent(h->stream_s, h->ev_enc_s, 0));
-        HIPCHK(h, gvom_launch_stats(h->stream_s, P, dtype, wpts.p, n, st.state, st.tags,
-                                    p.xy_eigen_dist, p.z_eigen_dist, (double *)st.base.p, (double *)st.metrics.p,
-                                    (const uint32_t *)st.rowvox.p));
-        HIPCHK(h, hipEventRecord(h->ev_sdone, h->stream_s));
-        h->s_pending = true;
-    }
+    if (h->stats && (rc = enqueue_scan_stats(h, P, dtype, st, n, n, nullptr, 0))) return rc;
     HT(h, 0, t0);                                        // scan: launches
     // Wait only for k_trace: k_encode's first thread publishes {seq, any-in-grid} to host-mapped
     // memory.  The caller gets control back while k_encode still runs; everything it can do next
@@ -1016,7 +1055,7 @@ VIS void gvom_destroy(gvom_t *h)
     auto fb = [](Buf &b) { if (b.p) hipFree(b.p); b.p = nullptr; b.bytes = 0; };
     hipFree(h->hit); hipFree(h->total); hipFree(h->mh);
     hipFree(h->x_send_ids); hipFree(h->x_send_pay); hipFree(h->x_recv_ids); hipFree(h->x_recv_pay);
-    hipFree(h->x_qcnt); hipFree(h->x_ecnt); fb(h->x_send_eps); fb(h->x_recv_eps);
+    hipFree(h->x_qcnt); hipFree(h->x_ecnt); hipFree(h->x_spcnt); fb(h->x_send_eps); fb(h->x_recv_eps); fb(h->x_send_sp); fb(h->x_recv_sp);
     if (h->x_host) hipHostFree(h->x_host);
     for (auto &s : h->slots) { hipFree(s.state); hipFree(s.code16); hipFree(s.tags); fb(s.crows); fb(s.metrics); fb(s.base); fb(s.rowvox); }
     for (auto &f : h->fused) { hipFree(f.state); hipFree(f.tags); fb(f.rows); fb(f.metrics); }
@@ -1110,6 +1149,36 @@ VIS int gvom_shard_recv_reserve(gvom_t *h, const int64_t *recv_eps)
     return ensure(h, h->x_recv_eps, (size_t)(tot > 0 ? tot : 1) * 8);
 }
 
+// Per-voxel statistics on a sharded map (handles created with GVOM_FLAG_VOXEL_STATISTICS): after gvom_shard_scan_local,
+// send_returns[d] = returns (3 values of the cloud's type each) this rank has for rank d -- every return whose
+// (2 xy_eigen_dist + 1)-row neighbourhood reaches into d's rows; the transport moves GVOM_XBUF_SEND_RETURNS to the peers'
+// GVOM_XBUF_RECV_RETURNS (sized by gvom_shard_stats_reserve from the exchanged counts) before gvom_shard_scan_merge.
+VIS int gvom_shard_stats_counts(gvom_t *h, int64_t *send_returns)
+{
+    if (!h || !h->sharded || !send_returns) return GVOM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    for (int d = 0; d < h->world; ++d) send_returns[d] = (h->stats && h->pending) ? (int64_t)h->x_host[2 * h->world + 2 + d] : 0;
+    return GVOM_OK;
+}
+
+VIS int gvom_shard_stats_reserve(gvom_t *h, const int64_t *recv_returns, int dtype)
+{
+    if (!h || !h->sharded || !recv_returns || (dtype != GVOM_DTYPE_F32 && dtype != GVOM_DTYPE_F64)) return GVOM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    if (h->pending_n > 0 && dtype != h->pending_dtype) { h->err = "the ranks' clouds differ in type"; return GVOM_ERR_INVALID; }
+    h->pending_dtype = dtype;                             // (a rank with an empty share takes the others' type)
+    int64_t tot = 0;
+    for (int sidx = 0; sidx < h->world; ++sidx) {
+        h->x_recv_sp_off[sidx] = tot;
+        if (recv_returns[sidx] < 0) return GVOM_ERR_INVALID;
+        tot += sidx == h->rank ? 0 : recv_returns[sidx];
+    }
+    h->x_recv_sp_off[h->world] = tot;
+    const size_t esz3 = (h->pending_dtype == GVOM_DTYPE_F32 ? 4 : 8) * 3;
+    return ensure(h, h->x_recv_sp, (size_t)(tot > 0 ? tot : 1) * esz3);
+}
+
 VIS int gvom_shard_buffer(gvom_t *h, int which, int peer, void **ptr, int64_t *capacity_bytes)
 {
     if (!h || !h->sharded || !ptr || peer < 0 || peer >= h->world) return GVOM_ERR_INVALID;
@@ -1125,6 +1194,17 @@ VIS int gvom_shard_buffer(gvom_t *h, int which, int peer, void **ptr, int64_t *c
     case GVOM_XBUF_RECV_EPS:
         *ptr = (char *)h->x_recv_eps.p + (size_t)h->x_recv_ep_off[peer] * 8;
         cap = (h->x_recv_ep_off[peer + 1] - h->x_recv_ep_off[peer]) * 8; break;
+    case GVOM_XBUF_SEND_RETURNS: {
+        const size_t esz3 = (h->pending_dtype == GVOM_DTYPE_F32 ? 4 : 8) * 3;
+        if (!h->x_send_sp.p) return GVOM_NO_DATA;
+        *ptr = (char *)h->x_send_sp.p + (size_t)peer * (size_t)h->x_ep_cap * esz3; cap = h->x_ep_cap * (int64_t)esz3; break;
+    }
+    case GVOM_XBUF_RECV_RETURNS: {
+        const size_t esz3 = (h->pending_dtype == GVOM_DTYPE_F32 ? 4 : 8) * 3;
+        if (!h->x_recv_sp.p) return GVOM_NO_DATA;
+        *ptr = (char *)h->x_recv_sp.p + (size_t)h->x_recv_sp_off[peer] * esz3;
+        cap = (h->x_recv_sp_off[peer + 1] - h->x_recv_sp_off[peer]) * (int64_t)esz3; break;
+    }
     default: return GVOM_ERR_INVALID;
     }
     if (capacity_bytes) *capacity_bytes = cap;
@@ -1154,6 +1234,13 @@ VIS int gvom_shard_scan_merge(gvom_t *h, const int64_t *recv_quads, const int64_
     const size_t cap = std::max<size_t>(1, (size_t)h->pending_n + (size_t)tot_eps);
     int rc;
     if ((rc = ensure(h, st.crows, cap * 16))) return rc;
+    if (h->stats) {                                       // rows of the received endpoints: behind the rank's own (contents kept)
+        const size_t old_rows = st.rowvox.bytes / 4;
+        if ((rc = ensure_keep(h, st.metrics, cap * 80)) || (rc = ensure_keep(h, st.base, cap * 8 * GVOM_BASE_PITCH)) ||
+            (rc = ensure_keep(h, st.rowvox, cap * 4))) return rc;
+        if (st.rowvox.bytes / 4 > old_rows)
+            HIPCHK(h, hipMemsetAsync((uint32_t *)st.rowvox.p + old_rows, 0xFF, st.rowvox.bytes - old_rows * 4, h->stream));
+    }
     double t0 = now_ns();
     {   // everything received, whatever the source, in one launch each (quads, endpoints)
         ShardUnpack X;
@@ -1163,7 +1250,9 @@ VIS int gvom_shard_scan_merge(gvom_t *h, const int64_t *recv_quads, const int64_
             if (sidx < h->world && sidx != h->rank) acc += (uint32_t)recv_quads[sidx];
         }
         hipError_t le = gvom_launch_unpack(h->stream, P, X, h->x_recv_ids, h->x_recv_pay, (uint32_t)h->x_myQ, (uint32_t)tot_eps,
-                                           h->x_recv_eps.p, (long)h->pending_n, h->hit, h->total, h->mh, st.state, st.tags);
+                                           h->x_recv_eps.p, (long)h->pending_n, h->hit, h->total, h->mh, st.state, st.tags,
+                                           h->stats ? (double *)st.metrics.p : nullptr, h->stats ? (double *)st.base.p : nullptr,
+                                           h->stats ? (uint32_t *)st.rowvox.p : nullptr);
         if (le != hipSuccess) { scan_abort(h); HIPCHK(h, le); }
     }
     const uint32_t seq = ++h->scan_seq;
@@ -1172,6 +1261,12 @@ VIS int gvom_shard_scan_merge(gvom_t *h, const int64_t *recv_quads, const int64_
                                        (unsigned long long *)h->counters_host_dev, seq, h->resident_blocks);
     if (le != hipSuccess) { scan_abort(h); HIPCHK(h, le); }
     if (h->profiling) { HIPCHK(h, hipEventRecord(h->ev[2], h->stream)); h->ev_scan = true; }
+    if (h->stats) {
+        // this rank's own returns (all of them: a return outside its rows can still reach into them) and the ones the
+        // other ranks sent, in the direct form over this rank's rows
+        const int64_t tot_sp = h->world > 1 ? h->x_recv_sp_off[h->world] : 0;
+        if ((rc = enqueue_scan_stats(h, P, h->pending_dtype, st, h->pending_n, (int64_t)cap, h->x_recv_sp.p, tot_sp))) return rc;
+    }
     HT(h, 0, t0);
     // (no host wait: everything the caller can do next with this handle is stream-ordered behind k_encode)
     scan_commit(h, accept != 0);

@@ -329,6 +329,42 @@ VIS int gvom_comm_exchange_scan(gvom_comm_t *c, gvom_t *h, const int64_t *send_q
     return GVOM_OK;
 }
 
+// Statistics handles: the returns every other rank needs of this one (gvom_shard_stats_counts) -> their receive
+// regions (gvom_shard_stats_reserve), bytes_per_return = 12 (float32 clouds) or 24.  One grouped send / recv.
+VIS int gvom_comm_exchange_stats(gvom_comm_t *c, gvom_t *h, const int64_t *send_returns, const int64_t *recv_returns,
+                                 int bytes_per_return)
+{
+    if (!c || !h || !send_returns || !recv_returns || (bytes_per_return != 12 && bytes_per_return != 24)) return GVOM_ERR_INVALID;
+    if (c->world == 1) return GVOM_OK;
+    if (!c->nccl) { c->err = "host-only communicator: no device collectives"; return GVOM_ERR_INVALID; }
+    if (hipSetDevice(c->device) != hipSuccess) { c->err = "hipSetDevice failed"; return GVOM_ERR_HIP; }
+    hipStream_t st = (hipStream_t)gvom_stream(h);
+    NCCLCHK(c, c->rccl.GroupStart());
+    int rc = GVOM_OK;
+    for (int p = 0; p < c->world && rc == GVOM_OK; ++p) {
+        if (p == c->rank) continue;
+        for (int dir = 0; dir < 2 && rc == GVOM_OK; ++dir) {
+            const int64_t cnt = dir == 0 ? send_returns[p] : recv_returns[p];
+            if (cnt < 0) { c->err = "negative count"; rc = GVOM_ERR_INVALID; break; }
+            if (cnt == 0) continue;
+            void *ptr = nullptr;
+            int64_t cap = 0;
+            const size_t bytes = (size_t)cnt * (size_t)bytes_per_return;
+            if (gvom_shard_buffer(h, dir == 0 ? GVOM_XBUF_SEND_RETURNS : GVOM_XBUF_RECV_RETURNS, p, &ptr, &cap) || (int64_t)bytes > cap) {
+                c->err = "statistics exchange region missing or smaller than the announced count";
+                rc = GVOM_ERR_INVALID;
+                break;
+            }
+            const ncclResult_t r = dir == 0 ? c->rccl.Send(ptr, bytes, ncclUint8, p, c->nccl, st) : c->rccl.Recv(ptr, bytes, ncclUint8, p, c->nccl, st);
+            if (r != ncclSuccess) { c->err = std::string("ncclSend/Recv failed: ") + c->rccl.GetErrorString(r); rc = GVOM_ERR_HIP; }
+        }
+    }
+    const ncclResult_t ge = c->rccl.GroupEnd();
+    if (rc != GVOM_OK) return rc;
+    if (ge != ncclSuccess) { c->err = std::string("ncclGroupEnd failed: ") + c->rccl.GetErrorString(ge); return GVOM_ERR_HIP; }
+    return GVOM_OK;
+}
+
 // The combine's exchange: in-place all-gather of the handle's [height | inferred height | positive
 // density] rows (GVOM_BUF_HEIGHT_MAPS; a rank's rows are one contiguous block) on the handle's stream.
 VIS int gvom_comm_allgather_rows(gvom_comm_t *c, gvom_t *h)

@@ -72,6 +72,7 @@ struct ScanParams {
     int    off[3];        // element offsets of x, y, z inside a point record (0, 1, 2 unless PointCloud2 ingest)
     int    in_f32;        // 1: the records hold float32 fields that are widened to the (float64) compute type,
                           //    as ros_numpy hands the reference a float64 array (stride and offsets in 4-byte units)
+    int    stat_e;        // xy_eigen_dist (sharded statistics: which ranks a return's neighbourhood reaches)
     int    shard_world, shard_rank, shard_rows;   // ranks of a sharded map (1, 0, xy when unsharded): rank r owns storage rows [r*shard_rows, (r+1)*shard_rows)
     int    dbg;           // diagnostic build only
     long   tl_words;      // diagnostic build only: words of per-wave records in tl; 8 summary words follow
@@ -83,6 +84,10 @@ struct ShardExchange {
     uint2    *ep_send;    // [world][ep_cap] {voxel L, min-height sample}
     uint32_t *ep_cnt;     // [world * 16] (one counter per 64-B line)
     long      ep_cap;
+    // per-voxel statistics on a sharded map: a return goes (x, y, z in the cloud's type) to every OTHER rank that owns a
+    // storage row of its (2 xy_eigen_dist + 1)-row neighbourhood -- at most two ranks (slabs are at least that high)
+    void     *sp_send;    // [world][ep_cap] x 3 values; nullptr: statistics off
+    uint32_t *sp_cnt;     // [world * 16]
 };
 
 #define GVOM_PACK_CHUNK 64     // quads per k_pack workgroup
@@ -147,11 +152,12 @@ hipError_t gvom_launch_trace(hipStream_t s, const ScanParams &P, const ShardExch
                              uint32_t *counters, double *stat_sums, double *stat_base,
                              uint32_t *stat_rowvox);
 hipError_t gvom_launch_pack(hipStream_t s, const ScanParams &P, uint32_t *total, const uint32_t *tags, uint32_t *send_ids,
-                            void *send_pay, uint32_t *qcnt, uint32_t *ecnt, uint32_t *counters,
+                            void *send_pay, uint32_t *qcnt, uint32_t *ecnt, uint32_t *spcnt, uint32_t *counters,
                             unsigned long long *host_out, uint32_t seq);
 hipError_t gvom_launch_unpack(hipStream_t s, const ScanParams &P, const ShardUnpack &X, const uint32_t *ids_all,
                               const void *pay_all, uint32_t my_quads, uint32_t ne, const void *eps, long row_base,
-                              uint32_t *hit, uint32_t *total, uint32_t *mh, int32_t *state, uint32_t *tags);
+                              uint32_t *hit, uint32_t *total, uint32_t *mh, int32_t *state, uint32_t *tags,
+                              double *stat_sums, double *stat_base, uint32_t *stat_rowvox);
 hipError_t gvom_launch_encode(hipStream_t s, const ScanParams &P, uint32_t *hit, uint32_t *total, uint32_t *mh,
                               int32_t *state, uint16_t *code16, uint4 *crows, const uint32_t *tags,
                               uint32_t *counters, unsigned long long *host_flag, uint32_t seq, unsigned resident_blocks);
@@ -166,9 +172,11 @@ hipError_t gvom_launch_map2d(hipStream_t s, const Map2dParams &P, const int32_t 
                              double *out_rough, int32_t *out_vis, const uint32_t *blockcounts,
                              int nblocks, unsigned long long *host_counter);
 // ---- optional per-voxel statistics (gvom.py:1172-1299, 858-909, 1333-1378, 454-473)
+// nrows: candidate compact rows (the scan's returns, + received endpoints on a sharded map); extra / n_extra: returns
+// received from other ranks (sharded statistics), accumulated like the rank's own
 hipError_t gvom_launch_stats(hipStream_t s, const ScanParams &P, int dtype, const void *world, int64_t n,
                              const int32_t *state, const uint32_t *tags, int xy_e, int z_e, double *base,
-                             double *sums, const uint32_t *rowvox);
+                             double *sums, const uint32_t *rowvox, int64_t nrows, const void *extra, int64_t n_extra);
 hipError_t gvom_launch_fuse_stats(hipStream_t s, const FuseParams &P, const FuseDescs &KD, const MapDesc *descs_dev,
                                   const int32_t *fstate, const uint32_t *ftags, float *fmetrics);
 hipError_t gvom_launch_voxel_cloud(hipStream_t s, const Map2dParams &P, double o0, double o1, double o2,

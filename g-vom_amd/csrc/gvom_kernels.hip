@@ -515,6 +515,40 @@ __device__ __forceinline__ void trace_item(const ScanParams &P, const ShardExcha
                 if (foreign && d == dd) X.ep_send[(size_t)dd * X.ep_cap + base + (uint32_t)__popcll(m & lanemask_lt())] = make_uint2(E.L, E.mbits);
                 fm &= ~m;
             }
+            if (X.sp_send) {
+                // statistics: this return adds to every occupied voxel of its neighbourhood (gvom.py:1188-1220): the ranks
+                // that own the first and the last in-window row of it get the return itself (the rank's own returns stay in
+                // `world`); rows wrap with the storage, slabs are >= 2 e + 1 rows, so those two ranks are all there are
+                int t0 = -1, t1 = -1;
+                const double ay = floor((double)y / P.xy_res - P.origin[1]);
+                if (pass && fabs(ay) < 1e9) {
+                    const int yb = (int)ay, lo = max(yb - P.stat_e, 0), hi = min(yb + P.stat_e, P.xy - 1);
+                    if (lo <= hi) {
+                        t0 = wrap_add(lo, P.om[1], P.xy) / P.shard_rows;
+                        t1 = wrap_add(hi, P.om[1], P.xy) / P.shard_rows;
+                        if (t1 == t0) t1 = -1;
+                    }
+                }
+#pragma unroll 1
+                for (int pass_k = 0; pass_k < 2; ++pass_k) {
+                    const int d = pass_k == 0 ? t0 : t1;
+                    const bool go = d >= 0 && d != P.shard_rank;
+                    unsigned long long gm = lanes(go);
+                    while (gm != 0ull) {                                     // wave-uniform: the destinations present
+                        const int first = __ffsll((long long)gm) - 1;
+                        const int dd = __builtin_amdgcn_readlane(d, first);
+                        const unsigned long long m = lanes(go && d == dd);
+                        uint32_t base = 0;
+                        if (lane == first) base = atomicAdd(&X.sp_cnt[dd * 16], (uint32_t)__popcll(m));
+                        base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
+                        if (go && d == dd) {
+                            T *dst = (T *)X.sp_send + ((size_t)dd * X.ep_cap + base + (uint32_t)__popcll(m & lanemask_lt())) * 3;
+                            dst[0] = x; dst[1] = y; dst[2] = z;
+                        }
+                        gm &= ~m;
+                    }
+                }
+            }
         }
         endpoint_commit(P, lane, i, mine, E.L, E.A, E.mbits, hit, total, mh, state, tags, stat_sums, stat_base, stat_rowvox);
         if (P.ep_row >= 0) { TL_MARK(P, widx, 2); return; }
@@ -650,14 +684,15 @@ __global__ __launch_bounds__(256) void k_pack(const ScanParams P, uint32_t *tota
 // counts of k_pack / k_trace's endpoint lists -> host-mapped memory (the host sizes the exchange with
 // them) and re-armed: out[d] = quads for rank d, out[world + d] = endpoints, out[2*world] = some return
 // of THIS rank landed in the grid, then the sequence number
-__global__ void k_shard_publish(int world, uint32_t *qcnt, uint32_t *ecnt, uint32_t *counters,
+__global__ void k_shard_publish(int world, uint32_t *qcnt, uint32_t *ecnt, uint32_t *spcnt, uint32_t *counters,
                                 unsigned long long *host_out, uint32_t seq)
 {
     const int d = threadIdx.x;
     if (d < world) {
         __hip_atomic_store(&host_out[d], (unsigned long long)qcnt[d * 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&host_out[world + d], (unsigned long long)ecnt[d * 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        qcnt[d * 16] = 0; ecnt[d * 16] = 0;
+        __hip_atomic_store(&host_out[2 * world + 2 + d], (unsigned long long)spcnt[d * 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        qcnt[d * 16] = 0; ecnt[d * 16] = 0; spcnt[d * 16] = 0;
     }
     __syncthreads();
     if (d == 0) {
@@ -704,7 +739,8 @@ __global__ __launch_bounds__(256) void k_unpack_quads(const ScanParams P, const 
 // concatenated by source rank): the owner's share of k_trace's endpoint work; rows continue behind
 // this rank's own returns
 __global__ __launch_bounds__(256) void k_unpack_eps(const ScanParams P, uint32_t ne, const uint2 *__restrict__ eps, long row_base,
-                                                    uint32_t *hit, uint32_t *total, uint32_t *mh, int32_t *state, uint32_t *tags)
+                                                    uint32_t *hit, uint32_t *total, uint32_t *mh, int32_t *state, uint32_t *tags,
+                                                    double *stat_sums, double *stat_base, uint32_t *stat_rowvox)
 {
     const int lane = threadIdx.x & (WAVE - 1);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -716,7 +752,7 @@ __global__ __launch_bounds__(256) void k_unpack_eps(const ScanParams P, uint32_t
         const uint32_t sx = L % (uint32_t)P.xy, rz = L / (uint32_t)P.xy;
         A = acc_idx((int)sx, (int)(rz / (uint32_t)P.zs), (int)(rz % (uint32_t)P.zs), P.zs, P.sxq);
     }
-    endpoint_commit(P, lane, row_base + (long)i, live, L, A, mbits, hit, total, mh, state, tags, nullptr, nullptr, nullptr);
+    endpoint_commit(P, lane, row_base + (long)i, live, L, A, mbits, hit, total, mh, state, tags, stat_sums, stat_base, stat_rowvox);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2159,22 +2195,27 @@ __global__ __launch_bounds__(256) void k_voxel_cloud(const Map2dParams P, double
 
 hipError_t gvom_launch_stats(hipStream_t s, const ScanParams &P, int dtype, const void *world, int64_t n,
                              const int32_t *state, const uint32_t *tags, int xy_e, int z_e, double *base,
-                             double *sums, const uint32_t *rowvox)
+                             double *sums, const uint32_t *rowvox, int64_t nrows, const void *extra, int64_t n_extra)
 {
     // slab-sharded handles use the direct form only (a neighbour voxel's moments may live on another rank)
     const int direct_only = (P.sy_hi - P.sy_lo) < P.xy ? 1 : 0;
-    const unsigned blocks = (unsigned)((n + 255) / 256);
-    if (dtype == 0)
-        hipLaunchKernelGGL(k_stats<float>, dim3(blocks), dim3(256), 0, s, P, (const float *)world, (long)n, state,
-                           tags, xy_e, z_e, base, sums, direct_only);
-    else
-        hipLaunchKernelGGL(k_stats<double>, dim3(blocks), dim3(256), 0, s, P, (const double *)world, (long)n, state,
-                           tags, xy_e, z_e, base, sums, direct_only);
-    if (n > 0) {
-        unsigned gb = (unsigned)((n + 4 * GATHER_CPW - 1) / (4 * GATHER_CPW));   // a wave per GATHER_CPW candidate rows
+    for (int part = 0; part < 2; ++part) {
+        const void *pts = part == 0 ? world : extra;
+        const int64_t np = part == 0 ? n : n_extra;
+        if (np <= 0 || !pts) continue;
+        const unsigned blocks = (unsigned)((np + 255) / 256);
+        if (dtype == 0)
+            hipLaunchKernelGGL(k_stats<float>, dim3(blocks), dim3(256), 0, s, P, (const float *)pts, (long)np, state,
+                               tags, xy_e, z_e, base, sums, direct_only);
+        else
+            hipLaunchKernelGGL(k_stats<double>, dim3(blocks), dim3(256), 0, s, P, (const double *)pts, (long)np, state,
+                               tags, xy_e, z_e, base, sums, direct_only);
+    }
+    if (nrows > 0) {
+        unsigned gb = (unsigned)((nrows + 4 * GATHER_CPW - 1) / (4 * GATHER_CPW));   // a wave per GATHER_CPW candidate rows
         if (gb > 16384) gb = 16384;
         hipLaunchKernelGGL(k_stats_gather, dim3(gb), dim3(256), 0, s, P, state, tags, xy_e, z_e, base, sums, rowvox,
-                           (uint32_t)n, direct_only);
+                           (uint32_t)nrows, direct_only);
     }
     return hipGetLastError();
 }
@@ -2350,26 +2391,27 @@ hipError_t gvom_launch_trace(hipStream_t s, const ScanParams &P, const ShardExch
 }
 
 hipError_t gvom_launch_pack(hipStream_t s, const ScanParams &P, uint32_t *total, const uint32_t *tags, uint32_t *send_ids,
-                            void *send_pay, uint32_t *qcnt, uint32_t *ecnt, uint32_t *counters,
+                            void *send_pay, uint32_t *qcnt, uint32_t *ecnt, uint32_t *spcnt, uint32_t *counters,
                             unsigned long long *host_out, uint32_t seq)
 {
     const uint32_t slab_quads = ((uint32_t)P.shard_rows >> 2) * (uint32_t)P.zs * (uint32_t)P.nseg;
     if (P.shard_world > 1 && slab_quads > 0)
         hipLaunchKernelGGL(k_pack, dim3((slab_quads + GVOM_PACK_CHUNK - 1) / GVOM_PACK_CHUNK, (unsigned)P.shard_world - 1u),
                            dim3(256), 0, s, P, total, tags, send_ids, (uint4 *)send_pay, qcnt);
-    hipLaunchKernelGGL(k_shard_publish, dim3(1), dim3(64), 0, s, P.shard_world, qcnt, ecnt, counters, host_out, seq);
+    hipLaunchKernelGGL(k_shard_publish, dim3(1), dim3(64), 0, s, P.shard_world, qcnt, ecnt, spcnt, counters, host_out, seq);
     return hipGetLastError();
 }
 
 hipError_t gvom_launch_unpack(hipStream_t s, const ScanParams &P, const ShardUnpack &X, const uint32_t *ids_all,
                               const void *pay_all, uint32_t my_quads, uint32_t ne, const void *eps, long row_base,
-                              uint32_t *hit, uint32_t *total, uint32_t *mh, int32_t *state, uint32_t *tags)
+                              uint32_t *hit, uint32_t *total, uint32_t *mh, int32_t *state, uint32_t *tags,
+                              double *stat_sums, double *stat_base, uint32_t *stat_rowvox)
 {
     const uint32_t nq = X.q_off[P.shard_world];
     if (nq) hipLaunchKernelGGL(k_unpack_quads, dim3((nq + 3) / 4), dim3(256), 0, s, P, X, ids_all, (const uint32_t *)pay_all,
                                my_quads, total, tags);
     if (ne) hipLaunchKernelGGL(k_unpack_eps, dim3((ne + 255) / 256), dim3(256), 0, s, P, ne, (const uint2 *)eps, row_base, hit,
-                               total, mh, state, tags);
+                               total, mh, state, tags, stat_sums, stat_base, stat_rowvox);
     return hipGetLastError();
 }
 

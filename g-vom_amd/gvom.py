@@ -92,6 +92,8 @@ ABI = [
     ("gvom_shard_buffer", _I, [_P, _I, _I, ctypes.POINTER(_P), ctypes.POINTER(_I64)]),
     ("gvom_shard_recv_reserve", _I, [_P, ctypes.POINTER(_I64)]),
     ("gvom_shard_scan_merge", _I, [_P, ctypes.POINTER(_I64), ctypes.POINTER(_I64), _I]),
+    ("gvom_shard_stats_counts", _I, [_P, ctypes.POINTER(_I64)]),
+    ("gvom_shard_stats_reserve", _I, [_P, ctypes.POINTER(_I64), _I]),
     ("gvom_combine_fuse", _I, [_P, ctypes.POINTER(_I64)]),
     ("gvom_set_combined_cell_count", _I, [_P, _I64]),
     ("gvom_sync", _I, [_P]),
@@ -103,6 +105,7 @@ ABI = [
     ("gvom_comm_barrier", _I, [_P]),
     ("gvom_comm_exchange_scan", _I, [_P, _P, ctypes.POINTER(_I64), ctypes.POINTER(_I64), ctypes.POINTER(_I64),
                                      ctypes.POINTER(_I64)]),
+    ("gvom_comm_exchange_stats", _I, [_P, _P, ctypes.POINTER(_I64), ctypes.POINTER(_I64), _I]),
     ("gvom_comm_allgather_rows", _I, [_P, _P]),
     ("gvom_comm_rank", _I, [_P]),
     ("gvom_comm_world", _I, [_P]),

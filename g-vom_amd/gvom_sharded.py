@@ -43,7 +43,7 @@ import numpy as np
 
 import gvom as _gvom
 
-XBUF_SEND_IDS, XBUF_SEND_QUADS, XBUF_SEND_EPS, XBUF_RECV_IDS, XBUF_RECV_QUADS, XBUF_RECV_EPS = range(6)
+XBUF_SEND_IDS, XBUF_SEND_QUADS, XBUF_SEND_EPS, XBUF_RECV_IDS, XBUF_RECV_QUADS, XBUF_RECV_EPS, XBUF_SEND_RETURNS, XBUF_RECV_RETURNS = range(8)
 _I64P = ctypes.POINTER(ctypes.c_int64)
 
 
@@ -55,11 +55,13 @@ def _vec(values):
 class HipShardBackend(object):
     """Per-rank compute on one MI355X through the C ABI (include/gvom_hip.h, gvom_shard_* entry points)."""
 
-    def __init__(self, params, rank, world, device):
+    def __init__(self, params, rank, world, device, voxel_statistics=False):
         self.rank, self.world = rank, world
-        self.g = _gvom.Gvom(*params, device=device, _shard=(rank, world))
+        self.g = _gvom.Gvom(*params, device=device, voxel_statistics=voxel_statistics, _shard=(rank, world))
         self.lib, self.h = self.g._lib, self.g._h
         self.xy = params[2]
+        self.has_stats = bool(voxel_statistics)
+        self.dtype_code = 0                       # cloud type of the scan in flight (0 float32, 1 float64)
 
     def scan_local(self, pointcloud, ego, tf):
         """This rank's share of the scan -> (send_quads[world], send_eps[world], any_in_grid, n).
@@ -85,7 +87,17 @@ class HipShardBackend(object):
         src = ctypes.c_void_p(int(dptr)) if on_device else (_gvom._ptr(pc) if n else None)
         g._check(self.lib.gvom_shard_scan_local(self.h, src, 1 if on_device else 0, int(n), stride, code, ego_c,
                                                 _gvom._ptr(t), sq, se, ctypes.byref(any_)))
+        self.dtype_code = code
         return list(sq), list(se), int(any_.value), n
+
+    def stats_counts(self):
+        """returns this rank holds for every other rank's statistics (voxel_statistics handles)"""
+        sp = (ctypes.c_int64 * self.world)()
+        self.g._check(self.lib.gvom_shard_stats_counts(self.h, sp))
+        return list(sp)
+
+    def stats_reserve(self, recv_returns, dtype_code):
+        self.g._check(self.lib.gvom_shard_stats_reserve(self.h, _vec(recv_returns), int(dtype_code)))
 
     def recv_reserve(self, recv_eps):
         self.g._check(self.lib.gvom_shard_recv_reserve(self.h, _vec(recv_eps)))
@@ -155,6 +167,9 @@ class RcclComm(object):
 
     def allgather_rows(self, backend):
         self._check(self.lib.gvom_comm_allgather_rows(self.c, backend.h))
+
+    def exchange_stats(self, backend, send_r, recv_r, bytes_per_return):
+        self._check(self.lib.gvom_comm_exchange_stats(self.c, backend.h, _vec(send_r), _vec(recv_r), int(bytes_per_return)))
 
     def close(self):
         c, self.c = self.c, ctypes.c_void_p()
@@ -238,6 +253,18 @@ class ThreadComm(object):
         self._drain(backend)
         f.barrier.wait()                                 # nobody repacks before everyone has pulled
 
+    def exchange_stats(self, backend, send_r, recv_r, bytes_per_return):
+        f = self.f
+        f.backends[self.rank] = backend
+        backend.sync()
+        f.barrier.wait()
+        for s in range(self.world):
+            if s != self.rank and recv_r[s]:
+                self._copy(backend, backend.buffer(XBUF_RECV_RETURNS, s)[0], f.backends[s].buffer(XBUF_SEND_RETURNS, self.rank)[0],
+                           recv_r[s] * bytes_per_return)
+        self._drain(backend)
+        f.barrier.wait()
+
     def allgather_rows(self, backend):
         f = self.f
         f.backends[self.rank] = backend
@@ -259,7 +286,10 @@ class ShardedGvom(object):
     RANK'S share of the scan (any length, possibly empty); the union of the shares is one logical
     scan, and the result equals gvom.Gvom fed with the concatenated cloud, bit for bit.
 
-    keyword arguments: comm (RcclComm / ThreadComm / a test double), device, backend (test double)."""
+    keyword arguments: comm (RcclComm / ThreadComm / a test double), device, backend (test double),
+    voxel_statistics (the reference's per-voxel mean / covariance path, as gvom.Gvom's: every rank also gets the returns
+    whose neighbourhood reaches into its rows; make_debug_voxel_map() then returns THIS RANK'S voxels -- the ranks'
+    rows together are the unsharded mapper's)."""
 
     def __init__(self, *params, **kw):
         self.comm = kw.pop("comm")
@@ -271,8 +301,9 @@ class ShardedGvom(object):
                              % (self.xy_size, self.world))
         backend = kw.pop("backend", None)
         device = kw.pop("device", None)
+        stats = bool(kw.pop("voxel_statistics", False))
         if backend is None:
-            backend = HipShardBackend(params, self.rank, self.world, 0 if device is None else device)
+            backend = HipShardBackend(params, self.rank, self.world, 0 if device is None else device, stats)
         self.b = backend
         self.ego_position = [0, 0, 0]
         self._cells_dirty = False
@@ -298,7 +329,9 @@ class ShardedGvom(object):
         send_q, send_e, any_, n = self.b.scan_local(pointcloud, ego_position, transform)
         # one host-side exchange: what every rank packed for every other rank, who saw a return in
         # the grid, how many returns the scan has
-        table = self.comm.exchange_host(list(send_q) + list(send_e) + [any_, n])
+        stats = getattr(self.b, "has_stats", False) and W > 1
+        send_r = self.b.stats_counts() if stats else []
+        table = self.comm.exchange_host(list(send_q) + list(send_e) + [any_, n] + ([self.b.dtype_code] + list(send_r) if stats else []))
         recv_q = [table[s][me] if s != me else 0 for s in range(W)]
         recv_e = [table[s][W + me] if s != me else 0 for s in range(W)]
         accept = any(row[2 * W] for row in table)
@@ -308,6 +341,15 @@ class ShardedGvom(object):
         se = [send_e[d] if d != me else 0 for d in range(W)]
         self.last_exchange_bytes = (1028 * sum(sq) + 8 * sum(se), 1028 * sum(recv_q) + 8 * sum(recv_e))
         self.comm.exchange_scan(self.b, sq, se, recv_q, recv_e)      # the scan's only device exchange
+        if stats:
+            # the returns whose neighbourhood reaches into another rank's rows (statistics only: the maps do not need them)
+            codes = set(row[2 * W + 2] for row in table if row[2 * W + 1] > 0)
+            if len(codes) > 1:
+                raise ValueError("the ranks' clouds differ in type (float32 / float64)")
+            code = codes.pop() if codes else 0
+            recv_r = [table[s][2 * W + 3 + me] if s != me else 0 for s in range(W)]
+            self.b.stats_reserve(recv_r, code)
+            self.comm.exchange_stats(self.b, [send_r[d] if d != me else 0 for d in range(W)], recv_r, 12 if code == 0 else 24)
         self.b.scan_merge(recv_q, recv_e, accept)
         if me == 0:
             if total_n == 0:
@@ -315,6 +357,10 @@ class ShardedGvom(object):
             elif not accept:
                 print("[WARNING] The pointcloud points don't overlap with any voxels, nothing will happen!")
         return None
+
+    def make_debug_voxel_map(self):
+        """this rank's rows of the debug voxel cloud (gvom.py:363-378); None without voxel_statistics"""
+        return self.b.g.make_debug_voxel_map()
 
     def combine_maps(self):
         rc = self.b.combine_fuse()

@@ -26,7 +26,8 @@
 extern "C" {
 #endif
 
-#define GVOM_ABI_VERSION 3   /* 3: rank-exchange (shard) and communicator entry points, gvom_set_tuning, flags;
+#define GVOM_ABI_VERSION 4   /* 4: per-voxel statistics on sharded maps (gvom_shard_stats_*, gvom_comm_exchange_stats);
+                              * 3: rank-exchange (shard) and communicator entry points, gvom_set_tuning, flags;
                               *    2: *_into outputs column-major; occupancy and PointCloud2 entry points */
 
 /* return codes (>= 0: the reference's documented outcomes; < 0: failures) */
@@ -197,9 +198,18 @@ int gvom_shard_scan_local(gvom_t *h, const void *xyz, int on_device, int64_t n, 
 #define GVOM_XBUF_RECV_IDS   3
 #define GVOM_XBUF_RECV_QUADS 4
 #define GVOM_XBUF_RECV_EPS   5   /* valid after gvom_shard_recv_reserve                  */
+#define GVOM_XBUF_SEND_RETURNS 6 /* statistics handles: returns {x, y, z} of the cloud's type for rank `peer` */
+#define GVOM_XBUF_RECV_RETURNS 7 /* valid after gvom_shard_stats_reserve                 */
 int gvom_shard_buffer(gvom_t *h, int which, int peer, void **ptr, int64_t *capacity_bytes);
 int gvom_shard_recv_reserve(gvom_t *h, const int64_t *recv_eps);
 int gvom_shard_scan_merge(gvom_t *h, const int64_t *recv_quads, const int64_t *recv_eps, int accept);
+/* Per-voxel statistics on a sharded map (GVOM_FLAG_VOXEL_STATISTICS; 2*xy_eigen_dist + 1 <= rows per rank): a return adds
+ * to every occupied voxel of its neighbourhood (gvom.py:1188-1220), so besides the endpoints every rank gets the returns
+ * whose neighbourhood reaches into its rows: send_returns[d] after gvom_shard_scan_local, GVOM_XBUF_SEND_RETURNS ->
+ * the peers' GVOM_XBUF_RECV_RETURNS (gvom_comm_exchange_stats) sized by gvom_shard_stats_reserve, before
+ * gvom_shard_scan_merge.  All ranks must pass clouds of one type (float32 or float64). */
+int gvom_shard_stats_counts(gvom_t *h, int64_t *send_returns);
+int gvom_shard_stats_reserve(gvom_t *h, const int64_t *recv_returns, int dtype /* GVOM_DTYPE_*: the scan's cloud type */);
 int gvom_combine_fuse(gvom_t *h, int64_t *local_cells);
 int gvom_set_combined_cell_count(gvom_t *h, int64_t global_cells);
 #define GVOM_BUF_HEIGHT_MAPS  0   /* [sy][height row | inferred-height row | positive-density row], f64 */
@@ -222,6 +232,8 @@ int  gvom_comm_exchange_host(gvom_comm_t *c, const int64_t *mine, int k, int64_t
 int  gvom_comm_barrier(gvom_comm_t *c);
 int  gvom_comm_exchange_scan(gvom_comm_t *c, gvom_t *h, const int64_t *send_quads, const int64_t *send_eps,
                              const int64_t *recv_quads, const int64_t *recv_eps);
+int  gvom_comm_exchange_stats(gvom_comm_t *c, gvom_t *h, const int64_t *send_returns, const int64_t *recv_returns,
+                              int bytes_per_return);
 int  gvom_comm_allgather_rows(gvom_comm_t *c, gvom_t *h);
 int  gvom_comm_rank(gvom_comm_t *c);
 int  gvom_comm_world(gvom_comm_t *c);

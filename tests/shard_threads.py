@@ -7,14 +7,15 @@ import threading
 import gvom_sharded
 
 
-def run_ranks(world, params, body, device=0):
-    """body(rank, sharded_gvom) -> result; returns [result per rank]; re-raises the first failure."""
+def run_ranks(world, params, body, device=0, **kw):
+    """body(rank, sharded_gvom) -> result; returns [result per rank]; re-raises the first failure.
+    kw: further keyword arguments of ShardedGvom (voxel_statistics=True, ...)."""
     fabric = gvom_sharded.ThreadFabric(world)
     results, errors = [None] * world, [None] * world
 
     def worker(r):
         try:
-            sh = gvom_sharded.ShardedGvom(*params, comm=fabric.comm(r), device=device)
+            sh = gvom_sharded.ShardedGvom(*params, comm=fabric.comm(r), device=device, **kw)
             results[r] = body(r, sh)
         except BaseException as e:          # noqa: BLE001 -- reported to the caller below
             errors[r] = e

@@ -56,6 +56,55 @@ def test_sharded_map_equals_single_handle_over_a_moving_window(world):
         assert run_ranks(world, params, body) == [True] * world
 
 
+@pytest.mark.parametrize("world,dtype", [(2, np.float32), (4, np.float32), (4, np.float64)])
+def test_sharded_voxel_statistics_equal_the_unsharded_handle(world, dtype):
+    """SURVEY 8f rank 2 on a sharded map ("absent on sharded handles"): with voxel_statistics=True every rank
+    also receives the returns whose 27-voxel neighbourhood reaches into its rows, and make_debug_voxel_map() returns the
+    rank's own voxels.  The ranks' rows together must be the unsharded mapper's debug cloud -- positions, hit counts and
+    solid factors exactly, eigenvalue columns to the tolerance of the other statistics tests (float accumulation order is
+    unspecified on both sides) -- over a moving window with ragged shares, and the returned maps stay bit-identical."""
+    import gvom
+    import synth
+    from shard_threads import run_ranks
+    params = (0.2, 0.2, 64, 32, 2, 1.0, 0.5, 0.5, 0.3, 2.0, 4.0, 1.0, 1, 1)
+    scene = synth.make_scene(2, extent=5.5)
+    steps = []
+    for k in range(4):
+        ego = (0.5 * k, -0.35 * k, 0.04 * k)
+        shares = [synth.lidar_scan(scene, beams=16, azimuths=512, sensor=ego, yaw=0.002 * r, noise_seed=10 * k + r, dtype=dtype)[:8192 - 701 * r]
+                  for r in range(world)]
+        if k == 1:
+            shares[1] = shares[1][:0]                            # a rank without returns in this scan
+        steps.append((shares, ego))
+    steps.insert(3, ([sh + dtype(900.0) for sh in steps[2][0]], steps[2][1]))       # a scan every rank rejects (gvom.py:147-150)
+    ref = gvom.Gvom(*params, voxel_statistics=True)
+    want = []
+    for shares, ego in steps:
+        ref.process_pointcloud(np.concatenate(shares, 0), ego)
+        maps = ref.combine_maps()
+        want.append((maps, ref.make_debug_voxel_map()))
+    assert want[-1][1] is not None and want[-1][1].shape[0] > 500
+
+    def body(r, sh):
+        parts = []
+        for (shares, ego), (wmaps, _) in zip(steps, want):
+            sh.process_pointcloud(shares[r], ego)
+            got = sh.combine_maps()
+            for a, b in zip(got, wmaps):
+                assert np.array_equal(a, b)
+            parts.append(np.array(sh.make_debug_voxel_map(), copy=True))
+        return parts
+
+    parts = run_ranks(world, params, body, voxel_statistics=True)
+    for k, (_, wcloud) in enumerate(want):
+        got = np.concatenate([parts[r][k] for r in range(world)], 0)
+        assert got.shape == wcloud.shape, (k, got.shape, wcloud.shape)
+        g = got[np.lexsort((got[:, 2], got[:, 1], got[:, 0]))]
+        w = wcloud[np.lexsort((wcloud[:, 2], wcloud[:, 1], wcloud[:, 0]))]
+        assert np.array_equal(g[:, :5], w[:, :5]), "step %d: positions / solid factor / hit count" % k
+        np.testing.assert_allclose(g[:, 5:], w[:, 5:], rtol=1e-4, atol=2e-5, err_msg="step %d: eigenvalue columns" % k)
+
+
 @pytest.mark.parametrize("cfg,worlds,scans,buffer", [("c2", "4,8", "3", "1"), ("c4", "4", "6", "4")])
 def test_sharded_map_at_full_size(cfg, worlds, scans, buffer):
     """tests/fuzz/shard_big.py: the weak-scaling clouds of the bench on the c2 grid (4 and 8 ranks x
