@@ -302,6 +302,7 @@ def run_config(hip, name, steps, warmup, poses, full):
     b3, k = timed_blocks(step_ros, k, steps, 0.2)
     out["value_ros_f64_tf"] = n_pts * steps / _median(b3) / 1e6
     out.update(ros_two_threads(g, scans64, n_pts))
+    out.update(ros_two_threads(g, scans64, n_pts, paced=True))
 
     # combine_maps_occupancy (combine + the ROS node's post-processing on the GPU, 5 B/cell over PCIe)
     def step_occ(k):
@@ -355,14 +356,16 @@ def run_config(hip, name, steps, warmup, poses, full):
     return out, (alg, stages, params, scans)
 
 
-def ros_two_threads(g, scans64, n_pts, min_s=0.6):
+def ros_two_threads(g, scans64, n_pts, min_s=0.6, paced=False):
     """The node's real calling pattern (gvom_ros.py:61-62, 82-115): a lidar thread hands float64 clouds + a 4x4 transform
-    to process_pointcloud while a timer thread calls combine_maps on the same mapper, both as fast as they can.  The
-    upload of scan k + 1 and its trace overlap the maps of combine k (ctypes drops the GIL around the library calls)."""
+    to process_pointcloud while a timer thread calls combine_maps on the same mapper.  paced = False: both as fast as
+    they can (the timer then combines about twice per scan); paced = True: the timer combines once per new scan, so
+    the upload and the trace of scan k + 1 overlap the maps of combine k (ctypes drops the GIL around the library calls)."""
     import threading
     stop = threading.Event()
     n = {"scans": 0, "maps": 0}
     err = []
+    sfx = "_paced" if paced else ""
 
     def lidar():
         k = 0
@@ -376,8 +379,14 @@ def ros_two_threads(g, scans64, n_pts, min_s=0.6):
             err.append(e)
 
     def timer():
+        seen = 0
         try:
             while not stop.is_set():
+                if paced:
+                    if n["scans"] == seen:
+                        time.sleep(0)                   # (yield: the lidar thread holds the GIL only between its calls)
+                        continue
+                    seen = n["scans"]
                 if g.combine_maps() is not None:
                     n["maps"] += 1
         except Exception as e:                          # pragma: no cover
@@ -395,8 +404,9 @@ def ros_two_threads(g, scans64, n_pts, min_s=0.6):
         t.join(30)
     if err:
         raise err[0]
-    return {"value_ros_two_threads": (s1 - s0) * n_pts / (t1 - t0) / 1e6, "scans_per_s_ros_two_threads": (s1 - s0) / (t1 - t0),
-            "maps_per_s_ros_two_threads": (m1 - m0) / (t1 - t0)}
+    return {"value_ros_two_threads" + sfx: (s1 - s0) * n_pts / (t1 - t0) / 1e6,
+            "scans_per_s_ros_two_threads" + sfx: (s1 - s0) / (t1 - t0),
+            "maps_per_s_ros_two_threads" + sfx: (m1 - m0) / (t1 - t0)}
 
 
 def step_roofline(alg, res, config):
@@ -510,7 +520,7 @@ def run_single(args):
         "value_semantics": "value: cloud resident in HBM (driver contract); value_host_f32: host numpy in (gvom.py:110); "
                            "value_ros_f64_tf: float64 host array + 4x4 transform, the unchanged gvom_ros.py:106-109 path, one thread; "
                            "value_ros_two_threads: the same inputs from a lidar thread while a timer thread calls combine_maps "
-                           "(the node's two callbacks, gvom_ros.py:61-62, 113-115), both free-running; "
+                           "(the node's two callbacks, gvom_ros.py:61-62, 113-115), both free-running (_paced: one combine per new scan); "
                            "value_async_combine: combine_maps_async() (extension), the next scan traced while the maps "
                            "of the pending combine are stored to host memory -- same maps, one step later",
         "stage_ms": res["stage_ms"], "host_us": res["host_us"],
@@ -520,6 +530,7 @@ def run_single(args):
     out["roofline"]["step"] = step_roofline(alg, res, name)
     for key in ("value_ros_two_threads", "scans_per_s_ros_two_threads", "maps_per_s_ros_two_threads"):
         out[key] = res[key]
+        out[key + "_paced"] = res[key + "_paced"]
     if not args.no_extra:
         st = run_with_statistics(hip, name, min(steps, 200), min(args.warmup, 40), poses)
         out["value_with_statistics"] = st["value"]

@@ -1,0 +1,14 @@
+#!/bin/bash
+# The randomised campaigns outside the suite, on the final library (one line each into the log).  Usage: tools/campaigns.sh <logfile> [which...]
+LOG=${1:-gpurun_out/campaigns.txt}; shift
+: > $LOG
+run() { echo "== $*" | tee -a $LOG; timeout -k 10 1000 "$@" 2>&1 | tail -n 4 | tee -a $LOG; }
+for W in ${@:-many mid shard stats}; do
+  case $W in
+    many)  run python3 tests/fuzz/fuzz_many.py 1000 3000 ;;
+    mid)   run python3 tests/fuzz/fuzz_mid.py 0 300 ;;
+    shard) for rep in 1 2 3; do run python3 tests/fuzz/fuzz_shard.py 70000 3000; done ;;
+    shard1) run python3 tests/fuzz/fuzz_shard.py 70000 3000 ;;
+    stats) run python3 tests/fuzz/fuzz_many.py 5000 300 stats ;;
+  esac
+done
