@@ -564,7 +564,7 @@ def spawn_ranks(args):
         ndev = int(probe.stdout.strip().splitlines()[-1])
     except Exception:
         ndev = 0
-    if ndev < args.gpus:
+    if ndev < (1 if args.share_device else args.gpus):
         sys.stderr.write("bench.py: --gpus %d, but %d HIP device(s) are visible\n" % (args.gpus, ndev))
         sys.exit(2)
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
@@ -597,6 +597,12 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the short runs of the other configs")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--transport", default="auto", choices=["auto", "rccl", "peer"],
+                    help="N > 1: device data between the ranks over RCCL, by peer copies (exported regions pulled with "
+                         "hipMemcpyAsync), or RCCL with peer copies as the fallback when RCCL cannot initialise (default)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="N > 1 REHEARSAL on a box with fewer GPUs: every rank uses device 0 (peer copies; RCCL refuses it). "
+                         "The line says so; it is not a scaling measurement")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "0"))
     if args.gpus > 1 and world == 0:

@@ -171,6 +171,8 @@ def run(args):
     ndev = hip.device_count()
     if ndev < 1:
         raise RuntimeError("rank %d sees no HIP device" % rank)
+    if args.share_device:                             # rehearsal: all ranks on one GPU
+        local_rank = 0
     if local_rank >= ndev:                            # a launcher that shows every rank only its own GPU
         if os.environ.get("HIP_VISIBLE_DEVICES") is None and os.environ.get("ROCR_VISIBLE_DEVICES") is None and ndev < world:
             raise RuntimeError("rank %d: %d ranks but only %d HIP device(s) visible" % (rank, world, ndev))
@@ -184,7 +186,8 @@ def run(args):
         pc, pose = make_share(name, rank, world, k)
         scans.append(((hip.to_device(pc).value, pc.shape[0], pc.dtype), pose))
     n_local = scans[0][0][1]
-    rccl = gvom_sharded.RcclComm(rank, world, local_rank, gvom_sharded.rendezvous_name())
+    rccl = gvom_sharded.RcclComm(rank, world, local_rank, gvom_sharded.rendezvous_name(),
+                                 transport="peer" if args.share_device else args.transport)
     comm = ExchangeTimer(rccl, hip)
     sh = gvom_sharded.ShardedGvom(*params, comm=comm, device=local_rank)
     big = name in ("c4", "c5")
@@ -255,9 +258,14 @@ def run(args):
                        "grid": [params[2], params[2], params[3]], "buffer_size": params[4], "poses": poses,
                        "input": "device-resident f32 xyz", "host_affinity_rank0": affinity,
                        "timing": "median of %d blocks of %d steps, max over ranks" % (len(blocks), steps),
-                       "exchange": "per scan: sparse all-to-all of dirty accumulator quads (1 KiB + id) and endpoints (8 B), "
-                                   "grouped ncclSend/ncclRecv; per combine: in-place ncclAllGather of height|inferred|density "
-                                   "rows (24 B/cell); counts through shared memory"},
+                       "exchange": "per scan: sparse all-to-all of dirty accumulator quads (1 KiB + id) and endpoints (8 B); "
+                                   "per combine: in-place all-gather of height|inferred|density rows (24 B/cell); counts "
+                                   "through shared memory; transport: see \"transport\""},
+            "transport": {"rccl": "RCCL (grouped ncclSend/ncclRecv, ncclAllGather)",
+                          "peer": "peer copies (exported regions, hipMemcpyAsync pulled by the receiver, two host barriers per exchange)"}[rccl.transport]
+                         + ("" if args.transport != "auto" or rccl.transport == "rccl" or args.share_device else " -- RCCL could not initialise"),
+            "rehearsal_on_one_device": bool(args.share_device),
+            "peer_transport_rank0": rccl.peer_stats() if rccl.transport == "peer" else None,
             "map_hz": steps / med, "blocks": len(blocks),
             "ms_per_step_min": min(blocks) / steps * 1e3, "ms_per_step_max": max(blocks) / steps * 1e3,
             "stage_ms_rank0": stage_ms,
@@ -266,8 +274,8 @@ def run(args):
                                        "exchange_scan_ms": row[2] * 1e-6, "allgather_rows_ms": row[3] * 1e-6}
                                       for r, row in enumerate(table)],
                          "slowest_rank_wire_GBs": (max(worst[0], worst[1]) / (worst[2] * 1e-9) / 1e9) if worst[2] else None,
-                         "note": "HIP events on the handle's stream around the grouped ncclSend/ncclRecv and the "
-                                 "ncclAllGather (they include the wait for the slowest peer); bytes = quads x 1028 + endpoints x 8"},
+                         "note": "HIP events on the handle's stream around the scan's exchange and the combine's all-gather "
+                                 "(they include the wait for the slowest peer); bytes = quads x 1028 + endpoints x 8"},
             "roofline": {"bound": "hbm", "kernel": "k_trace", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0 if achieved else None, "traffic": None,
                          "avg_launch_ms": tr_ms, "algorithmic_bytes_per_launch": trace_alg["bytes"] if trace_alg else None,

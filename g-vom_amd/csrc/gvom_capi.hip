@@ -20,6 +20,7 @@
 #include <unistd.h>
 #include <immintrin.h>
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -77,6 +78,7 @@ struct gvom_handle {
     uint32_t *hit = nullptr, *total = nullptr, *mh = nullptr;   // dense accumulators (hit, ray passes, min-height), zero between scans
     size_t acc_elems = 0;
     int tune_segs = 0, tune_ep_row = -2, tune_period = 0; // gvom_set_tuning (0 / -2: automatic)
+    uint64_t alloc_gen = 0;                             // changes whenever a send region of this handle is re-allocated
     // rank exchange of a sharded map (world > 1): send / receive regions, indexed by peer rank
     uint32_t *x_send_ids = nullptr, *x_recv_ids = nullptr;     // quad ids: [Q] by owner / [world][myQ] by source
     void *x_send_pay = nullptr, *x_recv_pay = nullptr;         // 1 KiB per quad, same indexing
@@ -194,6 +196,9 @@ inline double now_ns() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return 
         }                                                                                       \
     } while (0)
 
+// (process-wide: a value names one state of one handle's allocations -- gvom_alloc_generation)
+static std::atomic<uint64_t> g_alloc_generation{0};
+
 int ensure(gvom_handle *h, Buf &b, size_t bytes)
 {
     if (b.bytes >= bytes) return GVOM_OK;
@@ -202,6 +207,7 @@ int ensure(gvom_handle *h, Buf &b, size_t bytes)
     b.p = nullptr; b.bytes = 0;
     HIPCHK(h, hipMalloc(&b.p, want));
     b.bytes = want;
+    if (&b == &h->x_send_eps || &b == &h->x_send_sp) h->alloc_gen = ++g_alloc_generation;   // (see gvom_alloc_generation)
     return GVOM_OK;
 }
 
@@ -306,6 +312,7 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, b
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev)
         return GVOM_ERR_NO_DEVICE;
     gvom_handle *h = new gvom_handle();
+    h->alloc_gen = ++g_alloc_generation;
     h->prm = *params;
     h->device = device_id;
     h->rank = rank; h->world = world; h->sharded = sharded;
@@ -1886,6 +1893,11 @@ VIS int gvom_set_profiling(gvom_t *h, int on)
 }
 
 VIS void *gvom_stream(gvom_t *h) { return h ? (void *)h->stream : nullptr; }
+// A value that differs between any two handles of the process and changes whenever one of the handle's SEND regions
+// (gvom_shard_buffer GVOM_XBUF_SEND_*; the only grow-only buffers another rank ever reads) has been re-allocated:
+// whoever caches something derived from their addresses (the peer transport's exported allocations) knows when to
+// look again.  (GVOM_BUF_HEIGHT_MAPS and the quad regions are allocated once, with the handle.)
+VIS uint64_t gvom_alloc_generation(gvom_t *h) { return h ? h->alloc_gen : 0; }
 
 VIS const char *gvom_last_error(gvom_t *h) { return h ? h->err.c_str() : "null handle"; }
 

@@ -4,6 +4,12 @@
 //   * device data: grouped ncclSend / ncclRecv (the scan's quads and endpoints: a sparse all-to-all
 //     whose sizes are only known after the trace) and an in-place ncclAllGather (the combine's
 //     height-map rows), on the LIBRARY's stream -- no host synchronisation in between;
+//   * device data, second transport (GVOM_TRANSPORT_PEER): PEER COPIES -- every rank exports its send regions
+//     (hipIpcGetMemHandle; handles and per-destination offsets travel through the shared-memory segment), the
+//     receiver maps them once (hipIpcOpenMemHandle, lazy peer access) and PULLS its bytes with hipMemcpyAsync on
+//     its own handle's stream: over xGMI between the GPUs of a node, inside one GPU's memory when several ranks
+//     share a device.  No RCCL involved: it is what a one-GPU box can run with several rank PROCESSES (RCCL
+//     refuses two ranks on one device), and what GVOM_TRANSPORT_AUTO falls back to when RCCL cannot initialise;
 //   * host data: the ranks are the processes of ONE node, so the small per-scan vectors (counts,
 //     in-grid flags) and the ncclUniqueId travel through a POSIX shared-memory segment
 //     (/dev/shm/<name>): ~1 us, no GPU involved.  Double-buffered slots, sequence numbers, C11 atomics.
@@ -70,6 +76,14 @@ struct Slot {                                  // one rank's mailbox for one exc
     char pad[64];
 };
 
+#define GVOM_PEER_KINDS 5                   // exported regions: send ids, send quads, send endpoints, send returns, height-map rows
+struct PeerExport {                            // one exported region of one rank (peer transport)
+    hipIpcMemHandle_t handle;                  // of the ALLOCATION the region lies in
+    uint64_t generation;                       // changes whenever `handle` does (0: nothing exported yet)
+    uint64_t size;                             // of the allocation
+    uint64_t offset[GVOM_COMM_MAX_RANKS];      // byte offset, inside the allocation, of the part meant for rank d
+};
+
 struct Segment {                               // the shared-memory rendezvous of one communicator
     std::atomic<uint32_t> magic;               // set last by rank 0
     uint32_t world;
@@ -79,7 +93,13 @@ struct Segment {                               // the shared-memory rendezvous o
     int64_t creator_pid;                       // rank 0's process and its start time (/proc/<pid>/stat field 22): a joiner only
     uint64_t creator_start;                    // attaches to a segment whose creator is ALIVE -- a crashed job's is not
     ncclUniqueId id;
+    // (the fields above keep their offsets: tests/test_comm_rendezvous.py writes stale segments byte by byte)
+    std::atomic<uint32_t> rccl_failed;         // GVOM_TRANSPORT_AUTO: ranks whose ncclCommInitRank failed
+    std::atomic<uint32_t> poison;              // rank + 1 of a rank whose device exchange failed: nobody waits for it again
+    int64_t rank_pid[GVOM_COMM_MAX_RANKS];     // the ranks' processes (0 until attached), so that a wait for a rank that has
+    uint64_t rank_start[GVOM_COMM_MAX_RANKS];  // died ends in an error at once instead of after the timeout
     Slot slots[2][GVOM_COMM_MAX_RANKS];
+    PeerExport exports[GVOM_COMM_MAX_RANKS][GVOM_PEER_KINDS];   // written by their rank between two barriers only
 };
 
 inline double now_s() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + t.tv_nsec * 1e-9; }
@@ -104,6 +124,23 @@ uint64_t proc_start_time(int64_t pid)
     }
     return 0;
 }
+// a process that can still take part in an exchange: it exists, is the one recorded (start time) and is not a zombie
+bool proc_running(int64_t pid, uint64_t start)
+{
+    if (pid <= 0) return true;                                         // unknown: assume so
+    char path[64], buf[1024];
+    snprintf(path, sizeof path, "/proc/%lld/stat", (long long)pid);
+    FILE *f = fopen(path, "r");
+    if (!f) return kill((pid_t)pid, 0) == 0 || errno == EPERM;         // (no /proc: the pid test alone)
+    const size_t n = fread(buf, 1, sizeof buf - 1, f);
+    fclose(f);
+    buf[n] = 0;
+    const char *p = strrchr(buf, ')');
+    if (!p || !p[1] || !p[2]) return true;
+    if (p[2] == 'Z' || p[2] == 'X' || p[2] == 'x') return false;
+    const uint64_t st = proc_start_time(pid);
+    return st == 0 || start == 0 || st == start;
+}
 bool creator_alive(const Segment *sg)
 {
     const int64_t pid = sg->creator_pid;
@@ -115,10 +152,25 @@ bool creator_alive(const Segment *sg)
 
 }  // namespace
 
+struct PeerImport {                            // a peer's exported allocation, mapped into this process
+    uint64_t generation = 0;
+    void *base = nullptr;
+};
+struct PeerOwn {                               // what this rank has exported of one kind
+    void *base = nullptr;
+    size_t size = 0;
+    uint64_t alloc_gen = ~0ull;
+};
+
 struct gvom_comm {
     int rank = 0, world = 1, device = 0;
+    int transport = GVOM_TRANSPORT_RCCL;       // the one in use (never AUTO)
     Rccl rccl;
     ncclComm_t nccl = nullptr;
+    PeerImport imports[GVOM_COMM_MAX_RANKS][GVOM_PEER_KINDS];
+    PeerOwn own[GVOM_PEER_KINDS];
+    uint64_t peer_bytes = 0, peer_copies = 0;  // pulled so far (diagnostics)
+    uint64_t export_seq = 0, peer_open_retries = 0;
     Segment *seg = nullptr;
     std::string shm_name, err;
     uint64_t calls = 0;                        // host exchanges so far
@@ -138,6 +190,121 @@ namespace {
         }                                                                                      \
     } while (0)
 
+#define HIPCHK_C(c, call)                                                                      \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            (c)->err = std::string(#call) + " failed: " + hipGetErrorString(e_);               \
+            return GVOM_ERR_HIP;                                                               \
+        }                                                                                      \
+    } while (0)
+
+// ---- peer transport -------------------------------------------------------------------------------
+// Publishes the allocation that holds the regions `ptr[d]` (d != rank; null entries: nothing for d) as export `kind`
+// of this rank: handle of the allocation + the regions' offsets inside it.  The handle is taken again only when the
+// handle's buffers have been re-allocated since (gvom_alloc_generation).  Call between two barriers' worth of quiet:
+// readers look at the export only after the barrier that follows.
+int peer_publish(gvom_comm *c, gvom_t *h, int kind, void *const *ptr)
+{
+    PeerExport &e = c->seg->exports[c->rank][kind];
+    void *any = nullptr;
+    for (int d = 0; d < c->world; ++d) if (d != c->rank && ptr[d]) { any = ptr[d]; break; }
+    if (!any) return GVOM_OK;                                          // nothing of this kind goes anywhere
+    void *base = nullptr;
+    size_t size = 0;
+    HIPCHK_C(c, hipMemGetAddressRange((hipDeviceptr_t *)&base, &size, (hipDeviceptr_t)any));
+    PeerOwn &o = c->own[kind];
+    const uint64_t gen = gvom_alloc_generation(h);
+    if (o.base != base || o.size != size || o.alloc_gen != gen) {
+        hipIpcMemHandle_t hd;
+        HIPCHK_C(c, hipIpcGetMemHandle(&hd, base));
+        memcpy(&e.handle, &hd, sizeof hd);
+        e.generation = ((uint64_t)(c->rank + 1) << 48) | ++c->export_seq;
+        e.size = size;
+        o.base = base; o.size = size; o.alloc_gen = gen;
+    }
+    for (int d = 0; d < c->world; ++d) {
+        if (d == c->rank || !ptr[d]) { e.offset[d] = ~0ull; continue; }
+        const size_t off = (size_t)((char *)ptr[d] - (char *)base);
+        if ((char *)ptr[d] < (char *)base || off >= size) { c->err = "exchange regions of one kind lie in different allocations"; return GVOM_ERR_INVALID; }
+        e.offset[d] = off;
+    }
+    return GVOM_OK;
+}
+
+// Address, in this process, of what rank s exported as `kind` for this rank (mapped on first use and whenever s has
+// exported a new allocation).
+int peer_source(gvom_comm *c, int s, int kind, void **src)
+{
+    const PeerExport &e = c->seg->exports[s][kind];
+    PeerImport &im = c->imports[s][kind];
+    if (e.generation == 0 || e.offset[c->rank] == ~0ull) { c->err = "a peer announced data it has not exported"; return GVOM_ERR_INVALID; }
+    if (im.generation != e.generation) {
+        if (im.base) { (void)hipIpcCloseMemHandle(im.base); im.base = nullptr; im.generation = 0; }
+        hipIpcMemHandle_t hd;
+        memcpy(&hd, &e.handle, sizeof hd);
+        // (the exporter hands its allocation over through a helper thread of the HSA runtime that starts with its FIRST
+        // export; a peer that asks in the same millisecond can be too early -- seen once in ~20 first exchanges with four
+        // rank processes: "invalid device pointer" -- so a refusal is asked again a few times before it counts)
+        hipError_t oe = hipSuccess;
+        for (int attempt = 0; attempt < 50; ++attempt) {
+            oe = hipIpcOpenMemHandle(&im.base, hd, hipIpcMemLazyEnablePeerAccess);
+            if (oe == hipSuccess) break;
+            (void)hipGetLastError();
+            ++c->peer_open_retries;
+            usleep(2000 + 1000 * attempt);
+        }
+        if (oe != hipSuccess) {
+            im.base = nullptr;
+            c->err = "hipIpcOpenMemHandle failed (" + std::string(hipGetErrorString(oe)) + "): export " + std::to_string(kind) +
+                     " of rank " + std::to_string(s) + ", " + std::to_string(e.size) + " bytes, generation " +
+                     std::to_string(e.generation & 0xffffffffffffull);
+            return GVOM_ERR_HIP;
+        }
+        im.generation = e.generation;
+    }
+    *src = (char *)im.base + e.offset[c->rank];
+    return GVOM_OK;
+}
+
+struct PeerPull { int kind, recv_which; int64_t unit; const int64_t *recv_counts; };
+
+// One exchange by peer copies: every rank has published its regions (peer_publish); barrier; every rank pulls what
+// the others hold for it -- hipMemcpyAsync on ITS OWN handle's stream, the ordering ncclRecv on that stream gives --
+// and waits for its copies; barrier (the senders may rewrite their regions).
+int peer_pull(gvom_comm *c, gvom_t *h, hipStream_t st, const PeerPull *pulls, int n_pulls)
+{
+    HIPCHK_C(c, hipStreamSynchronize(st));                             // what I export is complete
+    int rc = gvom_comm_barrier(c);
+    if (rc) return rc;
+    for (int s = 0; s < c->world && rc == GVOM_OK; ++s) {
+        if (s == c->rank) continue;
+        for (int k = 0; k < n_pulls && rc == GVOM_OK; ++k) {
+            const int64_t cnt = pulls[k].recv_counts[s];
+            if (cnt < 0) { c->err = "negative count"; rc = GVOM_ERR_INVALID; break; }
+            if (cnt == 0) continue;
+            const size_t bytes = (size_t)cnt * (size_t)pulls[k].unit;
+            void *dst = nullptr, *src = nullptr;
+            int64_t cap = 0;
+            if (gvom_shard_buffer(h, pulls[k].recv_which, s, &dst, &cap) || (int64_t)bytes > cap) {
+                c->err = "exchange region missing or smaller than the announced count";
+                rc = GVOM_ERR_INVALID;
+                break;
+            }
+            if ((rc = peer_source(c, s, pulls[k].kind, &src))) break;
+            const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, st);
+            if (e != hipSuccess) { c->err = std::string("hipMemcpyAsync (peer copy) failed: ") + hipGetErrorString(e); rc = GVOM_ERR_HIP; break; }
+            c->peer_bytes += bytes; ++c->peer_copies;
+        }
+    }
+    // (even a failed rank passes the second barrier: the others would wait for it for ever)
+    const hipError_t se = hipStreamSynchronize(st);
+    const int rb = gvom_comm_barrier(c);
+    if (rc) return rc;
+    if (se != hipSuccess) { c->err = std::string("hipStreamSynchronize failed: ") + hipGetErrorString(se); return GVOM_ERR_HIP; }
+    return rb;
+}
+
 }  // namespace
 
 extern "C" {
@@ -148,12 +315,19 @@ extern "C" {
 // device < 0: HOST-ONLY communicator -- the shared-memory rendezvous and gvom_comm_exchange_host /
 // gvom_comm_barrier without RCCL or any HIP call (the CPU tests exercise the multi-process rendezvous
 // with it); the device collectives return GVOM_ERR_INVALID on it.
-VIS int gvom_comm_create(int rank, int world, int device, const char *name, gvom_comm_t **out)
+// transport: GVOM_TRANSPORT_RCCL (grouped ncclSend / ncclRecv + ncclAllGather), GVOM_TRANSPORT_PEER (peer copies through
+// exported allocations: see the head of this file) or GVOM_TRANSPORT_AUTO (RCCL; if RCCL cannot be loaded or
+// ncclCommInitRank fails on ANY rank, every rank uses peer copies -- gvom_comm_transport says which it became).
+VIS int gvom_comm_create2(int rank, int world, int device, const char *name, int transport, gvom_comm_t **out)
 {
     if (!out || !name || world < 1 || world > GVOM_COMM_MAX_RANKS || rank < 0 || rank >= world) return GVOM_ERR_INVALID;
+    if (transport != GVOM_TRANSPORT_RCCL && transport != GVOM_TRANSPORT_PEER && transport != GVOM_TRANSPORT_AUTO) return GVOM_ERR_INVALID;
     *out = nullptr;
     gvom_comm *c = new gvom_comm();
     c->rank = rank; c->world = world; c->device = device;
+    c->transport = transport == GVOM_TRANSPORT_PEER ? GVOM_TRANSPORT_PEER : GVOM_TRANSPORT_RCCL;
+    const bool want_rccl = transport != GVOM_TRANSPORT_PEER, may_fall_back = transport == GVOM_TRANSPORT_AUTO;
+    bool rccl_ok = want_rccl;                                          // (this rank's view)
     c->shm_name = std::string("/") + name;
     if (const char *t = getenv("GVOM_COMM_TIMEOUT_S")) { const double v = atof(t); if (v > 0.0) c->timeout_s = v; }
     bool created = false;                                              // rank 0: the name exists and is ours
@@ -166,7 +340,11 @@ VIS int gvom_comm_create(int rank, int world, int device, const char *name, gvom
     };
     const bool host_only = device < 0;
     if (!host_only) {
-        if (!c->rccl.load(c->err)) return fail(c->err, GVOM_ERR_NO_DEVICE);
+        if (want_rccl && !c->rccl.load(c->err)) {
+            if (!may_fall_back) return fail(c->err, GVOM_ERR_NO_DEVICE);
+            fprintf(stderr, "gvom_comm_create(rank %d of %d): %s -- falling back to peer copies\n", rank, world, c->err.c_str());
+            rccl_ok = false;
+        }
         if (hipSetDevice(device) != hipSuccess) return fail("hipSetDevice failed", GVOM_ERR_NO_DEVICE);
     }
     if (rank == 0) {
@@ -183,7 +361,12 @@ VIS int gvom_comm_create(int rank, int world, int device, const char *name, gvom
         c->seg->created_s = wall_s();
         c->seg->creator_pid = (int64_t)getpid();
         c->seg->creator_start = proc_start_time((int64_t)getpid());
-        if (!host_only && c->rccl.GetUniqueId(&c->seg->id) != ncclSuccess) return fail("ncclGetUniqueId failed", GVOM_ERR_HIP);
+        if (!host_only && rccl_ok && c->rccl.GetUniqueId(&c->seg->id) != ncclSuccess) {
+            if (!may_fall_back) return fail("ncclGetUniqueId failed", GVOM_ERR_HIP);
+            rccl_ok = false;
+        }
+        // (AUTO: a rank 0 without RCCL says so BEFORE the others could try ncclCommInitRank on an id that was never made)
+        if (!host_only && want_rccl && !rccl_ok) c->seg->rccl_failed.fetch_add(1, std::memory_order_acq_rel);
         c->seg->id_ready.store(1, std::memory_order_release);
         c->seg->magic.store(0x47564f4du, std::memory_order_release);
     } else {
@@ -226,22 +409,55 @@ VIS int gvom_comm_create(int rank, int world, int device, const char *name, gvom
         }
         if (c->seg->world != (uint32_t)world) return fail("world size differs from rank 0's", GVOM_ERR_INVALID);
     }
-    if (!host_only) {
-        ncclUniqueId id;
-        memcpy(&id, &c->seg->id, sizeof id);
-        ncclResult_t r = c->rccl.CommInitRank(&c->nccl, world, id, rank);
-        if (r != ncclSuccess) return fail(std::string("ncclCommInitRank failed: ") + c->rccl.GetErrorString(r), GVOM_ERR_HIP);
+    if (!host_only && want_rccl) {
+        if (rank != 0 && !rccl_ok) c->seg->rccl_failed.fetch_add(1, std::memory_order_acq_rel);     // (rank 0 has counted itself)
+        // nobody joins a communicator that some rank is already known to be missing from
+        if (rccl_ok && !(may_fall_back && c->seg->rccl_failed.load(std::memory_order_acquire) != 0u)) {
+            ncclUniqueId id;
+            memcpy(&id, &c->seg->id, sizeof id);
+            ncclResult_t r = c->rccl.CommInitRank(&c->nccl, world, id, rank);
+            if (r != ncclSuccess) {
+                c->nccl = nullptr;
+                const std::string why = std::string("ncclCommInitRank failed: ") + c->rccl.GetErrorString(r);
+                if (!may_fall_back) return fail(why, GVOM_ERR_HIP);
+                fprintf(stderr, "gvom_comm_create(rank %d of %d): %s -- falling back to peer copies\n", rank, world, why.c_str());
+                c->seg->rccl_failed.fetch_add(1, std::memory_order_acq_rel);
+            }
+        }
     }
+    c->seg->rank_start[rank] = proc_start_time((int64_t)getpid());
+    c->seg->rank_pid[rank] = (int64_t)getpid();
     // the name can go once everybody is attached (the mapping stays valid)
     if (c->seg->attached.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint32_t)world) shm_unlink(c->shm_name.c_str());
+    if (!host_only && may_fall_back) {
+        // every rank has tried by the time this barrier is passed: one failure anywhere -> peer copies everywhere
+        if (gvom_comm_barrier(c) != GVOM_OK) return fail("rendezvous barrier: " + c->err, GVOM_ERR_HIP);
+        if (c->seg->rccl_failed.load(std::memory_order_acquire) != 0u) {
+            if (c->nccl) { c->rccl.CommDestroy(c->nccl); c->nccl = nullptr; }
+            c->transport = GVOM_TRANSPORT_PEER;
+        }
+    }
     *out = c;
     return GVOM_OK;
 }
+
+VIS int gvom_comm_create(int rank, int world, int device, const char *name, gvom_comm_t **out)
+{
+    return gvom_comm_create2(rank, world, device, name, GVOM_TRANSPORT_RCCL, out);
+}
+
+VIS int gvom_comm_transport(gvom_comm_t *c) { return c ? c->transport : -1; }
 
 VIS void gvom_comm_destroy(gvom_comm_t *c)
 {
     if (!c) return;
     if (c->nccl) { hipSetDevice(c->device); c->rccl.CommDestroy(c->nccl); }
+    if (c->transport == GVOM_TRANSPORT_PEER && c->device >= 0) {
+        hipSetDevice(c->device);
+        for (int s = 0; s < c->world; ++s)
+            for (int k = 0; k < GVOM_PEER_KINDS; ++k)
+                if (c->imports[s][k].base) (void)hipIpcCloseMemHandle(c->imports[s][k].base);
+    }
     if (c->seg) munmap(c->seg, sizeof(Segment));
     if (c->rank == 0) shm_unlink(c->shm_name.c_str());                 // harmless if already gone
     delete c;
@@ -263,7 +479,7 @@ VIS int gvom_comm_exchange_host(gvom_comm_t *c, const int64_t *mine, int k, int6
     const double deadline = now_s() + c->timeout_s;
     for (int r = 0; r < c->world; ++r) {
         unsigned spins = 0;
-        double slow_since = 0.0;
+        double slow_since = 0.0, next_look = 0.0;
         while (slots[r].seq.load(std::memory_order_acquire) != call) {
             _mm_pause();
             if ((++spins & 0xfff) == 0) {
@@ -272,7 +488,20 @@ VIS int gvom_comm_exchange_host(gvom_comm_t *c, const int64_t *mine, int k, int6
                 const double t = now_s();
                 if (slow_since == 0.0) slow_since = t;
                 if (t > deadline) { c->err = "host exchange timed out (a rank is missing)"; return GVOM_ERR_HIP; }
-                if (t - slow_since > 5e-3) usleep(t - slow_since > 1.0 ? 1000 : 50);
+                if (t - slow_since > 5e-3) {
+                    // late by milliseconds: look whether the rank can still come
+                    const uint32_t bad = c->seg->poison.load(std::memory_order_acquire);
+                    if (bad) { c->err = "rank " + std::to_string(bad - 1) + " reported a failed device exchange"; return GVOM_ERR_HIP; }
+                    if (t > next_look) {
+                        next_look = t + 0.05;
+                        if (slots[r].seq.load(std::memory_order_acquire) != call &&
+                            !proc_running(c->seg->rank_pid[r], c->seg->rank_start[r])) {
+                            c->err = "rank " + std::to_string(r) + "'s process is gone";
+                            return GVOM_ERR_HIP;
+                        }
+                    }
+                    usleep(t - slow_since > 1.0 ? 1000 : 50);
+                }
             }
         }
         memcpy(all + (size_t)r * k, slots[r].values, (size_t)k * 8);
@@ -290,14 +519,32 @@ VIS int gvom_comm_barrier(gvom_comm_t *c)
 // send_* / recv_*: [world] counts (quads: 4-byte id + 1 KiB each; endpoints: 8 bytes each); the
 // caller has exchanged them (gvom_comm_exchange_host) and called gvom_shard_recv_reserve.  One
 // grouped ncclSend / ncclRecv on the handle's stream; returns without synchronising.
-VIS int gvom_comm_exchange_scan(gvom_comm_t *c, gvom_t *h, const int64_t *send_quads, const int64_t *send_eps,
+static int exchange_scan_impl(gvom_comm_t *c, gvom_t *h, const int64_t *send_quads, const int64_t *send_eps,
                                 const int64_t *recv_quads, const int64_t *recv_eps)
 {
     if (!c || !h || !send_quads || !send_eps || !recv_quads || !recv_eps) return GVOM_ERR_INVALID;
     if (c->world == 1) return GVOM_OK;
-    if (!c->nccl) { c->err = "host-only communicator: no device collectives"; return GVOM_ERR_INVALID; }
+    if (c->device < 0) { c->err = "host-only communicator: no device collectives"; return GVOM_ERR_INVALID; }
     if (hipSetDevice(c->device) != hipSuccess) { c->err = "hipSetDevice failed"; return GVOM_ERR_HIP; }
     hipStream_t st = (hipStream_t)gvom_stream(h);
+    if (c->transport == GVOM_TRANSPORT_PEER) {
+        static const int send_which[3] = {GVOM_XBUF_SEND_IDS, GVOM_XBUF_SEND_QUADS, GVOM_XBUF_SEND_EPS};
+        for (int k = 0; k < 3; ++k) {
+            void *ptr[GVOM_COMM_MAX_RANKS] = {};
+            for (int d = 0; d < c->world; ++d) {
+                const int64_t cnt = k < 2 ? send_quads[d] : send_eps[d];
+                int64_t cap = 0;
+                if (d == c->rank || cnt <= 0) continue;
+                if (gvom_shard_buffer(h, send_which[k], d, &ptr[d], &cap) || !ptr[d]) { c->err = "send region missing"; return GVOM_ERR_INVALID; }
+            }
+            const int rc = peer_publish(c, h, k, ptr);
+            if (rc) return rc;
+        }
+        const PeerPull pulls[3] = {{0, GVOM_XBUF_RECV_IDS, 4, recv_quads}, {1, GVOM_XBUF_RECV_QUADS, 1024, recv_quads},
+                                   {2, GVOM_XBUF_RECV_EPS, 8, recv_eps}};
+        return peer_pull(c, h, st, pulls, 3);
+    }
+    if (!c->nccl) { c->err = "communicator without RCCL"; return GVOM_ERR_INVALID; }
     NCCLCHK(c, c->rccl.GroupStart());
     // (inside the group every failure path must still close it: an open group stays with the thread)
     int rc = GVOM_OK;
@@ -331,14 +578,27 @@ VIS int gvom_comm_exchange_scan(gvom_comm_t *c, gvom_t *h, const int64_t *send_q
 
 // Statistics handles: the returns every other rank needs of this one (gvom_shard_stats_counts) -> their receive
 // regions (gvom_shard_stats_reserve), bytes_per_return = 12 (float32 clouds) or 24.  One grouped send / recv.
-VIS int gvom_comm_exchange_stats(gvom_comm_t *c, gvom_t *h, const int64_t *send_returns, const int64_t *recv_returns,
+static int exchange_stats_impl(gvom_comm_t *c, gvom_t *h, const int64_t *send_returns, const int64_t *recv_returns,
                                  int bytes_per_return)
 {
     if (!c || !h || !send_returns || !recv_returns || (bytes_per_return != 12 && bytes_per_return != 24)) return GVOM_ERR_INVALID;
     if (c->world == 1) return GVOM_OK;
-    if (!c->nccl) { c->err = "host-only communicator: no device collectives"; return GVOM_ERR_INVALID; }
+    if (c->device < 0) { c->err = "host-only communicator: no device collectives"; return GVOM_ERR_INVALID; }
     if (hipSetDevice(c->device) != hipSuccess) { c->err = "hipSetDevice failed"; return GVOM_ERR_HIP; }
     hipStream_t st = (hipStream_t)gvom_stream(h);
+    if (c->transport == GVOM_TRANSPORT_PEER) {
+        void *ptr[GVOM_COMM_MAX_RANKS] = {};
+        for (int d = 0; d < c->world; ++d) {
+            int64_t cap = 0;
+            if (d == c->rank || send_returns[d] <= 0) continue;
+            if (gvom_shard_buffer(h, GVOM_XBUF_SEND_RETURNS, d, &ptr[d], &cap) || !ptr[d]) { c->err = "send region missing"; return GVOM_ERR_INVALID; }
+        }
+        const int rcp = peer_publish(c, h, 3, ptr);
+        if (rcp) return rcp;
+        const PeerPull pull = {3, GVOM_XBUF_RECV_RETURNS, bytes_per_return, recv_returns};
+        return peer_pull(c, h, st, &pull, 1);
+    }
+    if (!c->nccl) { c->err = "communicator without RCCL"; return GVOM_ERR_INVALID; }
     NCCLCHK(c, c->rccl.GroupStart());
     int rc = GVOM_OK;
     for (int p = 0; p < c->world && rc == GVOM_OK; ++p) {
@@ -367,10 +627,10 @@ VIS int gvom_comm_exchange_stats(gvom_comm_t *c, gvom_t *h, const int64_t *send_
 
 // The combine's exchange: in-place all-gather of the handle's [height | inferred height | positive
 // density] rows (GVOM_BUF_HEIGHT_MAPS; a rank's rows are one contiguous block) on the handle's stream.
-VIS int gvom_comm_allgather_rows(gvom_comm_t *c, gvom_t *h)
+static int allgather_rows_impl(gvom_comm_t *c, gvom_t *h)
 {
     if (!c || !h) return GVOM_ERR_INVALID;
-    if (!c->nccl) { c->err = "host-only communicator: no device collectives"; return GVOM_ERR_INVALID; }
+    if (c->device < 0) { c->err = "host-only communicator: no device collectives"; return GVOM_ERR_INVALID; }
     void *ptr = nullptr;
     int64_t bytes = 0, row = 0;
     int rc = gvom_device_buffer(h, GVOM_BUF_HEIGHT_MAPS, &ptr, &bytes, &row);
@@ -378,7 +638,65 @@ VIS int gvom_comm_allgather_rows(gvom_comm_t *c, gvom_t *h)
     if (bytes % c->world) { c->err = "height-map rows do not divide among the ranks"; return GVOM_ERR_INVALID; }
     if (hipSetDevice(c->device) != hipSuccess) { c->err = "hipSetDevice failed"; return GVOM_ERR_HIP; }
     const size_t share = (size_t)(bytes / c->world);
+    if (c->transport == GVOM_TRANSPORT_PEER) {
+        if (c->world == 1) return GVOM_OK;
+        hipStream_t st = (hipStream_t)gvom_stream(h);
+        // every rank offers ITS rows (the same part whoever asks) and pulls the others' into the same place of its own buffer
+        void *mine[GVOM_COMM_MAX_RANKS] = {};
+        for (int d = 0; d < c->world; ++d) if (d != c->rank) mine[d] = (char *)ptr + share * c->rank;
+        if ((rc = peer_publish(c, h, 4, mine))) return rc;
+        HIPCHK_C(c, hipStreamSynchronize(st));                         // my rows are complete
+        if ((rc = gvom_comm_barrier(c))) return rc;
+        for (int s = 0; s < c->world && rc == GVOM_OK; ++s) {
+            void *src = nullptr;
+            if (s == c->rank) continue;
+            if ((rc = peer_source(c, s, 4, &src))) break;
+            const hipError_t e = hipMemcpyAsync((char *)ptr + share * s, src, share, hipMemcpyDefault, st);
+            if (e != hipSuccess) { c->err = std::string("hipMemcpyAsync (peer copy) failed: ") + hipGetErrorString(e); rc = GVOM_ERR_HIP; }
+            c->peer_bytes += share; ++c->peer_copies;
+        }
+        const hipError_t se = hipStreamSynchronize(st);                // nobody's next fusion rewrites its rows before everyone has pulled
+        const int rb = gvom_comm_barrier(c);
+        if (rc) return rc;
+        if (se != hipSuccess) { c->err = std::string("hipStreamSynchronize failed: ") + hipGetErrorString(se); return GVOM_ERR_HIP; }
+        return rb;
+    }
+    if (!c->nccl) { c->err = "communicator without RCCL"; return GVOM_ERR_INVALID; }
     NCCLCHK(c, c->rccl.AllGather((char *)ptr + share * c->rank, ptr, share, ncclUint8, c->nccl, (hipStream_t)gvom_stream(h)));
+    return GVOM_OK;
+}
+
+VIS int gvom_comm_exchange_scan(gvom_comm_t *c, gvom_t *h, const int64_t *send_quads, const int64_t *send_eps,
+                                const int64_t *recv_quads, const int64_t *recv_eps)
+{
+    const int rc = exchange_scan_impl(c, h, send_quads, send_eps, recv_quads, recv_eps);
+    // a rank whose device exchange failed will not come to the next rendezvous: the others must not wait for it
+    if (rc != GVOM_OK && c && c->seg && c->world > 1) c->seg->poison.store((uint32_t)c->rank + 1u, std::memory_order_release);
+    return rc;
+}
+
+VIS int gvom_comm_exchange_stats(gvom_comm_t *c, gvom_t *h, const int64_t *send_returns, const int64_t *recv_returns,
+                                 int bytes_per_return)
+{
+    const int rc = exchange_stats_impl(c, h, send_returns, recv_returns, bytes_per_return);
+    // a rank whose device exchange failed will not come to the next rendezvous: the others must not wait for it
+    if (rc != GVOM_OK && c && c->seg && c->world > 1) c->seg->poison.store((uint32_t)c->rank + 1u, std::memory_order_release);
+    return rc;
+}
+
+VIS int gvom_comm_allgather_rows(gvom_comm_t *c, gvom_t *h)
+{
+    const int rc = allgather_rows_impl(c, h);
+    // a rank whose device exchange failed will not come to the next rendezvous: the others must not wait for it
+    if (rc != GVOM_OK && c && c->seg && c->world > 1) c->seg->poison.store((uint32_t)c->rank + 1u, std::memory_order_release);
+    return rc;
+}
+
+// peer transport bookkeeping: {bytes pulled, copies, exports made, refused hipIpcOpenMemHandle calls that were repeated}
+VIS int gvom_comm_peer_stats(gvom_comm_t *c, int64_t out[4])
+{
+    if (!c || !out) return GVOM_ERR_INVALID;
+    out[0] = (int64_t)c->peer_bytes; out[1] = (int64_t)c->peer_copies; out[2] = (int64_t)c->export_seq; out[3] = (int64_t)c->peer_open_retries;
     return GVOM_OK;
 }
 

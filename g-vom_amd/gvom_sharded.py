@@ -133,24 +133,41 @@ class HipShardBackend(object):
         self.g._check(self.lib.gvom_sync(self.h))
 
 
-class RcclComm(object):
-    """The product transport: RCCL over xGMI for device data, a shared-memory segment for the small
-    host-side vectors (libgvom_hip.so: gvom_comm_*).  One per rank; `name` must be the same on all
-    ranks and unique to this job on the node."""
+TRANSPORTS = {"rccl": 0, "peer": 1, "auto": 2}
 
-    def __init__(self, rank, world, device, name):
+
+class RcclComm(object):
+    """The product transport between rank PROCESSES (libgvom_hip.so: gvom_comm_*): a shared-memory segment for the
+    small host-side vectors, and for device data
+      transport="rccl"  RCCL over xGMI (grouped ncclSend / ncclRecv, in-place ncclAllGather on the handle's stream),
+      transport="peer"  peer copies: exported send regions (hipIpcGetMemHandle) pulled by the receiver with
+                        hipMemcpyAsync on its handle's stream -- xGMI between GPUs, and the only transport that runs
+                        several ranks on ONE GPU (RCCL refuses that),
+      transport="auto"  RCCL, and peer copies on every rank if RCCL cannot initialise on some rank.
+    One per rank; `name` must be the same on all ranks and unique to this job on the node.  `.transport` says which
+    one is in use."""
+
+    def __init__(self, rank, world, device, name, transport="rccl"):
         self.rank, self.world = rank, world
         self.lib = _gvom.load_library()
         self.c = ctypes.c_void_p()
-        rc = self.lib.gvom_comm_create(rank, world, device, name.encode(), ctypes.byref(self.c))
+        rc = self.lib.gvom_comm_create2(rank, world, device, name.encode(), TRANSPORTS[transport], ctypes.byref(self.c))
         if rc != 0:
             self.c = ctypes.c_void_p()
-            raise _gvom.GvomBackendError("gvom_comm_create failed with code %d (rank %d of %d)" % (rc, rank, world))
+            raise _gvom.GvomBackendError("gvom_comm_create2 failed with code %d (rank %d of %d, transport %s)"
+                                         % (rc, rank, world, transport))
+        self.transport = {0: "rccl", 1: "peer"}[self.lib.gvom_comm_transport(self.c)]
 
     def _check(self, rc):
         if rc != 0:
             raise _gvom.GvomBackendError("communicator call failed (%d): %s"
                                          % (rc, self.lib.gvom_comm_last_error(self.c).decode()))
+
+    def peer_stats(self):
+        """peer transport: bytes pulled, copies, exports made, refused opens that were repeated"""
+        out = (ctypes.c_int64 * 4)()
+        self._check(self.lib.gvom_comm_peer_stats(self.c, out))
+        return dict(zip(("bytes", "copies", "exports", "open_retries"), (int(v) for v in out)))
 
     def exchange_host(self, values):
         k = len(values)

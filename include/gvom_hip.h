@@ -26,7 +26,9 @@
 extern "C" {
 #endif
 
-#define GVOM_ABI_VERSION 4   /* 4: per-voxel statistics on sharded maps (gvom_shard_stats_*, gvom_comm_exchange_stats);
+#define GVOM_ABI_VERSION 5   /* 5: second transport between ranks (peer copies: gvom_comm_create2, gvom_comm_transport),
+                              *    gvom_alloc_generation;
+                              * 4: per-voxel statistics on sharded maps (gvom_shard_stats_*, gvom_comm_exchange_stats);
                               * 3: rank-exchange (shard) and communicator entry points, gvom_set_tuning, flags;
                               *    2: *_into outputs column-major; occupancy and PointCloud2 entry points */
 
@@ -226,7 +228,22 @@ int gvom_combine_map2d_into(gvom_t *h, double origin_world[3], void *pinned_out)
  * gvom_comm_exchange_host / gvom_comm_barrier, no RCCL and no HIP call; the device collectives return
  * GVOM_ERR_INVALID) -- the CPU tests run the multi-process rendezvous with it. */
 typedef struct gvom_comm gvom_comm_t;
-int  gvom_comm_create(int rank, int world, int device, const char *name, gvom_comm_t **out);
+int  gvom_comm_create(int rank, int world, int device, const char *name, gvom_comm_t **out);   /* = create2(..., GVOM_TRANSPORT_RCCL) */
+/* Transports for the DEVICE data (the host-side vectors always travel through the shared-memory segment):
+ * RCCL  grouped ncclSend / ncclRecv and an in-place ncclAllGather on the handle's stream, no host synchronisation;
+ * PEER  peer copies: every rank exports its send regions (hipIpcGetMemHandle), the receiver maps them (lazy peer
+ *       access) and pulls its bytes with hipMemcpyAsync on its own handle's stream, bracketed by two host barriers --
+ *       xGMI between the GPUs of a node, plain device copies when several ranks share ONE GPU (which RCCL refuses:
+ *       this is the transport a one-GPU box can run several rank processes with);
+ * AUTO  RCCL; if librccl cannot be loaded or ncclCommInitRank fails on any rank, every rank uses PEER.
+ * gvom_comm_transport: the transport in use (GVOM_TRANSPORT_RCCL or GVOM_TRANSPORT_PEER). */
+#define GVOM_TRANSPORT_RCCL 0
+#define GVOM_TRANSPORT_PEER 1
+#define GVOM_TRANSPORT_AUTO 2
+int  gvom_comm_create2(int rank, int world, int device, const char *name, int transport, gvom_comm_t **out);
+int  gvom_comm_transport(gvom_comm_t *c);
+/* peer transport bookkeeping: {bytes pulled, copies, exports made, refused hipIpcOpenMemHandle calls that were repeated} */
+int  gvom_comm_peer_stats(gvom_comm_t *c, int64_t out[4]);
 void gvom_comm_destroy(gvom_comm_t *c);
 int  gvom_comm_exchange_host(gvom_comm_t *c, const int64_t *mine, int k, int64_t *all);
 int  gvom_comm_barrier(gvom_comm_t *c);
@@ -303,6 +320,10 @@ int gvom_host_timing(gvom_t *h, double us[8]);
 int gvom_set_tuning(gvom_t *h, const char *name, int value);
 /* Raw HIP stream the library launches on (hipStream_t as void*), for external event timing. */
 void *gvom_stream(gvom_t *h);
+/* differs between any two handles of the process and changes whenever a SEND region of `h` (GVOM_XBUF_SEND_*: the only
+ * grow-only buffers another rank reads) has been re-allocated: tells a cache of addresses derived from gvom_shard_buffer
+ * when to look again */
+uint64_t gvom_alloc_generation(gvom_t *h);
 
 const char *gvom_last_error(gvom_t *h);      /* never NULL */
 int gvom_backend_info(char *buf, size_t len); /* "gfx950 ..." device + build string */

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), "libgvom_hip.so does not export %s" % name
     bound = {n for n, _, _ in gvom.ABI}
     assert set(declared) == bound, (set(declared) ^ bound)
-    assert gvom.load_library().gvom_abi_version() == 4
+    assert gvom.load_library().gvom_abi_version() == 5
 
 
 def test_params_struct_layout_matches_header():

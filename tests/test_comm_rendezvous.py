@@ -15,8 +15,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 WORKER = os.path.join(HERE, "_comm_worker.py")
 
 
-def _run(world, name, rounds, delay_ms=0):
-    procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), name, str(rounds), str(delay_ms)],
+def _run(world, name, rounds, delay_ms=0, die_at=-1):
+    procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), name, str(rounds), str(delay_ms), str(die_at)],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     outs = []
     for p in procs:
@@ -37,6 +37,20 @@ def test_ranks_rendezvous_and_exchange(world):
     for r, (rc, out) in enumerate(outs):
         assert rc == 0 and ("ok %d" % r) in out, (r, rc, out)
     assert not os.path.exists("/dev/shm/" + name)                      # the name is gone once everybody has attached
+
+
+def test_a_rank_that_dies_ends_the_others_wait_at_once():
+    """A rank process that disappears between two exchanges (a crash, an exception that ends the interpreter): the
+    others' next exchange must end in an error naming it within a moment, not after GVOM_COMM_TIMEOUT_S (600 s) --
+    the segment records every rank's pid and start time and a wait of more than a few milliseconds looks them up
+    (a zombie counts as gone: its launcher may not have reaped it yet)."""
+    name = "gvom_test_dies_%d" % os.getpid()
+    t0 = time.time()
+    outs = _run(3, name, 200, die_at=120)
+    assert time.time() - t0 < 30.0
+    assert outs[2][0] == 7
+    for r in (0, 1):
+        assert outs[r][0] == 5 and "round 120" in outs[r][1] and "rank 2's process is gone" in outs[r][1], outs[r]
 
 
 def test_a_segment_left_behind_by_a_crashed_job_is_not_joined():

@@ -168,6 +168,31 @@ def test_rccl_binding_with_one_rank():
         comm.close()
 
 
+@pytest.mark.parametrize("world,stats", [(2, False), (4, False), (2, True)])
+def test_rank_processes_on_one_gpu_through_the_peer_transport(world, stats):
+    """tests/shard_procs.py: the ranks as PROCESSES, the library's own communicator (shared-memory rendezvous and count
+    exchange) and its peer-copy transport (exported send regions, pulled by the receiver on its handle's stream) --
+    RCCL refuses two ranks on one device, so this is the multi-process device exchange a one-GPU box can run: seven
+    steps with growing ragged shares (regions re-allocated and exported again), an empty share, a scan every rank
+    rejects and a float64 scan with a transform; every rank's maps and cell counts equal an unsharded mapper's, with
+    statistics also the ranks' voxel clouds."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import shard_procs
+    ok, text = shard_procs.launch(world, "peer", stats)
+    assert ok, text[-3000:]
+    assert text.count("combines equal the unsharded mapper's") == world, text[-3000:]
+
+
+def test_auto_transport_falls_back_to_peer_copies_when_rccl_cannot_start():
+    """GVOM_TRANSPORT_AUTO on one GPU with two rank processes: ncclCommInitRank refuses the duplicate device on both
+    ranks, both agree on peer copies through the rendezvous, and the maps equal the unsharded mapper's."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import shard_procs
+    ok, text = shard_procs.launch(2, "auto", False)
+    assert ok, text[-3000:]
+    assert text.count("(peer transport): ") == 2, text[-3000:]
+
+
 # (the randomised campaign runs LAST: the deterministic full-size and RCCL tests above must not sit behind it
 # under `pytest -x`)
 def test_sharded_kernels_fuzz_against_unsharded_handle():
