@@ -64,7 +64,8 @@ struct ScanParams {
     int    nseg;          // tiles per (sy, sz) row
     int    nsegs;         // k_trace: step segments s = (seg_start[s], seg_start[s+1]], the last one open-ended
     int    seg_start[10];
-    int    ep_row;        // k_trace: blockIdx.y of the endpoint blocks (the other rows are the segments, ascending)
+    int    ep_row;        // k_trace: blockIdx.y of the endpoint blocks (the other rows are the segments)
+    int    prio_div;      // k_trace: issue priority of a wave = min(3, steps it still has to walk / prio_div); 0: hardware default
     int    lc_period;     // k_trace: flush the wave's line cache every lc_period committing steps
     int    f32_sqrt;      // GVOM_FLAG_CUDA_F32_SQRT: ray_length = sqrtf(f32 sum) (real Numba-CUDA typing, gvom.py:1109)
     int    sxq;           // accumulator layout: 4x4 (x,y) patches per row of patches = ceil(xy/4) + padding

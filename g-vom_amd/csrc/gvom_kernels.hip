@@ -176,9 +176,12 @@ __device__ __forceinline__ uint32_t acc_idx24(uint32_t sx, uint32_t sy, uint32_t
 // the integer form); callers use LIT = true (the reference's literal f64 expression) wherever a
 // coordinate may come that close to zero, and always when |origin| >= 2^30.
 // Returns "inside the window"; wx/wy/wz are only meaningful then.
+// (o0..o2, uxy, zpad: the integer form's wave-uniform constants -- (int)origin, xy, xy - zs -- handed in by walk_steps,
+// which pins them in scalar registers across its loop; the literal form reads P)
 template <bool LIT>
 __device__ __forceinline__ bool window_voxel(const ScanParams &P, float px, float py, float pz,
-                                             uint32_t &wx, uint32_t &wy, uint32_t &wz)
+                                             uint32_t &wx, uint32_t &wy, uint32_t &wz,
+                                             uint32_t o0 = 0, uint32_t o1 = 0, uint32_t o2 = 0, uint32_t uxy_ = 0, uint32_t zpad = 0)
 {
     if (LIT) {
         const double fx = floor((double)px - P.origin[0]);
@@ -188,15 +191,14 @@ __device__ __forceinline__ bool window_voxel(const ScanParams &P, float px, floa
         wx = in ? (uint32_t)(int)fx : 0u; wy = in ? (uint32_t)(int)fy : 0u; wz = in ? (uint32_t)(int)fz : 0u;
         return in;
     }
-    wx = (uint32_t)cvt_floor_i32(px) - (uint32_t)(int)P.origin[0];
-    wy = (uint32_t)cvt_floor_i32(py) - (uint32_t)(int)P.origin[1];
-    wz = (uint32_t)cvt_floor_i32(pz) - (uint32_t)(int)P.origin[2];
+    wx = (uint32_t)cvt_floor_i32(px) - o0;
+    wy = (uint32_t)cvt_floor_i32(py) - o1;
+    wz = (uint32_t)cvt_floor_i32(pz) - o2;
     // ONE compare for the three axes (its result is the lane mask the step body needs, no boolean to
     // re-materialise): z is padded up to the xy bound with a saturating add ("negative" differences are
     // huge unsigned values and stay huge).  Requires z_size <= xy_size: callers take the literal form for
     // grids taller than wide.
-    const uint32_t uxy = (uint32_t)P.xy;
-    return max(max(wx, wy), __builtin_elementwise_add_sat(wz, uxy - (uint32_t)P.zs)) < uxy;
+    return max(max(wx, wy), __builtin_elementwise_add_sat(wz, zpad)) < uxy_;
 }
 // Number of DDA steps the reference's length test lets a ray take (gvom.py:1127,1149):
 //   length_0 = 0, length_j = fl(length_{j-1} + step_len) in f64; step j runs iff length_{j-1} < lim,
@@ -322,6 +324,19 @@ __device__ __forceinline__ RaySetup ray_setup(const ScanParams &P, T x, T y, T z
     return R;
 }
 
+// The step loop's wave-uniform constants, read from the kernel arguments ONCE per wave (k_trace_p: outside its item loop,
+// whose other arguments are re-read per item -- see there): twelve scalar registers that stay put.
+struct WalkConsts { uint32_t uxy, uzs, usxq, unseg, om0, om1, om2, o0, o1, o2, zpad, epoch; };
+__device__ __forceinline__ WalkConsts walk_consts(const ScanParams &P)
+{
+    WalkConsts C;
+    C.uxy = (uint32_t)P.xy; C.uzs = (uint32_t)P.zs; C.usxq = (uint32_t)P.sxq; C.unseg = (uint32_t)P.nseg;
+    C.om0 = (uint32_t)P.om[0]; C.om1 = (uint32_t)P.om[1]; C.om2 = (uint32_t)P.om[2];
+    C.o0 = (uint32_t)(int)P.origin[0]; C.o1 = (uint32_t)(int)P.origin[1]; C.o2 = (uint32_t)(int)P.origin[2];
+    C.zpad = C.uxy - C.uzs; C.epoch = P.epoch;
+    return C;
+}
+
 // ------------------------------------------------------------------------------------------
 // walk_steps: at most `steps` lock-step DDA steps of a 64-ray bundle, total += 1 per step
 // (gvom.py:1119-1150).  The step body is straight-line: ray state in natural (x,y,z) order (x and y as
@@ -339,10 +354,10 @@ __device__ __forceinline__ RaySetup ray_setup(const ScanParams &P, T x, T y, T z
 template <bool LIT, bool P2>
 __device__ __forceinline__ void walk_steps(const ScanParams &P, int lane, uint32_t &j, uint32_t cnt, float &px_, float &py_, float &pz,
                                            float incx, float incy, float incz, bool &active, int steps,
-                                           uint32_t *lck, uint32_t *lcc, uint32_t *total, uint32_t *tags)
+                                           uint32_t *lck, uint32_t *lcc, uint32_t *total, uint32_t *tags, const WalkConsts &C)
 {
-    const uint32_t uxy = (uint32_t)P.xy, uzs = (uint32_t)P.zs, usxq = (uint32_t)P.sxq, unseg = (uint32_t)P.nseg;
-    const uint32_t om0 = (uint32_t)P.om[0], om1 = (uint32_t)P.om[1], om2 = (uint32_t)P.om[2];
+    const uint32_t uxy = C.uxy, uzs = C.uzs, usxq = C.usxq, unseg = C.unseg, om0 = C.om0, om1 = C.om1, om2 = C.om2;
+    const uint32_t o0 = C.o0, o1 = C.o1, o2 = C.o2, zpad = C.zpad, epoch = C.epoch;
     lds_u32 *const keys3 = (lds_u32 *)lck;
     lds_u32 *const cnt3 = (lds_u32 *)lcc;
     glb_u32 *const total1 = (glb_u32 *)total;
@@ -366,7 +381,7 @@ __device__ __forceinline__ void walk_steps(const ScanParams &P, int lane, uint32
         pxy += incxy; pz += incz;
         uint32_t sx, sy, sz;                                              // toroidal storage coordinates
         uint32_t wx, wy, wz;                                              // window voxel
-        const bool commit = window_voxel<LIT>(P, pxy.x, pxy.y, pz, wx, wy, wz);
+        const bool commit = window_voxel<LIT>(P, pxy.x, pxy.y, pz, wx, wy, wz, o0, o1, o2, uxy, zpad);
         if (P2) { sx = (wx + om0) & (uxy - 1u); sy = (wy + om1) & (uxy - 1u); sz = (wz + om2) & (uzs - 1u); }
         else { sx = min(wx + om0, wx + om0 - uxy); sy = min(wy + om1, wy + om1 - uxy); sz = min(wz + om2, wz + om2 - uzs); }
         cmask = lanes(commit);
@@ -391,7 +406,7 @@ __device__ __forceinline__ void walk_steps(const ScanParams &P, int lane, uint32
             if (miss) {
                 __hip_atomic_compare_exchange_strong(&keys3[LC_KEYPOS(hh)], &was, line, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
                                                      __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (!GVOM_DBG(P, 2)) tags[mad24s(mad24s(sy, uzs, sz), unseg, sx >> 6)] = P.epoch;
+                if (!GVOM_DBG(P, 2)) tags[mad24s(mad24s(sy, uzs, sz), unseg, sx >> 6)] = epoch;
             }
             // (independent of the look-up: issued while the LDS compare-and-swap is in flight)
             const uint32_t run = 1u + (uint32_t)__builtin_ctz((uint32_t)(ends >> lane));   // lanes in my run (<= 32: see `ends`; never 0)
@@ -417,6 +432,20 @@ __device__ __forceinline__ void walk_steps(const ScanParams &P, int lane, uint32
     if (dirty) lc_flush(P, lck, lcc, total, lane);
 }
 
+// Issue priority of the wave by the work it still has in front of it (s_setprio: the SIMD's arbiter takes the ready wave of
+// the highest priority, the oldest among equals).  Every step is a ~1000-cycle dependent chain of which ~220 are VALU
+// issue slots: 4 to 5 walking waves saturate a SIMD, and with equal priorities the YOUNGEST waves of a SIMD get what
+// the older ones leave -- next to nothing -- until those have finished, and then walk on alone, latency-bound, as the
+// kernel's tail.  Longest-remaining-work-first lets the waves of a SIMD finish together.
+__device__ __forceinline__ void prio_by_remaining(uint32_t rem, uint32_t div)
+{
+    const uint32_t q = rem / div;                      // (wave-uniform: scalar unit)
+    if (q >= 3u) __builtin_amdgcn_s_setprio(3);
+    else if (q == 2u) __builtin_amdgcn_s_setprio(2);
+    else if (q == 1u) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+}
+
 // A wave's steps, in runs of at most `period` steps (the line cache is flushed after each run): per run the
 // step loop takes the literal f64 lookup iff a coordinate of some active ray may come within 2^-21 of
 // zero during the run (or the origin is beyond 2^30) -- a ray that crosses a coordinate plane costs one
@@ -424,12 +453,16 @@ __device__ __forceinline__ void walk_steps(const ScanParams &P, int lane, uint32
 template <bool BIG>
 __device__ __forceinline__ void walk_item(const ScanParams &P, int lane, uint32_t j, uint32_t cnt, float px, float py, float pz,
                                           float incx, float incy, float incz, bool active, int steps, int period,
-                                          uint32_t *lck, uint32_t *lcc, uint32_t *total, uint32_t *tags)
+                                          uint32_t *lck, uint32_t *lcc, uint32_t *total, uint32_t *tags, uint32_t jend, const WalkConsts &C)
 {
     const bool p2 = ((P.xy & (P.xy - 1)) | (P.zs & (P.zs - 1))) == 0;
     while (steps > 0 && lanes(active) != 0ull) {
         const int run = min(steps, period);
         steps -= run;
+        if (P.prio_div > 0) {
+            const uint32_t ju = (uint32_t)__builtin_amdgcn_readfirstlane((int)j);
+            prio_by_remaining(jend > ju ? jend - ju : 0u, (uint32_t)P.prio_div);
+        }
         // (the positions visited run monotonically from p + inc -- the first one, an exact f32 add as in
         // the loop -- to about p + run * inc; the margin is far above the rounding of that estimate, which
         // is below run * ulp(run) wherever the hull is near zero; NaN estimates compare false: such a
@@ -444,11 +477,11 @@ __device__ __forceinline__ void walk_item(const ScanParams &P, int lane, uint32_
             lit = lanes(active & nz) != 0ull;
         }
         if (lit) {
-            if (p2) walk_steps<true, true>(P, lane, j, cnt, px, py, pz, incx, incy, incz, active, run, lck, lcc, total, tags);
-            else walk_steps<true, false>(P, lane, j, cnt, px, py, pz, incx, incy, incz, active, run, lck, lcc, total, tags);
+            if (p2) walk_steps<true, true>(P, lane, j, cnt, px, py, pz, incx, incy, incz, active, run, lck, lcc, total, tags, C);
+            else walk_steps<true, false>(P, lane, j, cnt, px, py, pz, incx, incy, incz, active, run, lck, lcc, total, tags, C);
         } else {
-            if (p2) walk_steps<false, true>(P, lane, j, cnt, px, py, pz, incx, incy, incz, active, run, lck, lcc, total, tags);
-            else walk_steps<false, false>(P, lane, j, cnt, px, py, pz, incx, incy, incz, active, run, lck, lcc, total, tags);
+            if (p2) walk_steps<false, true>(P, lane, j, cnt, px, py, pz, incx, incy, incz, active, run, lck, lcc, total, tags, C);
+            else walk_steps<false, false>(P, lane, j, cnt, px, py, pz, incx, incy, incz, active, run, lck, lcc, total, tags, C);
         }
     }
 }
@@ -482,7 +515,7 @@ __device__ __forceinline__ void trace_item(const ScanParams &P, const ShardExcha
                                            T *__restrict__ world, uint32_t *hit, uint32_t *total, uint32_t *mh, int32_t *state,
                                            uint32_t *tags, uint32_t *counters, double *stat_sums, double *stat_base,
                                            uint32_t *stat_rowvox, int row, long bundle, int lane, uint32_t *lck, uint32_t *lcc,
-                                           size_t widx)
+                                           size_t widx, const WalkConsts &C)
 {
     const long i = bundle * 64 + lane;
     const bool live = i < n;
@@ -555,6 +588,7 @@ __device__ __forceinline__ void trace_item(const ScanParams &P, const ShardExcha
     }
     const int seg = P.ep_row >= 0 ? row - (row > P.ep_row ? 1 : 0) : row;
     const uint32_t j0 = (uint32_t)P.seg_start[seg];
+    if (P.prio_div > 0) __builtin_amdgcn_s_setprio(3);   // set-up and replay: everything is still in front of this wave
     // ---- later segments: leave before the f64 set-up when no ray of the wave can still be running ----
     // After j0 steps `length` is >= j0 * (1 - 2^-22) (every step adds |1 / sd| with |sd| <= 1 + 2^-23),
     // and a ray stops once length >= ray_length - 1 (gvom.py:1127): a ray with ray_length <= j0 + 0.9
@@ -585,8 +619,15 @@ __device__ __forceinline__ void trace_item(const ScanParams &P, const ShardExcha
         px = pxy.x; py = pxy.y;
     }
     const int steps = seg == P.nsegs - 1 ? 0x3fffffff : P.seg_start[seg + 1] - (int)j0;
+    uint32_t jend = 0;                                   // last step any ray of the wave takes in this segment (priority only)
+    if (P.prio_div > 0) {
+        uint32_t m = active ? min(cnt, j0 + (uint32_t)min(steps, 1 << 20)) : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+        jend = (uint32_t)__builtin_amdgcn_readfirstlane((int)m);
+    }
     TL_MARK(P, widx, 1);
-    walk_item<BIG>(P, lane, j0, cnt, px, py, pz, R.incx, R.incy, R.incz, active, steps, P.lc_period, lck, lcc, total, tags);
+    walk_item<BIG>(P, lane, j0, cnt, px, py, pz, R.incx, R.incy, R.incz, active, steps, P.lc_period, lck, lcc, total, tags, jend, C);
     TL_MARK(P, widx, 2);
 }
 
@@ -618,7 +659,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(8, 8))
         for (int q = 0; q < 16; ++q) LC_ST(&lcc[q * 64 + lane], 0u);
     }
     trace_item<T, BIG>(P, X, in, stride, n, world, hit, total, mh, state, tags, counters, stat_sums, stat_base, stat_rowvox,
-                       row, bundle, lane, lck, lcc, widx);
+                       row, bundle, lane, lck, lcc, widx, walk_consts(P));
 }
 
 // ------------------------------------------------------------------------------------------

@@ -315,7 +315,8 @@ int gvom_set_profiling(gvom_t *h, int on);
 int gvom_host_timing(gvom_t *h, double us[8]);
 /* Performance knobs that never change a result.  name: "segs" (step segments per ray in the trace
  * kernel), "period" (committing steps between two flushes of a wave's LDS line cache), "ep_row"
- * (dispatch row of the endpoint blocks; -1: inside segment 0's waves); 0 / 0 / -2 = automatic.
+ * (dispatch row of the endpoint blocks; -1: inside segment 0's waves), "prio" (steps of remaining walk per issue-priority
+ * level of a trace wave, s_setprio; 0: the hardware's own arbitration); 0 / 0 / -2 / -1 = automatic.
  * "epoch_bias" (test hook) advances the 32-bit tile-epoch counter, e.g. to just below its wrap. */
 int gvom_set_tuning(gvom_t *h, const char *name, int value);
 /* Raw HIP stream the library launches on (hipStream_t as void*), for external event timing. */

@@ -671,13 +671,15 @@ def test_trace_far_origin_uses_f64_lookup(gvom_mod):
 def test_trace_tuning_knobs_leave_results_unchanged(gvom_mod):
     """k_trace splits every ray into step segments handled by different waves (set-up + replay of the
     earlier steps + the segment's own steps); the segment count, the flush period of a wave's LDS line
-    cache and the dispatch row of the endpoint blocks are performance knobs (gvom_set_tuning) and must
-    leave bit-identical scan slots.  segs=1 is the unsegmented walk, segs=9 / period=1 the extremes."""
+    cache, the dispatch row of the endpoint blocks and the waves' issue priorities are performance knobs
+    (gvom_set_tuning) and must leave bit-identical scan slots.  segs=1 is the unsegmented walk, segs=9 / period=1 the extremes."""
     params, scans = synth.config_inputs("c2", n_scans=2)
     ref = None
-    for segs, period, ep_row in ((0, 0, -2), (1, 12, 0), (2, 1, 1), (3, 32, 3), (6, 12, 6), (9, 5, 4), (5, 16, -1), (1, 7, -1)):
+    # (+ prio: steps per issue-priority level of a wave's remaining work; 0 = the hardware's default arbitration)
+    for segs, period, ep_row, prio in ((0, 0, -2, -1), (1, 12, 0, 0), (2, 1, 1, 8), (3, 32, 3, 1), (6, 12, 6, 0), (9, 5, 4, 3),
+                                       (5, 16, -1, 100), (1, 7, -1, 8)):
         g = gvom_mod.Gvom(*params)
-        g.set_tuning("segs", segs); g.set_tuning("period", period); g.set_tuning("ep_row", ep_row)
+        g.set_tuning("segs", segs); g.set_tuning("period", period); g.set_tuning("ep_row", ep_row); g.set_tuning("prio", prio)
         slots = []
         for pc, ego, tf in scans:
             g.process_pointcloud(pc, ego, tf)
@@ -689,7 +691,7 @@ def test_trace_tuning_knobs_leave_results_unchanged(gvom_mod):
         else:
             for a, b_ in zip(ref, slots):
                 for x, y in zip(a, b_):
-                    assert np.array_equal(x, y), "segs %d / period %d / ep_row %d differs" % (segs, period, ep_row)
+                    assert np.array_equal(x, y), "segs %d / period %d / ep_row %d / prio %d differs" % (segs, period, ep_row, prio)
 
 
 @pytest.mark.parametrize("occ_params", [(50, -10, 0), (12.5, -6.0, 1.5)])

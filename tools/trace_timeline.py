@@ -19,6 +19,8 @@ import gvom                  # noqa: E402
 import synth                 # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 and "=" not in sys.argv[1] else "m256"
+save = [kv.split("=", 1)[1] for kv in sys.argv[1:] if kv.startswith("save=")]       # save=<file.npy>: the raw per-wave records
+sys.argv = [a for a in sys.argv if not a.startswith("save=")]
 hip = bench.Hip(); hip.set_device(0)
 params, scans = synth.config_inputs(name, n_scans=4)
 scans = (scans * 4)[:4]
@@ -38,6 +40,8 @@ assert rc == 0, rc
 gx, gy = grid[0], grid[1]
 w = buf[:gx * gy * 8 * 4].reshape(gy, gx * 8, 4).astype(np.int64)
 modes = buf[gx * gy * 8 * 4:gx * gy * 8 * 4 + 3]
+if save:
+    np.save(save[0], w)              # [row][workgroup * 8 + wave][start, set-up done, end, where]; the scan is scans[0] of synth.config_inputs(name, 4)
 print("run steps by lookup mode (upper bounds: a run may end early): integer + window test %d, literal f64 %d, integer without window test %d"
       % (modes[0], modes[1], modes[2]))
 started = w[:, :, 0] > 0
