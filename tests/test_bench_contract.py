@@ -29,7 +29,8 @@ def test_roofline_object_has_the_contract_keys():
 
 
 def _bench(argv, env_extra=None, timeout=300):
-    env = dict(os.environ, GVOM_COMM_TIMEOUT_S="20", **(env_extra or {}))
+    env = dict(os.environ, GVOM_COMM_TIMEOUT_S="20")
+    env.update(env_extra or {})
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
     return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, stdout=subprocess.PIPE,
@@ -121,6 +122,22 @@ def test_sharded_bench_leg_with_one_rank():
     r = d["roofline"]
     assert r["kernel"] == "k_trace" and 0 < r["frac"] < 1 and r["algorithmic_bytes_per_launch"] > 1e7
     assert len(d["exchange"]["per_rank"]) == 1 and d["exchange"]["per_rank"][0]["sent_bytes"] == 0
+
+
+@pytest.mark.gpu
+def test_sharded_bench_rehearsal_with_two_rank_processes_on_one_gpu():
+    """`bench.py --gpus 2 --share-device`: the N > 1 leg as the driver starts it (bench.py spawns the ranks, one process each,
+    rendezvous through shared memory), with both ranks on the one GPU this box has and the library's peer-copy transport
+    (RCCL refuses two ranks on one device): real multi-process exchanges of device data, and the line's own verdict that
+    the sharded maps equal an unsharded mapper's."""
+    p = _bench(["--gpus", "2", "--share-device", "--steps", "30", "--warmup", "10", "--no-cpu"], {"GVOM_COMM_TIMEOUT_S": "120"}, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    d = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["rehearsal_on_one_device"] is True and d["transport"].startswith("peer copies")
+    assert d["sharded_equals_unsharded"] is True and d["verify"]["differing_cells"] == 0
+    assert d["config"]["points_per_step"] == 2 * d["config"]["points_per_gpu"]
+    assert len(d["exchange"]["per_rank"]) == 2 and all(r["sent_bytes"] > 1e6 and r["received_bytes"] > 1e6 for r in d["exchange"]["per_rank"])
+    assert d["peer_transport_rank0"]["copies"] > 100
 
 
 @pytest.mark.gpu
