@@ -22,6 +22,8 @@
 #include <rccl/rccl.h>
 
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <dlfcn.h>
 #include <errno.h>
 #include <fcntl.h>
@@ -30,7 +32,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <time.h>
@@ -96,6 +101,7 @@ struct Segment {                               // the shared-memory rendezvous o
     // (the fields above keep their offsets: tests/test_comm_rendezvous.py writes stale segments byte by byte)
     std::atomic<uint32_t> rccl_failed;         // GVOM_TRANSPORT_AUTO: ranks whose ncclCommInitRank failed
     std::atomic<uint32_t> poison;              // rank + 1 of a rank whose device exchange failed: nobody waits for it again
+    std::atomic<uint32_t> arrived;             // ranks that have mapped the segment (GVOM_TRANSPORT_AUTO waits for all before ncclCommInitRank)
     int64_t rank_pid[GVOM_COMM_MAX_RANKS];     // the ranks' processes (0 until attached), so that a wait for a rank that has
     uint64_t rank_start[GVOM_COMM_MAX_RANKS];  // died ends in an error at once instead of after the timeout
     Slot slots[2][GVOM_COMM_MAX_RANKS];
@@ -409,16 +415,59 @@ VIS int gvom_comm_create2(int rank, int world, int device, const char *name, int
         }
         if (c->seg->world != (uint32_t)world) return fail("world size differs from rank 0's", GVOM_ERR_INVALID);
     }
+    if (!host_only && may_fall_back) {
+        // (the ranks of a job start seconds to minutes apart: the watchdog below must time RCCL, not the slowest interpreter)
+        c->seg->arrived.fetch_add(1, std::memory_order_acq_rel);
+        const double deadline = now_s() + c->timeout_s;
+        while (c->seg->arrived.load(std::memory_order_acquire) < (uint32_t)world) {
+            if (now_s() > deadline) return fail("not every rank arrived at the rendezvous", GVOM_ERR_HIP);
+            usleep(200);
+        }
+    }
     if (!host_only && want_rccl) {
         if (rank != 0 && !rccl_ok) c->seg->rccl_failed.fetch_add(1, std::memory_order_acq_rel);     // (rank 0 has counted itself)
         // nobody joins a communicator that some rank is already known to be missing from
         if (rccl_ok && !(may_fall_back && c->seg->rccl_failed.load(std::memory_order_acquire) != 0u)) {
             ncclUniqueId id;
             memcpy(&id, &c->seg->id, sizeof id);
-            ncclResult_t r = c->rccl.CommInitRank(&c->nccl, world, id, rank);
+            ncclResult_t r = ncclSuccess;
+            std::string why;
+            if (!may_fall_back) {
+                r = c->rccl.CommInitRank(&c->nccl, world, id, rank);
+            } else {
+                // AUTO: ncclCommInitRank is a collective that can also HANG (a rank that failed early leaves the others
+                // waiting inside it; a bootstrap interface that does not route).  It runs on a helper thread; this one
+                // gives up -- for every rank, through the segment -- when it has not returned within
+                // GVOM_RCCL_INIT_TIMEOUT_S (default 90 s, counted from the moment ALL ranks have arrived) or as soon
+                // as some rank reports its failure.  A helper that never returns is left behind (detached).
+                struct InitJob { std::mutex m; std::condition_variable cv; bool done = false; ncclComm_t comm = nullptr; ncclResult_t res = ncclSuccess; };
+                auto job = std::make_shared<InitJob>();
+                auto init = c->rccl.CommInitRank;
+                std::thread([job, init, world, id, rank, device]() {
+                    (void)hipSetDevice(device);
+                    ncclComm_t cm = nullptr;
+                    const ncclResult_t res = init(&cm, world, id, rank);
+                    std::lock_guard<std::mutex> lk(job->m);
+                    job->comm = cm; job->res = res; job->done = true;
+                    job->cv.notify_all();
+                }).detach();
+                double patience = 90.0;
+                if (const char *t = getenv("GVOM_RCCL_INIT_TIMEOUT_S")) { const double v = atof(t); if (v > 0.0) patience = v; }
+                const double give_up = now_s() + patience;
+                std::unique_lock<std::mutex> lk(job->m);
+                bool abandoned = false;
+                while (!job->done) {
+                    job->cv.wait_for(lk, std::chrono::milliseconds(50));
+                    if (job->done) break;
+                    if (c->seg->rccl_failed.load(std::memory_order_acquire) != 0u) { abandoned = true; why = "another rank could not initialise RCCL"; break; }
+                    if (now_s() > give_up) { abandoned = true; why = "ncclCommInitRank did not return within " + std::to_string((int)patience) + " s"; break; }
+                }
+                if (abandoned) r = ncclInternalError;
+                else { r = job->res; c->nccl = job->comm; }
+            }
             if (r != ncclSuccess) {
                 c->nccl = nullptr;
-                const std::string why = std::string("ncclCommInitRank failed: ") + c->rccl.GetErrorString(r);
+                if (why.empty()) why = std::string("ncclCommInitRank failed: ") + c->rccl.GetErrorString(r);
                 if (!may_fall_back) return fail(why, GVOM_ERR_HIP);
                 fprintf(stderr, "gvom_comm_create(rank %d of %d): %s -- falling back to peer copies\n", rank, world, why.c_str());
                 c->seg->rccl_failed.fetch_add(1, std::memory_order_acq_rel);

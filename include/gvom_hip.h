@@ -235,7 +235,8 @@ int  gvom_comm_create(int rank, int world, int device, const char *name, gvom_co
  *       access) and pulls its bytes with hipMemcpyAsync on its own handle's stream, bracketed by two host barriers --
  *       xGMI between the GPUs of a node, plain device copies when several ranks share ONE GPU (which RCCL refuses:
  *       this is the transport a one-GPU box can run several rank processes with);
- * AUTO  RCCL; if librccl cannot be loaded or ncclCommInitRank fails on any rank, every rank uses PEER.
+ * AUTO  RCCL; if librccl cannot be loaded, or ncclCommInitRank fails on any rank or does not return within
+ *       GVOM_RCCL_INIT_TIMEOUT_S (default 90 s after the last rank has arrived), every rank uses PEER.
  * gvom_comm_transport: the transport in use (GVOM_TRANSPORT_RCCL or GVOM_TRANSPORT_PEER). */
 #define GVOM_TRANSPORT_RCCL 0
 #define GVOM_TRANSPORT_PEER 1

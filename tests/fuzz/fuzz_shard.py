@@ -125,6 +125,8 @@ if __name__ == "__main__":
                 check_case(seed)
         except AssertionError as e:
             bad.append((seed, (2, 4, 8)[seed % 3], str(e)[:200]))
+        if (seed - first + 1) % 200 == 0:                   # (a long campaign shows that it is alive)
+            print("... %d seeds, %d failures so far" % (seed - first + 1, len(bad)), file=sys.stderr, flush=True)
     print("checked %d seeds, %d failures" % (count, len(bad)))
     for b in bad[:20]:
         print("  seed %d world %d: %s" % b)
