@@ -257,6 +257,11 @@ void fill_scan_params(const gvom_handle *h, const int64_t origin[3], const doubl
     P.off[0] = h->in_off[0]; P.off[1] = h->in_off[1]; P.off[2] = h->in_off[2];
     P.in_f32 = h->in_f32 ? 1 : 0;
     P.nseg = h->nseg;
+    {
+        auto lg = [](int v) { int k = 0; while ((1 << k) < v) ++k; return (1 << k) == v ? k : -1; };
+        P.lg_nseg = lg(h->nseg); P.lg_zs = lg(p.z_size);
+        if (P.lg_nseg < 0 || P.lg_zs < 0) P.lg_nseg = P.lg_zs = -1;
+    }
     P.sxq = h->sxq;
     P.shard_world = h->world; P.shard_rank = h->rank; P.shard_rows = h->world > 1 ? p.xy_size / h->world : p.xy_size;
     P.stat_e = p.xy_eigen_dist;
@@ -580,6 +585,9 @@ int scan_launch(gvom_handle *h, std::unique_lock<std::mutex> &lk, const void *de
     if (h->epoch >= 0xFFFFFF00u && (rc = renumber_epochs(h))) return rc;
     ScanParams P;
     fill_scan_params(h, origin, tf, P, n);
+    // (a combine in flight -- combine_maps_async, or a second thread inside combine_maps -- has k_map2d's PCIe stores running
+    // beside this trace: raised trace waves would take its issue slots (pipelined m256 91.7 us per step against 89.6, c3 122.0 / 115.5))
+    if (h->pending_combine && h->tune_prio < 0) P.prio_div = 0;
     Slot &st = h->slots[h->staging];
     // the staging slot may still be a SOURCE of a fusion running on the second stream (asynchronous combine: the
     // second scan after gvom_combine_begin writes the slot the ring has just evicted)

@@ -62,6 +62,7 @@ struct ScanParams {
     int    om[3];         // origin mod size (storage offset)
     int    sy_lo, sy_hi;  // storage rows ENCODED by this handle: [sy_lo, sy_hi) (a rank's slab; all rows otherwise)
     int    nseg;          // tiles per (sy, sz) row
+    int    lg_nseg, lg_zs;  // log2 of nseg and zs when BOTH are powers of two, else -1 (k_encode decomposes quad numbers by shifts then)
     int    nsegs;         // k_trace: step segments s = (seg_start[s], seg_start[s+1]], the last one open-ended
     int    seg_start[10];
     int    ep_row;        // k_trace: blockIdx.y of the endpoint blocks (the other rows are the segments)

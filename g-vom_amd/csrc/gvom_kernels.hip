@@ -845,7 +845,9 @@ __global__ __launch_bounds__(ENC_T) void k_encode(const ScanParams P, uint32_t t
         uint32_t dmask;
         {
             const uint32_t u = u0 + ((lane >> 2) & 1);
-            const uint32_t seg = u % nseg, sz = (u / nseg) % P.zs, q = u / (nseg * P.zs);
+            uint32_t seg, sz, q;
+            if (P.lg_nseg >= 0) { seg = u & (nseg - 1); sz = (u >> P.lg_nseg) & (P.zs - 1); q = u >> (P.lg_nseg + P.lg_zs); }   // (power-of-two grids: no division)
+            else { seg = u % nseg; sz = (u / nseg) % P.zs; q = u / (nseg * P.zs); }
             const uint32_t syl = q * 4 + (lane & 3);
             const bool ok = lane < 8 && u < t_end && syl < (uint32_t)xy && (int)syl >= P.sy_lo && (int)syl < P.sy_hi;
             const uint32_t tagv = tags[ok ? (syl * P.zs + sz) * nseg + seg : 0];
@@ -856,7 +858,9 @@ __global__ __launch_bounds__(ENC_T) void k_encode(const ScanParams P, uint32_t t
         for (int j = 0; j < 2; ++j) {
             if (((dmask >> (4 * j)) & 0xfu) == 0) continue;          // wave-uniform
             const uint32_t u = u0 + j;
-            const uint32_t seg = u % nseg, sz = (u / nseg) % P.zs, q = u / (nseg * P.zs);
+            uint32_t seg, sz, q;
+            if (P.lg_nseg >= 0) { seg = u & (nseg - 1); sz = (u >> P.lg_nseg) & (P.zs - 1); q = u >> (P.lg_nseg + P.lg_zs); }
+            else { seg = u % nseg; sz = (u / nseg) % P.zs; q = u / (nseg * P.zs); }
             const uint32_t sy = q * 4 + r, sx0 = seg * 64 + p4 * 4;
             const bool dirty = ((dmask >> (4 * j + r)) & 1u) && sx0 < (uint32_t)xy;
             const uint32_t A0 = dirty ? acc_idx((int)sx0, (int)sy, (int)sz, P.zs, P.sxq) : (uint32_t)(lane * 4);

@@ -6,12 +6,17 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "g-vom_amd")]
 import bench, gvom, synth
+knobs = [a for a in sys.argv[1:] if "=" in a]                    # result-neutral tuning: name=value (gvom_set_tuning)
+sys.argv = [a for a in sys.argv if "=" not in a]
 name = sys.argv[1] if len(sys.argv) > 1 else "m256"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
 hip = bench.Hip(); hip.set_device(0)
 params, scans = synth.config_inputs(name, n_scans=8)
 dev = [(hip.to_device(pc), pc.shape[0], pc.dtype, ego, tf) for (pc, ego, tf) in scans]
 g = gvom.Gvom(*params)
+for kv in knobs:
+    g.set_tuning(kv.split("=")[0], int(kv.split("=")[1]))
+def occ(k): scan(k); g.combine_maps_occupancy()
 def scan(k):
     d, n, dt, ego, tf = dev[k % len(dev)]; g.process_pointcloud_device(d.value, n, dt, ego, tf)
 def timed(f, n):
@@ -27,4 +32,5 @@ def piped(k):
     if pend[0] is not None: pend[0].result()
     pend[0] = g.combine_maps_async()
 print("%s: synchronous %.1f us | async + result at once %.1f us |" % (name, timed(sync, steps), timed(at_once, steps)), end=" ")
-print("pipelined %.1f us" % timed(piped, steps)); pend[0].result()
+print("pipelined %.1f us |" % timed(piped, steps), end=" "); pend[0].result()
+print("synchronous occupancy %.1f us %s" % (timed(occ, steps), " ".join(knobs)))
