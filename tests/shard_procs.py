@@ -6,7 +6,8 @@ allocations re-exported when a region has grown, the scan's sparse all-to-all, t
 all-gather -- moving real device data between real processes.  Every rank compares what it gets with an unsharded
 mapper fed the concatenated shares.  The launcher makes no HIP call.
 
-usage: tests/shard_procs.py <world> [transport=peer] [stats=0]      exit code 0 iff every rank ran and matched"""
+usage: tests/shard_procs.py <world> [transport=peer] [stats=0] [repeat=1]      exit code 0 iff every rank ran and matched
+(repeat > 1: the seven steps over and over on the same maps -- a soak of the transport)"""
 import os
 import subprocess
 import sys
@@ -44,7 +45,7 @@ def plan(world):
     return steps
 
 
-def rank_main(rank, world, name, transport, stats):
+def rank_main(rank, world, name, transport, stats, repeat=1):
     for p in (ROOT, os.path.join(ROOT, "g-vom_amd")):
         sys.path.insert(0, p)
     import contextlib
@@ -57,7 +58,8 @@ def rank_main(rank, world, name, transport, stats):
     sh = gvom_sharded.ShardedGvom(*PARAMS, comm=comm, device=0, voxel_statistics=stats)
     ref = gvom.Gvom(*PARAMS, voxel_statistics=stats)
     n_maps = 0
-    for k, (shares, ego, tf) in enumerate(plan(world)):
+    steps = plan(world)
+    for k, (shares, ego, tf) in enumerate(steps * repeat):
         with contextlib.redirect_stdout(io.StringIO()):
             sh.process_pointcloud(shares[rank], ego, tf)
             ref.process_pointcloud(np.concatenate(shares, 0), ego, tf)
@@ -87,12 +89,12 @@ def rank_main(rank, world, name, transport, stats):
           (rank, world, comm.transport, ", statistics" if stats else "", n_maps, ps), flush=True)
 
 
-def launch(world, transport="peer", stats=False, timeout=240):
+def launch(world, transport="peer", stats=False, timeout=240, repeat=1):
     """-> (ok, text).  Starts the rank processes and collects what they say."""
     name = "gvom_procs_%d_%d" % (os.getpid(), world)
     env = dict(os.environ, GVOM_COMM_TIMEOUT_S="120", HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--rank", str(r), str(world), name, transport,
-                               "1" if stats else "0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+                               "1" if stats else "0", str(repeat)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
              for r in range(world)]
     ok, text = True, []
     for r, p in enumerate(procs):
@@ -109,9 +111,10 @@ def launch(world, transport="peer", stats=False, timeout=240):
 
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "--rank":
-        rank_main(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5], sys.argv[6] == "1")
+        rank_main(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5], sys.argv[6] == "1", int(sys.argv[7]) if len(sys.argv) > 7 else 1)
         sys.exit(0)
     W = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-    ok, text = launch(W, sys.argv[2] if len(sys.argv) > 2 else "peer", len(sys.argv) > 3 and sys.argv[3] == "1")
+    rep = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+    ok, text = launch(W, sys.argv[2] if len(sys.argv) > 2 else "peer", len(sys.argv) > 3 and sys.argv[3] == "1", timeout=240 + 2 * rep, repeat=rep)
     print(text)
     sys.exit(0 if ok else 1)
