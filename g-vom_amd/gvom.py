@@ -139,6 +139,9 @@ ABI = [
 ]
 
 
+ABI_VERSION = 5          # include/gvom_hip.h GVOM_ABI_VERSION this binding was written against
+
+
 def load_library(path=None):
     """dlopen libgvom_hip.so and bind every C-ABI entry point.  Raises GvomBackendError."""
     global _lib
@@ -162,6 +165,9 @@ def load_library(path=None):
                 raise GvomBackendError("%s does not export %s" % (p, name))
             f.restype = res
             f.argtypes = args
+        if L.gvom_abi_version() != ABI_VERSION:
+            raise GvomBackendError("%s has C ABI version %d, this binding needs %d: rebuild it (`make -C %s`)"
+                                   % (p, L.gvom_abi_version(), ABI_VERSION, _HERE))
         if path is None:
             _lib = L
         return L

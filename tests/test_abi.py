@@ -29,7 +29,10 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), "libgvom_hip.so does not export %s" % name
     bound = {n for n, _, _ in gvom.ABI}
     assert set(declared) == bound, (set(declared) ^ bound)
-    assert gvom.load_library().gvom_abi_version() == 5
+    import re
+    header = open(os.path.join(ROOT, "include", "gvom_hip.h")).read()
+    declared_version = int(re.search(r"#define\s+GVOM_ABI_VERSION\s+(\d+)", header).group(1))
+    assert gvom.load_library().gvom_abi_version() == declared_version == gvom.ABI_VERSION
 
 
 def test_params_struct_layout_matches_header():
