@@ -68,6 +68,9 @@ def make_share(name, rank, world, k):
     return np.concatenate(parts, 0), pose
 
 
+FELL_BACK = False        # set by run(): AUTO ended up on peer copies (a helper thread may still sit inside ncclCommInitRank)
+
+
 class ExchangeTimer(object):
     """Wraps a communicator: HIP events on the handle's stream around the scan's exchange and the combine's
     all-gather (the collectives run on that stream), read back after the step has synchronised."""
@@ -187,7 +190,7 @@ def run(args):
         scans.append(((hip.to_device(pc).value, pc.shape[0], pc.dtype), pose))
     n_local = scans[0][0][1]
     rccl = gvom_sharded.RcclComm(rank, world, local_rank, gvom_sharded.rendezvous_name(),
-                                 transport="peer" if args.share_device else args.transport)
+                                 transport="peer" if (args.share_device and not os.environ.get("GVOM_BENCH_REHEARSE_AUTO")) else args.transport)
     comm = ExchangeTimer(rccl, hip)
     sh = gvom_sharded.ShardedGvom(*params, comm=comm, device=local_rank)
     big = name in ("c4", "c5")
@@ -263,7 +266,8 @@ def run(args):
                                    "through shared memory; transport: see \"transport\""},
             "transport": {"rccl": "RCCL (grouped ncclSend/ncclRecv, ncclAllGather)",
                           "peer": "peer copies (exported regions, hipMemcpyAsync pulled by the receiver, two host barriers per exchange)"}[rccl.transport]
-                         + ("" if args.transport != "auto" or rccl.transport == "rccl" or args.share_device else " -- RCCL could not initialise"),
+                         + ("" if args.transport != "auto" or rccl.transport == "rccl" or (args.share_device and not os.environ.get("GVOM_BENCH_REHEARSE_AUTO"))
+                            else " -- RCCL could not initialise"),
             "rehearsal_on_one_device": bool(args.share_device),
             "peer_transport_rank0": rccl.peer_stats() if rccl.transport == "peer" else None,
             "map_hz": steps / med, "blocks": len(blocks),
@@ -285,5 +289,7 @@ def run(args):
                                  "PMC traffic is profiled on the N = 1 run"},
         }
     fence()
+    global FELL_BACK
+    FELL_BACK = args.transport == "auto" and rccl.transport == "peer" and not (args.share_device and not os.environ.get("GVOM_BENCH_REHEARSE_AUTO"))
     rccl.close()
     return out

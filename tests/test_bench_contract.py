@@ -141,6 +141,18 @@ def test_sharded_bench_rehearsal_with_two_rank_processes_on_one_gpu():
 
 
 @pytest.mark.gpu
+def test_sharded_bench_falls_back_to_peer_copies_when_rccl_refuses():
+    """The N > 1 leg with its default transport (AUTO) where RCCL cannot start -- two ranks on one device: both ranks agree
+    on peer copies, the line says so, the maps are verified, and the rank processes leave with exit code 0."""
+    p = _bench(["--gpus", "2", "--share-device", "--steps", "20", "--warmup", "6", "--no-cpu"],
+               {"GVOM_COMM_TIMEOUT_S": "120", "GVOM_BENCH_REHEARSE_AUTO": "1"}, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    d = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    assert d["transport"].startswith("peer copies") and "RCCL could not initialise" in d["transport"]
+    assert d["sharded_equals_unsharded"] is True and d["n_gpus"] == 2
+
+
+@pytest.mark.gpu
 def test_sharded_bench_leg_runs_baseline_config_c4():
     """BASELINE.json config 4 (512 x 512 x 128, buffer 4, the 1,048,576-point cloud) through the sharded leg with the
     one rank a one-GPU box allows -- the workload is c4's, not a silent substitute, and the line says the sharded
