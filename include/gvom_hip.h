@@ -237,7 +237,11 @@ int  gvom_comm_create(int rank, int world, int device, const char *name, gvom_co
  *       this is the transport a one-GPU box can run several rank processes with);
  * AUTO  RCCL; if librccl cannot be loaded, or ncclCommInitRank fails on any rank or does not return within
  *       GVOM_RCCL_INIT_TIMEOUT_S (default 90 s after the last rank has arrived), every rank uses PEER.
- * gvom_comm_transport: the transport in use (GVOM_TRANSPORT_RCCL or GVOM_TRANSPORT_PEER). */
+ * gvom_comm_transport: the transport in use (GVOM_TRANSPORT_RCCL or GVOM_TRANSPORT_PEER).
+ * Failure semantics: a rank whose device exchange failed marks the communicator (for every rank) as broken, and a rank
+ * whose process has gone is noticed by whoever waits for it next: the others' next gvom_comm_exchange_host / _barrier
+ * returns GVOM_ERR_HIP with a message naming the rank instead of waiting GVOM_COMM_TIMEOUT_S.  A broken communicator stays
+ * broken: destroy it. */
 #define GVOM_TRANSPORT_RCCL 0
 #define GVOM_TRANSPORT_PEER 1
 #define GVOM_TRANSPORT_AUTO 2
