@@ -104,3 +104,25 @@ def test_rank_zero_removes_its_segment_when_creation_fails():
     rc = lib.gvom_comm_create(0, 2, 4096, name.encode(), ctypes.byref(c))
     assert rc != 0 and not c
     assert not os.path.exists("/dev/shm/" + name)
+
+
+def test_transport_selection_and_bookkeeping_of_a_host_only_communicator():
+    """gvom_comm_create2's transport argument: unknown values are refused (library and binding), a host-only communicator
+    (device -1) takes any of them without touching RCCL or HIP, reports a transport and all-zero peer-copy statistics."""
+    import ctypes
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "g-vom_amd"))
+    import gvom
+    import gvom_sharded
+    lib = gvom.load_library()
+    c = ctypes.c_void_p()
+    assert lib.gvom_comm_create2(0, 1, -1, b"gvom_test_tr_%d" % os.getpid(), 7, ctypes.byref(c)) != 0 and not c.value
+    with pytest.raises(KeyError):
+        gvom_sharded.RcclComm(0, 1, -1, "gvom_test_tr2_%d" % os.getpid(), transport="carrier pigeon")
+    for tr, want in (("rccl", "rccl"), ("peer", "peer"), ("auto", "rccl")):
+        comm = gvom_sharded.RcclComm(0, 1, -1, "gvom_test_tr3_%d_%s" % (os.getpid(), tr), transport=tr)
+        try:
+            assert comm.transport == want
+            assert comm.peer_stats() == {"bytes": 0, "copies": 0, "exports": 0, "open_retries": 0}
+            assert comm.exchange_host([3, 4]) == [[3, 4]]
+        finally:
+            comm.close()
