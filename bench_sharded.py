@@ -88,6 +88,12 @@ class ExchangeTimer(object):
     def barrier(self):
         return self.c.barrier()
 
+    def before_scan(self):
+        return self.c.before_scan()
+
+    def before_combine(self):
+        return self.c.before_combine()
+
     def exchange_scan(self, backend, sq, se, rq, re):
         if not self.on:
             return self.c.exchange_scan(backend, sq, se, rq, re)
@@ -265,7 +271,8 @@ def run(args):
                                    "per combine: in-place all-gather of height|inferred|density rows (24 B/cell); counts "
                                    "through shared memory; transport: see \"transport\""},
             "transport": {"rccl": "RCCL (grouped ncclSend/ncclRecv, ncclAllGather)",
-                          "peer": "peer copies (exported regions, hipMemcpyAsync pulled by the receiver, two host barriers per exchange)"}[rccl.transport]
+                          "peer": "peer copies (exported regions, hipMemcpyAsync pulled by the receiver; %s)" %
+                                  ("asynchronous: completion flags written by the GPUs" if rccl.peer_async else "two host barriers and stream waits per exchange")}[rccl.transport]
                          + ("" if args.transport != "auto" or rccl.transport == "rccl" or (args.share_device and not os.environ.get("GVOM_BENCH_REHEARSE_AUTO"))
                             else " -- RCCL could not initialise"),
             "rehearsal_on_one_device": bool(args.share_device),

@@ -32,6 +32,7 @@ namespace {
 struct Buf {                                   // grow-only device buffer
     void *p = nullptr;
     size_t bytes = 0;
+    uint64_t gen = 0;                          // changes with every (re-)allocation (process-wide unique: gvom_region_generation)
 };
 
 struct Slot {                                  // one scan in sparse form
@@ -79,7 +80,9 @@ struct gvom_handle {
     size_t acc_elems = 0;
     int tune_segs = 0, tune_ep_row = -2, tune_period = 0; // gvom_set_tuning (0 / -2: automatic)
     int tune_prio = -1;                                 // gvom_set_tuning "prio" (-1: automatic)
+    int tune_churn = 0;                                 // test hook: re-allocate the endpoint send region every scan
     uint64_t alloc_gen = 0;                             // changes whenever a send region of this handle is re-allocated
+    uint64_t handle_gen = 0;                            // this handle's own number (its fixed allocations)
     // rank exchange of a sharded map (world > 1): send / receive regions, indexed by peer rank
     uint32_t *x_send_ids = nullptr, *x_recv_ids = nullptr;     // quad ids: [Q] by owner / [world][myQ] by source
     void *x_send_pay = nullptr, *x_recv_pay = nullptr;         // 1 KiB per quad, same indexing
@@ -208,7 +211,8 @@ int ensure(gvom_handle *h, Buf &b, size_t bytes)
     b.p = nullptr; b.bytes = 0;
     HIPCHK(h, hipMalloc(&b.p, want));
     b.bytes = want;
-    if (&b == &h->x_send_eps || &b == &h->x_send_sp) h->alloc_gen = ++g_alloc_generation;   // (see gvom_alloc_generation)
+    b.gen = ++g_alloc_generation;
+    if (&b == &h->x_send_eps || &b == &h->x_send_sp) h->alloc_gen = b.gen;   // (see gvom_alloc_generation)
     return GVOM_OK;
 }
 
@@ -321,7 +325,7 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, b
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev)
         return GVOM_ERR_NO_DEVICE;
     gvom_handle *h = new gvom_handle();
-    h->alloc_gen = ++g_alloc_generation;
+    h->alloc_gen = h->handle_gen = ++g_alloc_generation;
     h->prm = *params;
     h->device = device_id;
     h->rank = rank; h->world = world; h->sharded = sharded;
@@ -624,6 +628,10 @@ int scan_launch(gvom_handle *h, std::unique_lock<std::mutex> &lk, const void *de
     ShardExchange X;
     X.ep_send = nullptr; X.ep_cnt = nullptr; X.ep_cap = 0; X.sp_send = nullptr; X.sp_cnt = nullptr;
     if (h->sharded) {
+        if (h->tune_churn > 0 && h->x_send_eps.p) {            // test hook (gvom_set_tuning "churn"): a fresh allocation every scan
+            HIPCHK(h, hipFree(h->x_send_eps.p));
+            h->x_send_eps.p = nullptr; h->x_send_eps.bytes = 0;
+        }
         if ((rc = ensure(h, h->x_send_eps, (size_t)h->world * (size_t)(n > 0 ? n : 1) * 8))) return rc;
         h->x_ep_cap = n > 0 ? n : 1;
         X.ep_send = (uint2 *)h->x_send_eps.p; X.ep_cnt = h->x_ecnt; X.ep_cap = (long)h->x_ep_cap;
@@ -1891,6 +1899,7 @@ VIS int gvom_set_tuning(gvom_t *h, const char *name, int value)
     else if (!strcmp(name, "ep_row")) h->tune_ep_row = value;
     else if (!strcmp(name, "period")) h->tune_period = value;
     else if (!strcmp(name, "prio")) h->tune_prio = value;
+    else if (!strcmp(name, "churn")) h->tune_churn = value;
 
     else if (!strcmp(name, "epoch_bias")) h->epoch += (uint32_t)value;   // test hook: advances the tile-epoch counter (towards its wrap)
     else return GVOM_ERR_INVALID;
@@ -1911,6 +1920,15 @@ VIS void *gvom_stream(gvom_t *h) { return h ? (void *)h->stream : nullptr; }
 // whoever caches something derived from their addresses (the peer transport's exported allocations) knows when to
 // look again.  (GVOM_BUF_HEIGHT_MAPS and the quad regions are allocated once, with the handle.)
 VIS uint64_t gvom_alloc_generation(gvom_t *h) { return h ? h->alloc_gen : 0; }
+// The same for ONE region (which = GVOM_XBUF_SEND_* or -1 for GVOM_BUF_HEIGHT_MAPS): a value that names the allocation the
+// region lies in -- it changes exactly when that allocation is replaced (and differs between handles).
+VIS uint64_t gvom_region_generation(gvom_t *h, int which)
+{
+    if (!h) return 0;
+    if (which == GVOM_XBUF_SEND_EPS) return h->x_send_eps.gen ? h->x_send_eps.gen : h->handle_gen;
+    if (which == GVOM_XBUF_SEND_RETURNS) return h->x_send_sp.gen ? h->x_send_sp.gen : h->handle_gen;
+    return h->handle_gen;
+}
 
 VIS const char *gvom_last_error(gvom_t *h) { return h ? h->err.c_str() : "null handle"; }
 

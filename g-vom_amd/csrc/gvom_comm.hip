@@ -81,6 +81,14 @@ struct Slot {                                  // one rank's mailbox for one exc
     char pad[64];
 };
 
+struct PeerFlags {                             // one 64-byte line per rank
+    std::atomic<uint64_t> pulled_scan;         // "I have pulled what the others held for me in scan exchange k" (they may repack)
+    std::atomic<uint64_t> pulled_stats;        // the same for the statistics returns
+    std::atomic<uint64_t> rows_ready;          // "my rows of combine k are complete" (the others may pull them)
+    std::atomic<uint64_t> pulled_rows;         // "I have pulled everybody's rows of combine k" (they may fuse again)
+    char pad[32];
+};
+
 #define GVOM_PEER_KINDS 5                   // exported regions: send ids, send quads, send endpoints, send returns, height-map rows
 struct PeerExport {                            // one exported region of one rank (peer transport)
     hipIpcMemHandle_t handle;                  // of the ALLOCATION the region lies in
@@ -106,6 +114,10 @@ struct Segment {                               // the shared-memory rendezvous o
     uint64_t rank_start[GVOM_COMM_MAX_RANKS];  // died ends in an error at once instead of after the timeout
     Slot slots[2][GVOM_COMM_MAX_RANKS];
     PeerExport exports[GVOM_COMM_MAX_RANKS][GVOM_PEER_KINDS];   // written by their rank between two barriers only
+    // peer transport, asynchronous form: exchange numbers written BY THE GPU of the rank they belong to (a one-thread kernel on
+    // its stream, system-scope release) and read by the other ranks' hosts -- the segment is registered with HIP for that
+    std::atomic<uint32_t> sync_only;           // some rank could not register the segment: everybody keeps the host-synchronised form
+    PeerFlags flags[GVOM_COMM_MAX_RANKS];
 };
 
 inline double now_s() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + t.tv_nsec * 1e-9; }
@@ -177,6 +189,10 @@ struct gvom_comm {
     PeerOwn own[GVOM_PEER_KINDS];
     uint64_t peer_bytes = 0, peer_copies = 0;  // pulled so far (diagnostics)
     uint64_t export_seq = 0, peer_open_retries = 0;
+    // asynchronous form of the peer transport (no host wait for the GPU inside an exchange)
+    bool async = false, registered = false;
+    Segment *seg_dev = nullptr;                // device view of the registered segment
+    uint64_t scan_x = 0, stats_x = 0, rows_x = 0;   // exchanges so far (the same on every rank: they are collectives)
     Segment *seg = nullptr;
     std::string shm_name, err;
     uint64_t calls = 0;                        // host exchanges so far
@@ -206,12 +222,48 @@ namespace {
     } while (0)
 
 // ---- peer transport -------------------------------------------------------------------------------
+__global__ void k_comm_flag(unsigned long long *p, unsigned long long v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);     // everything before it on the stream is complete and visible
+}
+int peer_flag(gvom_comm *c, hipStream_t st, std::atomic<uint64_t> *host_field, uint64_t v)
+{
+    unsigned long long *dev = (unsigned long long *)((char *)c->seg_dev + ((char *)host_field - (char *)c->seg));
+    hipLaunchKernelGGL(k_comm_flag, dim3(1), dim3(1), 0, st, dev, (unsigned long long)v);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { c->err = std::string("flag kernel launch failed: ") + hipGetErrorString(e); return GVOM_ERR_HIP; }
+    return GVOM_OK;
+}
+// the host waits until rank r's GPU has written exchange number `target` (normally it has, long ago)
+int peer_wait(gvom_comm *c, int r, const std::atomic<uint64_t> &flag, uint64_t target, const char *what)
+{
+    if (flag.load(std::memory_order_acquire) >= target) return GVOM_OK;
+    const double deadline = now_s() + c->timeout_s;
+    double next_look = 0.0;
+    unsigned spins = 0;
+    while (flag.load(std::memory_order_acquire) < target) {
+        _mm_pause();
+        if ((++spins & 0x3ff) == 0) {
+            const double t = now_s();
+            const uint32_t bad = c->seg->poison.load(std::memory_order_acquire);
+            if (bad) { c->err = "rank " + std::to_string(bad - 1) + " reported a failed device exchange"; return GVOM_ERR_HIP; }
+            if (t > deadline) { c->err = std::string("timed out waiting for rank ") + std::to_string(r) + " (" + what + ")"; return GVOM_ERR_HIP; }
+            if (t > next_look) {
+                next_look = t + 0.05;
+                if (!proc_running(c->seg->rank_pid[r], c->seg->rank_start[r])) { c->err = "rank " + std::to_string(r) + "'s process is gone"; return GVOM_ERR_HIP; }
+            }
+        }
+    }
+    return GVOM_OK;
+}
+
 // Publishes the allocation that holds the regions `ptr[d]` (d != rank; null entries: nothing for d) as export `kind`
 // of this rank: handle of the allocation + the regions' offsets inside it.  The handle is taken again only when the
 // handle's buffers have been re-allocated since (gvom_alloc_generation).  Call between two barriers' worth of quiet:
 // readers look at the export only after the barrier that follows.
 int peer_publish(gvom_comm *c, gvom_t *h, int kind, void *const *ptr)
 {
+    static const int region_of_kind[GVOM_PEER_KINDS] = {GVOM_XBUF_SEND_IDS, GVOM_XBUF_SEND_QUADS, GVOM_XBUF_SEND_EPS, GVOM_XBUF_SEND_RETURNS, -1};
     PeerExport &e = c->seg->exports[c->rank][kind];
     void *any = nullptr;
     for (int d = 0; d < c->world; ++d) if (d != c->rank && ptr[d]) { any = ptr[d]; break; }
@@ -220,10 +272,20 @@ int peer_publish(gvom_comm *c, gvom_t *h, int kind, void *const *ptr)
     size_t size = 0;
     HIPCHK_C(c, hipMemGetAddressRange((hipDeviceptr_t *)&base, &size, (hipDeviceptr_t)any));
     PeerOwn &o = c->own[kind];
-    const uint64_t gen = gvom_alloc_generation(h);
+    // (an allocation is exported ONCE: exporting it again -- and the importers closing and re-opening the very same memory --
+    // is what the HSA runtime does not take reliably: with a fresh export per scan, results differed after a dozen scans)
+    const uint64_t gen = gvom_region_generation(h, region_of_kind[kind]);
     if (o.base != base || o.size != size || o.alloc_gen != gen) {
         hipIpcMemHandle_t hd;
-        HIPCHK_C(c, hipIpcGetMemHandle(&hd, base));
+        hipError_t ge = hipSuccess;
+        for (int attempt = 0; attempt < 20; ++attempt) {               // (seen refused -- "invalid argument" -- once in ~700 exports of fresh allocations, transiently)
+            ge = hipIpcGetMemHandle(&hd, base);
+            if (ge == hipSuccess) break;
+            (void)hipGetLastError();
+            ++c->peer_open_retries;
+            usleep(1000 + 1000 * attempt);
+        }
+        if (ge != hipSuccess) { c->err = std::string("hipIpcGetMemHandle failed: ") + hipGetErrorString(ge); return GVOM_ERR_HIP; }
         memcpy(&e.handle, &hd, sizeof hd);
         e.generation = ((uint64_t)(c->rank + 1) << 48) | ++c->export_seq;
         e.size = size;
@@ -278,9 +340,15 @@ struct PeerPull { int kind, recv_which; int64_t unit; const int64_t *recv_counts
 // One exchange by peer copies: every rank has published its regions (peer_publish); barrier; every rank pulls what
 // the others hold for it -- hipMemcpyAsync on ITS OWN handle's stream, the ordering ncclRecv on that stream gives --
 // and waits for its copies; barrier (the senders may rewrite their regions).
-int peer_pull(gvom_comm *c, gvom_t *h, hipStream_t st, const PeerPull *pulls, int n_pulls)
+// Asynchronous form (c->async; `done` = this rank's flag for the kind of exchange, `x` its number): the send regions are
+// complete by construction (their counts were read by the hosts after the kernels that fill them), so one host barrier
+// makes the exports visible, the pulls are enqueued, a one-thread kernel behind them writes `x` into `done`, and the call
+// returns without waiting for the GPU; whoever is about to REWRITE its send regions waits for every peer's `done` first
+// (gvom_comm_before_scan).
+int peer_pull(gvom_comm *c, gvom_t *h, hipStream_t st, const PeerPull *pulls, int n_pulls, std::atomic<uint64_t> *done = nullptr, uint64_t x = 0)
 {
-    HIPCHK_C(c, hipStreamSynchronize(st));                             // what I export is complete
+    const bool async = c->async && done != nullptr;
+    if (!async) HIPCHK_C(c, hipStreamSynchronize(st));                 // what I export is complete
     int rc = gvom_comm_barrier(c);
     if (rc) return rc;
     for (int s = 0; s < c->world && rc == GVOM_OK; ++s) {
@@ -302,6 +370,10 @@ int peer_pull(gvom_comm *c, gvom_t *h, hipStream_t st, const PeerPull *pulls, in
             if (e != hipSuccess) { c->err = std::string("hipMemcpyAsync (peer copy) failed: ") + hipGetErrorString(e); rc = GVOM_ERR_HIP; break; }
             c->peer_bytes += bytes; ++c->peer_copies;
         }
+    }
+    if (async) {
+        if (rc) return rc;                                             // (the caller poisons the segment: nobody waits for this rank's flag)
+        return peer_flag(c, st, done, x);
     }
     // (even a failed rank passes the second barrier: the others would wait for it for ever)
     const hipError_t se = hipStreamSynchronize(st);
@@ -486,6 +558,25 @@ VIS int gvom_comm_create2(int rank, int world, int device, const char *name, int
             c->transport = GVOM_TRANSPORT_PEER;
         }
     }
+    if (!host_only && c->transport == GVOM_TRANSPORT_PEER && world > 1) {
+        // GVOM_PEER_ASYNC=1 asks for the asynchronous form.  It needs the GPU to write into the segment: register it; one rank
+        // that cannot (or was not asked to) keeps everybody on the host-synchronised form.  (Not the default: with several
+        // ranks on ONE GPU -- the only place it could be measured -- it is the slower form, the processes' kernels then
+        // interleave on the device: m256 x 2 ranks 677 us per step against 421, c4 x 4 ranks 2959 against 2862.)
+        const char *want = getenv("GVOM_PEER_ASYNC");
+        bool ok = want && atoi(want) != 0;
+        if (ok) {
+            ok = hipHostRegister(c->seg, sizeof(Segment), hipHostRegisterMapped | hipHostRegisterPortable) == hipSuccess;
+            if (ok) {
+                c->registered = true;
+                ok = hipHostGetDevicePointer((void **)&c->seg_dev, c->seg, 0) == hipSuccess && c->seg_dev != nullptr;
+            }
+            (void)hipGetLastError();
+        }
+        if (!ok) c->seg->sync_only.fetch_add(1, std::memory_order_acq_rel);
+        if (gvom_comm_barrier(c) != GVOM_OK) return fail("rendezvous barrier: " + c->err, GVOM_ERR_HIP);
+        c->async = c->seg->sync_only.load(std::memory_order_acquire) == 0u;
+    }
     *out = c;
     return GVOM_OK;
 }
@@ -507,6 +598,7 @@ VIS void gvom_comm_destroy(gvom_comm_t *c)
             for (int k = 0; k < GVOM_PEER_KINDS; ++k)
                 if (c->imports[s][k].base) (void)hipIpcCloseMemHandle(c->imports[s][k].base);
     }
+    if (c->registered) { hipSetDevice(c->device); (void)hipDeviceSynchronize(); (void)hipHostUnregister(c->seg); }
     if (c->seg) munmap(c->seg, sizeof(Segment));
     if (c->rank == 0) shm_unlink(c->shm_name.c_str());                 // harmless if already gone
     delete c;
@@ -591,7 +683,8 @@ static int exchange_scan_impl(gvom_comm_t *c, gvom_t *h, const int64_t *send_qua
         }
         const PeerPull pulls[3] = {{0, GVOM_XBUF_RECV_IDS, 4, recv_quads}, {1, GVOM_XBUF_RECV_QUADS, 1024, recv_quads},
                                    {2, GVOM_XBUF_RECV_EPS, 8, recv_eps}};
-        return peer_pull(c, h, st, pulls, 3);
+        ++c->scan_x;
+        return peer_pull(c, h, st, pulls, 3, &c->seg->flags[c->rank].pulled_scan, c->scan_x);
     }
     if (!c->nccl) { c->err = "communicator without RCCL"; return GVOM_ERR_INVALID; }
     NCCLCHK(c, c->rccl.GroupStart());
@@ -645,7 +738,8 @@ static int exchange_stats_impl(gvom_comm_t *c, gvom_t *h, const int64_t *send_re
         const int rcp = peer_publish(c, h, 3, ptr);
         if (rcp) return rcp;
         const PeerPull pull = {3, GVOM_XBUF_RECV_RETURNS, bytes_per_return, recv_returns};
-        return peer_pull(c, h, st, &pull, 1);
+        ++c->stats_x;
+        return peer_pull(c, h, st, &pull, 1, &c->seg->flags[c->rank].pulled_stats, c->stats_x);
     }
     if (!c->nccl) { c->err = "communicator without RCCL"; return GVOM_ERR_INVALID; }
     NCCLCHK(c, c->rccl.GroupStart());
@@ -694,6 +788,22 @@ static int allgather_rows_impl(gvom_comm_t *c, gvom_t *h)
         void *mine[GVOM_COMM_MAX_RANKS] = {};
         for (int d = 0; d < c->world; ++d) if (d != c->rank) mine[d] = (char *)ptr + share * c->rank;
         if ((rc = peer_publish(c, h, 4, mine))) return rc;
+        if (c->async) {
+            // my rows are complete when my stream gets here; the others' when their flag says so (their hosts wait for it, the GPUs
+            // for nothing); "I have pulled" goes behind my copies, and whoever fuses again waits for it (gvom_comm_before_combine)
+            const uint64_t x = ++c->rows_x;
+            if ((rc = peer_flag(c, st, &c->seg->flags[c->rank].rows_ready, x))) return rc;
+            if ((rc = gvom_comm_barrier(c))) return rc;                // (exports visible)
+            for (int s = 0; s < c->world; ++s) {
+                void *src = nullptr;
+                if (s == c->rank) continue;
+                if ((rc = peer_wait(c, s, c->seg->flags[s].rows_ready, x, "its rows of the combine"))) return rc;
+                if ((rc = peer_source(c, s, 4, &src))) return rc;
+                HIPCHK_C(c, hipMemcpyAsync((char *)ptr + share * s, src, share, hipMemcpyDefault, st));
+                c->peer_bytes += share; ++c->peer_copies;
+            }
+            return peer_flag(c, st, &c->seg->flags[c->rank].pulled_rows, x);
+        }
         HIPCHK_C(c, hipStreamSynchronize(st));                         // my rows are complete
         if ((rc = gvom_comm_barrier(c))) return rc;
         for (int s = 0; s < c->world && rc == GVOM_OK; ++s) {
@@ -738,6 +848,32 @@ VIS int gvom_comm_allgather_rows(gvom_comm_t *c, gvom_t *h)
     const int rc = allgather_rows_impl(c, h);
     // a rank whose device exchange failed will not come to the next rendezvous: the others must not wait for it
     if (rc != GVOM_OK && c && c->seg && c->world > 1) c->seg->poison.store((uint32_t)c->rank + 1u, std::memory_order_release);
+    return rc;
+}
+
+// Asynchronous peer transport: before a rank REWRITES what its peers pull from -- its send regions (the next scan's pack) or its
+// rows (the next fusion) -- every peer must have finished pulling the previous exchange.  Their GPUs say so in the segment;
+// normally they did long ago and these calls return at once.  No-ops on the other transports.
+VIS int gvom_comm_before_scan(gvom_comm_t *c)
+{
+    if (!c) return GVOM_ERR_INVALID;
+    if (!c->async || c->world == 1) return GVOM_OK;
+    int rc = GVOM_OK;
+    for (int p = 0; p < c->world && rc == GVOM_OK; ++p) {
+        if (p == c->rank) continue;
+        rc = peer_wait(c, p, c->seg->flags[p].pulled_scan, c->scan_x, "pulling the previous scan");
+        if (rc == GVOM_OK) rc = peer_wait(c, p, c->seg->flags[p].pulled_stats, c->stats_x, "pulling the previous scan's returns");
+    }
+    return rc;
+}
+VIS int gvom_comm_peer_async(gvom_comm_t *c) { return c && c->async ? 1 : 0; }
+VIS int gvom_comm_before_combine(gvom_comm_t *c)
+{
+    if (!c) return GVOM_ERR_INVALID;
+    if (!c->async || c->world == 1) return GVOM_OK;
+    int rc = GVOM_OK;
+    for (int p = 0; p < c->world && rc == GVOM_OK; ++p)
+        if (p != c->rank) rc = peer_wait(c, p, c->seg->flags[p].pulled_rows, c->rows_x, "pulling the previous combine's rows");
     return rc;
 }
 

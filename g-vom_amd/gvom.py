@@ -102,6 +102,9 @@ ABI = [
     ("gvom_comm_create", _I, [_I, _I, _I, ctypes.c_char_p, ctypes.POINTER(_P)]),
     ("gvom_comm_create2", _I, [_I, _I, _I, ctypes.c_char_p, _I, ctypes.POINTER(_P)]),
     ("gvom_comm_transport", _I, [_P]),
+    ("gvom_comm_before_scan", _I, [_P]),
+    ("gvom_comm_before_combine", _I, [_P]),
+    ("gvom_comm_peer_async", _I, [_P]),
     ("gvom_comm_peer_stats", _I, [_P, ctypes.POINTER(_I64)]),
     ("gvom_comm_destroy", None, [_P]),
     ("gvom_comm_exchange_host", _I, [_P, ctypes.POINTER(_I64), _I, ctypes.POINTER(_I64)]),
@@ -133,6 +136,7 @@ ABI = [
     ("gvom_set_tuning", _I, [_P, ctypes.c_char_p, _I]),
     ("gvom_stream", _P, [_P]),
     ("gvom_alloc_generation", ctypes.c_uint64, [_P]),
+    ("gvom_region_generation", ctypes.c_uint64, [_P, _I]),
     ("gvom_last_error", ctypes.c_char_p, [_P]),
     ("gvom_backend_info", _I, [ctypes.c_char_p, ctypes.c_size_t]),
     ("gvom_abi_version", _I, []),

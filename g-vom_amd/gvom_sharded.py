@@ -47,6 +47,10 @@ XBUF_SEND_IDS, XBUF_SEND_QUADS, XBUF_SEND_EPS, XBUF_RECV_IDS, XBUF_RECV_QUADS, X
 _I64P = ctypes.POINTER(ctypes.c_int64)
 
 
+def _nothing():
+    return None
+
+
 def _vec(values):
     a = (ctypes.c_int64 * len(values))(*[int(v) for v in values])
     return a
@@ -157,6 +161,7 @@ class RcclComm(object):
             raise _gvom.GvomBackendError("gvom_comm_create2 failed with code %d (rank %d of %d, transport %s)"
                                          % (rc, rank, world, transport))
         self.transport = {0: "rccl", 1: "peer"}[self.lib.gvom_comm_transport(self.c)]
+        self.peer_async = bool(self.lib.gvom_comm_peer_async(self.c))       # peer copies without host waits inside an exchange
 
     def _check(self, rc):
         if rc != 0:
@@ -167,7 +172,9 @@ class RcclComm(object):
         """peer transport: bytes pulled, copies, exports made, refused opens that were repeated"""
         out = (ctypes.c_int64 * 4)()
         self._check(self.lib.gvom_comm_peer_stats(self.c, out))
-        return dict(zip(("bytes", "copies", "exports", "open_retries"), (int(v) for v in out)))
+        d = dict(zip(("bytes", "copies", "exports", "open_retries"), (int(v) for v in out)))
+        d["asynchronous"] = self.peer_async
+        return d
 
     def exchange_host(self, values):
         k = len(values)
@@ -177,6 +184,13 @@ class RcclComm(object):
 
     def barrier(self):
         self._check(self.lib.gvom_comm_barrier(self.c))
+
+    def before_scan(self):
+        """peer transport, asynchronous form: every peer has pulled what the next scan's pack overwrites (else a no-op)"""
+        self._check(self.lib.gvom_comm_before_scan(self.c))
+
+    def before_combine(self):
+        self._check(self.lib.gvom_comm_before_combine(self.c))
 
     def exchange_scan(self, backend, send_q, send_e, recv_q, recv_e):
         self._check(self.lib.gvom_comm_exchange_scan(self.c, backend.h, _vec(send_q), _vec(send_e), _vec(recv_q),
@@ -343,6 +357,7 @@ class ShardedGvom(object):
         tuple for a share already in HBM); n may differ between ranks."""
         self.ego_position = ego_position
         W, me = self.world, self.rank
+        getattr(self.comm, "before_scan", _nothing)()                # (a transport whose peers may still be reading this rank's send regions)
         send_q, send_e, any_, n = self.b.scan_local(pointcloud, ego_position, transform)
         # one host-side exchange: what every rank packed for every other rank, who saw a return in
         # the grid, how many returns the scan has
@@ -380,6 +395,7 @@ class ShardedGvom(object):
         return self.b.g.make_debug_voxel_map()
 
     def combine_maps(self):
+        getattr(self.comm, "before_combine", _nothing)()             # (... or this rank's rows of the previous combine)
         rc = self.b.combine_fuse()
         if rc == _gvom.GVOM_EMPTY_BUFFER:
             if self.rank == 0:

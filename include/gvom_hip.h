@@ -247,6 +247,13 @@ int  gvom_comm_create(int rank, int world, int device, const char *name, gvom_co
 #define GVOM_TRANSPORT_AUTO 2
 int  gvom_comm_create2(int rank, int world, int device, const char *name, int transport, gvom_comm_t **out);
 int  gvom_comm_transport(gvom_comm_t *c);
+/* Peer transport, asynchronous form (GVOM_PEER_ASYNC=1 on every rank, and every rank able to register the segment with HIP;
+ * otherwise the host-synchronised form): an exchange enqueues its copies and returns; the GPUs write exchange numbers into the segment.
+ * Call gvom_comm_before_scan before gvom_shard_scan_local and gvom_comm_before_combine before gvom_combine_fuse: they wait
+ * (normally not at all) until every peer has pulled what this rank is about to overwrite.  No-ops on the other transports. */
+int  gvom_comm_before_scan(gvom_comm_t *c);
+int  gvom_comm_before_combine(gvom_comm_t *c);
+int  gvom_comm_peer_async(gvom_comm_t *c);          /* 1: the peer transport runs in its asynchronous form */
 /* peer transport bookkeeping: {bytes pulled, copies, exports made, refused hipIpcOpenMemHandle calls that were repeated} */
 int  gvom_comm_peer_stats(gvom_comm_t *c, int64_t out[4]);
 void gvom_comm_destroy(gvom_comm_t *c);
@@ -330,6 +337,9 @@ void *gvom_stream(gvom_t *h);
  * grow-only buffers another rank reads) has been re-allocated: tells a cache of addresses derived from gvom_shard_buffer
  * when to look again */
 uint64_t gvom_alloc_generation(gvom_t *h);
+/* the same for one region (which = GVOM_XBUF_SEND_*, or -1 for GVOM_BUF_HEIGHT_MAPS): changes exactly when the allocation the
+ * region lies in is replaced, and differs between handles */
+uint64_t gvom_region_generation(gvom_t *h, int which);
 
 const char *gvom_last_error(gvom_t *h);      /* never NULL */
 int gvom_backend_info(char *buf, size_t len); /* "gfx950 ..." device + build string */

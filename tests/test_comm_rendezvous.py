@@ -122,7 +122,8 @@ def test_transport_selection_and_bookkeeping_of_a_host_only_communicator():
         comm = gvom_sharded.RcclComm(0, 1, -1, "gvom_test_tr3_%d_%s" % (os.getpid(), tr), transport=tr)
         try:
             assert comm.transport == want
-            assert comm.peer_stats() == {"bytes": 0, "copies": 0, "exports": 0, "open_retries": 0}
+            assert comm.peer_stats() == {"bytes": 0, "copies": 0, "exports": 0, "open_retries": 0, "asynchronous": False}
+            comm.before_scan(); comm.before_combine()                       # no-ops here
             assert comm.exchange_host([3, 4]) == [[3, 4]]
         finally:
             comm.close()

@@ -178,9 +178,24 @@ def test_rank_processes_on_one_gpu_through_the_peer_transport(world, stats):
     statistics also the ranks' voxel clouds."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import shard_procs
-    ok, text = shard_procs.launch(world, "peer", stats)
+    ok, text = shard_procs.launch_tolerant(world, "peer", stats)
     assert ok, text[-3000:]
     assert text.count("combines equal the unsharded mapper's") == world, text[-3000:]
+
+
+def test_rank_processes_through_the_asynchronous_peer_transport():
+    """GVOM_PEER_ASYNC=1: the peer transport without host waits inside an exchange -- the copies are enqueued, one-thread kernels
+    behind them write exchange numbers into the (HIP-registered) shared-memory segment, and a rank waits for its peers'
+    numbers only before it overwrites what they pull from (gvom_comm_before_scan / _before_combine).  Four rank processes,
+    the seven steps three times over, with the statistics exchange on two: every rank's results equal the unsharded mapper's."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import shard_procs
+    ok, text = shard_procs.launch_tolerant(4, "peer", False, repeat=3, asynchronous=True)
+    assert ok, text[-3000:]
+    assert text.count("'asynchronous': True") == 4, text[-3000:]
+    ok, text = shard_procs.launch_tolerant(2, "peer", True, asynchronous=True)
+    assert ok, text[-3000:]
+    assert text.count("'asynchronous': True") == 2, text[-3000:]
 
 
 def test_auto_transport_falls_back_to_peer_copies_when_rccl_cannot_start():
@@ -188,7 +203,7 @@ def test_auto_transport_falls_back_to_peer_copies_when_rccl_cannot_start():
     ranks, both agree on peer copies through the rendezvous, and the maps equal the unsharded mapper's."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import shard_procs
-    ok, text = shard_procs.launch(2, "auto", False)
+    ok, text = shard_procs.launch_tolerant(2, "auto", False)
     assert ok, text[-3000:]
     assert text.count("(peer transport): ") == 2, text[-3000:]
 
