@@ -37,6 +37,16 @@ def _bench(argv, env_extra=None, timeout=300):
                           stderr=subprocess.PIPE, timeout=timeout)
 
 
+def _bench_peer(argv, env_extra=None, timeout=300):
+    """_bench for runs whose ranks exchange by peer copies: the HSA runtime's inter-process calls are refused once in several
+    hundred exports ("invalid argument" / "invalid device pointer": the library reports it loudly on every rank); such a run
+    is started once more.  A run whose maps DIFFER (exit code 3) never is."""
+    p = _bench(argv, env_extra, timeout)
+    if p.returncode not in (0, 3) and b"hipIpc" in p.stderr:
+        p = _bench(argv, env_extra, timeout)
+    return p
+
+
 def test_more_ranks_than_devices_is_refused_before_anything_is_spawned():
     """`python bench.py --gpus 2` without a launcher on a box with fewer than 2 GPUs (here: none): the parent --
     which makes no HIP call itself, the device count comes from a child process -- refuses with a clear message and
@@ -130,7 +140,7 @@ def test_sharded_bench_rehearsal_with_two_rank_processes_on_one_gpu():
     rendezvous through shared memory), with both ranks on the one GPU this box has and the library's peer-copy transport
     (RCCL refuses two ranks on one device): real multi-process exchanges of device data, and the line's own verdict that
     the sharded maps equal an unsharded mapper's."""
-    p = _bench(["--gpus", "2", "--share-device", "--steps", "30", "--warmup", "10", "--no-cpu"], {"GVOM_COMM_TIMEOUT_S": "120"}, timeout=600)
+    p = _bench_peer(["--gpus", "2", "--share-device", "--steps", "30", "--warmup", "10", "--no-cpu"], {"GVOM_COMM_TIMEOUT_S": "120"}, timeout=600)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     d = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["rehearsal_on_one_device"] is True and d["transport"].startswith("peer copies")
@@ -144,8 +154,8 @@ def test_sharded_bench_rehearsal_with_two_rank_processes_on_one_gpu():
 def test_sharded_bench_falls_back_to_peer_copies_when_rccl_refuses():
     """The N > 1 leg with its default transport (AUTO) where RCCL cannot start -- two ranks on one device: both ranks agree
     on peer copies, the line says so, the maps are verified, and the rank processes leave with exit code 0."""
-    p = _bench(["--gpus", "2", "--share-device", "--steps", "20", "--warmup", "6", "--no-cpu"],
-               {"GVOM_COMM_TIMEOUT_S": "120", "GVOM_BENCH_REHEARSE_AUTO": "1"}, timeout=600)
+    p = _bench_peer(["--gpus", "2", "--share-device", "--steps", "20", "--warmup", "6", "--no-cpu"],
+                    {"GVOM_COMM_TIMEOUT_S": "120", "GVOM_BENCH_REHEARSE_AUTO": "1"}, timeout=600)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     d = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1])
     assert d["transport"].startswith("peer copies") and "RCCL could not initialise" in d["transport"]
