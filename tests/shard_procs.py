@@ -86,6 +86,7 @@ def rank_main(rank, world, name, transport, stats, repeat=1):
                 np.testing.assert_allclose(mine[:, 5:], whole[idx][:, 5:], rtol=1e-4, atol=2e-5)
     comm.barrier()
     ps = comm.peer_stats()
+    ps["open_fds"] = len(os.listdir("/proc/self/fd"))
     comm.close()
     print("rank %d of %d (%s transport%s): %d combines equal the unsharded mapper's; %s" %
           (rank, world, comm.transport, ", statistics" if stats else "", n_maps, ps), flush=True)
