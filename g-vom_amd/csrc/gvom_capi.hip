@@ -83,6 +83,8 @@ struct gvom_handle {
     int tune_churn = 0;                                 // test hook: re-allocate the endpoint send region every scan
     uint64_t alloc_gen = 0;                             // changes whenever a send region of this handle is re-allocated
     uint64_t handle_gen = 0;                            // this handle's own number (its fixed allocations)
+    bool exported = false;                              // a transport has exported this handle's send regions to other processes
+    std::vector<void *> retired;                        // outgrown send regions (possibly still mapped by peers): freed with the handle
     // rank exchange of a sharded map (world > 1): send / receive regions, indexed by peer rank
     uint32_t *x_send_ids = nullptr, *x_recv_ids = nullptr;     // quad ids: [Q] by owner / [world][myQ] by source
     void *x_send_pay = nullptr, *x_recv_pay = nullptr;         // 1 KiB per quad, same indexing
@@ -203,10 +205,21 @@ inline double now_ns() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return 
 // (process-wide: a value names one state of one handle's allocations -- gvom_alloc_generation)
 static std::atomic<uint64_t> g_alloc_generation{0};
 
+// Allocations another process may map (the peer transport exports the send regions and the height-map rows) are whole
+// multiples of 2 MiB: the HSA runtime carves smaller ones out of shared 2 MiB blocks, and a block cannot be exported
+// twice -- a second small region landing in an exported block is what hipIpcGetMemHandle refused ("invalid argument").
+inline size_t exportable_size(size_t bytes) { const size_t g = (size_t)2 << 20; return ((bytes ? bytes : 1) + g - 1) / g * g; }
+
 int ensure(gvom_handle *h, Buf &b, size_t bytes)
 {
     if (b.bytes >= bytes) return GVOM_OK;
     size_t want = bytes + bytes / 2 + 256;
+    const bool exported = &b == &h->x_send_eps || &b == &h->x_send_sp;
+    if (exported) want = exportable_size(want);
+    // (a region another process may have mapped is never freed while the handle lives: freed and re-allocated, the new region
+    // tends to get the old one's address, and importers that re-open "it" were seen reading the OLD memory -- a silently
+    // different map after ~50 scans of the churn test.  Growth is geometric: the retired regions add up to less than the last.)
+    if (b.p && exported) { h->retired.push_back(b.p); b.p = nullptr; }
     if (b.p) HIPCHK(h, hipFree(b.p));
     b.p = nullptr; b.bytes = 0;
     HIPCHK(h, hipMalloc(&b.p, want));
@@ -415,7 +428,7 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, b
     CK(hipMalloc((void **)&h->blockcounts, (size_t)(h->fuse_blocks > 0 ? h->fuse_blocks : 1) * 4));
     CK(hipMemsetAsync(h->blockcounts, 0, (size_t)(h->fuse_blocks > 0 ? h->fuse_blocks : 1) * 4, h->stream));
     h->hs = 3 * xy;
-    CK(hipMalloc((void **)&h->hmaps, h->cells2d * 24));
+    CK(hipMalloc((void **)&h->hmaps, sharded ? exportable_size(h->cells2d * 24) : h->cells2d * 24));
     h->height = h->hmaps; h->inferred = h->hmaps + xy;
     double **maps[4] = {&h->slope_x, &h->slope_y, &h->rough, &h->guessed};
     for (auto m : maps) CK(hipMalloc((void **)m, h->cells2d * 8));
@@ -428,8 +441,8 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, b
         // rank exchange regions (DESIGN.md "Multi-GPU"): a quad = 4 storage rows x 64 sx at one sz
         h->x_Q = (size_t)(xy / 4) * zs * h->nseg;
         h->x_myQ = h->x_Q / world;
-        CK(hipMalloc((void **)&h->x_send_ids, h->x_Q * 4));
-        CK(hipMalloc(&h->x_send_pay, h->x_Q * 1024));
+        CK(hipMalloc((void **)&h->x_send_ids, exportable_size(h->x_Q * 4)));
+        CK(hipMalloc(&h->x_send_pay, exportable_size(h->x_Q * 1024)));
         CK(hipMalloc((void **)&h->x_recv_ids, h->x_Q * 4));
         CK(hipMalloc(&h->x_recv_pay, h->x_Q * 1024));
         CK(hipMalloc((void **)&h->x_qcnt, (size_t)world * 64));
@@ -629,7 +642,7 @@ int scan_launch(gvom_handle *h, std::unique_lock<std::mutex> &lk, const void *de
     X.ep_send = nullptr; X.ep_cnt = nullptr; X.ep_cap = 0; X.sp_send = nullptr; X.sp_cnt = nullptr;
     if (h->sharded) {
         if (h->tune_churn > 0 && h->x_send_eps.p) {            // test hook (gvom_set_tuning "churn"): a fresh allocation every scan
-            HIPCHK(h, hipFree(h->x_send_eps.p));
+            h->retired.push_back(h->x_send_eps.p);               // (as a region that grows: retired, not freed)
             h->x_send_eps.p = nullptr; h->x_send_eps.bytes = 0;
         }
         if ((rc = ensure(h, h->x_send_eps, (size_t)h->world * (size_t)(n > 0 ? n : 1) * 8))) return rc;
@@ -1081,8 +1094,22 @@ VIS void gvom_destroy(gvom_t *h)
     if (h->stream) hipStreamSynchronize(h->stream);
     auto fb = [](Buf &b) { if (b.p) hipFree(b.p); b.p = nullptr; b.bytes = 0; };
     hipFree(h->hit); hipFree(h->total); hipFree(h->mh);
-    hipFree(h->x_send_ids); hipFree(h->x_send_pay); hipFree(h->x_recv_ids); hipFree(h->x_recv_pay);
-    hipFree(h->x_qcnt); hipFree(h->x_ecnt); hipFree(h->x_spcnt); fb(h->x_send_eps); fb(h->x_recv_eps); fb(h->x_send_sp); fb(h->x_recv_sp);
+    // Regions another process has had mapped (the peer transport exported them: "exported" is set through gvom_set_tuning) are NOT
+    // given back while the process lives: a later allocation tends to get their address, and importers that open "it" have been
+    // seen reading the old memory.  The graveyard is bounded; beyond it they are freed after all.
+    static std::atomic<size_t> graveyard{0};
+    auto bury = [&](void *ptr, size_t bytes) {
+        if (!ptr) return;
+        if (h->exported && graveyard.load() + bytes <= ((size_t)4 << 30)) { graveyard += bytes; return; }
+        hipFree(ptr);
+    };
+    for (void *r : h->retired) bury(r, (size_t)2 << 20);
+    bury(h->x_send_ids, exportable_size(h->x_Q * 4)); bury(h->x_send_pay, exportable_size(h->x_Q * 1024));
+    bury(h->x_send_eps.p, h->x_send_eps.bytes); bury(h->x_send_sp.p, h->x_send_sp.bytes);
+    h->x_send_eps.p = nullptr; h->x_send_sp.p = nullptr;
+    if (h->exported && h->sharded) { bury(h->hmaps, exportable_size(h->cells2d * 24)); h->hmaps = nullptr; }
+    hipFree(h->x_recv_ids); hipFree(h->x_recv_pay);
+    hipFree(h->x_qcnt); hipFree(h->x_ecnt); hipFree(h->x_spcnt); fb(h->x_recv_eps); fb(h->x_recv_sp);
     if (h->x_host) hipHostFree(h->x_host);
     for (auto &s : h->slots) { hipFree(s.state); hipFree(s.code16); hipFree(s.tags); fb(s.crows); fb(s.metrics); fb(s.base); fb(s.rowvox); }
     for (auto &f : h->fused) { hipFree(f.state); hipFree(f.tags); fb(f.rows); fb(f.metrics); }
@@ -1900,6 +1927,7 @@ VIS int gvom_set_tuning(gvom_t *h, const char *name, int value)
     else if (!strcmp(name, "period")) h->tune_period = value;
     else if (!strcmp(name, "prio")) h->tune_prio = value;
     else if (!strcmp(name, "churn")) h->tune_churn = value;
+    else if (!strcmp(name, "exported")) h->exported = value != 0;       // (set by the peer transport, gvom_comm.hip)
 
     else if (!strcmp(name, "epoch_bias")) h->epoch += (uint32_t)value;   // test hook: advances the tile-epoch counter (towards its wrap)
     else return GVOM_ERR_INVALID;

@@ -276,6 +276,7 @@ int peer_publish(gvom_comm *c, gvom_t *h, int kind, void *const *ptr)
     // is what the HSA runtime does not take reliably: with a fresh export per scan, results differed after a dozen scans)
     const uint64_t gen = gvom_region_generation(h, region_of_kind[kind]);
     if (o.base != base || o.size != size || o.alloc_gen != gen) {
+        (void)gvom_set_tuning(h, "exported", 1);                    // (its regions are kept out of the allocator for good: gvom_capi.hip, destroy)
         hipIpcMemHandle_t hd;
         hipError_t ge = hipSuccess;
         for (int attempt = 0; attempt < 20; ++attempt) {               // (seen refused -- "invalid argument" -- once in ~700 exports of fresh allocations, transiently)
