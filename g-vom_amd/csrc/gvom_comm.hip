@@ -36,6 +36,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <vector>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <time.h>
@@ -170,14 +171,16 @@ bool creator_alive(const Segment *sg)
 
 }  // namespace
 
-struct PeerImport {                            // a peer's exported allocation, mapped into this process
-    uint64_t generation = 0;
+struct PeerImport {                            // a peer's exported allocation, mapped into this process (kept until the communicator goes:
+    uint64_t generation = 0;                   // memory that was mapped once is never closed and opened again)
     void *base = nullptr;
 };
-struct PeerOwn {                               // what this rank has exported of one kind
+struct PeerOwn {                               // an allocation this rank has exported (once: its handle is kept for whenever it is current again)
     void *base = nullptr;
     size_t size = 0;
     uint64_t alloc_gen = ~0ull;
+    uint64_t generation = 0;
+    hipIpcMemHandle_t handle;
 };
 
 struct gvom_comm {
@@ -185,8 +188,8 @@ struct gvom_comm {
     int transport = GVOM_TRANSPORT_RCCL;       // the one in use (never AUTO)
     Rccl rccl;
     ncclComm_t nccl = nullptr;
-    PeerImport imports[GVOM_COMM_MAX_RANKS][GVOM_PEER_KINDS];
-    PeerOwn own[GVOM_PEER_KINDS];
+    std::vector<PeerImport> imports[GVOM_COMM_MAX_RANKS][GVOM_PEER_KINDS];
+    std::vector<PeerOwn> own[GVOM_PEER_KINDS];
     uint64_t peer_bytes = 0, peer_copies = 0;  // pulled so far (diagnostics)
     uint64_t export_seq = 0, peer_open_retries = 0;
     // asynchronous form of the peer transport (no host wait for the GPU inside an exchange)
@@ -271,26 +274,32 @@ int peer_publish(gvom_comm *c, gvom_t *h, int kind, void *const *ptr)
     void *base = nullptr;
     size_t size = 0;
     HIPCHK_C(c, hipMemGetAddressRange((hipDeviceptr_t *)&base, &size, (hipDeviceptr_t)any));
-    PeerOwn &o = c->own[kind];
     // (an allocation is exported ONCE: exporting it again -- and the importers closing and re-opening the very same memory --
     // is what the HSA runtime does not take reliably: with a fresh export per scan, results differed after a dozen scans)
     const uint64_t gen = gvom_region_generation(h, region_of_kind[kind]);
-    if (o.base != base || o.size != size || o.alloc_gen != gen) {
+    PeerOwn *o = nullptr;
+    for (PeerOwn &k : c->own[kind]) if (k.base == base && k.size == size && k.alloc_gen == gen) { o = &k; break; }
+    if (!o) {
         (void)gvom_set_tuning(h, "exported", 1);                    // (its regions are kept out of the allocator for good: gvom_capi.hip, destroy)
-        hipIpcMemHandle_t hd;
+        PeerOwn n;
         hipError_t ge = hipSuccess;
-        for (int attempt = 0; attempt < 20; ++attempt) {               // (seen refused -- "invalid argument" -- once in ~700 exports of fresh allocations, transiently)
-            ge = hipIpcGetMemHandle(&hd, base);
+        for (int attempt = 0; attempt < 20; ++attempt) {               // (a refusal is asked again a few times before it counts)
+            ge = hipIpcGetMemHandle(&n.handle, base);
             if (ge == hipSuccess) break;
             (void)hipGetLastError();
             ++c->peer_open_retries;
             usleep(1000 + 1000 * attempt);
         }
         if (ge != hipSuccess) { c->err = std::string("hipIpcGetMemHandle failed: ") + hipGetErrorString(ge); return GVOM_ERR_HIP; }
-        memcpy(&e.handle, &hd, sizeof hd);
-        e.generation = ((uint64_t)(c->rank + 1) << 48) | ++c->export_seq;
+        n.base = base; n.size = size; n.alloc_gen = gen;
+        n.generation = ((uint64_t)(c->rank + 1) << 48) | ++c->export_seq;
+        c->own[kind].push_back(n);
+        o = &c->own[kind].back();
+    }
+    if (e.generation != o->generation) {                              // (another allocation is current than at the last exchange)
+        memcpy(&e.handle, &o->handle, sizeof o->handle);
         e.size = size;
-        o.base = base; o.size = size; o.alloc_gen = gen;
+        e.generation = o->generation;
     }
     for (int d = 0; d < c->world; ++d) {
         if (d == c->rank || !ptr[d]) { e.offset[d] = ~0ull; continue; }
@@ -306,15 +315,16 @@ int peer_publish(gvom_comm *c, gvom_t *h, int kind, void *const *ptr)
 int peer_source(gvom_comm *c, int s, int kind, void **src)
 {
     const PeerExport &e = c->seg->exports[s][kind];
-    PeerImport &im = c->imports[s][kind];
     if (e.generation == 0 || e.offset[c->rank] == ~0ull) { c->err = "a peer announced data it has not exported"; return GVOM_ERR_INVALID; }
-    if (im.generation != e.generation) {
-        if (im.base) { (void)hipIpcCloseMemHandle(im.base); im.base = nullptr; im.generation = 0; }
+    PeerImport *found = nullptr;
+    for (PeerImport &k : c->imports[s][kind]) if (k.generation == e.generation) { found = &k; break; }
+    if (!found) {
+        PeerImport im;
         hipIpcMemHandle_t hd;
         memcpy(&hd, &e.handle, sizeof hd);
         // (the exporter hands its allocation over through a helper thread of the HSA runtime that starts with its FIRST
-        // export; a peer that asks in the same millisecond can be too early -- seen once in ~20 first exchanges with four
-        // rank processes: "invalid device pointer" -- so a refusal is asked again a few times before it counts)
+        // export; a peer that asks in the same millisecond can be too early -- "invalid device pointer" -- so a refusal is
+        // asked again a few times before it counts)
         hipError_t oe = hipSuccess;
         for (int attempt = 0; attempt < 50; ++attempt) {
             oe = hipIpcOpenMemHandle(&im.base, hd, hipIpcMemLazyEnablePeerAccess);
@@ -324,14 +334,16 @@ int peer_source(gvom_comm *c, int s, int kind, void **src)
             usleep(2000 + 1000 * attempt);
         }
         if (oe != hipSuccess) {
-            im.base = nullptr;
             c->err = "hipIpcOpenMemHandle failed (" + std::string(hipGetErrorString(oe)) + "): export " + std::to_string(kind) +
                      " of rank " + std::to_string(s) + ", " + std::to_string(e.size) + " bytes, generation " +
                      std::to_string(e.generation & 0xffffffffffffull);
             return GVOM_ERR_HIP;
         }
         im.generation = e.generation;
+        c->imports[s][kind].push_back(im);
+        found = &c->imports[s][kind].back();
     }
+    const PeerImport &im = *found;
     *src = (char *)im.base + e.offset[c->rank];
     return GVOM_OK;
 }
@@ -597,7 +609,7 @@ VIS void gvom_comm_destroy(gvom_comm_t *c)
         hipSetDevice(c->device);
         for (int s = 0; s < c->world; ++s)
             for (int k = 0; k < GVOM_PEER_KINDS; ++k)
-                if (c->imports[s][k].base) (void)hipIpcCloseMemHandle(c->imports[s][k].base);
+                for (PeerImport &im : c->imports[s][k]) if (im.base) (void)hipIpcCloseMemHandle(im.base);
     }
     if (c->registered) { hipSetDevice(c->device); (void)hipDeviceSynchronize(); (void)hipHostUnregister(c->seg); }
     if (c->seg) munmap(c->seg, sizeof(Segment));
