@@ -9,7 +9,11 @@
 //     receiver maps them once (hipIpcOpenMemHandle, lazy peer access) and PULLS its bytes with hipMemcpyAsync on
 //     its own handle's stream: over xGMI between the GPUs of a node, inside one GPU's memory when several ranks
 //     share a device.  No RCCL involved: it is what a one-GPU box can run with several rank PROCESSES (RCCL
-//     refuses two ranks on one device), and what GVOM_TRANSPORT_AUTO falls back to when RCCL cannot initialise;
+//     refuses two ranks on one device), and what GVOM_TRANSPORT_AUTO falls back to when RCCL cannot initialise.
+//     Three rules keep the HSA runtime's inter-process memory honest (each found as a silently different map or a refused
+//     call under tests/shard_procs.py's churn hook): an allocation is exported ONCE and a mapping
+//     opened ONCE (both kept until the communicator goes), exported regions are whole multiples of 2 MiB, and a region a
+//     peer may have mapped is never given back to the allocator while the process lives (gvom_capi.hip);
 //   * host data: the ranks are the processes of ONE node, so the small per-scan vectors (counts,
 //     in-grid flags) and the ncclUniqueId travel through a POSIX shared-memory segment
 //     (/dev/shm/<name>): ~1 us, no GPU involved.  Double-buffered slots, sequence numbers, C11 atomics.
