@@ -198,6 +198,19 @@ def test_rank_processes_through_the_asynchronous_peer_transport():
     assert text.count("'asynchronous': True") == 2, text[-3000:]
 
 
+def test_peer_transport_with_a_new_exported_region_every_scan(monkeypatch):
+    """The rules that keep inter-process memory honest, under the abuse that found them (test hook gvom_set_tuning("churn"): the
+    endpoint send region is re-allocated, and therefore exported and mapped, on EVERY scan): an allocation exported once, a
+    mapping opened once, regions of whole 2 MiB, nothing a peer may have mapped given back to the allocator.  Without any one of
+    them this run ends in differing maps or a refused hipIpc call (profiles/r3_peer_churn.txt); four rank processes, 105 scans."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import shard_procs
+    monkeypatch.setenv("GVOM_TEST_CHURN", "1")
+    ok, text = shard_procs.launch_tolerant(4, "peer", False, repeat=15)
+    assert ok, text[-3000:]
+    assert text.count("105 combines equal the unsharded mapper's") == 4, text[-3000:]
+
+
 def test_auto_transport_falls_back_to_peer_copies_when_rccl_cannot_start():
     """GVOM_TRANSPORT_AUTO on one GPU with two rank processes: ncclCommInitRank refuses the duplicate device on both
     ranks, both agree on peer copies through the rendezvous, and the maps equal the unsharded mapper's."""
