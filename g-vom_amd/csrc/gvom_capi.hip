@@ -80,6 +80,9 @@ struct gvom_handle {
     size_t acc_elems = 0;
     int tune_segs = 0, tune_ep_row = -2, tune_period = 0; // gvom_set_tuning (0 / -2: automatic)
     int tune_prio = -1;                                 // gvom_set_tuning "prio" (-1: automatic)
+    int tune_ilv = 0;                                   // gvom_set_tuning "interleave": sub-clouds per cloud (0: automatic, 1: off)
+    int last_knobs[5] = {0, 0, 0, 0, 1};                // gvom_get_tuning: segs, period, ep_row, prio, interleave of the last scan
+    int64_t probe_n = -1; uint32_t probe_age = 0;       // layout probe (k_layout_probe): the length it last looked at, scans since
     int tune_churn = 0;                                 // test hook: re-allocate the endpoint send region every scan
     uint64_t alloc_gen = 0;                             // changes whenever a send region of this handle is re-allocated
     uint64_t handle_gen = 0;                            // this handle's own number (its fixed allocations)
@@ -308,6 +311,23 @@ void fill_scan_params(const gvom_handle *h, const int64_t origin[3], const doubl
         // m256 40.1 / 40.1 / 39.0 / 40.4 us, c2 39.2 / - / 36.7 / -, c3 70.6 / - / 68.2 / -, c4 unchanged
         P.prio_div = h->tune_prio >= 0 ? h->tune_prio : 8;
         P.f32_sqrt = h->f32_sqrt ? 1 : 0;
+        P.ilv_lg = 0; P.ilv_len = n_points;
+        {
+            // automatic: what the layout probe found in the previous cloud of as many returns, at most 4 sub-clouds side by
+            // side (c5, 16 sensors: interleave 4 / 8 / 16 -> k_trace 1450 / 1653 / 1745 us: a wave should keep >= 16 azimuths)
+            int K = h->tune_ilv > 1 ? h->tune_ilv : 1;
+            if (h->tune_ilv == 0 && h->counters_host) {
+                // the layout probe's last answer {n << 8 | log2 K} (host-mapped; written by a kernel of an EARLIER scan)
+                const unsigned long long w = *(volatile unsigned long long *)(h->counters_host + 8);
+                if ((int64_t)(w >> 8) == n_points) K = 1 << (int)(w & 7ull);
+            }
+            if (K > 64 || (K & (K - 1)) != 0 || n_points <= 0 || n_points % K != 0) K = 1;
+            while ((1 << P.ilv_lg) < K) ++P.ilv_lg;
+            P.ilv_len = n_points / K;
+            // interleaved sub-clouds keep a wave's 64 rays inside a few accumulator lines per step: the line cache holds a
+            // longer run (c4, interleave 4: period 12 / 16 / 24 / 32 -> 390 / 379 / 370 / 372 us)
+            if (K > 1 && h->tune_period <= 0) P.lc_period = 24;
+        }
         P.dbg = gvom_diag_env("GVOM_TRACE_DEBUG");
         const double w_last = nsegs <= 3 ? 0.35 : 0.6;
         const double unit = nsegs >= 3 ? (double)maxsteps / ((nsegs - 2) + 0.85 + w_last) : (double)maxsteps / nsegs;
@@ -605,6 +625,8 @@ int scan_launch(gvom_handle *h, std::unique_lock<std::mutex> &lk, const void *de
     // (a combine in flight -- combine_maps_async, or a second thread inside combine_maps -- has k_map2d's PCIe stores running
     // beside this trace: raised trace waves would take its issue slots (pipelined m256 91.7 us per step against 89.6, c3 122.0 / 115.5))
     if (h->pending_combine && h->tune_prio < 0) P.prio_div = 0;
+    h->last_knobs[0] = P.nsegs; h->last_knobs[1] = P.lc_period; h->last_knobs[2] = P.ep_row; h->last_knobs[3] = P.prio_div;
+    h->last_knobs[4] = 1 << P.ilv_lg;
     Slot &st = h->slots[h->staging];
     // the staging slot may still be a SOURCE of a fusion running on the second stream (asynchronous combine: the
     // second scan after gvom_combine_begin writes the slot the ring has just evicted)
@@ -664,7 +686,15 @@ int scan_launch(gvom_handle *h, std::unique_lock<std::mutex> &lk, const void *de
         P.tl = (unsigned long long *)h->tl.p;
     }
 #endif
-    hipError_t le = gvom_launch_trace(h->stream, P, X, dtype, big, dev_pts, stride_elems, n,
+    hipError_t le = hipSuccess;
+    if (h->tune_ilv == 0 && n >= 8192 && (n != h->probe_n || ++h->probe_age >= 32)) {
+        // layout probe: in front of k_trace (the caller may free the cloud as soon as this call has returned, i.e. once
+        // k_trace is done), on the first cloud of a new length and every 32nd scan after it; its answer serves LATER scans
+        h->probe_n = n; h->probe_age = 0;
+        le = gvom_launch_layout_probe(h->stream, P, dtype, dev_pts, stride_elems, n, 2, (unsigned long long *)(h->counters_host_dev + 8));
+        if (le != hipSuccess) { scan_abort(h); HIPCHK(h, le); }
+    }
+    le = gvom_launch_trace(h->stream, P, X, dtype, big, dev_pts, stride_elems, n,
                                       h->stats ? wpts.p : nullptr, h->hit, h->total, h->mh, st.state,
                                       st.tags, h->counters, h->stats ? (double *)st.metrics.p : nullptr,
                                       h->stats ? (double *)st.base.p : nullptr,
@@ -1926,12 +1956,23 @@ VIS int gvom_set_tuning(gvom_t *h, const char *name, int value)
     else if (!strcmp(name, "ep_row")) h->tune_ep_row = value;
     else if (!strcmp(name, "period")) h->tune_period = value;
     else if (!strcmp(name, "prio")) h->tune_prio = value;
+    else if (!strcmp(name, "interleave")) h->tune_ilv = value;
     else if (!strcmp(name, "churn")) h->tune_churn = value;
     else if (!strcmp(name, "exported")) h->exported = value != 0;       // (set by the peer transport, gvom_comm.hip)
 
     else if (!strcmp(name, "epoch_bias")) h->epoch += (uint32_t)value;   // test hook: advances the tile-epoch counter (towards its wrap)
     else return GVOM_ERR_INVALID;
     return GVOM_OK;
+}
+
+VIS int gvom_get_tuning(gvom_t *h, const char *name, int *value)
+{
+    if (!h || !name || !value) return GVOM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    static const char *const names[5] = {"segs", "period", "ep_row", "prio", "interleave"};
+    for (int k = 0; k < 5; ++k)
+        if (!strcmp(name, names[k])) { *value = h->last_knobs[k]; return GVOM_OK; }
+    return GVOM_ERR_INVALID;
 }
 
 VIS int gvom_set_profiling(gvom_t *h, int on)

@@ -68,6 +68,12 @@ struct ScanParams {
     int    ep_row;        // k_trace: blockIdx.y of the endpoint blocks (the other rows are the segments)
     int    prio_div;      // k_trace: issue priority of a wave = min(3, steps it still has to walk / prio_div); 0: hardware default
     int    lc_period;     // k_trace: flush the wave's line cache every lc_period committing steps
+    int    ilv_lg;        // k_trace: log2 K of the sub-cloud interleave (0: lane l of bundle b takes return 64 b + l).  A cloud that is
+                          //   K equally long sub-clouds behind one another (K sensors, K sweeps) whose returns of equal position
+                          //   are neighbours in space: position p = 64 b + l takes return (p mod K) * ilv_len + p / K, so the K
+                          //   neighbours sit in neighbouring lanes of ONE wave (merged steps, shared accumulator lines).  A
+                          //   permutation of who traces which return: it cannot change a result.
+    long   ilv_len;       // returns per sub-cloud (n / K; n % K == 0 or ilv_lg = 0)
     int    f32_sqrt;      // GVOM_FLAG_CUDA_F32_SQRT: ray_length = sqrtf(f32 sum) (real Numba-CUDA typing, gvom.py:1109)
     int    sxq;           // accumulator layout: 4x4 (x,y) patches per row of patches = ceil(xy/4) + padding
     uint32_t epoch;       // this scan's tile epoch
@@ -163,6 +169,8 @@ hipError_t gvom_launch_unpack(hipStream_t s, const ScanParams &P, const ShardUnp
 hipError_t gvom_launch_encode(hipStream_t s, const ScanParams &P, uint32_t *hit, uint32_t *total, uint32_t *mh,
                               int32_t *state, uint16_t *code16, uint4 *crows, const uint32_t *tags,
                               uint32_t *counters, unsigned long long *host_flag, uint32_t seq, unsigned resident_blocks);
+hipError_t gvom_launch_layout_probe(hipStream_t s, const ScanParams &P, int dtype, const void *pts, int64_t stride_elems, int64_t n,
+                                    int max_lg, unsigned long long *host_word);
 hipError_t gvom_launch_publish_seq(hipStream_t s, unsigned long long *host_flag, uint32_t seq);
 hipError_t gvom_launch_fuse(hipStream_t s, const FuseParams &P, const FuseDescs &KD,
                             const MapDesc *descs_dev, int32_t *fstate, uint4 *frows,

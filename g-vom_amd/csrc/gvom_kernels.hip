@@ -517,8 +517,10 @@ __device__ __forceinline__ void trace_item(const ScanParams &P, const ShardExcha
                                            uint32_t *stat_rowvox, int row, long bundle, int lane, uint32_t *lck, uint32_t *lcc,
                                            size_t widx, const WalkConsts &C)
 {
-    const long i = bundle * 64 + lane;
-    const bool live = i < n;
+    const long pos = bundle * 64 + lane;
+    const bool live = pos < n;
+    // sub-cloud interleave (ScanParams::ilv_lg): which return this lane takes
+    const long i = P.ilv_lg ? (pos & ((1L << P.ilv_lg) - 1)) * P.ilv_len + (pos >> P.ilv_lg) : pos;
     T x = 0, y = 0, z = 0;
     if (live) load_return(P, in, stride, i, x, y, z);
     const T d2 = (x * x + y * y) + z * z;
@@ -2489,6 +2491,52 @@ hipError_t gvom_launch_encode(hipStream_t s, const ScanParams &P, uint32_t *hit,
 
 // one store of `seq` into host-mapped memory: launched behind the last kernel of a call, it tells the
 // spinning host that everything before it on the stream has completed (lower latency than an event wait)
+// Layout probe (ONE wave, a launch of its own in front of k_trace -- on the first cloud of a new length and every 32nd scan
+// after it): is this cloud K equally long sub-clouds behind one another -- K sensors at one place, K sweeps -- whose returns of
+// equal position point in neighbouring directions?  Then the next scans of as many returns are traced with their sub-clouds
+// interleaved (ScanParams::ilv_lg).  64 samples per candidate K, spread over sub-cloud 0: the return at the same position of
+// the next and of the last sub-cloud must lie closer in direction (seen from the sensor) than the return's own successor in
+// the cloud; K passes with 56 of 64.  The answer {n, log2 K} goes to host-mapped memory as one 8-byte store.  A heuristic that
+// decides WHO traces which return, never what is added where: any answer gives the same maps.
+template <typename T>
+__global__ __launch_bounds__(64) void k_layout_probe(const ScanParams P, const T *__restrict__ in, long stride, long n, int max_lg,
+                                                     unsigned long long *host_word)
+{
+    const int lane = threadIdx.x;
+    int best = 0;
+    for (int lg = 1; lg <= max_lg; ++lg) {
+        const long K = 1L << lg;
+        if (n % K != 0 || n / K < 4096) break;
+        const long M = n / K;
+        const long q = (M / 64) * lane + M / 128;                 // q + 1 < M
+        float e[3], d0[3];
+        bool good = true;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long idx = k == 0 ? q : (k == 1 ? q + 1 : (k == 2 ? q + M : q + (K - 1) * M));
+            T x, y, z;
+            load_return(P, in, stride, idx, x, y, z);
+            const float ux = (float)x * P.rinv[0] - P.pt0[0], uy = (float)y * P.rinv[0] - P.pt0[1], uz = (float)z * P.rinv[1] - P.pt0[2];
+            const float r = sqrtf((ux * ux + uy * uy) + uz * uz);
+            good = good && r > 0.0f && r < INFINITY;
+            const float dx = ux / r, dy = uy / r, dz = uz / r;
+            if (k == 0) { d0[0] = dx; d0[1] = dy; d0[2] = dz; }
+            else { const float a = dx - d0[0], b = dy - d0[1], c = dz - d0[2]; e[k - 1] = (a * a + b * b) + c * c; }
+        }
+        const bool pass = good && e[1] <= e[0] && e[2] <= e[0];       // (NaN compares false)
+        if (__popcll(lanes(pass)) >= 56) best = lg;
+    }
+    if (lane == 0)
+        __hip_atomic_store(host_word, ((unsigned long long)n << 8) | (unsigned long long)best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+hipError_t gvom_launch_layout_probe(hipStream_t s, const ScanParams &P, int dtype, const void *pts, int64_t stride_elems, int64_t n,
+                                    int max_lg, unsigned long long *host_word)
+{
+    if (dtype == 0) hipLaunchKernelGGL(k_layout_probe<float>, dim3(1), dim3(64), 0, s, P, (const float *)pts, (long)stride_elems, (long)n, max_lg, host_word);
+    else hipLaunchKernelGGL(k_layout_probe<double>, dim3(1), dim3(64), 0, s, P, (const double *)pts, (long)stride_elems, (long)n, max_lg, host_word);
+    return hipGetLastError();
+}
+
 __global__ void k_publish_seq(unsigned long long *host_flag, uint32_t seq)
 {
     __hip_atomic_store(host_flag, (unsigned long long)seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -134,6 +134,7 @@ ABI = [
     ("gvom_set_profiling", _I, [_P, _I]),
     ("gvom_host_timing", _I, [_P, ctypes.POINTER(ctypes.c_double * 8)]),
     ("gvom_set_tuning", _I, [_P, ctypes.c_char_p, _I]),
+    ("gvom_get_tuning", _I, [_P, ctypes.c_char_p, ctypes.POINTER(_I)]),
     ("gvom_stream", _P, [_P]),
     ("gvom_alloc_generation", ctypes.c_uint64, [_P]),
     ("gvom_region_generation", ctypes.c_uint64, [_P, _I]),
@@ -143,7 +144,7 @@ ABI = [
 ]
 
 
-ABI_VERSION = 5          # include/gvom_hip.h GVOM_ABI_VERSION this binding was written against
+ABI_VERSION = 6          # include/gvom_hip.h GVOM_ABI_VERSION this binding was written against
 
 
 def load_library(path=None):
@@ -790,8 +791,14 @@ class Gvom(object):
         return dict(zip(STAGE_NAMES, [float(v) for v in ms]))
 
     def set_tuning(self, name, value):
-        """Performance knobs that never change a result: "segs", "period", "ep_row" (include/gvom_hip.h)."""
+        """Performance knobs that never change a result: "segs", "period", "ep_row", "prio", "interleave" (include/gvom_hip.h)."""
         self._check(self._lib.gvom_set_tuning(self._h, name.encode(), int(value)))
+
+    def get_tuning(self, name):
+        """The value the last scan ran with (what "automatic" resolved to)."""
+        v = _I(0)
+        self._check(self._lib.gvom_get_tuning(self._h, name.encode(), ctypes.byref(v)))
+        return int(v.value)
 
     def host_timing(self):
         us = (ctypes.c_double * 8)()

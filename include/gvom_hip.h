@@ -26,7 +26,8 @@
 extern "C" {
 #endif
 
-#define GVOM_ABI_VERSION 5   /* 5: second transport between ranks (peer copies: gvom_comm_create2, gvom_comm_transport),
+#define GVOM_ABI_VERSION 6   /* 6: sub-cloud interleave of the trace ("interleave" knob, automatic by a layout probe), gvom_get_tuning;
+                              * 5: second transport between ranks (peer copies: gvom_comm_create2, gvom_comm_transport),
                               *    gvom_alloc_generation;
                               * 4: per-voxel statistics on sharded maps (gvom_shard_stats_*, gvom_comm_exchange_stats);
                               * 3: rank-exchange (shard) and communicator entry points, gvom_set_tuning, flags;
@@ -329,8 +330,16 @@ int gvom_host_timing(gvom_t *h, double us[8]);
  * kernel), "period" (committing steps between two flushes of a wave's LDS line cache), "ep_row"
  * (dispatch row of the endpoint blocks; -1: inside segment 0's waves), "prio" (steps of remaining walk per issue-priority
  * level of a trace wave, s_setprio; 0: the hardware's own arbitration); 0 / 0 / -2 / -1 = automatic.
+ * "interleave": K = 2 .. 64 (a power of two that divides the number of returns) declares the cloud to be K equally long
+ * sub-clouds behind one another -- K sensors at one place, K sweeps -- whose returns of equal position are neighbours in
+ * space; the trace then puts those neighbours into neighbouring lanes of one wave (merged steps, shared accumulator lines:
+ * 512^2 x 128, 4 x 262,144 returns: 11.5 M -> 4.1 M memory-side atomic requests, 549 -> 370 us).  0 (default): automatic -- a
+ * probe inside the trace kernel looks for that structure in every cloud (64 sampled returns per candidate K <= 4) and the
+ * next cloud of as many returns is traced accordingly; 1: off.  Only WHO traces which return changes, never a result.
  * "epoch_bias" (test hook) advances the 32-bit tile-epoch counter, e.g. to just below its wrap. */
 int gvom_set_tuning(gvom_t *h, const char *name, int value);
+/* The value the LAST scan ran with ("segs", "period", "ep_row", "prio", "interleave": what automatic resolved to). */
+int gvom_get_tuning(gvom_t *h, const char *name, int *value);
 /* Raw HIP stream the library launches on (hipStream_t as void*), for external event timing. */
 void *gvom_stream(gvom_t *h);
 /* differs between any two handles of the process and changes whenever a SEND region of `h` (GVOM_XBUF_SEND_*: the only

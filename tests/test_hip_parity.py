@@ -694,6 +694,68 @@ def test_trace_tuning_knobs_leave_results_unchanged(gvom_mod):
                     assert np.array_equal(x, y), "segs %d / period %d / ep_row %d / prio %d differs" % (segs, period, ep_row, prio)
 
 
+def test_sub_cloud_interleave_leaves_results_unchanged(gvom_mod):
+    """gvom_set_tuning("interleave", K): lane l of bundle b traces return (p mod K) * (n / K) + p / K, p = 64 b + l -- the K
+    sub-clouds of a multi-sensor cloud side by side in one wave.  A permutation of who traces which return: scan slots are
+    bit-identical for every K (a K that does not divide n, is no power of two or exceeds 64 is ignored), with and without the
+    other knobs, for float64 clouds with a transform, and for the cloud it is meant for (4 sensors interleaved in azimuth)."""
+    params, scans = synth.config_inputs("c2", n_scans=2)
+    ragged = [(pc[:-37], ego, tf) for pc, ego, tf in scans]                  # n = 131,035 = 5 * 73 * 359: only K = 1 divides it
+    f64 = [(pc.astype(np.float64), ego, scenarios.rot_z(0.01, (0.1, 0.0, 0.0))) for pc, ego, tf in scans]
+    p4, multi = synth.config_inputs("c4", n_scans=1)
+    p4 = (0.4, 0.4, 128, 32) + p4[4:]                                        # the 4-sensor cloud in a grid the test can densify
+    for prm, clouds, settings in ((params, scans, ((1, 0), (2, 0), (4, 12), (16, 16), (64, 5), (3, 0), (128, 0))),
+                                  (params, ragged, ((1, 0), (4, 0), (64, 0))),
+                                  (params, f64, ((1, 0), (8, 0))),
+                                  (p4, multi, ((1, 0), (4, 0), (16, 12)))):
+        ref = None
+        for K, period in settings:
+            g = gvom_mod.Gvom(*prm)
+            g.set_tuning("interleave", K); g.set_tuning("period", period)
+            slots = []
+            for pc, ego, tf in clouds:
+                g.process_pointcloud(pc, ego, tf)
+                b = g.last_buffer_index
+                slots.append(scenarios.dense_from_compact(scenarios.host(g.index_buffer[b]), scenarios.host(g.hit_count_buffer[b]),
+                                                          scenarios.host(g.total_count_buffer[b]), scenarios.host(g.min_height_buffer[b])))
+            maps = g.combine_maps()
+            if ref is None:
+                ref = (slots, maps)
+            else:
+                for a, b_ in zip(ref[0], slots):
+                    for x, y in zip(a, b_):
+                        assert np.array_equal(x, y), "interleave %d / period %d differs" % (K, period)
+                for x, y in zip(ref[1], maps):
+                    assert np.array_equal(x, y), "interleave %d: returned maps differ" % K
+
+
+def test_layout_probe_finds_interleaved_sensors_and_nothing_else(gvom_mod):
+    """Automatic interleave (the default): a probe inside k_trace looks at every cloud and the NEXT cloud of as many returns is
+    traced accordingly.  It must find the 4 sensors of the c4 cloud (and the sensor groups of a 16-sensor one), must not find
+    structure in a single sensor's scan or in random points, forgets its answer when the cloud's length changes -- and whatever
+    it answers, the slots equal those of a mapper with the interleave switched off."""
+    p4, multi = synth.config_inputs("c4", n_scans=2)
+    p4 = (0.4, 0.4, 128, 32) + p4[4:]
+    pc2, single = synth.config_inputs("c2", n_scans=2)
+    rnd = [(synth.uniform_cloud(65536, 7 + k, (-20, 20), (-20, 20), (-3, 3), np.float32), (0.1 * k, 0.0, 0.0), None) for k in range(2)]
+    f64tf = [(pc.astype(np.float64), ego, scenarios.rot_z(0.3, (0.0, 0.0, 0.0))) for pc, ego, tf in multi]
+    for prm, clouds, want in ((p4, multi, 4), (pc2, single, 1), (p4, rnd, 1), (p4, f64tf, 4)):
+        g, off = gvom_mod.Gvom(*prm), gvom_mod.Gvom(*prm)
+        off.set_tuning("interleave", 1)
+        used = []
+        for pc, ego, tf in clouds + [(clouds[0][0][:-64], clouds[0][1], clouds[0][2])]:
+            for m in (g, off):
+                m.process_pointcloud(pc, ego, tf)
+            used.append(g.get_tuning("interleave"))
+            assert off.get_tuning("interleave") == 1
+            a, b = [scenarios.dense_from_compact(*[scenarios.host(getattr(m, n)[m.last_buffer_index]) for n in
+                    ("index_buffer", "hit_count_buffer", "total_count_buffer", "min_height_buffer")]) for m in (g, off)]
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y)
+        # first cloud: nothing known yet; second: the probe's answer; third (another length): forgotten
+        assert used == [1, want, 1], (used, want)
+
+
 @pytest.mark.parametrize("occ_params", [(50, -10, 0), (12.5, -6.0, 1.5)])
 def test_combine_maps_occupancy_matches_node_postprocessing(gvom_mod, occ_params):
     """combine_maps_occupancy() == the ROS node's numpy post-processing
