@@ -362,18 +362,17 @@ __device__ __forceinline__ void walk_steps(const ScanParams &P, int lane, uint32
     lds_u32 *const cnt3 = (lds_u32 *)lcc;
     glb_u32 *const total1 = (glb_u32 *)total;
     uint32_t memo = LC_EMPTY;
-    bool dirty = false;
     uint32_t ju = (uint32_t)__builtin_amdgcn_readfirstlane((int)j);      // the step counter is the same in every lane
-    // A ray that has ended is parked at x = +inf: it never falls into the window again, so "takes part in
-    // this step" is the window test alone -- no per-lane flag carried around the loop.
-    v2f pxy = {active ? px_ : INFINITY, py_};
+    // Who takes part in a step: the rays that were running after the previous one (`alive`, a lane mask on the scalar unit)
+    // and are still inside the window; a ray runs on while it has steps left (gvom.py:1127).  The loop ends with the run's
+    // last step (cnt_run) or when no ray of the bundle runs any more: ONE condition, alive != 0.
+    const uint32_t cnt_run = min(cnt, ju + (uint32_t)steps);
+    unsigned long long alive = lanes(active);
+    v2f pxy = {px_, py_};
     const v2f incxy = {incx, incy};
     // left neighbour's key: lane 0 has none and keeps this value, which no accumulator index equals
     uint32_t leftk = 0xFFFFFFFFu;
-    int left = steps;
     unsigned long long cmask;
-    // (one back edge: the loop runs while steps are left and some ray of the bundle still takes part; the bookkeeping
-    // below is all a step with no participant does)
     do {
         ++ju;
         // every lane computes (a finished ray's lanes produce values nobody uses): no divergent
@@ -381,10 +380,10 @@ __device__ __forceinline__ void walk_steps(const ScanParams &P, int lane, uint32
         pxy += incxy; pz += incz;
         uint32_t sx, sy, sz;                                              // toroidal storage coordinates
         uint32_t wx, wy, wz;                                              // window voxel
-        const bool commit = window_voxel<LIT>(P, pxy.x, pxy.y, pz, wx, wy, wz, o0, o1, o2, uxy, zpad);
+        const bool inwin = window_voxel<LIT>(P, pxy.x, pxy.y, pz, wx, wy, wz, o0, o1, o2, uxy, zpad);
         if (P2) { sx = (wx + om0) & (uxy - 1u); sy = (wy + om1) & (uxy - 1u); sz = (wz + om2) & (uzs - 1u); }
         else { sx = min(wx + om0, wx + om0 - uxy); sy = min(wy + om1, wy + om1 - uxy); sz = min(wz + om2, wz + om2 - uzs); }
-        cmask = lanes(commit);
+        cmask = lanes(inwin) & alive;                                     // gvom.py:1135-1144 (left the grid)
         const uint32_t line = mad24s(mad24s(sy >> 2, uzs, sz), usxq, sx >> 2);   // accumulator line (acc_idx24)
         const uint32_t low4 = ((sy & 3u) << 2) | (sx & 3u);
         const uint32_t Ls = (line << 4) | low4;
@@ -415,21 +414,17 @@ __device__ __forceinline__ void walk_steps(const ScanParams &P, int lane, uint32
             const bool ok = (was == LC_EMPTY) | (was == line);
             memo = ok ? lrow : memo;
             // one LDS add for every head: a lane whose slot is taken adds into the spare entry behind the table (never
-            // read) and makes its global add in a branch the wave takes only when some lane needs it
+            // read) and makes its global add as well
             if (!GVOM_DBG(P, 128))
             __hip_atomic_fetch_add(&cnt3[ok ? hh * 16u + low4 : 1024u], run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (lanes(!ok) != 0ull) {
-                if (!ok) __hip_atomic_fetch_add(&total1[Ls], run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // table congested: direct add
-            }
+            if (!ok) __hip_atomic_fetch_add(&total1[Ls], run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // table congested: direct add
         }
-        // gvom.py:1127 (length test), 1135-1144 (left the grid): the ray ends after this step
-        pxy.x = (commit & (ju < cnt)) ? pxy.x : INFINITY;
-        dirty = dirty | (cmask != 0ull);
-    } while (--left > 0 && cmask != 0ull);
+        alive = cmask & lanes(ju < cnt_run);                              // gvom.py:1127 (length test)
+    } while (alive != 0ull);
     j = ju;
     px_ = pxy.x; py_ = pxy.y;
-    active = pxy.x < INFINITY;
-    if (dirty) lc_flush(P, lck, lcc, total, lane);
+    active = ((cmask >> lane) & 1ull) != 0ull && ju < cnt;
+    lc_flush(P, lck, lcc, total, lane);                                   // (a run in which no ray took a step finds an empty table)
 }
 
 // Issue priority of the wave by the work it still has in front of it (s_setprio: the SIMD's arbiter takes the ready wave of
@@ -611,8 +606,8 @@ __device__ __forceinline__ void trace_item(const ScanParams &P, const ShardExcha
         uint32_t wx, wy, wz;
         run = window_voxel<true>(P, px + R.incx, py + R.incy, pz + R.incz, wx, wy, wz);
     }
-    const uint32_t cnt = run ? ray_steps(R.lim, R.step_len, R.inv_step, 0x7ffffff0u) : 0u;     // steps the length test allows
-    const bool active = j0 < cnt && !GVOM_DBG(P, 8);
+    const uint32_t cnt = (run && !GVOM_DBG(P, 8)) ? ray_steps(R.lim, R.step_len, R.inv_step, 0x7ffffff0u) : 0u;     // steps the length test allows
+    const bool active = j0 < cnt;
     if (lanes(active) == 0ull) { TL_MARK(P, widx, 2); return; }   // wave-uniform: every ray of the bundle ends earlier
     {   // replay (the reference's exact f32 accumulation; x and y as one packed add)
         v2f pxy = {px, py};
