@@ -83,6 +83,7 @@ struct gvom_handle {
     int tune_ilv = 0;                                   // gvom_set_tuning "interleave": sub-clouds per cloud (0: automatic, 1: off)
     int last_knobs[5] = {0, 0, 0, 0, 1};                // gvom_get_tuning: segs, period, ep_row, prio, interleave of the last scan
     int64_t probe_n = -1; uint32_t probe_age = 0;       // layout probe (k_layout_probe): the length it last looked at, scans since
+    int tune_flag_kernel = 0;                           // gvom_set_tuning "flag_kernel": 1 = the combine's completion flag from a kernel of its own (round 3's form)
     int tune_churn = 0;                                 // test hook: re-allocate the endpoint send region every scan
     uint64_t alloc_gen = 0;                             // changes whenever a send region of this handle is re-allocated
     uint64_t handle_gen = 0;                            // this handle's own number (its fixed allocations)
@@ -985,7 +986,7 @@ int fuse_impl(gvom_handle *h, hipStream_t on = nullptr)
 // gathered: sharded run -- every row of the interleaved height buffer (heights + owner-computed
 // positive densities) has been all-gathered and this rank computes ALL rows of the outputs.
 int map2d_impl(gvom_handle *h, bool gathered, bool publish, char *out_dev, bool yx, const double *occ = nullptr,
-               hipStream_t on = nullptr)
+               hipStream_t on = nullptr, uint32_t done_seq = 0)
 {
     const hipStream_t ms = on ? on : h->stream;
     const gvom_params &p = h->prm;
@@ -1008,6 +1009,11 @@ int map2d_impl(gvom_handle *h, bool gathered, bool publish, char *out_dev, bool 
     P.nseg = h->nseg;
     P.hs = h->hs;
     P.epoch = F.epoch;
+    if (done_seq && !h->tune_flag_kernel) {       // the synchronous combine's completion flag (finish_combine): stored by k_map2d's last workgroup
+        P.done_flag = (unsigned long long *)(h->counters_host_dev + 4);
+        P.done_count = h->counters + GVOM_CNT_MAPDONE;
+        P.done_seq = done_seq;
+    }
     const size_t n2 = h->cells2d;
     int32_t *o_pos = (int32_t *)out_dev, *o_neg = o_pos + n2, *o_vis = o_neg + n2;
     double *o_rgh = (double *)(o_vis + n2);
@@ -1061,12 +1067,12 @@ void collect_stage_ms(gvom_handle *h)
 // Waits for the combine's kernels with the handle mutex RELEASED (a second thread -- the ROS node's
 // cloud callback -- can hand the next scan over meanwhile: its kernels queue up behind k_map2d and the
 // GPU does not idle between the steps); other combine calls are held off by combine_mu / pending_combine.
-int finish_combine(gvom_handle *h, std::unique_lock<std::mutex> &lk)
+int finish_combine(gvom_handle *h, std::unique_lock<std::mutex> &lk, uint32_t seq)
 {
-    // completion: a one-thread kernel behind k_map2d stores a sequence number into host-mapped memory and the
-    // host spins on it (an event wait notices the end of the stream several microseconds later)
-    const uint32_t seq = ++h->combine_seq;
-    HIPCHK(h, gvom_launch_publish_seq(h->stream, (unsigned long long *)(h->counters_host_dev + 4), seq));
+    // completion: k_map2d's last workgroup stores the sequence number into host-mapped memory (map2d_impl) and the host
+    // spins on it (an event wait notices the end of the stream several microseconds later; round 3's one-thread kernel
+    // behind k_map2d cost 4 us of every step)
+    if (h->tune_flag_kernel) HIPCHK(h, gvom_launch_publish_seq(h->stream, (unsigned long long *)(h->counters_host_dev + 4), seq));
     HIPCHK(h, hipEventRecord(h->ev_done, h->stream));
     h->pending_combine = true;
     hipError_t e = hipSuccess;
@@ -1368,11 +1374,12 @@ VIS int gvom_combine_maps(gvom_t *h, double origin_world[3], int32_t *positive, 
     double t0 = now_ns();
     int rc = fuse_impl(h);
     if (rc) return rc;
-    if ((rc = map2d_impl(h, false, true, h->out_host_dev, false))) return rc;
+    const uint32_t done_seq = ++h->combine_seq;
+    if ((rc = map2d_impl(h, false, true, h->out_host_dev, false, nullptr, nullptr, done_seq))) return rc;
     const size_t n2 = h->cells2d;
     char *stage = (char *)h->out_host;
     HT(h, 2, t0);                                        // combine: launches
-    if ((rc = finish_combine(h, lk))) return rc;
+    if ((rc = finish_combine(h, lk, done_seq))) return rc;
     HT(h, 3, t0);                                        // combine: wait
     if (positive) memcpy(positive, stage, n2 * 4);
     if (negative) memcpy(negative, stage + n2 * 4, n2 * 4);
@@ -1428,9 +1435,10 @@ VIS int gvom_combine_maps_into(gvom_t *h, double origin_world[3], void *pinned_o
     if (rc) return rc;
     char *dev = nullptr;
     HIPCHK(h, hipHostGetDevicePointer((void **)&dev, pinned_out, 0));
-    if ((rc = map2d_impl(h, false, true, dev, true))) return rc;
+    const uint32_t done_seq = ++h->combine_seq;
+    if ((rc = map2d_impl(h, false, true, dev, true, nullptr, nullptr, done_seq))) return rc;
     HT(h, 2, t0);
-    if ((rc = finish_combine(h, lk))) return rc;
+    if ((rc = finish_combine(h, lk, done_seq))) return rc;
     HT(h, 3, t0);
     if (origin_world) {
         const Fused &F = h->fused[h->cur];
@@ -1460,9 +1468,10 @@ VIS int gvom_combine_occupancy_into(gvom_t *h, double origin_world[3], void *pin
     char *dev = nullptr;
     HIPCHK(h, hipHostGetDevicePointer((void **)&dev, pinned_out, 0));
     const double occ[3] = {density_threshold, min_roughness, max_roughness};
-    if ((rc = map2d_impl(h, false, true, dev, true, occ))) return rc;
+    const uint32_t done_seq = ++h->combine_seq;
+    if ((rc = map2d_impl(h, false, true, dev, true, occ, nullptr, done_seq))) return rc;
     HT(h, 2, t0);
-    if ((rc = finish_combine(h, lk))) return rc;
+    if ((rc = finish_combine(h, lk, done_seq))) return rc;
     HT(h, 3, t0);
     if (origin_world) {
         const Fused &F = h->fused[h->cur];
@@ -1957,6 +1966,7 @@ VIS int gvom_set_tuning(gvom_t *h, const char *name, int value)
     else if (!strcmp(name, "period")) h->tune_period = value;
     else if (!strcmp(name, "prio")) h->tune_prio = value;
     else if (!strcmp(name, "interleave")) h->tune_ilv = value;
+    else if (!strcmp(name, "flag_kernel")) h->tune_flag_kernel = value;
     else if (!strcmp(name, "churn")) h->tune_churn = value;
     else if (!strcmp(name, "exported")) h->exported = value != 0;       // (set by the peer transport, gvom_comm.hip)
 

@@ -48,6 +48,7 @@ static inline int gvom_diag_env(const char *) { return 0; }
 // device counter block (uint32 words; 512 bytes).  The two counters k_trace adds to live on separate
 // cache lines: same-line atomics are serialised by the memory system.
 #define GVOM_CNT_INGRID 64     // != 0: some return of the scan in flight landed in the grid
+#define GVOM_CNT_MAPDONE 32    // k_map2d: workgroups that have finished (the last one stores the combine's completion flag)
 #define GVOM_CNT_WORDS 192
 
 struct ScanParams {
@@ -151,6 +152,12 @@ struct Map2dParams {
     double pos_thr, neg_thr, slope_thr, robot_height;
     int occ;                // 1: write the five int8 occupancy grids of gvom_ros.py:141-165 instead of the four maps
     double occ_density_thr, occ_min_rough, occ_max_rough;
+    // completion flag of the synchronous combine, stored by the LAST workgroup to finish (no kernel behind k_map2d): every
+    // wave waits for its own stores to be acknowledged, one lane per workgroup then counts itself in (device-scope atomic);
+    // whoever sees the count complete stores done_seq into host-mapped memory and re-arms the counter
+    unsigned long long *done_flag;   // nullptr: no flag
+    uint32_t *done_count;
+    uint32_t done_seq;
 };
 
 // ---- launchers (gvom_kernels.hip) --------------------------------------------------------

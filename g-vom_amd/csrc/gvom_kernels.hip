@@ -1541,7 +1541,8 @@ __device__ __forceinline__ void publish_block_counts(const uint32_t *blockcounts
         if (tid < o) s_red[tid] += s_red[tid + o];
         __syncthreads();
     }
-    if (tid == 0) *host_counter = s_red[0];
+    // (system scope: k_map2d publishes its completion before the kernel ends, the count must have left the L2 by then)
+    if (tid == 0) __hip_atomic_store((unsigned long long *)host_counter, s_red[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __global__ void k_publish_count(const uint32_t *blockcounts, int nblocks, unsigned long long *host_counter,
@@ -1886,6 +1887,21 @@ __global__ __launch_bounds__(512) void k_map2d(const Map2dParams P, const int32_
             const size_t c_xy = (size_t)gx * xy + gy;
             out_pos[c_xy] = o_pos[ox][oy]; out_neg[c_xy] = o_neg[ox][oy];
             out_vis[c_xy] = o_vis[ox][oy]; out_rough[c_xy] = o_rgh[ox][oy];
+        }
+    }
+    if (P.done_flag) {
+        // The maps lie in host memory once every wave's stores have been acknowledged (s_waitcnt vmcnt(0): system-scope
+        // stores are written through, and what still sat in this XCD's L2 leaves with the workgroup's one release); the flag
+        // store of the last workgroup travels the same ordered path behind them.
+        __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
+        __syncthreads();
+        if (tid == 0) {
+            if (!YX) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");       // (plain stores of the row-major form: write back, system scope)
+            const uint32_t arrived = __hip_atomic_fetch_add(P.done_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (arrived + 1u == gridDim.x * gridDim.y) {
+                __hip_atomic_store(P.done_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(P.done_flag, (unsigned long long)P.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
 }

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""A/B of result-neutral knob settings inside ONE process on ONE box: the settings take turns, block by block (boxes differ
+by 2-4 %, a fresh process by 1-2 %).  usage: tools/ab_knob.py <config> <steps per block> <blocks> <setting> <setting> ...
+setting = name=value[,name=value...] or "-" (defaults)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "g-vom_amd")]
+import numpy as np
+import bench, gvom, synth
+
+name, steps, blocks = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+settings = sys.argv[4:]
+hip = bench.Hip(); hip.set_device(0)
+params, scans = synth.config_inputs(name, n_scans=4)
+dev = [(hip.to_device(pc), pc.shape[0], pc.dtype, ego, tf) for (pc, ego, tf) in scans]
+gs = []
+for setting in settings:
+    g = gvom.Gvom(*params)
+    if setting != "-":
+        for kv in setting.split(","):
+            k, v = kv.split("="); g.set_tuning(k, int(v))
+    gs.append(g)
+def run(g, n):
+    for k in range(n):
+        d, npts, dt, ego, tf = dev[k % 4]; g.process_pointcloud_device(d.value, npts, dt, ego, tf); g.combine_maps()
+for g in gs: run(g, 40)
+acc = [[] for _ in gs]
+for b in range(blocks):
+    for i, g in enumerate(gs):
+        t0 = time.perf_counter(); run(g, steps); acc[i].append((time.perf_counter() - t0) / steps * 1e6)
+for s, a in zip(settings, acc):
+    print("%-32s median %7.2f us  min %7.2f  (blocks %d x %d steps)" % (s, float(np.median(a)), min(a), blocks, steps), flush=True)
