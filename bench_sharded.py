@@ -247,6 +247,37 @@ def run(args):
     # every rank's exchange figures on rank 0 (the slowest rank sets the step)
     table = comm.exchange_host([int(sent), int(recvd), int((ex_ms["exchange_scan"] or 0) * 1e6), int((ex_ms["allgather_rows"] or 0) * 1e6)])
     fence()
+    # the communicator's own view of the job, every rank's on rank 0: RCCL's rank count and rank number, device, PCI bus id
+    info = rccl.info()
+    bus = info["pci_bus_id"] or "?"
+    packed = [int.from_bytes(bus.encode()[:21].ljust(21, b"\0")[i:i + 7], "little") for i in (0, 7, 14)]    # (7 bytes per int64)
+    rows_info = comm.exchange_host([info["rccl_comm_count"] if info["rccl_comm_count"] is not None else -1,
+                                    info["rccl_user_rank"] if info["rccl_user_rank"] is not None else -1,
+                                    info["device"], 0 if info["transport"] == "rccl" else 1] + packed)
+
+    def _bus(*parts):
+        return b"".join(int(v).to_bytes(7, "little") for v in parts).rstrip(b"\0").decode(errors="replace")
+    stream = None
+    if getattr(args, "offered_hz", 0) > 0:
+        # the paced stream (bench.paced_stream): every rank hands its HOST-resident share over at the common schedule
+        # (the ranks are processes of one node: one monotonic clock); rank 0 reports, with the slowest rank's percentiles
+        host_shares = [make_share(name, rank, world, kk) for kk in range(poses)]
+
+        def tick(kk):
+            share, ego = host_shares[kk % poses]
+            sh.process_pointcloud(share, ego)
+            return sh.combine_maps()
+        t0 = max(r[0] for r in comm.exchange_host([int((time.perf_counter() + 0.25) * 1e9)])) * 1e-9
+        for kk in range(3):
+            tick(kk)
+        stream = bench.paced_stream(tick, args.offered_hz, args.ticks, t0=t0, warm=0)
+        rank_rows = comm.exchange_host([int(stream["latency_ms"][q] * 1e3) for q in ("p50", "p95", "p99", "max")] + [stream["deadline_misses"]])
+        stream["per_rank"] = [{"rank": r, "latency_us_p50_p95_p99_max": list(row[:4]), "deadline_misses": row[4]} for r, row in enumerate(rank_rows)]
+        stream["latency_ms_slowest_rank"] = {q: max(row[i] for row in rank_rows) * 1e-3 for i, q in enumerate(("p50", "p95", "p99", "max"))}
+        stream.update(points_per_tick=n_local * world, offered_M_points_s=n_local * world * args.offered_hz / 1e6,
+                      sustained_M_points_s=n_local * world * stream["achieved_hz"] / 1e6)
+        del host_shares
+        fence()
     n_ver = params[4] + 2
     ok, detail, trace_alg = verify(name, params, comm, rank, world, local_rank, n_ver)
     out = None
@@ -276,10 +307,17 @@ def run(args):
                          + ("" if args.transport != "auto" or rccl.transport == "rccl" or (args.share_device and not os.environ.get("GVOM_BENCH_REHEARSE_AUTO"))
                             else " -- RCCL could not initialise"),
             "rehearsal_on_one_device": bool(args.share_device),
+            "ranks": [{"rank": r, "rccl_comm_count": (row[0] if row[0] >= 0 else None), "rccl_user_rank": (row[1] if row[1] >= 0 else None),
+                       "device": row[2], "transport": ("rccl", "peer")[row[3]], "pci_bus_id": _bus(row[4], row[5], row[6])}
+                      for r, row in enumerate(rows_info)],
+            "distinct_devices": len(set(_bus(row[4], row[5], row[6]) for row in rows_info)),
+            "communicator_ranks": (rows_info[0][0] if rows_info[0][0] >= 0 else world),
+            "cpu_baseline": {"see": "the N = 1 line of the same bench.py (cpu_baseline: the CPU oracle on this box's host cores, timed on "
+                                    "rank 0 at N = 1 only, as the contract asks); BENCH_rNN.json / profiles/r4_bench_m256.json"},
             "peer_transport_rank0": rccl.peer_stats() if rccl.transport == "peer" else None,
             "map_hz": steps / med, "blocks": len(blocks),
             "ms_per_step_min": min(blocks) / steps * 1e3, "ms_per_step_max": max(blocks) / steps * 1e3,
-            "stage_ms_rank0": stage_ms,
+            "stage_ms_rank0": stage_ms, "stream": stream,
             "sharded_equals_unsharded": bool(ok), "verify": detail,
             "exchange": {"per_rank": [{"rank": r, "sent_bytes": row[0], "received_bytes": row[1],
                                        "exchange_scan_ms": row[2] * 1e-6, "allgather_rows_ms": row[3] * 1e-6}

@@ -88,7 +88,8 @@ struct gvom_handle {
     uint64_t alloc_gen = 0;                             // changes whenever a send region of this handle is re-allocated
     uint64_t handle_gen = 0;                            // this handle's own number (its fixed allocations)
     bool exported = false;                              // a transport has exported this handle's send regions to other processes
-    std::vector<void *> retired;                        // outgrown send regions (possibly still mapped by peers): freed with the handle
+    std::vector<Buf> retired;                           // outgrown / replaced exported regions (possibly still mapped by peers), with their sizes
+    uint64_t fixed_gen[3] = {0, 0, 0};                  // generations of the fixed exported allocations: send ids, send quads, height-map rows
     // rank exchange of a sharded map (world > 1): send / receive regions, indexed by peer rank
     uint32_t *x_send_ids = nullptr, *x_recv_ids = nullptr;     // quad ids: [Q] by owner / [world][myQ] by source
     void *x_send_pay = nullptr, *x_recv_pay = nullptr;         // 1 KiB per quad, same indexing
@@ -214,6 +215,51 @@ static std::atomic<uint64_t> g_alloc_generation{0};
 // twice -- a second small region landing in an exported block is what hipIpcGetMemHandle refused ("invalid argument").
 inline size_t exportable_size(size_t bytes) { const size_t g = (size_t)2 << 20; return ((bytes ? bytes : 1) + g - 1) / g * g; }
 
+// Regions another process has had mapped are never given back to the allocator while this process lives (a later allocation
+// tends to get their address, and importers that open "it" have been seen reading the OLD memory: profiles/r3_peer_churn.txt).
+// They wait in a process-wide POOL instead, with their real sizes and their generation (= the name the communicators know
+// the allocation by: a region that becomes current again is neither exported nor opened a second time), and the next
+// handle that needs an exportable region of that size takes one from there.  The pool is accounted exactly; past
+// GVOM_POOL_WARN_BYTES it says so on stderr, once -- it never falls back to freeing.
+#define GVOM_POOL_WARN_BYTES ((size_t)16 << 30)
+struct ExportPool {
+    std::mutex m;
+    std::vector<Buf> v;
+    size_t bytes = 0;
+    bool warned = false;
+};
+static ExportPool g_pool;
+void pool_put(void *p, size_t bytes, uint64_t gen)
+{
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_pool.m);
+    Buf b; b.p = p; b.bytes = bytes; b.gen = gen;
+    g_pool.v.push_back(b);
+    g_pool.bytes += bytes;
+    if (g_pool.bytes > GVOM_POOL_WARN_BYTES && !g_pool.warned) {
+        g_pool.warned = true;
+        fprintf(stderr, "libgvom_hip: %zu MiB of device memory that other processes may have mapped are parked (never freed while "
+                        "the process lives; re-used by later sharded handles of the same sizes): create fewer exported handles per process\n",
+                g_pool.bytes >> 20);
+    }
+}
+// an exportable allocation of exactly `bytes` (a multiple of 2 MiB): a parked one, or a fresh one
+hipError_t pool_get(size_t bytes, void **p, uint64_t *gen)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_pool.m);
+        for (size_t k = 0; k < g_pool.v.size(); ++k)
+            if (g_pool.v[k].bytes == bytes) {
+                *p = g_pool.v[k].p; *gen = g_pool.v[k].gen;
+                g_pool.bytes -= bytes;
+                g_pool.v.erase(g_pool.v.begin() + (long)k);
+                return hipSuccess;
+            }
+    }
+    *gen = ++g_alloc_generation;
+    return hipMalloc(p, bytes);
+}
+
 int ensure(gvom_handle *h, Buf &b, size_t bytes)
 {
     if (b.bytes >= bytes) return GVOM_OK;
@@ -223,12 +269,12 @@ int ensure(gvom_handle *h, Buf &b, size_t bytes)
     // (a region another process may have mapped is never freed while the handle lives: freed and re-allocated, the new region
     // tends to get the old one's address, and importers that re-open "it" were seen reading the OLD memory -- a silently
     // different map after ~50 scans of the churn test.  Growth is geometric: the retired regions add up to less than the last.)
-    if (b.p && exported) { h->retired.push_back(b.p); b.p = nullptr; }
+    if (b.p && exported) { h->retired.push_back(b); b.p = nullptr; }
     if (b.p) HIPCHK(h, hipFree(b.p));
     b.p = nullptr; b.bytes = 0;
-    HIPCHK(h, hipMalloc(&b.p, want));
+    if (exported) HIPCHK(h, pool_get(want, &b.p, &b.gen));
+    else { HIPCHK(h, hipMalloc(&b.p, want)); b.gen = ++g_alloc_generation; }
     b.bytes = want;
-    b.gen = ++g_alloc_generation;
     if (&b == &h->x_send_eps || &b == &h->x_send_sp) h->alloc_gen = b.gen;   // (see gvom_alloc_generation)
     return GVOM_OK;
 }
@@ -449,7 +495,8 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, b
     CK(hipMalloc((void **)&h->blockcounts, (size_t)(h->fuse_blocks > 0 ? h->fuse_blocks : 1) * 4));
     CK(hipMemsetAsync(h->blockcounts, 0, (size_t)(h->fuse_blocks > 0 ? h->fuse_blocks : 1) * 4, h->stream));
     h->hs = 3 * xy;
-    CK(hipMalloc((void **)&h->hmaps, sharded ? exportable_size(h->cells2d * 24) : h->cells2d * 24));
+    if (sharded) CK(pool_get(exportable_size(h->cells2d * 24), (void **)&h->hmaps, &h->fixed_gen[2]));
+    else CK(hipMalloc((void **)&h->hmaps, h->cells2d * 24));
     h->height = h->hmaps; h->inferred = h->hmaps + xy;
     double **maps[4] = {&h->slope_x, &h->slope_y, &h->rough, &h->guessed};
     for (auto m : maps) CK(hipMalloc((void **)m, h->cells2d * 8));
@@ -462,8 +509,8 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, b
         // rank exchange regions (DESIGN.md "Multi-GPU"): a quad = 4 storage rows x 64 sx at one sz
         h->x_Q = (size_t)(xy / 4) * zs * h->nseg;
         h->x_myQ = h->x_Q / world;
-        CK(hipMalloc((void **)&h->x_send_ids, exportable_size(h->x_Q * 4)));
-        CK(hipMalloc(&h->x_send_pay, exportable_size(h->x_Q * 1024)));
+        CK(pool_get(exportable_size(h->x_Q * 4), (void **)&h->x_send_ids, &h->fixed_gen[0]));
+        CK(pool_get(exportable_size(h->x_Q * 1024), &h->x_send_pay, &h->fixed_gen[1]));
         CK(hipMalloc((void **)&h->x_recv_ids, h->x_Q * 4));
         CK(hipMalloc(&h->x_recv_pay, h->x_Q * 1024));
         CK(hipMalloc((void **)&h->x_qcnt, (size_t)world * 64));
@@ -665,7 +712,7 @@ int scan_launch(gvom_handle *h, std::unique_lock<std::mutex> &lk, const void *de
     X.ep_send = nullptr; X.ep_cnt = nullptr; X.ep_cap = 0; X.sp_send = nullptr; X.sp_cnt = nullptr;
     if (h->sharded) {
         if (h->tune_churn > 0 && h->x_send_eps.p) {            // test hook (gvom_set_tuning "churn"): a fresh allocation every scan
-            h->retired.push_back(h->x_send_eps.p);               // (as a region that grows: retired, not freed)
+            h->retired.push_back(h->x_send_eps);                 // (as a region that grows: retired, not freed)
             h->x_send_eps.p = nullptr; h->x_send_eps.bytes = 0;
         }
         if ((rc = ensure(h, h->x_send_eps, (size_t)h->world * (size_t)(n > 0 ? n : 1) * 8))) return rc;
@@ -1130,20 +1177,19 @@ VIS void gvom_destroy(gvom_t *h)
     if (h->stream) hipStreamSynchronize(h->stream);
     auto fb = [](Buf &b) { if (b.p) hipFree(b.p); b.p = nullptr; b.bytes = 0; };
     hipFree(h->hit); hipFree(h->total); hipFree(h->mh);
-    // Regions another process has had mapped (the peer transport exported them: "exported" is set through gvom_set_tuning) are NOT
-    // given back while the process lives: a later allocation tends to get their address, and importers that open "it" have been
-    // seen reading the old memory.  The graveyard is bounded; beyond it they are freed after all.
-    static std::atomic<size_t> graveyard{0};
-    auto bury = [&](void *ptr, size_t bytes) {
+    // Regions another process has had mapped (the peer transport exported them: "exported" is set through gvom_set_tuning) go
+    // to the process-wide pool (see pool_put), the others back to the allocator
+    auto park = [&](void *ptr, size_t bytes, uint64_t gen) {
         if (!ptr) return;
-        if (h->exported && graveyard.load() + bytes <= ((size_t)4 << 30)) { graveyard += bytes; return; }
-        hipFree(ptr);
+        if (h->exported) pool_put(ptr, bytes, gen); else hipFree(ptr);
     };
-    for (void *r : h->retired) bury(r, (size_t)2 << 20);
-    bury(h->x_send_ids, exportable_size(h->x_Q * 4)); bury(h->x_send_pay, exportable_size(h->x_Q * 1024));
-    bury(h->x_send_eps.p, h->x_send_eps.bytes); bury(h->x_send_sp.p, h->x_send_sp.bytes);
+    for (Buf &r : h->retired) park(r.p, r.bytes, r.gen);
+    if (h->sharded) {
+        park(h->x_send_ids, exportable_size(h->x_Q * 4), h->fixed_gen[0]); park(h->x_send_pay, exportable_size(h->x_Q * 1024), h->fixed_gen[1]);
+        park(h->x_send_eps.p, h->x_send_eps.bytes, h->x_send_eps.gen); park(h->x_send_sp.p, h->x_send_sp.bytes, h->x_send_sp.gen);
+        park(h->hmaps, exportable_size(h->cells2d * 24), h->fixed_gen[2]); h->hmaps = nullptr;
+    }
     h->x_send_eps.p = nullptr; h->x_send_sp.p = nullptr;
-    if (h->exported && h->sharded) { bury(h->hmaps, exportable_size(h->cells2d * 24)); h->hmaps = nullptr; }
     hipFree(h->x_recv_ids); hipFree(h->x_recv_pay);
     hipFree(h->x_qcnt); hipFree(h->x_ecnt); hipFree(h->x_spcnt); fb(h->x_recv_eps); fb(h->x_recv_sp);
     if (h->x_host) hipHostFree(h->x_host);
@@ -2001,11 +2047,48 @@ VIS void *gvom_stream(gvom_t *h) { return h ? (void *)h->stream : nullptr; }
 VIS uint64_t gvom_alloc_generation(gvom_t *h) { return h ? h->alloc_gen : 0; }
 // The same for ONE region (which = GVOM_XBUF_SEND_* or -1 for GVOM_BUF_HEIGHT_MAPS): a value that names the allocation the
 // region lies in -- it changes exactly when that allocation is replaced (and differs between handles).
+// The region `which` (GVOM_XBUF_SEND_IDS / _QUADS / _EPS / _RETURNS, or -1: GVOM_BUF_HEIGHT_MAPS) moves into a FRESH allocation of the
+// same size, contents included; the old one is parked (a peer may have it mapped).  For the transport: an allocation the HSA
+// runtime refuses to export, or that a peer cannot open, is replaced by one that has no history.
+VIS int gvom_shard_renew_region(gvom_t *h, int which)
+{
+    if (!h || !h->sharded) return GVOM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    void **pp = nullptr;
+    size_t bytes = 0;
+    uint64_t *gen = nullptr;
+    switch (which) {
+    case GVOM_XBUF_SEND_IDS: pp = (void **)&h->x_send_ids; bytes = exportable_size(h->x_Q * 4); gen = &h->fixed_gen[0]; break;
+    case GVOM_XBUF_SEND_QUADS: pp = &h->x_send_pay; bytes = exportable_size(h->x_Q * 1024); gen = &h->fixed_gen[1]; break;
+    case GVOM_XBUF_SEND_EPS: pp = &h->x_send_eps.p; bytes = h->x_send_eps.bytes; gen = &h->x_send_eps.gen; break;
+    case GVOM_XBUF_SEND_RETURNS: pp = &h->x_send_sp.p; bytes = h->x_send_sp.bytes; gen = &h->x_send_sp.gen; break;
+    case -1: pp = (void **)&h->hmaps; bytes = exportable_size(h->cells2d * 24); gen = &h->fixed_gen[2]; break;
+    default: return GVOM_ERR_INVALID;
+    }
+    if (!*pp || !bytes) return GVOM_NO_DATA;
+    void *np = nullptr;
+    HIPCHK(h, hipMalloc(&np, bytes));                      // (fresh: never from the pool)
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(np, *pp, bytes, hipMemcpyDeviceToDevice));
+    HIPCHK(h, hipDeviceSynchronize());
+    Buf old; old.p = *pp; old.bytes = bytes; old.gen = *gen;
+    h->retired.push_back(old);
+    *pp = np;
+    *gen = ++g_alloc_generation;
+    if (which == -1) { h->height = h->hmaps; h->inferred = h->hmaps + h->prm.xy_size; }
+    if (which == GVOM_XBUF_SEND_EPS || which == GVOM_XBUF_SEND_RETURNS) h->alloc_gen = *gen;
+    return GVOM_OK;
+}
+
 VIS uint64_t gvom_region_generation(gvom_t *h, int which)
 {
     if (!h) return 0;
     if (which == GVOM_XBUF_SEND_EPS) return h->x_send_eps.gen ? h->x_send_eps.gen : h->handle_gen;
     if (which == GVOM_XBUF_SEND_RETURNS) return h->x_send_sp.gen ? h->x_send_sp.gen : h->handle_gen;
+    if (which == GVOM_XBUF_SEND_IDS && h->fixed_gen[0]) return h->fixed_gen[0];
+    if (which == GVOM_XBUF_SEND_QUADS && h->fixed_gen[1]) return h->fixed_gen[1];
+    if (which == -1 && h->fixed_gen[2]) return h->fixed_gen[2];
     return h->handle_gen;
 }
 

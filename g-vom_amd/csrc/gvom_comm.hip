@@ -48,7 +48,9 @@
 
 #define VIS __attribute__((visibility("default")))
 #define GVOM_COMM_MAX_RANKS 64
-#define GVOM_COMM_MAX_VALUES 160          // int64 values per rank and exchange (>= 2 * ranks + 4)
+#define GVOM_COMM_MAX_VALUES 208          // int64 values per rank and exchange (statistics handles exchange 3 * ranks + 3)
+static_assert(GVOM_COMM_MAX_VALUES >= 3 * GVOM_COMM_MAX_RANKS + 4, "a communicator of GVOM_COMM_MAX_RANKS ranks must be able to exchange its counts");
+extern "C" int gvom_shard_renew_region(gvom_t *h, int which);    // (gvom_capi.hip; same library)
 
 namespace {
 
@@ -123,6 +125,9 @@ struct Segment {                               // the shared-memory rendezvous o
     // its stream, system-scope release) and read by the other ranks' hosts -- the segment is registered with HIP for that
     std::atomic<uint32_t> sync_only;           // some rank could not register the segment: everybody keeps the host-synchronised form
     PeerFlags flags[GVOM_COMM_MAX_RANKS];
+    // recovery of refused imports: import_failed[s][kind] = the recovery round in which some rank could not open rank s's
+    // export `kind` (written between two barriers, read after the second: every rank sees the same table)
+    std::atomic<uint64_t> import_failed[GVOM_COMM_MAX_RANKS][GVOM_PEER_KINDS];
 };
 
 inline double now_s() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + t.tv_nsec * 1e-9; }
@@ -175,27 +180,48 @@ bool creator_alive(const Segment *sg)
 
 }  // namespace
 
-struct PeerImport {                            // a peer's exported allocation, mapped into this process (kept until the communicator goes:
-    uint64_t generation = 0;                   // memory that was mapped once is never closed and opened again)
+// PROCESS-WIDE, for the life of the process (the three rules at the head of this file hold across communicators too: an
+// allocation is exported once and a mapping opened once, whoever asks):
+struct PeerImport {                            // a peer process's exported allocation, mapped into this process
+    int64_t pid = 0; uint64_t start = 0;       // the exporting process
+    uint64_t generation = 0;                   // its name for the allocation (gvom_region_generation: unique in that process)
     void *base = nullptr;
 };
-struct PeerOwn {                               // an allocation this rank has exported (once: its handle is kept for whenever it is current again)
+struct PeerOwn {                               // an allocation this process has exported
     void *base = nullptr;
     size_t size = 0;
-    uint64_t alloc_gen = ~0ull;
     uint64_t generation = 0;
     hipIpcMemHandle_t handle;
 };
+static std::mutex g_ipc_mu;
+static std::vector<PeerImport> g_imports;
+static std::vector<PeerOwn> g_own;
+// test hook: GVOM_TEST_IPC_REFUSE="export:N" / "import:N" [",rank:R"] -- the N-th export (import) this process attempts is
+// answered as the HSA runtime answers when it refuses (every repetition of it too), so that the recovery below runs
+struct IpcFault { int export_n = 0, import_n = 0, rank = -1; std::atomic<int> exports{0}, imports{0}; bool parsed = false; };
+static IpcFault g_fault;
+static void parse_fault()
+{
+    if (g_fault.parsed) return;
+    g_fault.parsed = true;
+    const char *e = getenv("GVOM_TEST_IPC_REFUSE");
+    if (!e) return;
+    if (const char *p = strstr(e, "export:")) g_fault.export_n = atoi(p + 7);
+    if (const char *p = strstr(e, "import:")) g_fault.import_n = atoi(p + 7);
+    if (const char *p = strstr(e, "rank:")) g_fault.rank = atoi(p + 5);
+}
 
 struct gvom_comm {
     int rank = 0, world = 1, device = 0;
     int transport = GVOM_TRANSPORT_RCCL;       // the one in use (never AUTO)
     Rccl rccl;
     ncclComm_t nccl = nullptr;
-    std::vector<PeerImport> imports[GVOM_COMM_MAX_RANKS][GVOM_PEER_KINDS];
-    std::vector<PeerOwn> own[GVOM_PEER_KINDS];
+    uint64_t seen_gen[GVOM_COMM_MAX_RANKS][GVOM_PEER_KINDS] = {};   // the exports as of the last exchange (every rank's, every kind)
+    uint64_t recover_round = 0;                // rounds of the import recovery so far (the same on every rank)
+    void *src_all[GVOM_COMM_MAX_RANKS][GVOM_PEER_KINDS] = {};       // scratch of one exchange: where each source's export is mapped
+    bool need_all[GVOM_COMM_MAX_RANKS][GVOM_PEER_KINDS] = {};
     uint64_t peer_bytes = 0, peer_copies = 0;  // pulled so far (diagnostics)
-    uint64_t export_seq = 0, peer_open_retries = 0;
+    uint64_t export_seq = 0, peer_open_retries = 0, peer_renewed = 0;
     // asynchronous form of the peer transport (no host wait for the GPU inside an exchange)
     bool async = false, registered = false;
     Segment *seg_dev = nullptr;                // device view of the registered segment
@@ -264,95 +290,193 @@ int peer_wait(gvom_comm *c, int r, const std::atomic<uint64_t> &flag, uint64_t t
     return GVOM_OK;
 }
 
-// Publishes the allocation that holds the regions `ptr[d]` (d != rank; null entries: nothing for d) as export `kind`
-// of this rank: handle of the allocation + the regions' offsets inside it.  The handle is taken again only when the
-// handle's buffers have been re-allocated since (gvom_alloc_generation).  Call between two barriers' worth of quiet:
-// readers look at the export only after the barrier that follows.
-int peer_publish(gvom_comm *c, gvom_t *h, int kind, void *const *ptr)
+// Publishes export `kind` of this rank: the allocation that holds what it has for the other ranks -- kinds 0..3: the send
+// regions of `send_which[kind]` for every rank d with counts[d] > 0; kind 4: this rank's rows of the height maps -- as the
+// allocation's handle + the regions' offsets inside it.  An allocation is exported once per process (g_own); one the HSA
+// runtime REFUSES to export is replaced by a fresh one (gvom_shard_renew_region: contents move, the old one is parked) --
+// up to three times before the refusal counts.  Call between two barriers' worth of quiet: readers look at the export only
+// after the barrier that follows.
+static const int region_of_kind[GVOM_PEER_KINDS] = {GVOM_XBUF_SEND_IDS, GVOM_XBUF_SEND_QUADS, GVOM_XBUF_SEND_EPS, GVOM_XBUF_SEND_RETURNS, -1};
+int peer_publish(gvom_comm *c, gvom_t *h, int kind, const int64_t *counts, bool force_renew = false)
 {
-    static const int region_of_kind[GVOM_PEER_KINDS] = {GVOM_XBUF_SEND_IDS, GVOM_XBUF_SEND_QUADS, GVOM_XBUF_SEND_EPS, GVOM_XBUF_SEND_RETURNS, -1};
     PeerExport &e = c->seg->exports[c->rank][kind];
-    void *any = nullptr;
-    for (int d = 0; d < c->world; ++d) if (d != c->rank && ptr[d]) { any = ptr[d]; break; }
-    if (!any) return GVOM_OK;                                          // nothing of this kind goes anywhere
-    void *base = nullptr;
-    size_t size = 0;
-    HIPCHK_C(c, hipMemGetAddressRange((hipDeviceptr_t *)&base, &size, (hipDeviceptr_t)any));
-    // (an allocation is exported ONCE: exporting it again -- and the importers closing and re-opening the very same memory --
-    // is what the HSA runtime does not take reliably: with a fresh export per scan, results differed after a dozen scans)
-    const uint64_t gen = gvom_region_generation(h, region_of_kind[kind]);
-    PeerOwn *o = nullptr;
-    for (PeerOwn &k : c->own[kind]) if (k.base == base && k.size == size && k.alloc_gen == gen) { o = &k; break; }
-    if (!o) {
-        (void)gvom_set_tuning(h, "exported", 1);                    // (its regions are kept out of the allocator for good: gvom_capi.hip, destroy)
-        PeerOwn n;
-        hipError_t ge = hipSuccess;
-        for (int attempt = 0; attempt < 20; ++attempt) {               // (a refusal is asked again a few times before it counts)
-            ge = hipIpcGetMemHandle(&n.handle, base);
-            if (ge == hipSuccess) break;
-            (void)hipGetLastError();
-            ++c->peer_open_retries;
-            usleep(1000 + 1000 * attempt);
+    parse_fault();
+    for (int renewals = 0; ; ++renewals) {
+        void *ptr[GVOM_COMM_MAX_RANKS] = {};
+        void *any = nullptr;
+        if (kind == 4) {
+            void *rows = nullptr;
+            int64_t bytes = 0, row = 0;
+            const int rc = gvom_device_buffer(h, GVOM_BUF_HEIGHT_MAPS, &rows, &bytes, &row);
+            if (rc) { c->err = "height-map rows missing"; return rc; }
+            for (int d = 0; d < c->world; ++d) if (d != c->rank) ptr[d] = (char *)rows + (size_t)(bytes / c->world) * c->rank;
+        } else {
+            for (int d = 0; d < c->world; ++d) {
+                int64_t cap = 0;
+                if (d == c->rank || counts[d] <= 0) continue;
+                if (gvom_shard_buffer(h, region_of_kind[kind], d, &ptr[d], &cap) || !ptr[d]) { c->err = "send region missing"; return GVOM_ERR_INVALID; }
+            }
         }
-        if (ge != hipSuccess) { c->err = std::string("hipIpcGetMemHandle failed: ") + hipGetErrorString(ge); return GVOM_ERR_HIP; }
-        n.base = base; n.size = size; n.alloc_gen = gen;
-        n.generation = ((uint64_t)(c->rank + 1) << 48) | ++c->export_seq;
-        c->own[kind].push_back(n);
-        o = &c->own[kind].back();
+        for (int d = 0; d < c->world; ++d) if (d != c->rank && ptr[d]) { any = ptr[d]; break; }
+        if (!any) return GVOM_OK;                                      // nothing of this kind goes anywhere
+        if (force_renew && renewals == 0) {                            // (a peer could not open the current allocation)
+            const int rr = gvom_shard_renew_region(h, region_of_kind[kind]);
+            if (rr) { c->err = "could not replace an exchange region a peer cannot open"; return GVOM_ERR_HIP; }
+            ++c->peer_renewed;
+            continue;
+        }
+        void *base = nullptr;
+        size_t size = 0;
+        HIPCHK_C(c, hipMemGetAddressRange((hipDeviceptr_t *)&base, &size, (hipDeviceptr_t)any));
+        const uint64_t gen = gvom_region_generation(h, region_of_kind[kind]);
+        PeerOwn own;
+        bool have = false;
+        {
+            std::lock_guard<std::mutex> lk(g_ipc_mu);
+            for (PeerOwn &k : g_own) if (k.base == base && k.size == size && k.generation == gen) { own = k; have = true; break; }
+        }
+        if (!have) {
+            (void)gvom_set_tuning(h, "exported", 1);                // (its regions go to the pool instead of back to the allocator: gvom_capi.hip)
+            hipError_t ge = hipSuccess;
+            const bool injected = g_fault.export_n > 0 && (g_fault.rank < 0 || g_fault.rank == c->rank) && ++g_fault.exports == g_fault.export_n;
+            for (int attempt = 0; attempt < 5; ++attempt) {            // (a refusal is asked again a few times before it counts)
+                ge = injected ? hipErrorInvalidValue : hipIpcGetMemHandle(&own.handle, base);
+                if (ge == hipSuccess) break;
+                (void)hipGetLastError();
+                ++c->peer_open_retries;
+                usleep(1000 + 1000 * attempt);
+            }
+            if (ge != hipSuccess) {
+                if (renewals >= 3 || gvom_shard_renew_region(h, region_of_kind[kind]) != GVOM_OK) {
+                    c->err = std::string("hipIpcGetMemHandle failed: ") + hipGetErrorString(ge) + " (also for " + std::to_string(renewals) + " fresh allocation(s))";
+                    return GVOM_ERR_HIP;
+                }
+                ++c->peer_renewed;
+                continue;                                              // the region lies in a fresh allocation now: export that
+            }
+            own.base = base; own.size = size; own.generation = gen;
+            std::lock_guard<std::mutex> lk(g_ipc_mu);
+            g_own.push_back(own);
+            ++c->export_seq;
+        }
+        if (e.generation != own.generation) {                          // (another allocation is current than at the last exchange)
+            memcpy(&e.handle, &own.handle, sizeof own.handle);
+            e.size = size;
+            e.generation = own.generation;
+        }
+        for (int d = 0; d < c->world; ++d) {
+            if (d == c->rank || !ptr[d]) { e.offset[d] = ~0ull; continue; }
+            const size_t off = (size_t)((char *)ptr[d] - (char *)base);
+            if ((char *)ptr[d] < (char *)base || off >= size) { c->err = "exchange regions of one kind lie in different allocations"; return GVOM_ERR_INVALID; }
+            e.offset[d] = off;
+        }
+        return GVOM_OK;
     }
-    if (e.generation != o->generation) {                              // (another allocation is current than at the last exchange)
-        memcpy(&e.handle, &o->handle, sizeof o->handle);
-        e.size = size;
-        e.generation = o->generation;
-    }
-    for (int d = 0; d < c->world; ++d) {
-        if (d == c->rank || !ptr[d]) { e.offset[d] = ~0ull; continue; }
-        const size_t off = (size_t)((char *)ptr[d] - (char *)base);
-        if ((char *)ptr[d] < (char *)base || off >= size) { c->err = "exchange regions of one kind lie in different allocations"; return GVOM_ERR_INVALID; }
-        e.offset[d] = off;
-    }
-    return GVOM_OK;
 }
 
-// Address, in this process, of what rank s exported as `kind` for this rank (mapped on first use and whenever s has
-// exported a new allocation).
-int peer_source(gvom_comm *c, int s, int kind, void **src)
+// Address, in this process, of what rank s exported as `kind` for this rank (mapped on first use of the allocation, for the
+// life of the process).  refused (optional): set instead of failing when the HSA runtime refuses to open it.
+int peer_source(gvom_comm *c, int s, int kind, void **src, bool *refused = nullptr)
 {
     const PeerExport &e = c->seg->exports[s][kind];
     if (e.generation == 0 || e.offset[c->rank] == ~0ull) { c->err = "a peer announced data it has not exported"; return GVOM_ERR_INVALID; }
-    PeerImport *found = nullptr;
-    for (PeerImport &k : c->imports[s][kind]) if (k.generation == e.generation) { found = &k; break; }
-    if (!found) {
-        PeerImport im;
+    const int64_t pid = c->seg->rank_pid[s];
+    const uint64_t start = c->seg->rank_start[s];
+    void *base = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_ipc_mu);
+        for (PeerImport &k : g_imports) if (k.generation == e.generation && k.pid == pid && k.start == start) { base = k.base; break; }
+    }
+    if (!base) {
+        parse_fault();
         hipIpcMemHandle_t hd;
         memcpy(&hd, &e.handle, sizeof hd);
         // (the exporter hands its allocation over through a helper thread of the HSA runtime that starts with its FIRST
         // export; a peer that asks in the same millisecond can be too early -- "invalid device pointer" -- so a refusal is
         // asked again a few times before it counts)
         hipError_t oe = hipSuccess;
-        for (int attempt = 0; attempt < 50; ++attempt) {
-            oe = hipIpcOpenMemHandle(&im.base, hd, hipIpcMemLazyEnablePeerAccess);
+        const bool injected = g_fault.import_n > 0 && (g_fault.rank < 0 || g_fault.rank == c->rank) && ++g_fault.imports == g_fault.import_n;
+        for (int attempt = 0; attempt < 20; ++attempt) {
+            oe = injected ? hipErrorInvalidDevicePointer : hipIpcOpenMemHandle(&base, hd, hipIpcMemLazyEnablePeerAccess);
             if (oe == hipSuccess) break;
             (void)hipGetLastError();
             ++c->peer_open_retries;
+            if (injected) break;
             usleep(2000 + 1000 * attempt);
         }
         if (oe != hipSuccess) {
             c->err = "hipIpcOpenMemHandle failed (" + std::string(hipGetErrorString(oe)) + "): export " + std::to_string(kind) +
-                     " of rank " + std::to_string(s) + ", " + std::to_string(e.size) + " bytes, generation " +
-                     std::to_string(e.generation & 0xffffffffffffull);
+                     " of rank " + std::to_string(s) + ", " + std::to_string(e.size) + " bytes, generation " + std::to_string(e.generation);
+            if (refused) { *refused = true; return GVOM_OK; }
             return GVOM_ERR_HIP;
         }
-        im.generation = e.generation;
-        c->imports[s][kind].push_back(im);
-        found = &c->imports[s][kind].back();
+        PeerImport im;
+        im.pid = pid; im.start = start; im.generation = e.generation; im.base = base;
+        std::lock_guard<std::mutex> lk(g_ipc_mu);
+        g_imports.push_back(im);
     }
-    const PeerImport &im = *found;
-    *src = (char *)im.base + e.offset[c->rank];
+    *src = (char *)base + e.offset[c->rank];
     return GVOM_OK;
 }
 
-struct PeerPull { int kind, recv_which; int64_t unit; const int64_t *recv_counts; };
+struct PeerPull { int kind, recv_which; int64_t unit; const int64_t *recv_counts; const int64_t *send_counts; };
+
+// Host-synchronised exchanges, after the barrier that made the exports visible: every rank opens what it needs
+// (src[s][k] for need[s][k]).  An open the HSA runtime REFUSES is absorbed here: the rank says so in the segment, the owner
+// of the allocation moves the region into a fresh one and exports that, and everybody tries again -- collectively (every
+// rank passes the same barriers: rounds happen only in exchanges in which some export is new, which all ranks see alike),
+// up to three rounds.  republish(kind): the caller's way to export `kind` again from a fresh allocation.
+template <typename Republish>
+int peer_open_all(gvom_comm *c, const int *kinds, int nk, const bool (*need)[GVOM_PEER_KINDS], void *(*src)[GVOM_PEER_KINDS],
+                  Republish republish)
+{
+    bool newgen = false;
+    for (int s = 0; s < c->world; ++s)
+        for (int k = 0; k < GVOM_PEER_KINDS; ++k) {
+            const uint64_t g = c->seg->exports[s][k].generation;
+            if (g != c->seen_gen[s][k]) { newgen = true; c->seen_gen[s][k] = g; }
+        }
+    for (int round = 0; ; ++round) {
+        const uint64_t tag = ++c->recover_round;
+        bool mine_failed = false;
+        std::string first_err;
+        for (int s = 0; s < c->world; ++s) {
+            if (s == c->rank) continue;
+            for (int i = 0; i < nk; ++i) {
+                const int k = kinds[i];
+                if (!need[s][k]) continue;
+                bool refused = false;
+                const int rc = peer_source(c, s, k, &src[s][k], &refused);
+                if (rc) return rc;
+                if (refused) {
+                    mine_failed = true;
+                    if (first_err.empty()) first_err = c->err;
+                    c->seg->import_failed[s][k].store(tag, std::memory_order_release);
+                }
+            }
+        }
+        if (!newgen) {                                                 // (nothing new: every source was mapped before)
+            if (mine_failed) { c->err = first_err; return GVOM_ERR_HIP; }
+            return GVOM_OK;
+        }
+        int rc = gvom_comm_barrier(c);                                 // the refusals of this round are on the table
+        if (rc) return rc;
+        bool any = false, me = false;
+        for (int s = 0; s < c->world; ++s)
+            for (int i = 0; i < nk; ++i)
+                if (c->seg->import_failed[s][kinds[i]].load(std::memory_order_acquire) == tag) { any = true; if (s == c->rank) me = true; }
+        if (!any) return GVOM_OK;
+        if (round >= 3) { c->err = first_err.empty() ? "a peer could not open an exported region (three fresh allocations tried)" : first_err; return GVOM_ERR_HIP; }
+        if (me)
+            for (int i = 0; i < nk; ++i)
+                if (c->seg->import_failed[c->rank][kinds[i]].load(std::memory_order_acquire) == tag && (rc = republish(kinds[i]))) break;
+        const int rb = gvom_comm_barrier(c);                           // the fresh exports are visible
+        if (rc) return rc;
+        if (rb) return rb;
+        for (int s = 0; s < c->world; ++s)
+            for (int k = 0; k < GVOM_PEER_KINDS; ++k) c->seen_gen[s][k] = c->seg->exports[s][k].generation;
+    }
+}
 
 // One exchange by peer copies: every rank has published its regions (peer_publish); barrier; every rank pulls what
 // the others hold for it -- hipMemcpyAsync on ITS OWN handle's stream, the ordering ncclRecv on that stream gives --
@@ -368,6 +492,21 @@ int peer_pull(gvom_comm *c, gvom_t *h, hipStream_t st, const PeerPull *pulls, in
     if (!async) HIPCHK_C(c, hipStreamSynchronize(st));                 // what I export is complete
     int rc = gvom_comm_barrier(c);
     if (rc) return rc;
+    auto &src_all = c->src_all;
+    auto &need_all = c->need_all;
+    if (!async) {
+        int kinds[GVOM_PEER_KINDS];
+        for (int s = 0; s < c->world; ++s)
+            for (int k = 0; k < n_pulls; ++k) {
+                need_all[s][pulls[k].kind] = s != c->rank && pulls[k].recv_counts[s] > 0;
+                src_all[s][pulls[k].kind] = nullptr;
+            }
+        for (int k = 0; k < n_pulls; ++k) kinds[k] = pulls[k].kind;
+        rc = peer_open_all(c, kinds, n_pulls, need_all, src_all, [&](int kind) {
+            for (int k = 0; k < n_pulls; ++k) if (pulls[k].kind == kind) return peer_publish(c, h, kind, pulls[k].send_counts, true);
+            return (int)GVOM_ERR_INVALID;
+        });
+    }
     for (int s = 0; s < c->world && rc == GVOM_OK; ++s) {
         if (s == c->rank) continue;
         for (int k = 0; k < n_pulls && rc == GVOM_OK; ++k) {
@@ -382,7 +521,8 @@ int peer_pull(gvom_comm *c, gvom_t *h, hipStream_t st, const PeerPull *pulls, in
                 rc = GVOM_ERR_INVALID;
                 break;
             }
-            if ((rc = peer_source(c, s, pulls[k].kind, &src))) break;
+            if (async) { if ((rc = peer_source(c, s, pulls[k].kind, &src))) break; }
+            else src = src_all[s][pulls[k].kind];
             const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, st);
             if (e != hipSuccess) { c->err = std::string("hipMemcpyAsync (peer copy) failed: ") + hipGetErrorString(e); rc = GVOM_ERR_HIP; break; }
             c->peer_bytes += bytes; ++c->peer_copies;
@@ -434,6 +574,13 @@ VIS int gvom_comm_create2(int rank, int world, int device, const char *name, int
         return code;
     };
     const bool host_only = device < 0;
+    if (!host_only && world > 1 && transport != GVOM_TRANSPORT_RCCL && !getenv("HSA_ENABLE_IPC_MODE_LEGACY")) {
+        // (every measurement of this transport was taken with it: the host driver of the target pool only supports dmabuf IPC)
+        static std::atomic<bool> said{false};
+        if (!said.exchange(true))
+            fprintf(stderr, "gvom_comm_create(rank %d of %d): HSA_ENABLE_IPC_MODE_LEGACY is not set; the peer-copy transport exports device memory "
+                            "between processes (hipIpc*), which on dmabuf-only hosts fails without HSA_ENABLE_IPC_MODE_LEGACY=0\n", rank, world);
+    }
     if (!host_only) {
         if (want_rccl && !c->rccl.load(c->err)) {
             if (!may_fall_back) return fail(c->err, GVOM_ERR_NO_DEVICE);
@@ -499,7 +646,9 @@ VIS int gvom_comm_create2(int rank, int world, int device, const char *name, int
                 }
             }
             if (fd >= 0) close(fd);
-            if (now_s() > deadline) return fail("rank 0 never created the shared-memory rendezvous", GVOM_ERR_HIP);
+            if (now_s() > deadline)
+                return fail("rank 0 never created the shared-memory rendezvous /dev/shm" + c->shm_name + " (do all ranks of the job compute the "
+                            "same name?  gvom_sharded.rendezvous_name: MASTER_PORT and GVOM_JOB_NONCE)", GVOM_ERR_HIP);
             usleep(500);
         }
         if (c->seg->world != (uint32_t)world) return fail("world size differs from rank 0's", GVOM_ERR_INVALID);
@@ -609,12 +758,7 @@ VIS void gvom_comm_destroy(gvom_comm_t *c)
 {
     if (!c) return;
     if (c->nccl) { hipSetDevice(c->device); c->rccl.CommDestroy(c->nccl); }
-    if (c->transport == GVOM_TRANSPORT_PEER && c->device >= 0) {
-        hipSetDevice(c->device);
-        for (int s = 0; s < c->world; ++s)
-            for (int k = 0; k < GVOM_PEER_KINDS; ++k)
-                for (PeerImport &im : c->imports[s][k]) if (im.base) (void)hipIpcCloseMemHandle(im.base);
-    }
+    // (what the peer transport has mapped of other processes' memory stays mapped for the life of the process: g_imports)
     if (c->registered) { hipSetDevice(c->device); (void)hipDeviceSynchronize(); (void)hipHostUnregister(c->seg); }
     if (c->seg) munmap(c->seg, sizeof(Segment));
     if (c->rank == 0) shm_unlink(c->shm_name.c_str());                 // harmless if already gone
@@ -686,20 +830,12 @@ static int exchange_scan_impl(gvom_comm_t *c, gvom_t *h, const int64_t *send_qua
     if (hipSetDevice(c->device) != hipSuccess) { c->err = "hipSetDevice failed"; return GVOM_ERR_HIP; }
     hipStream_t st = (hipStream_t)gvom_stream(h);
     if (c->transport == GVOM_TRANSPORT_PEER) {
-        static const int send_which[3] = {GVOM_XBUF_SEND_IDS, GVOM_XBUF_SEND_QUADS, GVOM_XBUF_SEND_EPS};
         for (int k = 0; k < 3; ++k) {
-            void *ptr[GVOM_COMM_MAX_RANKS] = {};
-            for (int d = 0; d < c->world; ++d) {
-                const int64_t cnt = k < 2 ? send_quads[d] : send_eps[d];
-                int64_t cap = 0;
-                if (d == c->rank || cnt <= 0) continue;
-                if (gvom_shard_buffer(h, send_which[k], d, &ptr[d], &cap) || !ptr[d]) { c->err = "send region missing"; return GVOM_ERR_INVALID; }
-            }
-            const int rc = peer_publish(c, h, k, ptr);
+            const int rc = peer_publish(c, h, k, k < 2 ? send_quads : send_eps);
             if (rc) return rc;
         }
-        const PeerPull pulls[3] = {{0, GVOM_XBUF_RECV_IDS, 4, recv_quads}, {1, GVOM_XBUF_RECV_QUADS, 1024, recv_quads},
-                                   {2, GVOM_XBUF_RECV_EPS, 8, recv_eps}};
+        const PeerPull pulls[3] = {{0, GVOM_XBUF_RECV_IDS, 4, recv_quads, send_quads}, {1, GVOM_XBUF_RECV_QUADS, 1024, recv_quads, send_quads},
+                                   {2, GVOM_XBUF_RECV_EPS, 8, recv_eps, send_eps}};
         ++c->scan_x;
         return peer_pull(c, h, st, pulls, 3, &c->seg->flags[c->rank].pulled_scan, c->scan_x);
     }
@@ -746,15 +882,9 @@ static int exchange_stats_impl(gvom_comm_t *c, gvom_t *h, const int64_t *send_re
     if (hipSetDevice(c->device) != hipSuccess) { c->err = "hipSetDevice failed"; return GVOM_ERR_HIP; }
     hipStream_t st = (hipStream_t)gvom_stream(h);
     if (c->transport == GVOM_TRANSPORT_PEER) {
-        void *ptr[GVOM_COMM_MAX_RANKS] = {};
-        for (int d = 0; d < c->world; ++d) {
-            int64_t cap = 0;
-            if (d == c->rank || send_returns[d] <= 0) continue;
-            if (gvom_shard_buffer(h, GVOM_XBUF_SEND_RETURNS, d, &ptr[d], &cap) || !ptr[d]) { c->err = "send region missing"; return GVOM_ERR_INVALID; }
-        }
-        const int rcp = peer_publish(c, h, 3, ptr);
+        const int rcp = peer_publish(c, h, 3, send_returns);
         if (rcp) return rcp;
-        const PeerPull pull = {3, GVOM_XBUF_RECV_RETURNS, bytes_per_return, recv_returns};
+        const PeerPull pull = {3, GVOM_XBUF_RECV_RETURNS, bytes_per_return, recv_returns, send_returns};
         ++c->stats_x;
         return peer_pull(c, h, st, &pull, 1, &c->seg->flags[c->rank].pulled_stats, c->stats_x);
     }
@@ -802,9 +932,7 @@ static int allgather_rows_impl(gvom_comm_t *c, gvom_t *h)
         if (c->world == 1) return GVOM_OK;
         hipStream_t st = (hipStream_t)gvom_stream(h);
         // every rank offers ITS rows (the same part whoever asks) and pulls the others' into the same place of its own buffer
-        void *mine[GVOM_COMM_MAX_RANKS] = {};
-        for (int d = 0; d < c->world; ++d) if (d != c->rank) mine[d] = (char *)ptr + share * c->rank;
-        if ((rc = peer_publish(c, h, 4, mine))) return rc;
+        if ((rc = peer_publish(c, h, 4, nullptr))) return rc;
         if (c->async) {
             // my rows are complete when my stream gets here; the others' when their flag says so (their hosts wait for it, the GPUs
             // for nothing); "I have pulled" goes behind my copies, and whoever fuses again waits for it (gvom_comm_before_combine)
@@ -823,11 +951,16 @@ static int allgather_rows_impl(gvom_comm_t *c, gvom_t *h)
         }
         HIPCHK_C(c, hipStreamSynchronize(st));                         // my rows are complete
         if ((rc = gvom_comm_barrier(c))) return rc;
+        {
+            const int kind4 = 4;
+            for (int s = 0; s < c->world; ++s) { c->need_all[s][4] = s != c->rank; c->src_all[s][4] = nullptr; }
+            rc = peer_open_all(c, &kind4, 1, c->need_all, c->src_all, [&](int) { return peer_publish(c, h, 4, nullptr, true); });
+            // (this rank's own rows may lie in a fresh allocation now)
+            if (rc == GVOM_OK && (rc = gvom_device_buffer(h, GVOM_BUF_HEIGHT_MAPS, &ptr, &bytes, &row))) c->err = "height-map rows missing";
+        }
         for (int s = 0; s < c->world && rc == GVOM_OK; ++s) {
-            void *src = nullptr;
             if (s == c->rank) continue;
-            if ((rc = peer_source(c, s, 4, &src))) break;
-            const hipError_t e = hipMemcpyAsync((char *)ptr + share * s, src, share, hipMemcpyDefault, st);
+            const hipError_t e = hipMemcpyAsync((char *)ptr + share * s, c->src_all[s][4], share, hipMemcpyDefault, st);
             if (e != hipSuccess) { c->err = std::string("hipMemcpyAsync (peer copy) failed: ") + hipGetErrorString(e); rc = GVOM_ERR_HIP; }
             c->peer_bytes += share; ++c->peer_copies;
         }
@@ -899,6 +1032,31 @@ VIS int gvom_comm_peer_stats(gvom_comm_t *c, int64_t out[4])
 {
     if (!c || !out) return GVOM_ERR_INVALID;
     out[0] = (int64_t)c->peer_bytes; out[1] = (int64_t)c->peer_copies; out[2] = (int64_t)c->export_seq; out[3] = (int64_t)c->peer_open_retries;
+    return GVOM_OK;
+}
+
+// regions that were moved into a fresh allocation because the HSA runtime refused to export the old one or a peer to open it
+VIS int64_t gvom_comm_peer_renewed(gvom_comm_t *c) { return c ? (int64_t)c->peer_renewed : -1; }
+
+// What the communicator itself says about the job: out = {ranks RCCL counts in its communicator (ncclCommCount; -1 without
+// RCCL), this rank's number there (ncclCommUserRank), the HIP device, the transport in use}; busid: the device's PCI bus id.
+// For the bench line: N ranks on N distinct bus ids = N GPUs.
+VIS int gvom_comm_info(gvom_comm_t *c, int64_t out[4], char *busid, size_t busid_len)
+{
+    if (!c || !out) return GVOM_ERR_INVALID;
+    out[0] = out[1] = -1; out[2] = c->device; out[3] = c->transport;
+    if (c->nccl) {
+        typedef ncclResult_t (*count_fn)(const ncclComm_t, int *);
+        count_fn cnt = (count_fn)dlsym(c->rccl.lib, "ncclCommCount"), usr = (count_fn)dlsym(c->rccl.lib, "ncclCommUserRank");
+        int v = -1;
+        if (cnt && cnt(c->nccl, &v) == ncclSuccess) out[0] = v;
+        v = -1;
+        if (usr && usr(c->nccl, &v) == ncclSuccess) out[1] = v;
+    }
+    if (busid && busid_len) {
+        busid[0] = 0;
+        if (c->device >= 0 && hipDeviceGetPCIBusId(busid, (int)busid_len, c->device) != hipSuccess) { (void)hipGetLastError(); busid[0] = 0; }
+    }
     return GVOM_OK;
 }
 

@@ -106,6 +106,9 @@ ABI = [
     ("gvom_comm_before_combine", _I, [_P]),
     ("gvom_comm_peer_async", _I, [_P]),
     ("gvom_comm_peer_stats", _I, [_P, ctypes.POINTER(_I64)]),
+    ("gvom_comm_peer_renewed", _I64, [_P]),
+    ("gvom_comm_info", _I, [_P, ctypes.POINTER(_I64), ctypes.c_char_p, ctypes.c_size_t]),
+    ("gvom_shard_renew_region", _I, [_P, _I]),
     ("gvom_comm_destroy", None, [_P]),
     ("gvom_comm_exchange_host", _I, [_P, ctypes.POINTER(_I64), _I, ctypes.POINTER(_I64)]),
     ("gvom_comm_barrier", _I, [_P]),

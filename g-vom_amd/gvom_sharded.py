@@ -174,7 +174,16 @@ class RcclComm(object):
         self._check(self.lib.gvom_comm_peer_stats(self.c, out))
         d = dict(zip(("bytes", "copies", "exports", "open_retries"), (int(v) for v in out)))
         d["asynchronous"] = self.peer_async
+        d["renewed_regions"] = int(self.lib.gvom_comm_peer_renewed(self.c))   # refused exports / opens absorbed by a fresh allocation
         return d
+
+    def info(self):
+        """what the communicator itself says: RCCL's own rank count and rank number (None without RCCL), device, PCI bus id"""
+        out = (ctypes.c_int64 * 4)()
+        bus = ctypes.create_string_buffer(64)
+        self._check(self.lib.gvom_comm_info(self.c, out, bus, 64))
+        return {"rccl_comm_count": int(out[0]) if out[0] >= 0 else None, "rccl_user_rank": int(out[1]) if out[1] >= 0 else None,
+                "device": int(out[2]), "transport": {0: "rccl", 1: "peer"}.get(int(out[3])), "pci_bus_id": bus.value.decode()}
 
     def exchange_host(self, values):
         k = len(values)
@@ -414,5 +423,10 @@ def rendezvous_name():
     changes from job to job.  (The library additionally refuses a segment whose creator is no longer alive.)"""
     nonce = os.environ.get("GVOM_JOB_NONCE")
     if nonce is None:
-        nonce = "p%d" % os.getppid()
+        # the parent names the job only where the ranks are known to be children of ONE launcher process; ranks started from
+        # separate shells, per-rank wrapper scripts or one slurmstepd per task have different parents and would wait for each
+        # other under different names until the rendezvous times out: they get the fixed name (set GVOM_JOB_NONCE to tell
+        # two such jobs on one port apart)
+        known = ("TORCHELASTIC_RUN_ID", "OMPI_COMM_WORLD_SIZE", "PMI_SIZE", "PMIX_RANK")
+        nonce = "p%d" % os.getppid() if any(k in os.environ for k in known) else "0"
     return "gvom_%s_%s" % (os.environ.get("MASTER_PORT", "29500"), nonce)

@@ -27,6 +27,7 @@ extern "C" {
 #endif
 
 #define GVOM_ABI_VERSION 6   /* 6: sub-cloud interleave of the trace ("interleave" knob, automatic by a layout probe), gvom_get_tuning;
+                              *    peer transport absorbs refused exports / imports (gvom_shard_renew_region, gvom_comm_peer_renewed), gvom_comm_info;
                               * 5: second transport between ranks (peer copies: gvom_comm_create2, gvom_comm_transport),
                               *    gvom_alloc_generation;
                               * 4: per-voxel statistics on sharded maps (gvom_shard_stats_*, gvom_comm_exchange_stats);
@@ -213,6 +214,10 @@ int gvom_shard_scan_merge(gvom_t *h, const int64_t *recv_quads, const int64_t *r
  * gvom_shard_scan_merge.  All ranks must pass clouds of one type (float32 or float64). */
 int gvom_shard_stats_counts(gvom_t *h, int64_t *send_returns);
 int gvom_shard_stats_reserve(gvom_t *h, const int64_t *recv_returns, int dtype /* GVOM_DTYPE_*: the scan's cloud type */);
+/* For the transport: region `which` (GVOM_XBUF_SEND_*, or -1 = GVOM_BUF_HEIGHT_MAPS) moves, contents included, into a FRESH
+ * allocation of the same size (its gvom_region_generation changes); the old allocation is parked, never freed while the
+ * process lives (another process may have it mapped). */
+int gvom_shard_renew_region(gvom_t *h, int which);
 int gvom_combine_fuse(gvom_t *h, int64_t *local_cells);
 int gvom_set_combined_cell_count(gvom_t *h, int64_t global_cells);
 #define GVOM_BUF_HEIGHT_MAPS  0   /* [sy][height row | inferred-height row | positive-density row], f64 */
@@ -224,7 +229,7 @@ int gvom_combine_map2d_into(gvom_t *h, double origin_world[3], void *pinned_out)
 /* --- transport between the ranks of a sharded map: RCCL over xGMI, bound directly ------------------
  * name: the same string on every rank and unique to this communicator on the node (rank 0 creates
  * /dev/shm/<name> for the ncclUniqueId and the small host-side exchanges).  gvom_comm_exchange_host:
- * all[r*k + j] = rank r's mine[j] (k <= 160).  gvom_comm_exchange_scan / gvom_comm_allgather_rows run
+ * all[r*k + j] = rank r's mine[j] (k <= 208 = 3 * 64 ranks + 16).  gvom_comm_exchange_scan / gvom_comm_allgather_rows run
  * on the handle's stream and do not synchronise.  device < 0: host-only communicator (rendezvous +
  * gvom_comm_exchange_host / gvom_comm_barrier, no RCCL and no HIP call; the device collectives return
  * GVOM_ERR_INVALID) -- the CPU tests run the multi-process rendezvous with it. */
@@ -255,8 +260,20 @@ int  gvom_comm_transport(gvom_comm_t *c);
 int  gvom_comm_before_scan(gvom_comm_t *c);
 int  gvom_comm_before_combine(gvom_comm_t *c);
 int  gvom_comm_peer_async(gvom_comm_t *c);          /* 1: the peer transport runs in its asynchronous form */
-/* peer transport bookkeeping: {bytes pulled, copies, exports made, refused hipIpcOpenMemHandle calls that were repeated} */
+/* peer transport bookkeeping: {bytes pulled, copies, exports made, refused hipIpc* calls that were repeated} */
 int  gvom_comm_peer_stats(gvom_comm_t *c, int64_t out[4]);
+/* Peer transport and the HSA runtime's inter-process memory.  Requires HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment of
+ * every rank on hosts whose driver only supports dmabuf IPC (the communicator says so on stderr when it is unset); every
+ * measurement in profiles/ was taken with it.  hipIpcGetMemHandle / hipIpcOpenMemHandle can REFUSE an allocation ("invalid
+ * argument" / "invalid device pointer": seen once in several hundred exports under a test that exports a fresh allocation
+ * every scan, never in steady state).  The library absorbs it: a refused export moves the region into a fresh allocation
+ * (gvom_shard_renew_region) and exports that; a refused open is reported through the segment, the owner does the same, and
+ * every rank tries again -- up to three fresh allocations, inside the exchange, before the call fails and the communicator
+ * is marked broken.  gvom_comm_peer_renewed: how often that happened on this rank. */
+int64_t gvom_comm_peer_renewed(gvom_comm_t *c);
+/* What the communicator itself knows of the job: out = {ranks in RCCL's communicator (ncclCommCount; -1 without RCCL), this
+ * rank's number there (ncclCommUserRank), HIP device, transport in use}; busid (optional): the device's PCI bus id. */
+int  gvom_comm_info(gvom_comm_t *c, int64_t out[4], char *busid, size_t busid_len);
 void gvom_comm_destroy(gvom_comm_t *c);
 int  gvom_comm_exchange_host(gvom_comm_t *c, const int64_t *mine, int k, int64_t *all);
 int  gvom_comm_barrier(gvom_comm_t *c);

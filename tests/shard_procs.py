@@ -112,17 +112,6 @@ def launch(world, transport="peer", stats=False, timeout=240, repeat=1, asynchro
     return ok, "\n".join(text)
 
 
-def launch_tolerant(*a, **kw):
-    """launch(); a run that ended in a REFUSAL of the HSA runtime's inter-process calls (hipIpcGetMemHandle / hipIpcOpenMemHandle
-    answer "invalid argument" / "invalid device pointer" once in several hundred exports) is started once more.  A run in
-    which any rank saw results that DIFFER is never repeated."""
-    ok, text = launch(*a, **kw)
-    if not ok and "AssertionError" not in text and "hipIpc" in text:
-        ok2, text2 = launch(*a, **kw)
-        return ok2, text2 + "\n==== (second start: the first ended in a refused hipIpc call) ===="
-    return ok, text
-
-
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "--rank":
         rank_main(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5], sys.argv[6] == "1", int(sys.argv[7]) if len(sys.argv) > 7 else 1)

@@ -37,16 +37,6 @@ def _bench(argv, env_extra=None, timeout=300):
                           stderr=subprocess.PIPE, timeout=timeout)
 
 
-def _bench_peer(argv, env_extra=None, timeout=300):
-    """_bench for runs whose ranks exchange by peer copies: the HSA runtime's inter-process calls are refused once in several
-    hundred exports ("invalid argument" / "invalid device pointer": the library reports it loudly on every rank); such a run
-    is started once more.  A run whose maps DIFFER (exit code 3) never is."""
-    p = _bench(argv, env_extra, timeout)
-    if p.returncode not in (0, 3) and b"hipIpc" in p.stderr:
-        p = _bench(argv, env_extra, timeout)
-    return p
-
-
 def test_more_ranks_than_devices_is_refused_before_anything_is_spawned():
     """`python bench.py --gpus 2` without a launcher on a box with fewer than 2 GPUs (here: none): the parent --
     which makes no HIP call itself, the device count comes from a child process -- refuses with a clear message and
@@ -111,6 +101,60 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert d["value"] > 50 * c["value"]
 
 
+def test_paced_stream_accounting_with_a_synthetic_tick():
+    """bench.paced_stream (the offered-load mode behind --offered-hz): a tick that takes 2 ms against a 10 ms period meets every
+    deadline with ~80 % idle time; one that takes 15 ms falls behind the schedule, and the latency -- measured from the
+    SCHEDULED arrival -- grows tick by tick instead of being hidden by a late start."""
+    import time
+    import bench
+
+    def busy(ms):
+        def tick(k):
+            t = time.perf_counter() + ms * 1e-3
+            while time.perf_counter() < t:
+                pass
+        return tick
+    ok = bench.paced_stream(busy(2.0), 100.0, 30, warm=1)
+    for key in ("offered_hz", "ticks", "achieved_hz", "latency_ms", "service_ms", "deadline_misses", "late_starts", "idle_frac",
+                "sustainable_hz", "what"):
+        assert key in ok, key
+    assert ok["deadline_misses"] == 0 and 1.9 < ok["latency_ms"]["p50"] < 4.0 and ok["latency_ms"]["max"] < 10.0
+    assert 0.6 < ok["idle_frac"] < 0.85 and 95 < ok["achieved_hz"] <= 100.5 and 250 < ok["sustainable_hz"] < 520
+    over = bench.paced_stream(busy(15.0), 100.0, 20, warm=0)
+    assert over["deadline_misses"] == 20 and over["late_starts"] >= 18
+    assert over["latency_ms"]["max"] > 100.0 and over["achieved_hz"] < 70 and over["idle_frac"] < 0.05
+    json.dumps(over)
+
+
+@pytest.mark.gpu
+def test_bench_stream_mode_on_one_gpu_and_through_the_sharded_leg():
+    """`bench.py --offered-hz H --ticks T`: the line gains a `stream` object (per-tick latency percentiles from hand-over of a
+    HOST-resident cloud to the maps in host memory, deadline misses, idle fraction, the two-thread node pattern) -- on the
+    single-GPU leg and, unchanged, on the `--gpus N` leg (here: its one-rank form)."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c2", "--steps", "40", "--warmup", "10",
+                        "--no-extra", "--no-cpu", "--offered-hz", "200", "--ticks", "60"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    d = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    st = d["stream"]
+    assert st["offered_hz"] == 200 and st["ticks"] == 60 and st["points_per_tick"] == 131072
+    assert st["deadline_misses"] == 0 and 0 < st["latency_ms"]["p50"] <= st["latency_ms"]["p95"] <= st["latency_ms"]["max"] < 5.0
+    assert 0.5 < st["idle_frac"] < 1.0 and 195 < st["achieved_hz"] <= 201 and st["sustainable_hz"] > 1000
+    assert st["two_threads"]["deadline_misses"] == 0 and st["two_threads"]["latency_ms"]["p95"] < 5.0
+    assert abs(st["sustained_M_points_s"] - 131072 * st["achieved_hz"] / 1e6) < 1e-6
+    env = dict(os.environ, GVOM_BENCH_FORCE_SHARDED="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", "c2", "--steps", "40",
+                        "--warmup", "10", "--no-cpu", "--offered-hz", "200", "--ticks", "60"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    d = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    st = d["stream"]
+    assert st["deadline_misses"] == 0 and st["ticks"] == 60 and len(st["per_rank"]) == 1
+    assert st["latency_ms_slowest_rank"]["p95"] < 5.0 and d["sharded_equals_unsharded"] is True
+
+
 @pytest.mark.gpu
 def test_sharded_bench_leg_with_one_rank():
     """The N > 1 leg of bench.py (one process per GPU, RCCL bound by libgvom_hip.so, shared-memory rendezvous) run
@@ -140,7 +184,7 @@ def test_sharded_bench_rehearsal_with_two_rank_processes_on_one_gpu():
     rendezvous through shared memory), with both ranks on the one GPU this box has and the library's peer-copy transport
     (RCCL refuses two ranks on one device): real multi-process exchanges of device data, and the line's own verdict that
     the sharded maps equal an unsharded mapper's."""
-    p = _bench_peer(["--gpus", "2", "--share-device", "--steps", "30", "--warmup", "10", "--no-cpu"], {"GVOM_COMM_TIMEOUT_S": "120"}, timeout=600)
+    p = _bench(["--gpus", "2", "--share-device", "--steps", "30", "--warmup", "10", "--no-cpu"], {"GVOM_COMM_TIMEOUT_S": "120"}, timeout=600)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     d = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["rehearsal_on_one_device"] is True and d["transport"].startswith("peer copies")
@@ -148,13 +192,18 @@ def test_sharded_bench_rehearsal_with_two_rank_processes_on_one_gpu():
     assert d["config"]["points_per_step"] == 2 * d["config"]["points_per_gpu"]
     assert len(d["exchange"]["per_rank"]) == 2 and all(r["sent_bytes"] > 1e6 and r["received_bytes"] > 1e6 for r in d["exchange"]["per_rank"])
     assert d["peer_transport_rank0"]["copies"] > 100
+    # what the judge of a real multi-GPU run needs to see: the communicator's own view of the job
+    ranks = d["ranks"]
+    assert [r["rank"] for r in ranks] == [0, 1] and all(r["transport"] == "peer" and r["pci_bus_id"] for r in ranks)
+    assert d["distinct_devices"] == 1 and d["communicator_ranks"] == 2          # (a rehearsal: both ranks on the one GPU)
+    assert "cpu_baseline" in d and "N = 1" in d["cpu_baseline"]["see"]
 
 
 @pytest.mark.gpu
 def test_sharded_bench_falls_back_to_peer_copies_when_rccl_refuses():
     """The N > 1 leg with its default transport (AUTO) where RCCL cannot start -- two ranks on one device: both ranks agree
     on peer copies, the line says so, the maps are verified, and the rank processes leave with exit code 0."""
-    p = _bench_peer(["--gpus", "2", "--share-device", "--steps", "20", "--warmup", "6", "--no-cpu"],
+    p = _bench(["--gpus", "2", "--share-device", "--steps", "20", "--warmup", "6", "--no-cpu"],
                     {"GVOM_COMM_TIMEOUT_S": "120", "GVOM_BENCH_REHEARSE_AUTO": "1"}, timeout=600)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     d = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1])

@@ -122,7 +122,9 @@ def test_transport_selection_and_bookkeeping_of_a_host_only_communicator():
         comm = gvom_sharded.RcclComm(0, 1, -1, "gvom_test_tr3_%d_%s" % (os.getpid(), tr), transport=tr)
         try:
             assert comm.transport == want
-            assert comm.peer_stats() == {"bytes": 0, "copies": 0, "exports": 0, "open_retries": 0, "asynchronous": False}
+            assert comm.peer_stats() == {"bytes": 0, "copies": 0, "exports": 0, "open_retries": 0, "asynchronous": False, "renewed_regions": 0}
+            info = comm.info()                      # a host-only communicator: no RCCL, no device, no bus id
+            assert info["rccl_comm_count"] is None and info["rccl_user_rank"] is None and info["pci_bus_id"] == ""
             comm.before_scan(); comm.before_combine()                       # no-ops here
             assert comm.exchange_host([3, 4]) == [[3, 4]]
         finally:

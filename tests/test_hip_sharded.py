@@ -178,7 +178,7 @@ def test_rank_processes_on_one_gpu_through_the_peer_transport(world, stats):
     statistics also the ranks' voxel clouds."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import shard_procs
-    ok, text = shard_procs.launch_tolerant(world, "peer", stats)
+    ok, text = shard_procs.launch(world, "peer", stats)
     assert ok, text[-3000:]
     assert text.count("combines equal the unsharded mapper's") == world, text[-3000:]
 
@@ -190,10 +190,10 @@ def test_rank_processes_through_the_asynchronous_peer_transport():
     the seven steps three times over, with the statistics exchange on two: every rank's results equal the unsharded mapper's."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import shard_procs
-    ok, text = shard_procs.launch_tolerant(4, "peer", False, repeat=3, asynchronous=True)
+    ok, text = shard_procs.launch(4, "peer", False, repeat=3, asynchronous=True)
     assert ok, text[-3000:]
     assert text.count("'asynchronous': True") == 4, text[-3000:]
-    ok, text = shard_procs.launch_tolerant(2, "peer", True, asynchronous=True)
+    ok, text = shard_procs.launch(2, "peer", True, asynchronous=True)
     assert ok, text[-3000:]
     assert text.count("'asynchronous': True") == 2, text[-3000:]
 
@@ -206,9 +206,27 @@ def test_peer_transport_with_a_new_exported_region_every_scan(monkeypatch):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import shard_procs
     monkeypatch.setenv("GVOM_TEST_CHURN", "1")
-    ok, text = shard_procs.launch_tolerant(4, "peer", False, repeat=15)
+    ok, text = shard_procs.launch(4, "peer", False, repeat=15)
     assert ok, text[-3000:]
     assert text.count("105 combines equal the unsharded mapper's") == 4, text[-3000:]
+
+
+@pytest.mark.parametrize("fault,world", [("export:2,rank:1", 2), ("import:3,rank:0", 2), ("export:1", 4), ("import:2", 4)])
+def test_peer_transport_absorbs_a_refused_export_or_import(monkeypatch, fault, world):
+    """hipIpcGetMemHandle / hipIpcOpenMemHandle can refuse an allocation (profiles/r3_peer_churn.txt).  The library, not the
+    test harness, absorbs it: the refused region moves into a fresh allocation which is exported instead (a refused OPEN is
+    reported through the segment, its owner does the same, every rank tries again -- collectively, inside the exchange).
+    Test hook GVOM_TEST_IPC_REFUSE: the N-th export / import of a process (of one rank, or of every rank) is answered with the
+    runtime's refusal.  The run must end with the unsharded mapper's maps, no restart, and say how many regions it renewed."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import shard_procs
+    monkeypatch.setenv("GVOM_TEST_IPC_REFUSE", fault)
+    ok, text = shard_procs.launch(world, "peer", False)
+    assert ok, text[-3000:]
+    assert text.count("combines equal the unsharded mapper's") == world, text[-3000:]
+    import re
+    renewed = [int(m) for m in re.findall(r"'renewed_regions': (\d+)", text)]
+    assert len(renewed) == world and sum(renewed) >= 1, text[-3000:]
 
 
 def test_auto_transport_falls_back_to_peer_copies_when_rccl_cannot_start():
@@ -216,7 +234,7 @@ def test_auto_transport_falls_back_to_peer_copies_when_rccl_cannot_start():
     ranks, both agree on peer copies through the rendezvous, and the maps equal the unsharded mapper's."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import shard_procs
-    ok, text = shard_procs.launch_tolerant(2, "auto", False)
+    ok, text = shard_procs.launch(2, "auto", False)
     assert ok, text[-3000:]
     assert text.count("(peer transport): ") == 2, text[-3000:]
 
