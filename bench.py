@@ -129,23 +129,52 @@ def pin_to_gpu_numa(device):
         return None
 
 
+def usable_cores():
+    """(cores this process can actually run on, how that was found): the CPUs of its affinity mask, capped by the cgroup's CPU
+    quota -- a container that SEES 256 logical CPUs but holds a 16-CPU share is throttled beyond 16 busy threads (measured on
+    the GPU pool: every loop of the all-core oracle, even a plain fill, takes 5-70x longer at 128 threads than at 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    how = "affinity mask: %d" % n
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                txt = f.read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota = txt[0]
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    period = float(f.read().split()[0])
+            if quota not in ("max", "-1") and float(quota) > 0:
+                q = max(1, int(float(quota) / period + 0.5))
+                if q < n:
+                    n, how = q, how + "; cgroup CPU quota: %d" % q
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n, how
+
+
 def cpu_baseline(params, scans, budget_s=20.0):
     """Times the CPU oracle (C restatement of the reference's algorithm, oracle/gvom_oracle.c) on a
     bounded sample of the same workload -- whole steps (one scan + one combine) -- first on ONE
     thread, then its OpenMP build on ALL host cores this process may use."""
     from oracle import oracle
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores, cores_how = usable_cores()
     out = {}
-    # (beyond ~32 threads the scattered int32 atomics of the DDA, 10 M per scan, mostly onto the voxels near
-    # the sensor, cost more than the extra threads bring: 128 threads measured SLOWER than one)
-    # one thread, then the OpenMP build at 16 and at 32 threads (tools/cpu_thread_sweep.py, profiles/r3_cpu_thread_sweep.txt:
-    # 8 / 16 / 32 / 64 / 128 threads -> 1.58 / 2.36 / 1.80 / 1.08 / 0.58 M points/s on the 128-core box): the better one is reported
+    # one thread, then the OpenMP build on ALL the cores this process may use, and on 16 threads (round 3's best) beside it.
+    # (Round 3's all-core build got SLOWER beyond 16-32 threads -- rays dealt out in cloud order made every thread add into the
+    # same cache lines, and numpy's one-thread np.full / fresh pages were most of a step; now a thread traces one azimuth sector
+    # of the cloud, the V-sized fills run on all threads and the V-sized arrays are re-used: oracle/gvom_oracle.c, oracle.py.)
     sweep = {}
-    for key, threads_req, share in (("one", None, 0.6), ("t16", 16, 0.2), ("t32", 32, 0.2)):
-        if threads_req and threads_req > cores and key != "t16":
-            continue
-        threads = oracle.use_all_cores(threads_req is not None, threads=min(cores, threads_req) if threads_req else None)
+    legs = [("one", None, 0.5), ("all", cores, 0.35)] + ([("half", max(1, cores // 2), 0.15)] if cores >= 4 else [])
+    for key, threads_req, share in legs:
+        threads = oracle.use_all_cores(threads_req is not None, threads=threads_req)
         g = oracle.OracleGvom(*params)
+        g.reuse_buffers = True
+        for k in range(2 if threads_req else 0):          # (first touch of the re-used arrays)
+            pc, ego, tf = scans[k % len(scans)]
+            g.process_pointcloud(pc, ego, tf); g.combine_maps()
         pts = steps = 0
         t0 = time.perf_counter()
         while True:
@@ -160,15 +189,14 @@ def cpu_baseline(params, scans, budget_s=20.0):
         out[key] = (pts / el / 1e6, steps, el, threads)
         if threads_req:
             sweep[str(threads)] = pts / el / 1e6
-    out["all"] = max((out[k] for k in ("t16", "t32") if k in out), key=lambda r: r[0])
     oracle.use_all_cores(False)
     v1, s1, e1, _ = out["one"]
     vn, sn, en, tn = out["all"]
     return {"value": v1, "unit": "M points/s", "cores": 1, "kind": "port",
-            "value_all_cores": vn, "cores_all": tn, "host_cores_available": cores,
-            "cores_all_note": "%d OpenMP threads = the better of 16 and 32 in this run (%s M points/s); the full sweep "
-                              "8 / 16 / 32 / 64 / 128 threads is profiles/r3_cpu_thread_sweep.txt: beyond 16-32 the scattered atomics "
-                              "near the sensor cost more than the threads bring -- this is NOT all cores" % (tn, json.dumps(sweep)),
+            "value_all_cores": vn, "cores_all": tn, "host_cores_available": cores, "host_cores_how": cores_how,
+            "threads_sweep": sweep,
+            "cores_all_note": "%d OpenMP threads = every core this process can run on (%s); %s M points/s by thread count in this run; "
+                              "the sweep past the quota is profiles/r4_cpu_thread_sweep.txt" % (tn, cores_how, json.dumps(sweep)),
             "sample": "%d whole steps (scan+combine) of the same workload in %.1f s on one thread, %d steps in %.1f s "
                       "on %d OpenMP threads; oracle/gvom_oracle.c" % (s1, e1, sn, en, tn),
             "ms_per_step": e1 / s1 * 1e3, "ms_per_step_all_cores": en / sn * 1e3}

@@ -316,6 +316,12 @@ void fill_scan_params(const gvom_handle *h, const int64_t origin[3], const doubl
     P.pt0[1] = (float)(h->ego[1] / p.xy_resolution);
     P.pt0[2] = (float)(h->ego[2] / p.z_resolution);
     P.rinv[0] = (float)(1.0 / p.xy_resolution); P.rinv[1] = (float)(1.0 / p.z_resolution);
+    for (int k = 0; k < 3; ++k) {
+        const int64_t size = k < 2 ? p.xy_size : p.z_size;
+        const bool small = origin[k] > -(1ll << 18) && origin[k] < (1ll << 18) && size >= 5;
+        P.win_lo[k] = small ? (float)(origin[k] + 2) : 1.0f;      // (integers below 2^24: exact)
+        P.win_hi[k] = small ? (float)(origin[k] + size - 2) : 0.0f;
+    }
     P.xy = p.xy_size; P.zs = p.z_size;
     P.om[0] = (int)floor_mod(origin[0], p.xy_size);
     P.om[1] = (int)floor_mod(origin[1], p.xy_size);

@@ -351,7 +351,7 @@ __device__ __forceinline__ WalkConsts walk_consts(const ScanParams &P)
 // -- like the other reductions of this round it showed that the kernel is not bound by its instruction count;
 // DESIGN.md section 4.)
 // ------------------------------------------------------------------------------------------
-template <bool LIT, bool P2>
+template <bool LIT, bool P2, bool NOWIN>
 __device__ __forceinline__ void walk_steps(const ScanParams &P, int lane, uint32_t &j, uint32_t cnt, float &px_, float &py_, float &pz,
                                            float incx, float incy, float incz, bool &active, int steps,
                                            uint32_t *lck, uint32_t *lcc, uint32_t *total, uint32_t *tags, const WalkConsts &C)
@@ -380,10 +380,20 @@ __device__ __forceinline__ void walk_steps(const ScanParams &P, int lane, uint32
         pxy += incxy; pz += incz;
         uint32_t sx, sy, sz;                                              // toroidal storage coordinates
         uint32_t wx, wy, wz;                                              // window voxel
-        const bool inwin = window_voxel<LIT>(P, pxy.x, pxy.y, pz, wx, wy, wz, o0, o1, o2, uxy, zpad);
-        if (P2) { sx = (wx + om0) & (uxy - 1u); sy = (wy + om1) & (uxy - 1u); sz = (wz + om2) & (uzs - 1u); }
-        else { sx = min(wx + om0, wx + om0 - uxy); sy = min(wy + om1, wy + om1 - uxy); sz = min(wz + om2, wz + om2 - uzs); }
-        cmask = lanes(inwin) & alive;                                     // gvom.py:1135-1144 (left the grid)
+        if (NOWIN && P2) {
+            // every ray of the bundle that is still running stays inside the window for this whole run (walk_item has
+            // checked the run's first and last position with a margin): no window test, and on power-of-two grids the
+            // storage coordinate comes straight from the floor -- floor(p) - o + om, wrapped by the mask
+            sx = ((uint32_t)cvt_floor_i32(pxy.x) + (om0 - o0)) & (uxy - 1u);
+            sy = ((uint32_t)cvt_floor_i32(pxy.y) + (om1 - o1)) & (uxy - 1u);
+            sz = ((uint32_t)cvt_floor_i32(pz) + (om2 - o2)) & (uzs - 1u);
+            cmask = alive;
+        } else {
+            const bool inwin = window_voxel<LIT>(P, pxy.x, pxy.y, pz, wx, wy, wz, o0, o1, o2, uxy, zpad);
+            if (P2) { sx = (wx + om0) & (uxy - 1u); sy = (wy + om1) & (uxy - 1u); sz = (wz + om2) & (uzs - 1u); }
+            else { sx = min(wx + om0, wx + om0 - uxy); sy = min(wy + om1, wy + om1 - uxy); sz = min(wz + om2, wz + om2 - uzs); }
+            cmask = NOWIN ? alive : (lanes(inwin) & alive);               // gvom.py:1135-1144 (left the grid)
+        }
         const uint32_t line = mad24s(mad24s(sy >> 2, uzs, sz), usxq, sx >> 2);   // accumulator line (acc_idx24)
         const uint32_t low4 = ((sy & 3u) << 2) | (sx & 3u);
         const uint32_t Ls = (line << 4) | low4;
@@ -463,20 +473,28 @@ __device__ __forceinline__ void walk_item(const ScanParams &P, int lane, uint32_
         // is below run * ulp(run) wherever the hull is near zero; NaN estimates compare false: such a
         // lane is inactive or leaves the grid at once)
         bool lit = BIG || P.zs > P.xy;                       // (the integer window test assumes z_size <= xy_size)
+        bool nowin = false;
         if (!lit) {
             const float fs = (float)min((uint32_t)run, cnt - j);              // steps this ray can still take here (active lanes: cnt > j)
             const float ax = px + incx, ay = py + incy, az = pz + incz;
             const float qx = px + fs * incx, qy = py + fs * incy, qz = pz + fs * incz;
-            const bool nz = (fminf(ax, qx) <= 1e-4f && fmaxf(ax, qx) >= -1e-4f) || (fminf(ay, qy) <= 1e-4f && fmaxf(ay, qy) >= -1e-4f) ||
-                            (fminf(az, qz) <= 1e-4f && fmaxf(az, qz) >= -1e-4f);
+            const float lx = fminf(ax, qx), hx = fmaxf(ax, qx), ly = fminf(ay, qy), hy = fmaxf(ay, qy), lz = fminf(az, qz), hz = fmaxf(az, qz);
+            const bool nz = (lx <= 1e-4f && hx >= -1e-4f) || (ly <= 1e-4f && hy >= -1e-4f) || (lz <= 1e-4f && hz >= -1e-4f);
             lit = lanes(active & nz) != 0ull;
+            // The run's positions lie between its first and its last one (straight line; the f32 accumulation strays from it
+            // by less than run * ulp(|p|) <= 32 * 2^-6 voxels while |p| < 2^18, which win_lo / win_hi being set guarantees): a
+            // bundle whose running rays keep 2 voxels from every face of the window takes the step body without window test.
+            const bool safe = lx >= P.win_lo[0] && hx <= P.win_hi[0] && ly >= P.win_lo[1] && hy <= P.win_hi[1] && lz >= P.win_lo[2] && hz <= P.win_hi[2];
+            nowin = p2 && !lit && lanes(active & !safe) == 0ull;
         }
         if (lit) {
-            if (p2) walk_steps<true, true>(P, lane, j, cnt, px, py, pz, incx, incy, incz, active, run, lck, lcc, total, tags, C);
-            else walk_steps<true, false>(P, lane, j, cnt, px, py, pz, incx, incy, incz, active, run, lck, lcc, total, tags, C);
+            if (p2) walk_steps<true, true, false>(P, lane, j, cnt, px, py, pz, incx, incy, incz, active, run, lck, lcc, total, tags, C);
+            else walk_steps<true, false, false>(P, lane, j, cnt, px, py, pz, incx, incy, incz, active, run, lck, lcc, total, tags, C);
+        } else if (nowin) {
+            walk_steps<false, true, true>(P, lane, j, cnt, px, py, pz, incx, incy, incz, active, run, lck, lcc, total, tags, C);
         } else {
-            if (p2) walk_steps<false, true>(P, lane, j, cnt, px, py, pz, incx, incy, incz, active, run, lck, lcc, total, tags, C);
-            else walk_steps<false, false>(P, lane, j, cnt, px, py, pz, incx, incy, incz, active, run, lck, lcc, total, tags, C);
+            if (p2) walk_steps<false, true, false>(P, lane, j, cnt, px, py, pz, incx, incy, incz, active, run, lck, lcc, total, tags, C);
+            else walk_steps<false, false, false>(P, lane, j, cnt, px, py, pz, incx, incy, incz, active, run, lck, lcc, total, tags, C);
         }
     }
 }

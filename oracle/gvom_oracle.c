@@ -39,8 +39,42 @@
 #define ORC_ATOMIC ORC_PRAGMA(omp atomic)
 #define ORC_NF 32
 #define ORC_PARALLEL_UPDATES ORC_PRAGMA(omp parallel reduction(+ : updates))
-#define ORC_FOR_DYN ORC_PRAGMA(omp for schedule(dynamic, 512))
-#define ORC_NF_DECL int32_t *nf = (int32_t *)calloc((size_t)ORC_NF * ORC_NF * ORC_NF, 4);
+#define ORC_FOR_DYN ORC_PRAGMA(omp for schedule(dynamic, 1))
+/* WHO traces which ray (all-core build): the rays are grouped into azimuth sectors around the sensor (4 per thread) and a
+ * sector is traced by one thread, so that beyond the voxels next to the sensor -- which every ray crosses and which each
+ * thread accumulates privately, ORC_NF -- the threads add into disjoint wedges of the grid instead of taking turns at the
+ * same cache lines (with rays dealt out in cloud order, 128 threads were slower than one: profiles/r3_cpu_thread_sweep.txt).
+ * The adds stay atomic (sectors meet along their edges); sums are order-free, so the result is the one-thread build's. */
+#define ORC_SECTORS_DECL                                                                        \
+    int64_t nsec = 4 * (int64_t)omp_get_max_threads();                                          \
+    if (nsec > 2048) nsec = 2048;                                                               \
+    int32_t *sec_of = (int32_t *)malloc((size_t)(n > 0 ? n : 1) * 4);                           \
+    int64_t *sec_start = (int64_t *)calloc((size_t)nsec + 2, 8);                                \
+    int64_t *order = (int64_t *)malloc((size_t)(n > 0 ? n : 1) * 8);                            \
+    if (sec_of && sec_start && order) {                                                         \
+        ORC_PFOR                                                                                \
+        for (int64_t i = 0; i < n; ++i) {                                                       \
+            const double ax = (double)pts[i * stride] - ego[0], ay = (double)pts[i * stride + 1] - ego[1]; \
+            double a = (atan2(ay, ax) + 3.14159265358979323846) * (0.5 / 3.14159265358979323846) * (double)nsec; \
+            if (!(a >= 0.0)) a = 0.0;                                                           \
+            int64_t b = (int64_t)a;                                                             \
+            sec_of[i] = (int32_t)(b >= nsec ? nsec - 1 : b);                                    \
+        }                                                                                       \
+        for (int64_t i = 0; i < n; ++i) sec_start[sec_of[i] + 2] += 1;                          \
+        for (int64_t b = 0; b < nsec; ++b) sec_start[b + 2] += sec_start[b + 1];                \
+        for (int64_t i = 0; i < n; ++i) order[sec_start[sec_of[i] + 1]++] = i;                  \
+    } else { nsec = 1; sec_start = NULL; }
+#define ORC_SEC_BEGIN(B) (sec_start ? sec_start[B] : 0)
+#define ORC_SEC_END(B) (sec_start ? sec_start[(B) + 1] : n)
+#define ORC_RAY_OF(K) (sec_start ? order[K] : (K))
+#define ORC_SECTORS_FREE free(sec_of); free(sec_start); free(order);
+/* the threads' private copies of the ORC_NF^3 box around the sensor: one block per thread, summed into `total` by a
+ * parallel loop over the box's cells once every thread has finished tracing.  (Round 3 let every thread flush its own copy
+ * with atomics, all of them walking the box in the same order: T threads taking turns at each cache line made the flush
+ * cost grow with T^2 -- 26 of a 16-thread step's 38 ms, 2.6 s per step at 256 threads.) */
+#define ORC_NF_SHARED int32_t *nf_all = orc_nf_blocks((size_t)omp_get_max_threads());
+#define ORC_NF_DECL int32_t *nf = nf_all ? nf_all + (size_t)omp_get_thread_num() * ORC_NF * ORC_NF * ORC_NF : NULL; \
+    if (nf) memset(nf, 0, (size_t)ORC_NF * ORC_NF * ORC_NF * 4);
 #define ORC_NF_ADD(X, Y, Z)                                                                     \
     {                                                                                           \
         const uint64_t bx = (uint64_t)((X) - nfx), by = (uint64_t)((Y) - nfy), bz = (uint64_t)((Z) - nfz); \
@@ -48,23 +82,38 @@
         else { ORC_ATOMIC total[(X) + (Y) * xy + (Z) * xy * xy] += 1; }                         \
     }
 #define ORC_NF_FLUSH                                                                            \
-    if (nf) {                                                                                   \
-        for (int64_t bz = 0; bz < ORC_NF; ++bz) for (int64_t by = 0; by < ORC_NF; ++by) for (int64_t bx = 0; bx < ORC_NF; ++bx) { \
-            const int32_t v = nf[bx + ORC_NF * (by + ORC_NF * bz)];                             \
-            if (v) { ORC_ATOMIC total[(bx + nfx) + (by + nfy) * xy + (bz + nfz) * xy * xy] += v; } \
+    if (nf_all) {                                                                               \
+        const int64_t nthr = omp_get_num_threads();                                             \
+        ORC_PRAGMA(omp barrier)                                                                 \
+        ORC_PRAGMA(omp for schedule(static))                                                    \
+        for (int64_t c = 0; c < (int64_t)ORC_NF * ORC_NF * ORC_NF; ++c) {                       \
+            int32_t v = 0;                                                                      \
+            for (int64_t t = 0; t < nthr; ++t) v += nf_all[t * ORC_NF * ORC_NF * ORC_NF + c];   \
+            if (v) {                                                                            \
+                const int64_t bx = c % ORC_NF, by = (c / ORC_NF) % ORC_NF, bz = c / (ORC_NF * ORC_NF); \
+                /* (cells outside the grid were never counted privately: ORC_NF_ADD is only reached for in-grid voxels) */ \
+                ORC_ATOMIC total[(bx + nfx) + (by + nfy) * xy + (bz + nfz) * xy * xy] += v;     \
+            }                                                                                   \
         }                                                                                       \
-        free(nf);                                                                               \
     }
+#define ORC_NF_FREE
 #define ORC_PRAGMA_REDUCE_NIN ORC_PRAGMA(omp parallel for schedule(static) reduction(+ : n_in))
 #define ORC_PRAGMA_CAPTURE ORC_PRAGMA(omp atomic capture)
 #else
 #define ORC_PRAGMA_CAPTURE
 #define ORC_PARALLEL_UPDATES
 #define ORC_FOR_DYN
+#define ORC_SECTORS_DECL const int64_t nsec = 1;
+#define ORC_SEC_BEGIN(B) 0
+#define ORC_SEC_END(B) n
+#define ORC_RAY_OF(K) (K)
+#define ORC_SECTORS_FREE
 #define ORC_NF 32
+#define ORC_NF_SHARED
 #define ORC_NF_DECL
 #define ORC_NF_ADD(X, Y, Z) total[(X) + (Y) * xy + (Z) * xy * xy] += 1;
 #define ORC_NF_FLUSH
+#define ORC_NF_FREE
 #define ORC_PRAGMA_REDUCE_NIN
 #define ORC_PFOR
 #define ORC_PFOR_DYN
@@ -74,6 +123,21 @@
 /* ------------------------------------------------------------------------------------
  * helpers
  * ---------------------------------------------------------------------------------- */
+#ifdef ORC_OMP
+/* the threads' near-field blocks (ORC_NF_SHARED): kept between calls (calls of one process do not overlap: the Python host
+ * logic is one thread), each thread zeroes its own */
+static int32_t *orc_nf_blocks(size_t threads)
+{
+    static int32_t *blocks = NULL;
+    static size_t have = 0;
+    if (threads > have) {
+        free(blocks);
+        blocks = (int32_t *)malloc(threads * ORC_NF * ORC_NF * ORC_NF * 4);
+        have = blocks ? threads : 0;
+    }
+    return blocks;
+}
+#endif
 
 /* Python's max(a, b): returns a unless b > a (matters only for NaN, where no DDA step
  * is taken anyway).  gvom.py:1116 */
@@ -149,11 +213,15 @@ ORC_API int64_t orc_point_2_map_##SUF(double xy_res, double z_res, int64_t xy, i
     const int64_t nfy = (int64_t)floor(ego[1] / xy_res - origin[1]) - ORC_NF / 2;              \
     const int64_t nfz = (int64_t)floor(ego[2] / z_res - origin[2]) - ORC_NF / 2;               \
     (void)nfx; (void)nfy; (void)nfz;                                                            \
+    ORC_SECTORS_DECL                                                                            \
+    ORC_NF_SHARED                                                                               \
     ORC_PARALLEL_UPDATES                                                                        \
     {                                                                                           \
     ORC_NF_DECL                                                                                 \
     ORC_FOR_DYN                                                                                 \
-    for (int64_t i = 0; i < n; ++i) {                                                           \
+    for (int64_t sec = 0; sec < nsec; ++sec)                                                    \
+    for (int64_t kk = ORC_SEC_BEGIN(sec); kk < ORC_SEC_END(sec); ++kk) {                        \
+        const int64_t i = ORC_RAY_OF(kk);                                                       \
         const T *p = pts + i * stride;                                                          \
         /* :1064 d2 in the cloud's dtype, (x*x + y*y) + z*z */                                  \
         T d2 = (T)((T)((T)(p[0] * p[0]) + (T)(p[1] * p[1])) + (T)(p[2] * p[2]));                \
@@ -214,6 +282,8 @@ ORC_API int64_t orc_point_2_map_##SUF(double xy_res, double z_res, int64_t xy, i
     }                                                                                           \
     ORC_NF_FLUSH                                                                                \
     }                                                                                           \
+    ORC_SECTORS_FREE                                                                            \
+    ORC_NF_FREE                                                                                 \
     return updates;                                                                             \
 }                                                                                               \
                                                                                                 \
@@ -826,6 +896,14 @@ ORC_API int orc_abi_version(void) { return 1; }
 ORC_API void orc_set_cuda_f32_sqrt(int on) { orc_cuda_f32_sqrt = on ? 1 : 0; }
 
 /* threads the all-core build runs on (1 in the one-thread build) */
+/* the V-sized fills of gvom.py:114-121, 190-228 (__init_1D_array, gvom.py:1382-1394): value into n int32 words, on all threads
+ * in the all-core build (numpy's np.full is one thread, and 67 MB of it per scan and per combine was most of a 128-thread step) */
+ORC_API void orc_fill_i32(int32_t *dst, int64_t n, int32_t value)
+{
+    ORC_PFOR
+    for (int64_t i = 0; i < n; ++i) dst[i] = value;
+}
+
 ORC_API int orc_threads(void)
 {
 #ifdef ORC_OMP

@@ -64,6 +64,7 @@ def lib(path=None):
         L.orc_threads.restype = _c.c_int
         L.orc_set_cuda_f32_sqrt.argtypes = [_c.c_int]
         L.orc_set_threads.argtypes = [_c.c_int]
+        L.orc_fill_i32.argtypes = [_P, _i64, _c.c_int32]; L.orc_fill_i32.restype = None
         for suf in ("f32", "f64"):
             f = getattr(L, "orc_transform_pointcloud_" + suf)
             f.argtypes = [_P, _i64, _i64, _P]; f.restype = None
@@ -245,6 +246,22 @@ class OracleGvom:
         # accounting for bench.py's roofline arithmetic (exact integers)
         self.last_scan_updates = 0
         self.last_scan_points_in_grid = 0
+        # timed baseline only (bench.py cpu_baseline): V-sized int32 arrays that have left the ring / been replaced are filled
+        # and used again instead of being given back to the allocator (fresh pages cost a page fault per 4 KiB, in ONE
+        # thread for np.full: most of an all-core step).  Off by default: arrays handed out as attributes stay untouched.
+        self.reuse_buffers = False
+        self._free_v = []
+
+    def _take_v(self, value):
+        """a V-sized int32 array filled with `value` (gvom.py:114-121, 190: cuda.device_array + __init_1D_array), filled by the C
+        oracle -- on all threads in its all-core build"""
+        a = self._free_v.pop() if self._free_v else np.empty(self.voxel_count, np.int32)
+        lib().orc_fill_i32(_p(a), self.voxel_count, int(value))
+        return a
+
+    def _give_v(self, a):
+        if self.reuse_buffers and a is not None and len(self._free_v) < 8:
+            self._free_v.append(a)
 
     # gvom.py:99-175
     def process_pointcloud(self, pointcloud, ego_position, transform=None):
@@ -257,9 +274,9 @@ class OracleGvom:
         pc = _as_cloud(pointcloud)
         suf = "f32" if pc.dtype == np.float32 else "f64"
         V = self.voxel_count
-        tmp_hit = np.zeros(V, np.int32)
-        tmp_total = np.zeros(V, np.int32)
-        index_map = np.full(V, -1, np.int32)
+        tmp_hit = self._take_v(0)
+        tmp_total = self._take_v(0)
+        index_map = self._take_v(-1)
         origin = np.zeros(3)
         origin[0] = math.floor((ego_position[0] / self.xy_resolution) - self.xy_size / 2)   # :124
         origin[1] = math.floor((ego_position[1] / self.xy_resolution) - self.xy_size / 2)
@@ -275,6 +292,7 @@ class OracleGvom:
         cell_count = L.orc_assign_indices(_p(tmp_hit), _p(tmp_total), _p(index_map), V)      # :143
         if cell_count == 0:                                                                  # :148
             print("[WARNING] The pointcloud points don't overlap with any voxels, nothing will happen!")
+            self._give_v(tmp_hit); self._give_v(tmp_total); self._give_v(index_map)
             return
         hit = np.empty(cell_count, np.int32); total = np.empty(cell_count, np.int32)
         L.orc_move_data(_p(tmp_hit), _p(hit), _p(index_map), V)                              # :155
@@ -292,7 +310,9 @@ class OracleGvom:
                     self.min_distance, _p(index_map), _p(pc), point_count, pc.shape[1], _p(metrics),
                     _p(origin), self.xy_eigen_dist, self.z_eigen_dist)
                 L.orc_normalize_stats(ps, _p(metrics), cell_count)
+        self._give_v(tmp_hit); self._give_v(tmp_total)
         b = self.buffer_index                                                                # :163
+        self._give_v(self.index_buffer[b])
         self.metrics_buffer[b] = metrics
         self.index_buffer[b] = index_map
         self.hit_count_buffer[b] = hit
@@ -317,7 +337,7 @@ class OracleGvom:
         origin_world[1] = origin_world[1] * self.xy_resolution
         origin_world[2] = origin_world[2] * self.z_resolution
         cnt = np.zeros(1, np.int64)
-        self.combined_index_map = np.full(V, -1, np.int32)
+        self.combined_index_map = self._take_v(-1)
         for i in range(self.buffer_size):                                                    # :198
             if self.origin_buffer[i] is None:
                 continue
@@ -352,6 +372,7 @@ class OracleGvom:
                                   xy, zs)
         self.last_combined_hit_count = self.combined_hit_count                               # :268
         self.last_combined_total_count = self.combined_total_count
+        self._give_v(self.last_combined_index_map)
         self.last_combined_index_map = self.combined_index_map
         self.last_combined_min_height = self.combined_min_height
         self.last_combined_origin = self.combined_origin

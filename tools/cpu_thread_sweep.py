@@ -8,12 +8,19 @@ import synth
 from oracle import oracle
 params, scans = synth.config_inputs("m256", n_scans=4)
 cores = len(os.sched_getaffinity(0))
-print("host cores available: %d" % cores)
-for t in (1, 8, 16, 32, 64, 128):
+import bench
+print("logical CPUs in the affinity mask: %d; usable: %s" % (cores, bench.usable_cores()))
+for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+    if os.path.exists(f):
+        print(f, "=", open(f).read().strip())
+for t in sorted(set((1, 8, 12, 16, 20, 24, 32, 64, 128, bench.usable_cores()[0]))):
     if t > cores:
         continue
     th = oracle.use_all_cores(t > 1, threads=t if t > 1 else None)
     g = oracle.OracleGvom(*params)
+    g.reuse_buffers = True
+    for k in range(2):
+        pc, ego, tf = scans[k % 4]; g.process_pointcloud(pc, ego, tf); g.combine_maps()
     k, t0 = 0, time.perf_counter()
     while k < 3 or time.perf_counter() - t0 < 4.0:
         pc, ego, tf = scans[k % 4]; g.process_pointcloud(pc, ego, tf); g.combine_maps(); k += 1
