@@ -1112,7 +1112,8 @@ void collect_stage_ms(gvom_handle *h)
         h->stage_ms[2] = 0.0f;             // min-height runs inside the k_encode launch
     }
     if (h->ev_fuse) hipEventElapsedTime(&h->stage_ms[3], h->ev[4], h->ev[5]);
-    if (h->ev_map) hipEventElapsedTime(&h->stage_ms[4], h->ev[6], h->ev[7]);
+    // (the combine's completion flag goes out before k_map2d's launch has formally ended: wait for its event)
+    if (h->ev_map && hipEventSynchronize(h->ev[7]) == hipSuccess) hipEventElapsedTime(&h->stage_ms[4], h->ev[6], h->ev[7]);
     h->ev_scan = h->ev_fuse = h->ev_map = false;
     (void)hipGetLastError();               // never leave a sticky error behind for the launchers
 }
