@@ -83,6 +83,7 @@ struct gvom_handle {
     int tune_ilv = 0;                                   // gvom_set_tuning "interleave": sub-clouds per cloud (0: automatic, 1: off)
     int last_knobs[5] = {0, 0, 0, 0, 1};                // gvom_get_tuning: segs, period, ep_row, prio, interleave of the last scan
     int64_t probe_n = -1; uint32_t probe_age = 0;       // layout probe (k_layout_probe): the length it last looked at, scans since
+    int tune_fuse1 = 0;                                 // gvom_set_tuning "fuse1": 1 = the one-slot fusion through k_fuse4 as well (A/B)
     int tune_flag_kernel = 0;                           // gvom_set_tuning "flag_kernel": 1 = the combine's completion flag from a kernel of its own (round 3's form)
     int tune_churn = 0;                                 // test hook: re-allocate the endpoint send region every scan
     uint64_t alloc_gen = 0;                             // changes whenever a send region of this handle is re-allocated
@@ -987,6 +988,14 @@ int fuse_impl(gvom_handle *h, hipStream_t on = nullptr)
     P.sy_lo = h->sy_lo; P.sy_hi = h->sy_hi;
     P.nz = choose_nz(p.z_size, &P.zc, &P.cpw);
     P.dbg = gvom_diag_env("GVOM_FUSE_DEBUG");
+    // one slot in the ring (buffer_size 1, or a ring that has only just begun): k_fuse1 -- up to 8 waves per column block, 2
+    // chunks per wave where the grid is high enough (a shorter chain of dependent round trips per wave)
+    if (ns == 1 && P.zc == 16 && p.xy_size % 4 == 0 && h->tune_fuse1 != 1 && !(P.dbg & 8)) {
+        const int nchunks = (p.z_size + 15) / 16;
+        int nz = nchunks < 8 ? nchunks : 8;
+        int cpw = (nchunks + nz - 1) / nz;
+        if (cpw <= 4) { P.one_slot = 1; P.nz = nz; P.cpw = cpw; }
+    }
     P.nseg = h->nseg;
     P.hs = h->hs;
     F.epoch = ++h->epoch;
@@ -2020,6 +2029,7 @@ VIS int gvom_set_tuning(gvom_t *h, const char *name, int value)
     else if (!strcmp(name, "prio")) h->tune_prio = value;
     else if (!strcmp(name, "interleave")) h->tune_ilv = value;
     else if (!strcmp(name, "flag_kernel")) h->tune_flag_kernel = value;
+    else if (!strcmp(name, "fuse1")) h->tune_fuse1 = value;
     else if (!strcmp(name, "churn")) h->tune_churn = value;
     else if (!strcmp(name, "exported")) h->exported = value != 0;       // (set by the peer transport, gvom_comm.hip)
 

@@ -131,6 +131,7 @@ struct FuseParams {
     int nz;                 // z-chunks per workgroup (block = 64 * nz threads)
     int zc;                 // window-z cells per chunk (<= 64)
     int cpw;                // chunks per wave (a wave walks them in ascending z)
+    int one_slot;           // 1: k_fuse1 (one ring slot + the previous map; nz <= 8 waves of cpw <= 4 chunks)
     int dbg;                // diagnostic build only (GVOM_FUSE_DEBUG): 1 no code stores, 2 no emit, 4 all tiles dead
     double origin[3];       // fused origin (voxels)
     double ego[3];          // latest ego (gvom.py:294-295)

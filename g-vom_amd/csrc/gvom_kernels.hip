@@ -1546,6 +1546,201 @@ __global__ __launch_bounds__(1024) void k_fuse4(const FuseParams P, const FuseDe
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_fuse1: the fusion of ONE ring slot (+ the previous fused map) -- buffer_size = 1 rings (the headline 256^3 config, c2)
+// and any ring that holds a single scan.  Same column decomposition, lane layout, outputs and row numbering as k_fuse4,
+// built for latency: with one slot there is nothing to sum, so the slot is read through its 32-bit STATES (its free count
+// and, where it is occupied, its compact row arrive with the one load), the occupied voxels of a chunk are settled in ONE
+// round trip (both sources' rows are known), nothing is kept per cell between the two sources -- 64 VGPRs instead of
+// k_fuse4's 111, twice the waves per SIMD -- and a wave takes 2 chunks instead of 4 (workgroups of up to 8 waves): a wave's
+// chain of dependent round trips is 1 + 2 x 2 instead of 1 + 4 x 3.  (k_fuse4 at S = 1: 20 us for 50 MB on the 256^3 grid.)
+// ------------------------------------------------------------------------------------------
+#define FUSE1_LIST 256
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_fuse1(
+    const FuseParams P, const FuseDescs KD, int32_t *fstate, uint4 *frows, uint32_t *ftags, uint32_t *blockcounts,
+    double *height, double *inferred)
+{
+    __shared__ uint32_t s_cnt[8];
+    __shared__ unsigned long long s_live[8][2];
+    __shared__ unsigned long long s_zh[8][WAVE];           // per wave and column: min of (z << 32 | min-height bits) over occupied voxels
+    __shared__ uint32_t s_zf[8][WAVE];                     // per wave and column: lowest observed-free z
+    __shared__ uint16_t s_list[8][FUSE1_LIST];             // per wave: the occupied voxels of a chunk, compacted (j << 8 | lane << 2 | i)
+    __shared__ int32_t s_sts[8][FUSE1_LIST], s_stp[8][FUSE1_LIST];   // ... and the two sources' states there
+
+    const cptr_desc descs = (cptr_desc)KD.d;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane & 15, q = lane >> 4;
+    const int sxb = blockIdx.x * WAVE + 4 * g;            // first of this lane's 4 columns
+    const int sy = P.sy_lo + blockIdx.y;
+    const bool col_ok = sxb < P.xy;                        // xy % 4 == 0: all four or none
+    const int y = wrap_sub(sy, P.om[1], P.xy);
+    const bool has_prev = P.has_prev != 0;
+    const int dsx = descs[0].d[0], dsy = descs[0].d[1], dsz = descs[0].d[2];
+    const int dpx = has_prev ? descs[1].d[0] : 0, dpy = has_prev ? descs[1].d[1] : 0, dpz = has_prev ? descs[1].d[2] : 0;
+
+    uint32_t oks = 0, okp = 0;                             // bit i: the source's window contains column i of this lane
+    {
+        const bool ys = y + dsy >= 0 && y + dsy < P.xy, yp = has_prev && y + dpy >= 0 && y + dpy < P.xy;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int xw = wrap_sub(col_ok ? sxb + i : 0, P.om[0], P.xy);
+            if (col_ok && ys && xw + dsx >= 0 && xw + dsx < P.xy) oks |= 1u << i;
+            if (col_ok && yp && xw + dpx >= 0 && xw + dpx < P.xy) okp |= 1u << i;
+        }
+    }
+    const uint32_t colbase = (uint32_t)sy * P.zs * P.xy + (col_ok ? sxb : 0);
+    const uint32_t tbase = (uint32_t)sy * P.zs * P.nseg + blockIdx.x;
+    uint32_t running = 0;
+    int zfree[4] = {INT_MAX, INT_MAX, INT_MAX, INT_MAX};
+    s_zh[w][lane] = ((unsigned long long)INT_MAX << 32) | 0x3f800000ull;      // wave-private until the tail
+    s_zf[w][lane] = (uint32_t)INT_MAX;
+    const uint32_t rbase = ((blockIdx.y * gridDim.x + blockIdx.x) * (uint32_t)P.nz + w) * (uint32_t)(WAVE * P.zc * P.cpw);
+
+    {   // live-tile masks of the two sources for the (<= 64) tiles of this wave
+        const int cc_l = lane >> 4, k_l = lane & 15;
+        const int zl = (cc_l * P.nz + w) * P.zc + k_l;      // chunks are dealt round-robin to the waves
+        const bool valid_l = cc_l < P.cpw && k_l < P.zc && zl < P.zs;
+        const uint32_t tl = tbase + (uint32_t)wrap_add(valid_l ? zl : 0, P.om[2], P.zs) * P.nseg;
+        const uint32_t ts = ((gptr_u32)descs[0].tags)[tl];
+        const uint32_t tp = has_prev ? ((gptr_u32)descs[1].tags)[tl] : 0u;
+        const unsigned long long ms = __ballot(valid_l && ts == descs[0].epoch);
+        const unsigned long long mp = __ballot(has_prev && valid_l && tp == descs[1].epoch);
+        if (lane == 0) { s_live[w][0] = ms; s_live[w][1] = mp; }
+    }
+    const gptr_i32 ss = (gptr_i32)descs[0].state;
+    const gptr_i32 sp = (gptr_i32)descs[has_prev ? 1 : 0].state;
+
+    for (int cc = 0; cc < P.cpw; ++cc) {
+        const int z0 = (cc * P.nz + w) * P.zc;
+        if (z0 >= P.zs) break;
+        const int z1 = min(z0 + P.zc, P.zs);
+        const uint32_t lives = (uint32_t)(s_live[w][0] >> (16 * cc)) & 0xffffu;
+        const uint32_t livep = (uint32_t)(s_live[w][1] >> (16 * cc)) & 0xffffu;
+        if (__builtin_amdgcn_readfirstlane(lives | livep) == 0) continue;     // chunk dead in both sources
+
+        uint32_t roff[4];
+        v4i vs[4], vp[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                     // 8 unconditional 16-byte loads in flight
+            const int zq = z0 + 4 * j + q;
+            roff[j] = colbase + (uint32_t)wrap_add(zq < P.zs ? zq : 0, P.om[2], P.zs) * P.xy;
+            vs[j] = *(gptr_v4i)(ss + (((lives >> (4 * j + q)) & 1u) ? roff[j] : (uint32_t)(4 * lane)));
+            vp[j] = *(gptr_v4i)(sp + (((livep >> (4 * j + q)) & 1u) ? roff[j] : (uint32_t)(4 * lane)));
+        }
+        uint32_t n = 0;
+        // the occupied voxels listed so far: one lane per voxel, both sources' rows in one round trip
+        auto emit = [&]() {
+            for (uint32_t base = 0; base < n; base += WAVE) {
+                const uint32_t t = base + (uint32_t)lane;
+                const bool on = t < n;
+                const uint32_t e = s_list[w][on ? t : 0u];
+                const int sts = on ? s_sts[w][t] : -1, stp = on ? s_stp[w][t] : -1;
+                const int ci = (int)(e & 3u), go = (int)((e >> 2) & 15u), qo = (int)((e >> 6) & 3u), jo = (int)(e >> 8);
+                const int zv = z0 + 4 * jo + qo;
+                const int col = 4 * go + ci;
+                const int sxc = blockIdx.x * WAVE + col;
+                const uint32_t off = (uint32_t)sy * P.zs * P.xy + (uint32_t)wrap_add(zv, P.om[2], P.zs) * P.xy + (uint32_t)sxc;
+                const v4u rs = ((gptr_v4u)descs[0].rows)[sts >= 0 ? (uint32_t)sts : 0u];
+                const v4u rp = ((gptr_v4u)descs[has_prev ? 1 : 0].rows)[stp >= 0 ? (uint32_t)stp : 0u];
+                uint32_t hh = 0, tt = 0, mm = 0x3f800000u;
+                if (sts >= 0) { hh += rs.x; tt += rs.y; mm = min(mm, rs.z); }            // gvom.py:910-912
+                if (stp >= 0) { hh += rp.x; tt += rp.y; mm = min(mm, rp.z); }
+                const unsigned long long ob = __ballot(on);
+                if (on) {
+                    const uint32_t row = rbase + running + (uint32_t)__popcll(ob & lanemask_lt());
+                    fstate[off] = (int32_t)row;
+                    frows[row] = make_uint4(hh, tt, mm, 0u);
+                    atomicMin(&s_zh[w][col], ((unsigned long long)(uint32_t)zv << 32) | mm);   // lowest occupied level wins
+                }
+                running += (uint32_t)__popcll(ob);
+            }
+            n = 0;
+        };
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int zq = z0 + 4 * j + q;
+            const bool zs_in = ((lives >> (4 * j + q)) & 1u) && zq < z1 && zq + dsz >= 0 && zq + dsz < P.zs;
+            const bool zp_in = ((livep >> (4 * j + q)) & 1u) && zq < z1 && zq + dpz >= 0 && zq + dpz < P.zs;
+            const int a[4] = {vs[j].x, vs[j].y, vs[j].z, vs[j].w}, b[4] = {vp[j].x, vp[j].y, vp[j].z, vp[j].w};
+            int c[4];
+            uint32_t occ = 0;
+            int sts_[4], stp_[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int st = (zs_in && ((oks >> i) & 1u)) ? a[i] : -1;                 // -1: no effect
+                const int pv = (zp_in && ((okp >> i) & 1u)) ? b[i] : -1;
+                sts_[i] = st; stp_[i] = pv;
+                c[i] = -1;
+                if (st >= 0) occ |= 1u << i;                                              // gvom.py:963
+                else if (st < -1) c[i] = add_free(c[i], st + 1);                          // gvom.py:967
+                if (!((occ >> i) & 1u)) {
+                    if (pv >= 0 && c[i] >= -11) occ |= 1u << i;                           // gvom.py:992
+                    else if (pv < -1) c[i] = add_free(c[i], pv + 1);                      // gvom.py:996
+                }
+            }
+            if (!col_ok) occ = 0;
+            const bool inside = col_ok && zq < z1;
+            const bool nonempty = occ != 0u || c[0] != -1 || c[1] != -1 || c[2] != -1 || c[3] != -1;
+            const unsigned long long nb = __ballot(inside && nonempty);
+            if (((nb >> (16 * q)) & 0xffffull) && !GVOM_DBG(P, 1)) {          // some lane of MY tile (same q) has content
+                if (g == 0 && zq < z1) ftags[tbase + (uint32_t)wrap_add(zq, P.om[2], P.zs) * P.nseg] = P.epoch;
+                if (inside) {
+                    *reinterpret_cast<int4 *>(fstate + roff[j]) = make_int4(c[0], c[1], c[2], c[3]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (!((occ >> i) & 1u) && c[i] < -1 && zfree[i] == INT_MAX) zfree[i] = zq;     // gvom.py:551
+                }
+            }
+            if (__any(occ != 0u)) {                          // wave-uniform
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool o = (occ >> i) & 1u;
+                    const unsigned long long bm = __ballot(o);
+                    if (o) {
+                        const uint32_t at = n + (uint32_t)__popcll(bm & lanemask_lt());
+                        s_list[w][at] = (uint16_t)(((uint32_t)j << 8) | ((uint32_t)lane << 2) | (uint32_t)i);
+                        s_sts[w][at] = sts_[i]; s_stp[w][at] = stp_[i];
+                    }
+                    n += (uint32_t)__popcll(bm);
+                    if (n > FUSE1_LIST - WAVE) emit();     // the next column of cells (<= 64 voxels) might not fit
+                }
+            }
+        }
+        if (n) emit();
+    }   // chunks
+
+    // ---- column tail (as k_fuse4): lowest occupied z (+ its min-height) / lowest free z per column
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (zfree[i] != INT_MAX) atomicMin(&s_zf[w][4 * g + i], (uint32_t)zfree[i]);
+    if (lane == 0) s_cnt[w] = running;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int k = 0; k < P.nz; ++k) tot += s_cnt[k];
+        blockcounts[blockIdx.y * gridDim.x + blockIdx.x] = tot;
+    }
+    const int sx = blockIdx.x * WAVE + lane;
+    if (w == 0 && sx < P.xy && !GVOM_DBG(P, 16)) {
+        const int x = wrap_sub(sx, P.om[0], P.xy);
+        unsigned long long zh = ((unsigned long long)INT_MAX << 32) | 0x3f800000ull;
+        uint32_t zfu = (uint32_t)INT_MAX;
+        for (int k = 0; k < P.nz; ++k) { zh = min(zh, s_zh[k][lane]); zfu = min(zfu, s_zf[k][lane]); }
+        const int zo = (int)(zh >> 32), zf = (int)zfu;
+        const uint32_t hb = (uint32_t)zh;
+        double hval = -1000.0;
+        const double xp = ((P.origin[0] + (double)x) * P.xy_res) - P.ego[0];
+        const double yp = ((P.origin[1] + (double)y) * P.xy_res) - P.ego[1];
+        if (xp * xp + yp * yp <= P.radius2) hval = P.ego[2] - P.ground_to_lidar_height;
+        if (zo != INT_MAX)
+            hval = (((double)__uint_as_float(hb) + (double)zo) + P.origin[2]) * P.z_res;
+        height[(size_t)sy * P.hs + sx] = hval;
+        inferred[(size_t)sy * P.hs + sx] =
+            (zf != INT_MAX) ? ((double)zf + P.origin[2]) * P.z_res : -1000.0;
+    }
+}
+
 // sum of the per-workgroup occupied-voxel counts of k_fuse -> host-mapped memory
 __device__ __forceinline__ void publish_block_counts(const uint32_t *blockcounts, int nblocks,
                                                      volatile unsigned long long *host_counter,
@@ -2599,6 +2794,10 @@ hipError_t gvom_launch_fuse(hipStream_t s, const FuseParams &P, const FuseDescs 
 #define FUSE_LAUNCH(...) hipLaunchKernelGGL((__VA_ARGS__), grid, dim3(64 * P.nz), 0, s, P, KD, descs_dev, fstate, frows, \
                                           ftags, blockcounts, height, inferred)
     const bool mem = descs_dev != nullptr;
+    if (P.one_slot) {                                    // (the host has checked: one slot, 16-level chunks, xy % 4 == 0, descriptors by argument)
+        hipLaunchKernelGGL(k_fuse1, grid, dim3(64 * P.nz), 0, s, P, KD, fstate, frows, ftags, blockcounts, height, inferred);
+        return hipGetLastError();
+    }
     if (P.zc == 16 && (P.xy & 3) == 0 && !GVOM_DBG(P, 8)) {
         if (P.nslots <= 2) { if (mem) FUSE_LAUNCH(k_fuse4<2, true>); else FUSE_LAUNCH(k_fuse4<2, false>); }
         else { if (mem) FUSE_LAUNCH(k_fuse4<4, true>); else FUSE_LAUNCH(k_fuse4<4, false>); }

@@ -1034,6 +1034,41 @@ def test_tall_grids_use_the_generic_fusion_kernel(gvom_mod, grid):
     assert compare_records(got, want, float_tol=1e-5) > 20
 
 
+@pytest.mark.parametrize("grid", [(64, 32, 1), (64, 64, 1), (128, 256, 1), (32, 512, 1), (64, 128, 3), (48, 16, 1)])
+def test_one_slot_fusion_kernel_against_the_oracle_and_the_general_kernel(gvom_mod, grid):
+    """k_fuse1: the fusion of ONE ring slot (+ the previous fused map) -- every combine of a buffer_size = 1 mapper and the
+    first combine of any ring.  Grids of 2 ... 32 sixteen-level chunks (2, 4 and 8 waves per column block, 1, 2 and 4 chunks
+    per wave), a moving window with decaying previous-map voxels, float32 and float64 scans; a ring of 3 takes it for its first
+    combine only.  Compared with the oracle (returned maps, cell counts, the fused map densely) AND with the same mapper sent
+    through the general kernel (gvom_set_tuning("fuse1", 1)): bit-identical."""
+    xy, zs, buf = grid
+    params = (0.4, 0.1 if zs > 100 else 0.2, xy, zs, buf, 0.5, 0.5, 0.5, 0.3, 2.0, 2.0, 1.0, 1, 1)
+    rng = np.random.default_rng(xy * 7 + zs)
+    g, g4, w = gvom_mod.Gvom(*params), gvom_mod.Gvom(*params), oracle.OracleGvom(*params)
+    g4.set_tuning("fuse1", 1)
+    for k in range(7):
+        ego = (0.5 * k, -0.3 * k, 0.05 * k)
+        n = 9000
+        ground = np.stack([rng.uniform(-0.2 * xy, 0.2 * xy, n) + ego[0], rng.uniform(-0.2 * xy, 0.2 * xy, n) + ego[1],
+                           rng.normal(-0.8, 0.15, n) + ego[2]], axis=1)
+        # (returns that come and go: voxels of the previous map that the new scan sees through, gvom.py:992)
+        wall = np.stack([np.full(600, 3.0 + 0.4 * (k % 2)) + ego[0], rng.uniform(-2, 2, 600) + ego[1], rng.uniform(-0.8, 1.0, 600) + ego[2]], axis=1)
+        pc = np.concatenate([ground, wall], 0).astype(np.float32 if k % 2 else np.float64)
+        for m in (g, g4, w):
+            m.process_pointcloud(pc.copy(), ego)
+        a, a4, b = g.combine_maps(), g4.combine_maps(), w.combine_maps()
+        for i in range(5):
+            assert np.array_equal(a[i], a4[i], equal_nan=True), (k, i)
+        for i in (0, 1, 2, 4):
+            assert np.array_equal(a[i], b[i]), (k, i)
+        assert np.allclose(a[3], b[3], rtol=0, atol=1e-5)
+        assert g.combined_cell_count_cpu == g4.combined_cell_count_cpu == w.combined_cell_count_cpu, k
+    gd, gd4 = g.read_dense(gvom_mod.GVOM_WHICH_FUSED), g4.read_dense(gvom_mod.GVOM_WHICH_FUSED)
+    wd = scenarios.dense_from_compact(w.combined_index_map, w.combined_hit_count, w.combined_total_count, w.combined_min_height)
+    for j in range(4):
+        assert np.array_equal(gd[j], gd4[j]) and np.array_equal(np.asarray(wd[j]), gd[j]), j
+
+
 @pytest.mark.parametrize("grid", [(32, 16, 20), (30, 12, 24), (16, 300, 18), (32, 16, 40)])
 def test_long_rings_read_their_descriptors_from_memory(gvom_mod, grid):
     """More than 17 fusion sources (ring slots + previous map) no longer fit the kernel arguments: the
