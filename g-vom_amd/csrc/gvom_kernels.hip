@@ -5,12 +5,13 @@
 //
 //   k_trace   gvom.py:1040-1056 (transform) + :1060-1150 (hit + dominant-axis DDA)
 //             + the row-claim half of :1154-1160 (first hit of a voxel claims its compact row)
+//             + :1303-1329 (min-height: a third accumulator, atomicMax of 1.0f's bits minus the sample's)
 //   k_encode  gvom.py:1154-1168 (state code + dense->compact move) + the three V-sized clears
 //             of :114-121 (accumulators are cleared as they are read; no separate fill), only on
-//             the 64-voxel tiles the scan touched; its trailing blocks run the min-height pass
-//             gvom.py:1303-1329 (fill :1014-1015 folded into k_trace's row claim)
-//   k_fuse    gvom.py:943-968 x slots, :972-997, :821-912 (count/min lines 910-912) x (slots+1),
-//             :525-540 (height) and :544-554 (inferred height): ONE pass over the fused grid
+//             the 64-voxel tiles the scan touched
+//   k_fuse4   gvom.py:943-968 x slots, :972-997, :821-912 (count/min lines 910-912) x (slots+1),
+//   (k_fuse1  :525-540 (height) and :544-554 (inferred height): ONE pass over the fused grid
+//    k_fuse)  (k_fuse1: one ring slot; k_fuse: grids with xy % 4 != 0 or chunks other than 16 levels)
 //   k_map2d   gvom.py:665-734 (slope/roughness), :558-661 (guess height), :489-521 (positive),
 //             :479-485 (negative), :414-422 (visibility)
 //
@@ -324,8 +325,7 @@ __device__ __forceinline__ RaySetup ray_setup(const ScanParams &P, T x, T y, T z
     return R;
 }
 
-// The step loop's wave-uniform constants, read from the kernel arguments ONCE per wave (k_trace_p: outside its item loop,
-// whose other arguments are re-read per item -- see there): twelve scalar registers that stay put.
+// The step loop's wave-uniform constants, read from the kernel arguments ONCE per wave: twelve scalar registers that stay put.
 struct WalkConsts { uint32_t uxy, uzs, usxq, unseg, om0, om1, om2, o0, o1, o2, zpad, epoch; };
 __device__ __forceinline__ WalkConsts walk_consts(const ScanParams &P)
 {
@@ -340,16 +340,14 @@ __device__ __forceinline__ WalkConsts walk_consts(const ScanParams &P)
 // ------------------------------------------------------------------------------------------
 // walk_steps: at most `steps` lock-step DDA steps of a 64-ray bundle, total += 1 per step
 // (gvom.py:1119-1150).  The step body is straight-line: ray state in natural (x,y,z) order (x and y as
-// one packed f32 add), the step counter on the scalar unit, voxel lookup in 32-bit integers, left
-// neighbour's key by a DPP wave shift; lanes stepping into the same voxel as their left neighbour are
-// merged (run heads and run lengths by mask arithmetic on the scalar unit, the head mask goes straight into
-// EXEC) and the merged adds go into the wave-private LDS line cache (lc_flush), flushed every `period`
-// committing steps with one memory-side request per line; tile tags stamped on cache misses only.
+// one packed f32 add), the step counter and the mask of rays still running (`alive`) on the scalar unit,
+// voxel lookup in 32-bit integers, left neighbour's key by a DPP wave shift; lanes stepping into the same
+// voxel as their left neighbour are merged (run heads and run lengths by mask arithmetic on the scalar unit,
+// the head mask goes straight into EXEC) and the merged adds go into the wave-private LDS line cache
+// (lc_flush), flushed after the run with one memory-side request per line; tile tags stamped on cache misses only.
 // LIT: the reference's literal f64 lookup instead of the integer one (window_voxel).
-// (Round 3 also built a third form without the window test for the steps a ray provably spends inside the window:
-// 6 of 55 vector instructions fewer per step on three quarters of the steps, bit-exact, and not a microsecond faster
-// -- like the other reductions of this round it showed that the kernel is not bound by its instruction count;
-// DESIGN.md section 4.)
+// NOWIN (power-of-two grids): the run stays inside the window (walk_item has checked its first and last positions
+// with a margin): no window test, storage coordinates straight from the floor.
 // ------------------------------------------------------------------------------------------
 template <bool LIT, bool P2, bool NOWIN>
 __device__ __forceinline__ void walk_steps(const ScanParams &P, int lane, uint32_t &j, uint32_t cnt, float &px_, float &py_, float &pz,
