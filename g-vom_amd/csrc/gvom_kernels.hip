@@ -477,7 +477,12 @@ __device__ __forceinline__ void walk_item(const ScanParams &P, int lane, uint32_
             const float ax = px + incx, ay = py + incy, az = pz + incz;
             const float qx = px + fs * incx, qy = py + fs * incy, qz = pz + fs * incz;
             const float lx = fminf(ax, qx), hx = fmaxf(ax, qx), ly = fminf(ay, qy), hy = fmaxf(ay, qy), lz = fminf(az, qz), hz = fmaxf(az, qz);
-            const bool nz = (lx <= 1e-4f && hx >= -1e-4f) || (ly <= 1e-4f && hy >= -1e-4f) || (lz <= 1e-4f && hz >= -1e-4f);
+            // (the integer lookup differs from the literal one only for a position within 2^-21 BELOW zero: an axis whose first
+            // position is >= 0 and whose increment is >= 0 -- exact statements, no estimate involved -- only visits positions
+            // >= 0, e.g. every ray of a sensor that sits ON a coordinate plane and looks along it or away from it)
+            const bool nz = (lx <= 1e-4f && hx >= -1e-4f && !(incx >= 0.0f && ax >= 0.0f)) ||
+                            (ly <= 1e-4f && hy >= -1e-4f && !(incy >= 0.0f && ay >= 0.0f)) ||
+                            (lz <= 1e-4f && hz >= -1e-4f && !(incz >= 0.0f && az >= 0.0f));
             lit = lanes(active & nz) != 0ull;
             // The run's positions lie between its first and its last one (straight line; the f32 accumulation strays from it
             // by less than run * ulp(|p|) <= 32 * 2^-6 voxels while |p| < 2^18, which win_lo / win_hi being set guarantees): a
