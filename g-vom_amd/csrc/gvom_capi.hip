@@ -734,7 +734,9 @@ int scan_launch(gvom_handle *h, std::unique_lock<std::mutex> &lk, const void *de
 #ifdef GVOM_DIAG
     if (gvom_diag_env("GVOM_TRACE_TIMELINE") && n > 0) {
         h->tl_grid[0] = (int)((n + 511) / 512); h->tl_grid[1] = P.nsegs + (P.ep_row >= 0 ? 1 : 0);
-        const size_t bytes = (size_t)h->tl_grid[0] * h->tl_grid[1] * 8 * 32 + 64;
+        P.prof_on = gvom_diag_env("GVOM_TRACE_STEPPROF");
+        // (+ step profiles: 128 words for every 64th wave)
+        const size_t bytes = (size_t)h->tl_grid[0] * h->tl_grid[1] * 8 * 32 + 64 + ((size_t)h->tl_grid[0] * h->tl_grid[1] * 8 / 64 + 1) * 1024;
         P.tl_words = (long)h->tl_grid[0] * h->tl_grid[1] * 8 * 4;
         if ((rc = ensure(h, h->tl, bytes))) return rc;
         HIPCHK(h, hipMemsetAsync(h->tl.p, 0, bytes, h->stream));
@@ -2139,7 +2141,8 @@ VIS int gvom_diag_timeline(gvom_t *h, unsigned long long *out, int64_t max_words
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, sync_streams(h));
     grid[0] = h->tl_grid[0]; grid[1] = h->tl_grid[1];
-    const int64_t words = (int64_t)grid[0] * grid[1] * 8 * 4 + 8;      // + 8 summary words (steps by lookup mode)
+    const int64_t words = (int64_t)grid[0] * grid[1] * 8 * 4 + 8 +     // + 8 summary words (steps by lookup mode)
+                          ((int64_t)grid[0] * grid[1] * 8 / 64 + 1) * 128;   // + the step profiles of every 64th wave
     if (!h->tl.p || words <= 8) return GVOM_NO_DATA;
     HIPCHK(h, hipMemcpy(out, h->tl.p, (size_t)(words < max_words ? words : max_words) * 8, hipMemcpyDeviceToHost));
     return GVOM_OK;

@@ -86,6 +86,7 @@ struct ScanParams {
     int    stat_e;        // xy_eigen_dist (sharded statistics: which ranks a return's neighbourhood reaches)
     int    shard_world, shard_rank, shard_rows;   // ranks of a sharded map (1, 0, xy when unsharded): rank r owns storage rows [r*shard_rows, (r+1)*shard_rows)
     int    dbg;           // diagnostic build only
+    int    prof_on;       // diagnostic build only (GVOM_TRACE_STEPPROF): sampled waves record s_memtime stamps of their first 32 steps
     long   tl_words;      // diagnostic build only: words of per-wave records in tl; 8 summary words follow
     unsigned long long *tl;   // diagnostic build only (GVOM_TRACE_TIMELINE): 4 words per wave {start, set-up done, end, hardware id}
 };

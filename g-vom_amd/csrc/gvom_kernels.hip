@@ -326,7 +326,12 @@ __device__ __forceinline__ RaySetup ray_setup(const ScanParams &P, T x, T y, T z
 }
 
 // The step loop's wave-uniform constants, read from the kernel arguments ONCE per wave: twelve scalar registers that stay put.
-struct WalkConsts { uint32_t uxy, uzs, usxq, unseg, om0, om1, om2, o0, o1, o2, zpad, epoch; };
+struct WalkConsts { uint32_t uxy, uzs, usxq, unseg, om0, om1, om2, o0, o1, o2, zpad, epoch;
+#ifdef GVOM_DIAG
+    unsigned long long *prof;   // diagnostic build (GVOM_TRACE_STEPPROF): this wave's step profile block (nullptr: not sampled)
+    uint32_t prof_n;            // steps recorded so far
+#endif
+};
 __device__ __forceinline__ WalkConsts walk_consts(const ScanParams &P)
 {
     WalkConsts C;
@@ -371,7 +376,15 @@ __device__ __forceinline__ void walk_steps(const ScanParams &P, int lane, uint32
     // left neighbour's key: lane 0 has none and keeps this value, which no accumulator index equals
     uint32_t leftk = 0xFFFFFFFFu;
     unsigned long long cmask;
+#ifdef GVOM_DIAG
+    // step profile (sampled waves): s_memtime at the top of a step, in front of its head region, behind it, and at the loop's end
+    WalkConsts &CW = const_cast<WalkConsts &>(C);
+#define PROF_STAMP(k) do { if (CW.prof && CW.prof_n < 32u) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) CW.prof[CW.prof_n * 4u + (k)] = t_; } } while (0)
+#else
+#define PROF_STAMP(k) do { } while (0)
+#endif
     do {
+        PROF_STAMP(0);
         ++ju;
         // every lane computes (a finished ray's lanes produce values nobody uses): no divergent
         // region around the arithmetic
@@ -402,6 +415,7 @@ __device__ __forceinline__ void walk_steps(const ScanParams &P, int lane, uint32
         const unsigned long long hm = (lanes(leftk != Ls) | ~(cmask << 1) | (1ull << 32)) & cmask;   // heads of runs
         // a run ends in front of the next head or of the next lane without a step -- or with the half-wave
         const unsigned long long ends = ((hm | ~cmask) >> 1) | (1ull << 63) | (1ull << 31);
+        PROF_STAMP(1);
         if (__builtin_amdgcn_inverse_ballot_w64(hm) && !GVOM_DBG(P, 16)) {
             // memo: the (line, row-in-line) this lane added to last; a miss looks the line up
             // (or inserts it) and stamps the voxel's tile tag
@@ -427,8 +441,14 @@ __device__ __forceinline__ void walk_steps(const ScanParams &P, int lane, uint32
             __hip_atomic_fetch_add(&cnt3[ok ? hh * 16u + low4 : 1024u], run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (!ok) __hip_atomic_fetch_add(&total1[Ls], run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // table congested: direct add
         }
+        PROF_STAMP(2);
         alive = cmask & lanes(ju < cnt_run);                              // gvom.py:1127 (length test)
+        PROF_STAMP(3);
+#ifdef GVOM_DIAG
+        if (CW.prof) ++CW.prof_n;
+#endif
     } while (alive != 0ull);
+#undef PROF_STAMP
     j = ju;
     px_ = pxy.x; py_ = pxy.y;
     active = ((cmask >> lane) & 1ull) != 0ull && ju < cnt;
@@ -676,8 +696,14 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(8, 8))
 #pragma unroll
         for (int q = 0; q < 16; ++q) LC_ST(&lcc[q * 64 + lane], 0u);
     }
+    WalkConsts WC = walk_consts(P);
+#ifdef GVOM_DIAG
+    // (every 64th wave of the walking rows records the first 32 steps it takes: 4 stamps each, behind the per-wave records)
+    WC.prof = (P.tl && P.prof_on && (widx & 63) == 0 && row != P.ep_row) ? P.tl + P.tl_words + 8 + (widx >> 6) * 128 : nullptr;
+    WC.prof_n = 0;
+#endif
     trace_item<T, BIG>(P, X, in, stride, n, world, hit, total, mh, state, tags, counters, stat_sums, stat_base, stat_rowvox,
-                       row, bundle, lane, lck, lcc, widx, walk_consts(P));
+                       row, bundle, lane, lck, lcc, widx, WC);
 }
 
 // ------------------------------------------------------------------------------------------
