@@ -82,6 +82,7 @@ struct gvom_handle {
     int tune_prio = -1;                                 // gvom_set_tuning "prio" (-1: automatic)
     int tune_ilv = 0;                                   // gvom_set_tuning "interleave": sub-clouds per cloud (0: automatic, 1: off)
     int last_knobs[5] = {0, 0, 0, 0, 1};                // gvom_get_tuning: segs, period, ep_row, prio, interleave of the last scan
+    int64_t last_n = -1;                                // returns of the previous scan
     int64_t probe_n = -1; uint32_t probe_age = 0;       // layout probe (k_layout_probe): the length it last looked at, scans since
     int tune_fuse1 = 0;                                 // gvom_set_tuning "fuse1": 1 = the one-slot fusion through k_fuse4 as well (A/B)
     int tune_flag_kernel = 0;                           // gvom_set_tuning "flag_kernel": 1 = the combine's completion flag from a kernel of its own (round 3's form)
@@ -744,12 +745,17 @@ int scan_launch(gvom_handle *h, std::unique_lock<std::mutex> &lk, const void *de
     }
 #endif
     hipError_t le = hipSuccess;
-    if (h->tune_ilv == 0 && n >= 8192 && (n != h->probe_n || ++h->probe_age >= 32)) {
-        // layout probe: in front of k_trace (the caller may free the cloud as soon as this call has returned, i.e. once
-        // k_trace is done), on the first cloud of a new length and every 32nd scan after it; its answer serves LATER scans
-        h->probe_n = n; h->probe_age = 0;
-        le = gvom_launch_layout_probe(h->stream, P, dtype, dev_pts, stride_elems, n, 2, (unsigned long long *)(h->counters_host_dev + 8));
-        if (le != hipSuccess) { scan_abort(h); HIPCHK(h, le); }
+    if (h->tune_ilv == 0 && n >= 8192) {
+        // layout probe: only for clouds whose length is STABLE (the same as the previous scan's: a node that drops invalid
+        // returns hands over a different length every scan -- its sub-clouds do not start at multiples of n / K, nothing to find,
+        // nothing to pay), on the second cloud of a length and every 32nd scan after it; in front of k_trace (the caller may
+        // free the cloud as soon as this call has returned, i.e. once k_trace is done); its answer serves LATER scans
+        if (n == h->last_n && (n != h->probe_n || ++h->probe_age >= 32)) {
+            h->probe_n = n; h->probe_age = 0;
+            le = gvom_launch_layout_probe(h->stream, P, dtype, dev_pts, stride_elems, n, 2, (unsigned long long *)(h->counters_host_dev + 8));
+            if (le != hipSuccess) { scan_abort(h); HIPCHK(h, le); }
+        }
+        h->last_n = n;
     }
     le = gvom_launch_trace(h->stream, P, X, dtype, big, dev_pts, stride_elems, n,
                                       h->stats ? wpts.p : nullptr, h->hit, h->total, h->mh, st.state,

@@ -350,9 +350,10 @@ int gvom_host_timing(gvom_t *h, double us[8]);
  * "interleave": K = 2 .. 64 (a power of two that divides the number of returns) declares the cloud to be K equally long
  * sub-clouds behind one another -- K sensors at one place, K sweeps -- whose returns of equal position are neighbours in
  * space; the trace then puts those neighbours into neighbouring lanes of one wave (merged steps, shared accumulator lines:
- * 512^2 x 128, 4 x 262,144 returns: 11.5 M -> 4.1 M memory-side atomic requests, 549 -> 370 us).  0 (default): automatic -- a
- * probe inside the trace kernel looks for that structure in every cloud (64 sampled returns per candidate K <= 4) and the
- * next cloud of as many returns is traced accordingly; 1: off.  Only WHO traces which return changes, never a result.
+ * 512^2 x 128, 4 x 262,144 returns: 11.5 M -> 4.1 M memory-side atomic requests, 549 -> 355 us).  0 (default): automatic -- a
+ * one-wave probe kernel in front of the trace looks for that structure (64 sampled returns per candidate K <= 4) on the second
+ * cloud of a length and every 32nd after it, and the following clouds of that length are traced accordingly; clouds whose
+ * length changes from scan to scan are never probed; 1: off.  Only WHO traces which return changes, never a result.
  * "epoch_bias" (test hook) advances the 32-bit tile-epoch counter, e.g. to just below its wrap. */
 int gvom_set_tuning(gvom_t *h, const char *name, int value);
 /* The value the LAST scan ran with ("segs", "period", "ep_row", "prio", "interleave": what automatic resolved to). */

@@ -731,7 +731,7 @@ def test_sub_cloud_interleave_leaves_results_unchanged(gvom_mod):
 
 def test_layout_probe_finds_interleaved_sensors_and_nothing_else(gvom_mod):
     """Automatic interleave (the default): a probe inside k_trace looks at every cloud and the NEXT cloud of as many returns is
-    traced accordingly.  It must find the 4 sensors of the c4 cloud (and the sensor groups of a 16-sensor one), must not find
+    traced accordingly (clouds whose length changes from scan to scan are never probed).  It must find the 4 sensors of the c4 cloud (and the sensor groups of a 16-sensor one), must not find
     structure in a single sensor's scan or in random points, forgets its answer when the cloud's length changes -- and whatever
     it answers, the slots equal those of a mapper with the interleave switched off."""
     p4, multi = synth.config_inputs("c4", n_scans=2)
@@ -743,7 +743,7 @@ def test_layout_probe_finds_interleaved_sensors_and_nothing_else(gvom_mod):
         g, off = gvom_mod.Gvom(*prm), gvom_mod.Gvom(*prm)
         off.set_tuning("interleave", 1)
         used = []
-        for pc, ego, tf in clouds + [(clouds[0][0][:-64], clouds[0][1], clouds[0][2])]:
+        for pc, ego, tf in clouds + [clouds[0], (clouds[0][0][:-64], clouds[0][1], clouds[0][2])]:
             for m in (g, off):
                 m.process_pointcloud(pc, ego, tf)
             used.append(g.get_tuning("interleave"))
@@ -752,8 +752,9 @@ def test_layout_probe_finds_interleaved_sensors_and_nothing_else(gvom_mod):
                     ("index_buffer", "hit_count_buffer", "total_count_buffer", "min_height_buffer")]) for m in (g, off)]
             for x, y in zip(a, b):
                 assert np.array_equal(x, y)
-        # first cloud: nothing known yet; second: the probe's answer; third (another length): forgotten
-        assert used == [1, want, 1], (used, want)
+        # first cloud: nothing known; second (the same length: stable, the probe runs in front of it); third: the probe's answer;
+        # fourth (another length): forgotten
+        assert used == [1, 1, want, 1], (used, want)
 
 
 @pytest.mark.parametrize("occ_params", [(50, -10, 0), (12.5, -6.0, 1.5)])
