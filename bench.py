@@ -129,13 +129,13 @@ def pin_to_gpu_numa(device):
         return None
 
 
-def usable_cores():
+def usable_cores(cgroup_files=("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us")):
     """(cores this process can actually run on, how that was found): the CPUs of its affinity mask, capped by the cgroup's CPU
     quota -- a container that SEES 256 logical CPUs but holds a 16-CPU share is throttled beyond 16 busy threads (measured on
     the GPU pool: every loop of the all-core oracle, even a plain fill, takes 5-70x longer at 128 threads than at 16)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     how = "affinity mask: %d" % n
-    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+    for path in cgroup_files:
         try:
             with open(path) as f:
                 txt = f.read().split()
@@ -143,7 +143,7 @@ def usable_cores():
                 quota, period = txt[0], float(txt[1])
             else:
                 quota = txt[0]
-                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                with open(os.path.join(os.path.dirname(path), "cpu.cfs_period_us")) as f:
                     period = float(f.read().split()[0])
             if quota not in ("max", "-1") and float(quota) > 0:
                 q = max(1, int(float(quota) / period + 0.5))

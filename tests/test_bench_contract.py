@@ -101,6 +101,24 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert d["value"] > 50 * c["value"]
 
 
+def test_usable_cores_honours_the_cgroup_cpu_quota(tmp_path):
+    """cpu_baseline's "all cores" = the affinity mask capped by the container's CPU quota: the GPU box shows 256 logical CPUs and
+    holds 16 (cgroup v2 `cpu.max = 1600000 100000`); OpenMP threads beyond the quota are throttled, so they are not cores."""
+    import bench
+    mask = len(os.sched_getaffinity(0))
+    v2 = tmp_path / "cpu.max"
+    v2.write_text("200000 100000\n")
+    n, how = bench.usable_cores((str(v2),))
+    assert n == min(mask, 2) and (mask <= 2 or "quota: 2" in how)
+    v2.write_text("max 100000\n")
+    assert bench.usable_cores((str(v2),))[0] == mask
+    d = tmp_path / "cpu"; d.mkdir()
+    (d / "cpu.cfs_quota_us").write_text("-1\n"); (d / "cpu.cfs_period_us").write_text("100000\n")
+    assert bench.usable_cores((str(tmp_path / "missing"), str(d / "cpu.cfs_quota_us")))[0] == mask
+    (d / "cpu.cfs_quota_us").write_text("100000\n")
+    assert bench.usable_cores((str(d / "cpu.cfs_quota_us"),))[0] == 1
+
+
 def test_paced_stream_accounting_with_a_synthetic_tick():
     """bench.paced_stream (the offered-load mode behind --offered-hz): a tick that takes 2 ms against a 10 ms period meets every
     deadline with ~80 % idle time; one that takes 15 ms falls behind the schedule, and the latency -- measured from the
