@@ -561,8 +561,10 @@ def step_roofline(alg, res, config):
     a = sum(alg.values())
     meas = None
     # (the fusion kernel of the config: k_fuse1 for one-slot rings, k_fuse4 otherwise -- whichever the committed passes hold)
-    parts = [pmc_traffic(k, config) for k in ("k_trace", "k_encode")] + [pmc_traffic("k_fuse1", config) or pmc_traffic("k_fuse4", config)] + \
-            [pmc_traffic("k_map2d", config)]
+    import synth
+    one_slot = config in synth.CONFIGS and synth.CONFIGS[config][0][4] == 1
+    fuse = (pmc_traffic("k_fuse1", config) if one_slot else None) or pmc_traffic("k_fuse4", config)
+    parts = [pmc_traffic(k, config) for k in ("k_trace", "k_encode")] + [fuse, pmc_traffic("k_map2d", config)]
     if all(parts):
         meas = sum(p["bytes_per_launch"] for p in parts)
     return {"algorithmic_bytes": a, "frac_algorithmic": a / t / 1e9 / HBM_PEAK_GBS,
@@ -576,8 +578,12 @@ def roofline_of(alg, stages, profiled="m256"):
     null counter-derived fields rather than another workload's numbers (False / None: no counters at all)."""
     config = profiled if isinstance(profiled, str) else ("m256" if profiled else None)
     kern = {"trace": "k_trace", "encode": "k_encode", "fuse": "k_fuse4", "map2d": "k_map2d"}
-    if config and pmc_traffic("k_fuse1", config) and not pmc_traffic("k_fuse4", config):
-        kern["fuse"] = "k_fuse1"                         # one-slot rings (m256, c1, c2)
+    try:
+        import synth
+        if config and synth.CONFIGS[config][0][4] == 1 and pmc_traffic("k_fuse1", config):
+            kern["fuse"] = "k_fuse1"                     # one-slot rings (m256, c1, c2)
+    except (ImportError, KeyError):
+        pass
     ms = {s: v["median"] for s, v in stages.items()}
     dom = max(ms, key=lambda s: ms[s])
     achieved = alg[dom] / (ms[dom] * 1e-3) / 1e9
