@@ -218,6 +218,28 @@ def test_sharded_bench_rehearsal_with_two_rank_processes_on_one_gpu():
 
 
 @pytest.mark.gpu
+def test_sharded_bench_under_the_drivers_launcher():
+    """The driver starts the N > 1 bench as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...`: every rank process gets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the launcher
+    (bench.py spawns nothing then), the ranks find each other through the shared-memory rendezvous named after the port and the
+    launcher's pid, and rank 0 prints the one JSON line.  Rehearsed with both ranks on the one GPU (--share-device, peer copies)."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, GVOM_COMM_TIMEOUT_S="120", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "GVOM_JOB_NONCE"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-device", "--steps", "30",
+                        "--warmup", "10", "--no-cpu"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout.decode()[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 30 and d["sharded_equals_unsharded"] is True
+    assert [r["rank"] for r in d["ranks"]] == [0, 1] and d["communicator_ranks"] == 2
+
+
+@pytest.mark.gpu
 def test_sharded_bench_falls_back_to_peer_copies_when_rccl_refuses():
     """The N > 1 leg with its default transport (AUTO) where RCCL cannot start -- two ranks on one device: both ranks agree
     on peer copies, the line says so, the maps are verified, and the rank processes leave with exit code 0."""
