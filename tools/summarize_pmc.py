@@ -35,7 +35,13 @@ def trace_avgs():
     out = {}
     for f in files:
         for r in csv.DictReader(open(f)):
-            out[short(r["Name"])] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3}
+            # (template instantiations of one kernel -- k_fuse4<2>, k_fuse4<4> -- share a name here: call-weighted mean)
+            k, c, a = short(r["Name"]), int(r["Calls"]), float(r["AverageNs"]) / 1e3
+            if k in out:
+                tot = out[k]["calls"] + c
+                out[k] = {"calls": tot, "avg_us": (out[k]["avg_us"] * out[k]["calls"] + a * c) / tot}
+            else:
+                out[k] = {"calls": c, "avg_us": a}
     return out
 
 
