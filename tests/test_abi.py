@@ -91,32 +91,20 @@ def test_synthetic_inputs_are_seeded_and_shaped():
     assert s1[0][0].shape == (50000, 3) and s1[0][0].dtype == np.float64
 
 
-def test_hot_kernels_use_no_scratch_and_keep_their_occupancy(tmp_path):
+def test_hot_kernels_use_no_scratch_and_keep_their_occupancy():
     """The code objects inside the built library: the four hot kernels (every instantiation) must not touch scratch memory, and
     k_trace must fit 8 waves per SIMD (<= 64 VGPRs).  Round 4 lost 9 us of k_trace's 40 to an innocent-looking helper inlined
     into it -- 20 bytes of scratch, set up by every wave of the launch -- which no functional test can see."""
-    import subprocess
+    import sys
     import gvom
-    llvm = "/opt/rocm/lib/llvm/bin"
-    if not os.path.exists(os.path.join(llvm, "clang-offload-bundler")):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_regs
+    if not os.path.exists(os.path.join(kernel_regs.LLVM, "clang-offload-bundler")):
         pytest.skip("no ROCm LLVM tools")
-    lib = gvom.library_path()
-    fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "dev.co")
-    subprocess.check_call([os.path.join(llvm, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, lib, str(tmp_path / "discard.so")])
-    subprocess.check_call([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
-                           "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
-    notes = subprocess.check_output([os.path.join(llvm, "llvm-readelf"), "--notes", co]).decode()
-    kernels, cur = {}, None
-    for line in notes.splitlines():
-        t = line.strip()
-        if t.startswith(".name:"):
-            cur = t.split(":", 1)[1].strip()
-            kernels[cur] = {}
-        elif cur and ":" in t and t.split(":")[0] in (".private_segment_fixed_size", ".vgpr_count", ".sgpr_count"):
-            kernels[cur][t.split(":")[0]] = int(t.split(":")[1])
+    kernels = kernel_regs.kernels(gvom.library_path())
     hot = {k: v for k, v in kernels.items() if any(n in k for n in ("7k_trace", "8k_encode", "7k_fuse4", "7k_fuse1", "6k_fuse", "7k_map2d"))}
     assert len(hot) >= 12, sorted(kernels)
     for k, v in hot.items():
-        assert v[".private_segment_fixed_size"] == 0, (k, v)
+        assert v["scratch"] == 0, (k, v)
         if "7k_trace" in k:
-            assert v[".vgpr_count"] <= 64, (k, v)
+            assert v["vgpr"] <= 64, (k, v)
