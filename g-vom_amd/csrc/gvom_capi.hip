@@ -45,6 +45,7 @@ struct Slot {                                  // one scan in sparse form
     int64_t origin[3] = {0, 0, 0};
     int64_t count = 0;
     bool filled = false;
+    bool has_code16 = false;                   // the last encode wrote the 16-bit codes (k_fuse4 may read this slot)
     bool stats_valid = false;
     gvom_scan_stats stats = {0, 0, 0, 0};
 };
@@ -129,6 +130,24 @@ struct gvom_handle {
     MapDesc *descs_dev = nullptr, *descs_host = nullptr;
     uint32_t *blockcounts = nullptr;                    // per-workgroup occupied counts of k_fuse
     int fuse_blocks = 0;
+    int cnt_blocks = 0;                                 // entries of blockcounts the last fusion wrote (k_map2d sums them)
+    // EAGER FUSION (one-slot rings: buffer_size 1, unsharded, no statistics, xy % 16 == 0).  The scan launches k_encfuse
+    // behind k_trace instead of k_encode: the slot is encoded AND fused with the previous map in one pass over the
+    // accumulators, into the spare fused buffer, a spare height buffer and a spare count array -- speculating that the
+    // next call is combine_maps (the reference node's pattern: one combine per scan).  fuse_impl adopts the result (swaps
+    // the spares in) iff nothing has changed since; otherwise it is dropped and the combine runs k_fuse1 over the encoded
+    // slot as before.  Same results either way (tests: eager on / off / mixed call orders).
+    double *hmaps2 = nullptr;                           // spare [sy][3][sx] buffer (k_encfuse's column tails)
+    uint32_t *blockcounts2 = nullptr;
+    bool spec_valid = false;                            // a speculative fusion is waiting to be adopted
+    int spec_nxt = 0, spec_slot = 0, spec_blocks = 0;
+    uint32_t spec_epoch = 0;
+    int64_t spec_origin[3] = {0, 0, 0};
+    int tune_eager = -1;                                // gvom_set_tuning "eager": 0 off, 1 always, -1 automatic (off after 3 wasted in a row)
+    int eager_waste = 0;                                // speculations dropped in a row (saturates at 4)
+    int eager_stat[2] = {0, 0};                         // adopted / dropped since creation (gvom_get_tuning "eager_adopted" / "eager_dropped")
+    bool last_scan_spec = false;                        // the last accepted scan went through k_encfuse
+    bool fresh_scan = false;                            // a scan has been committed and no combine has looked at it yet
 
     double *hmaps = nullptr;                            // [sy][3][sx]: height | inferred height | positive density
     double *height = nullptr, *inferred = nullptr;      // = hmaps, hmaps + xy  (row stride hs = 3*xy)
@@ -502,6 +521,12 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, b
     h->fuse_blocks = ((xy + 63) / 64) * (h->sy_hi - h->sy_lo);
     CK(hipMalloc((void **)&h->blockcounts, (size_t)(h->fuse_blocks > 0 ? h->fuse_blocks : 1) * 4));
     CK(hipMemsetAsync(h->blockcounts, 0, (size_t)(h->fuse_blocks > 0 ? h->fuse_blocks : 1) * 4, h->stream));
+    h->cnt_blocks = h->fuse_blocks;
+    if (!sharded && params->buffer_size == 1 && !h->stats && xy % 16 == 0 && zs >= 4) {       // eager fusion possible
+        CK(hipMalloc((void **)&h->blockcounts2, (size_t)(h->fuse_blocks > 0 ? h->fuse_blocks : 1) * 4));
+        CK(hipMemsetAsync(h->blockcounts2, 0, (size_t)(h->fuse_blocks > 0 ? h->fuse_blocks : 1) * 4, h->stream));
+        CK(hipMalloc((void **)&h->hmaps2, h->cells2d * 24));
+    }
     h->hs = 3 * xy;
     if (sharded) CK(pool_get(exportable_size(h->cells2d * 24), (void **)&h->hmaps, &h->fixed_gen[2]));
     else CK(hipMalloc((void **)&h->hmaps, h->cells2d * 24));
@@ -666,6 +691,60 @@ bool wait_published(gvom_handle *h, std::unique_lock<std::mutex> &lk, volatile u
     return ok;
 }
 
+// what a fusion into the frame `origin` needs besides its sources (fuse_impl, eager_launch)
+void fill_fuse_frame(const gvom_handle *h, const int64_t origin[3], FuseParams &P)
+{
+    const gvom_params &p = h->prm;
+    memset(&P, 0, sizeof P);
+    P.xy = p.xy_size; P.zs = p.z_size;
+    P.om[0] = (int)floor_mod(origin[0], p.xy_size);
+    P.om[1] = (int)floor_mod(origin[1], p.xy_size);
+    P.om[2] = (int)floor_mod(origin[2], p.z_size);
+    P.sy_lo = h->sy_lo; P.sy_hi = h->sy_hi;
+    P.nseg = h->nseg;
+    P.hs = h->hs;
+    for (int k = 0; k < 3; ++k) { P.origin[k] = (double)origin[k]; P.ego[k] = h->ego[k]; }
+    P.xy_res = p.xy_resolution; P.z_res = p.z_resolution;
+    P.radius2 = p.robot_radius * p.robot_radius;
+    P.ground_to_lidar_height = p.ground_to_lidar_height;
+}
+
+// k_encfuse behind k_trace (eager fusion, see gvom_handle::hmaps2): the staging slot encoded and fused with the previous
+// map into the SPARE fused / height / count buffers.  Nothing the handle's readers look at changes before fuse_impl adopts it.
+int eager_launch(gvom_handle *h, const ScanParams &P, Slot &st, const int64_t origin[3], uint32_t seq)
+{
+    const gvom_params &p = h->prm;
+    const int nxt = h->has_combined ? 1 - h->cur : 0;
+    Fused &F = h->fused[nxt];
+    const Fused *prev = (h->has_combined && h->fused[h->cur].valid) ? &h->fused[h->cur] : nullptr;
+    FuseParams FP;
+    fill_fuse_frame(h, origin, FP);
+    FP.nslots = 1; FP.has_prev = prev ? 1 : 0;
+    MapDesc pd;
+    memset(&pd, 0, sizeof pd);
+    if (prev) {
+        pd.state = prev->state; pd.rows = (const uint4 *)prev->rows.p;
+        pd.d[0] = clamp_delta(origin[0] - prev->origin[0], p.xy_size);
+        pd.d[1] = clamp_delta(origin[1] - prev->origin[1], p.xy_size);
+        pd.d[2] = clamp_delta(origin[2] - prev->origin[2], p.z_size);
+        pd.epoch = prev->epoch; pd.tags = prev->tags;
+    }
+    int nw, nblocks; size_t row_cap;
+    gvom_encfuse_shape(p.xy_size, p.z_size, &nw, &nblocks, &row_cap);
+    if (row_cap >= 2147483648ull) { h->err = "fused row space exceeds 31 bits"; return GVOM_ERR_CAPACITY; }
+    int rc;
+    if ((rc = ensure(h, F.rows, row_cap * 16))) return rc;
+    F.valid = false;                                       // (the spare buffer: nobody reads it as a map)
+    FP.epoch = ++h->epoch;
+    HIPCHK(h, gvom_launch_encfuse(h->stream, P, FP, pd, h->hit, h->total, h->mh, st.state, (uint4 *)st.crows.p, st.tags,
+                                  F.state, (uint4 *)F.rows.p, F.tags, h->blockcounts2, h->hmaps2, h->hmaps2 + p.xy_size,
+                                  h->counters, (unsigned long long *)h->counters_host_dev, seq));
+    h->spec_valid = true; h->spec_nxt = nxt; h->spec_slot = h->staging; h->spec_blocks = nblocks; h->spec_epoch = FP.epoch;
+    h->spec_origin[0] = origin[0]; h->spec_origin[1] = origin[1]; h->spec_origin[2] = origin[2];
+    h->last_scan_spec = true;
+    return GVOM_OK;
+}
+
 int scan_launch(gvom_handle *h, std::unique_lock<std::mutex> &lk, const void *dev_pts, int64_t n, int64_t stride_elems,
                 int dtype, const double *tf, bool shard_local = false)
 {
@@ -791,10 +870,21 @@ int scan_launch(gvom_handle *h, std::unique_lock<std::mutex> &lk, const void *de
         h->pending_n = n;
         return GVOM_OK;
     }
-    le = gvom_launch_encode(h->stream, P, h->hit, h->total, h->mh, st.state, st.code16, (uint4 *)st.crows.p,
-                            st.tags, h->counters,
-                            (unsigned long long *)h->counters_host_dev, seq, h->resident_blocks);
-    if (le != hipSuccess) { scan_abort(h); HIPCHK(h, le); }
+    // one-slot rings: encode + fuse in one pass, speculating that combine_maps comes next (see gvom_handle::hmaps2)
+    const bool eager = h->hmaps2 && h->tune_eager != 0 && (h->tune_eager == 1 || h->eager_waste < 3) && !gvom_diag_env("GVOM_TRACE_DEBUG");
+    h->last_scan_spec = false;
+    if (eager) {
+        if ((rc = eager_launch(h, P, st, origin, seq))) { scan_abort(h); return rc; }
+        st.has_code16 = false;
+    } else {
+        // the 16-bit codes are read by k_fuse4 only: a one-slot ring fuses through k_fuse1 (unless the A/B knob says otherwise)
+        const bool codes = st.code16 && (p.buffer_size > 1 || h->tune_fuse1 == 1 || h->sharded);
+        le = gvom_launch_encode(h->stream, P, h->hit, h->total, h->mh, st.state, codes ? st.code16 : nullptr, (uint4 *)st.crows.p,
+                                st.tags, h->counters,
+                                (unsigned long long *)h->counters_host_dev, seq, h->resident_blocks);
+        if (le != hipSuccess) { scan_abort(h); HIPCHK(h, le); }
+        st.has_code16 = codes;
+    }
     if (h->profiling) { HIPCHK(h, hipEventRecord(h->ev[2], h->stream)); h->ev_scan = true; }
     if (h->stats && (rc = enqueue_scan_stats(h, P, dtype, st, n, n, nullptr, 0))) return rc;
     HT(h, 0, t0);                                        // scan: launches
@@ -834,12 +924,13 @@ void scan_commit(gvom_handle *h, bool accept)
     if (!h->pending) return;
     h->pending = false;
     h->stats_prev_committed = accept;
-    if (!accept) return;                                   // gvom.py:148-150: ring untouched
+    if (!accept) { h->spec_valid = false; h->last_scan_spec = false; return; }   // gvom.py:148-150: ring untouched (a speculative fusion of it is dropped)
     const int b = h->buffer_index;                         // gvom.py:163-175
     const int old = h->ring[b];
     h->ring[b] = h->staging;
     h->staging = old;
     h->slots[h->ring[b]].filled = true;
+    h->fresh_scan = true;
     h->slots[old].filled = false;
     h->last_buffer_index = b;
     h->buffer_index = (b + 1 >= h->prm.buffer_size) ? 0 : b + 1;
@@ -848,6 +939,7 @@ void scan_commit(gvom_handle *h, bool accept)
 int renumber_epochs(gvom_handle *h)
 {
     HIPCHK(h, sync_streams(h));
+    h->spec_valid = false;                                 // (its fused tiles carry an epoch of the old numbering)
     uint32_t next = 0;
     for (size_t k = 0; k < h->slots.size(); ++k) {
         Slot &sl = h->slots[k];
@@ -902,6 +994,11 @@ int process_impl(gvom_handle *h, const void *xyz, bool on_device, int64_t n, int
     // gvom_shard_scan_merge): k_trace's additions to this rank's rows were never encoded or zeroed
     if (h->pending && h->sharded) scan_abort(h);
     h->pending = false;
+    if (h->spec_valid) {                                   // a scan behind a scan: the speculative fusion of the first is dropped
+        h->spec_valid = false;
+        if (h->eager_waste < 4) ++h->eager_waste;
+        ++h->eager_stat[1];
+    }
     if (h->sharded && !defer) { h->err = "a sharded handle scans through gvom_shard_scan_local / gvom_shard_scan_merge"; return GVOM_ERR_INVALID; }
     if (n == 0 && !defer) return GVOM_EMPTY_CLOUD;                     // gvom.py:107-109 (a rank's share of a sharded scan may be empty)
     const void *dev = xyz;
@@ -959,18 +1056,41 @@ int fuse_impl(gvom_handle *h, hipStream_t on = nullptr)
     if (!last.filled) return GVOM_EMPTY_BUFFER;                        // gvom.py:179-181
     // before any map descriptor below copies an epoch
     if (h->epoch >= 0xFFFFFF00u) { int rc0 = renumber_epochs(h); if (rc0) return rc0; }
+    if (h->spec_valid && !on && h->spec_slot == h->ring[h->last_buffer_index] && h->spec_nxt == (h->has_combined ? 1 - h->cur : 0)) {
+        // eager fusion: k_encfuse has (or will have, in stream order) written exactly what this call would compute -- the one
+        // slot, the previous map and the ego are what they were when the scan launched it.  Adopt: swap the spares in.
+        Fused &S = h->fused[h->spec_nxt];
+        S.origin[0] = h->spec_origin[0]; S.origin[1] = h->spec_origin[1]; S.origin[2] = h->spec_origin[2];
+        S.epoch = h->spec_epoch;
+        S.valid = true;
+        std::swap(h->hmaps, h->hmaps2);
+        h->height = h->hmaps; h->inferred = h->hmaps + h->prm.xy_size;
+        std::swap(h->blockcounts, h->blockcounts2);
+        h->cnt_blocks = h->spec_blocks;
+        h->cur = h->spec_nxt;
+        h->has_combined = true;
+        h->maps_valid = false;
+        h->spec_valid = false;
+        h->eager_waste = 0;
+        ++h->eager_stat[0];
+        h->last_scan_spec = false; h->fresh_scan = false;
+        h->stage_ms[3] = 0.0f;                             // (the fusion's time is inside the scan's second kernel)
+        return GVOM_OK;
+    }
+    if (h->spec_valid) { h->spec_valid = false; ++h->eager_stat[1]; }
+    else if (h->fresh_scan && !h->last_scan_spec && h->eager_waste > 0) --h->eager_waste;   // a combine right behind a plainly encoded scan: the pattern is coming back
+    h->last_scan_spec = false;
+    h->fresh_scan = false;
+    h->cnt_blocks = h->fuse_blocks;
     if (!on) HIPCHK(h, join_map_stream(h));
     const int nxt = h->has_combined ? 1 - h->cur : 0;
     Fused &F = h->fused[nxt];
     const Fused *prev = (h->has_combined && h->fused[h->cur].valid) ? &h->fused[h->cur] : nullptr;
     F.origin[0] = last.origin[0]; F.origin[1] = last.origin[1]; F.origin[2] = last.origin[2];
     FuseParams P;
-    memset(&P, 0, sizeof P);
-    P.xy = p.xy_size; P.zs = p.z_size;
-    P.om[0] = (int)floor_mod(F.origin[0], p.xy_size);
-    P.om[1] = (int)floor_mod(F.origin[1], p.xy_size);
-    P.om[2] = (int)floor_mod(F.origin[2], p.z_size);
+    fill_fuse_frame(h, F.origin, P);
     int ns = 0;
+    bool all_codes = true;
     for (int i = 0; i < p.buffer_size; ++i) {                          // slot order, gvom.py:198
         const Slot &s = h->slots[h->ring[i]];
         if (!s.filled) continue;
@@ -981,6 +1101,7 @@ int fuse_impl(gvom_handle *h, hipStream_t on = nullptr)
         d.d[2] = clamp_delta(F.origin[2] - s.origin[2], p.z_size);
         d.epoch = s.epoch; d.tags = s.tags; d.metrics = h->stats ? s.metrics.p : nullptr;
         d.code16 = s.code16;
+        all_codes = all_codes && s.has_code16;
     }
     P.nslots = ns;
     P.has_prev = prev ? 1 : 0;
@@ -993,19 +1114,16 @@ int fuse_impl(gvom_handle *h, hipStream_t on = nullptr)
         d.epoch = prev->epoch; d.tags = prev->tags; d.metrics = h->stats ? prev->metrics.p : nullptr;
         d.code16 = nullptr;
     }
-    P.sy_lo = h->sy_lo; P.sy_hi = h->sy_hi;
     P.nz = choose_nz(p.z_size, &P.zc, &P.cpw);
     P.dbg = gvom_diag_env("GVOM_FUSE_DEBUG");
     // one slot in the ring (buffer_size 1, or a ring that has only just begun): k_fuse1 -- up to 8 waves per column block, 2
     // chunks per wave where the grid is high enough (a shorter chain of dependent round trips per wave)
-    if (ns == 1 && P.zc == 16 && p.xy_size % 4 == 0 && h->tune_fuse1 != 1 && !(P.dbg & 8)) {
+    if (ns == 1 && P.zc == 16 && p.xy_size % 4 == 0 && (h->tune_fuse1 != 1 || !all_codes) && !(P.dbg & 8)) {
         const int nchunks = (p.z_size + 15) / 16;
         int nz = nchunks < 8 ? nchunks : 8;
         int cpw = (nchunks + nz - 1) / nz;
         if (cpw <= 4) { P.one_slot = 1; P.nz = nz; P.cpw = cpw; }
     }
-    P.nseg = h->nseg;
-    P.hs = h->hs;
     F.epoch = ++h->epoch;
     P.epoch = F.epoch;
     // every wave of k_fuse owns a static range of 64*zc compact rows (no global reservation)
@@ -1014,10 +1132,6 @@ int fuse_impl(gvom_handle *h, hipStream_t on = nullptr)
     int rc;
     if ((rc = ensure(h, F.rows, row_cap * 16))) return rc;
     if (h->stats && (rc = ensure(h, F.metrics, row_cap * 40))) return rc;
-    for (int k = 0; k < 3; ++k) { P.origin[k] = (double)F.origin[k]; P.ego[k] = h->ego[k]; }
-    P.xy_res = p.xy_resolution; P.z_res = p.z_resolution;
-    P.radius2 = p.robot_radius * p.robot_radius;
-    P.ground_to_lidar_height = p.ground_to_lidar_height;
     const int nsrc = ns + (prev ? 1 : 0);
     // the previous k_fuse_stats reads (as its "previous map") the fused buffer this fusion writes, and the descriptor
     // table this call refills
@@ -1091,7 +1205,7 @@ int map2d_impl(gvom_handle *h, bool gathered, bool publish, char *out_dev, bool 
     HIPCHK(h, gvom_launch_map2d(ms, P, F.state, F.tags, (const uint4 *)F.rows.p,
                                 h->height, h->inferred, h->slope_x,
                                 h->slope_y, h->rough, h->guessed, o_pos, o_neg, o_rgh, o_vis,
-                                h->blockcounts, h->fuse_blocks,
+                                h->blockcounts, h->cnt_blocks,
                                 publish ? (unsigned long long *)(h->counters_host_dev + 2) : nullptr));
     if (h->profiling) { HIPCHK(h, hipEventRecord(h->ev[7], ms)); h->ev_map = true; }
     h->maps_valid = true;
@@ -1222,7 +1336,7 @@ VIS void gvom_destroy(gvom_t *h)
     fb(h->in_pts); fb(h->world_pts[0]); fb(h->world_pts[1]); fb(h->tl);
     hipFree(h->counters); if (h->counters_host) hipHostFree(h->counters_host);
     hipFree(h->descs_dev); if (h->descs_host) hipHostFree(h->descs_host);
-    hipFree(h->blockcounts);
+    hipFree(h->blockcounts); hipFree(h->blockcounts2); hipFree(h->hmaps2);
     hipFree(h->hmaps); hipFree(h->slope_x); hipFree(h->slope_y);
     hipFree(h->rough); hipFree(h->guessed);
     if (h->out_host) hipHostFree(h->out_host);
@@ -1420,6 +1534,7 @@ VIS int gvom_shard_scan_merge(gvom_t *h, const int64_t *recv_quads, const int64_
                                        st.tags, h->counters,
                                        (unsigned long long *)h->counters_host_dev, seq, h->resident_blocks);
     if (le != hipSuccess) { scan_abort(h); HIPCHK(h, le); }
+    st.has_code16 = st.code16 != nullptr;
     if (h->profiling) { HIPCHK(h, hipEventRecord(h->ev[2], h->stream)); h->ev_scan = true; }
     if (h->stats) {
         // this rank's own returns (all of them: a return outside its rows can still reach into them) and the ones the
@@ -2038,6 +2153,7 @@ VIS int gvom_set_tuning(gvom_t *h, const char *name, int value)
     else if (!strcmp(name, "interleave")) h->tune_ilv = value;
     else if (!strcmp(name, "flag_kernel")) h->tune_flag_kernel = value;
     else if (!strcmp(name, "fuse1")) h->tune_fuse1 = value;
+    else if (!strcmp(name, "eager")) { h->tune_eager = value; h->eager_waste = 0; }
     else if (!strcmp(name, "churn")) h->tune_churn = value;
     else if (!strcmp(name, "exported")) h->exported = value != 0;       // (set by the peer transport, gvom_comm.hip)
 
@@ -2053,6 +2169,8 @@ VIS int gvom_get_tuning(gvom_t *h, const char *name, int *value)
     static const char *const names[5] = {"segs", "period", "ep_row", "prio", "interleave"};
     for (int k = 0; k < 5; ++k)
         if (!strcmp(name, names[k])) { *value = h->last_knobs[k]; return GVOM_OK; }
+    if (!strcmp(name, "eager_adopted")) { *value = h->eager_stat[0]; return GVOM_OK; }
+    if (!strcmp(name, "eager_dropped")) { *value = h->eager_stat[1]; return GVOM_OK; }
     return GVOM_ERR_INVALID;
 }
 

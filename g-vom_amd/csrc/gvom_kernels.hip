@@ -268,8 +268,10 @@ __device__ __forceinline__ void endpoint_commit(const ScanParams &P, int lane, l
     if (ingrid && mbits && !GVOM_DBG(P, 4)) atomicMax(&mh[A], mbits);
     if (ehead && !GVOM_DBG(P, 4)) {
         const uint32_t run = (uint32_t)__ffsll((long long)~((followers >> lane) >> 1));   // 1 + followers
+        // ONE add per run: the endpoint's own `total += 1` (gvom.py:1090) is not accumulated -- it always equals its
+        // `hit += 1` (gvom.py:1089), so k_encode adds hit to the ray passes instead (two memory-side requests per run
+        // head and line instead of three)
         atomicAdd(&hit[A], run);
-        atomicAdd(&total[A], run);
         tags[(L / P.xy) * P.nseg + ((L % P.xy) >> 6)] = P.epoch;   // stamp the tile (idempotent)
         // the voxel's compact row = this return's.  Several runs (other waves) may end in the same
         // voxel: the last store wins, every candidate is a valid, unique row.
@@ -912,9 +914,10 @@ __global__ __launch_bounds__(ENC_T) void k_encode(const ScanParams P, uint32_t t
             const uint4 hv = *reinterpret_cast<const uint4 *>(hit + A0);
             const uint4 tv = *reinterpret_cast<const uint4 *>(total + A0);
             if (!dirty) continue;
-            const uint32_t h[4] = {hv.x, hv.y, hv.z, hv.w}, t[4] = {tv.x, tv.y, tv.z, tv.w};
+            // total = ray passes (k_trace's steps) + the endpoints' own count, which k_trace leaves in `hit` alone (endpoint_commit)
+            const uint32_t h[4] = {hv.x, hv.y, hv.z, hv.w}, t[4] = {tv.x + hv.x, tv.y + hv.y, tv.z + hv.z, tv.w + hv.w};
             int32_t st[4];
-            const uint32_t any_h = h[0] | h[1] | h[2] | h[3], any_t = t[0] | t[1] | t[2] | t[3];
+            const uint32_t any_h = h[0] | h[1] | h[2] | h[3], any_t = tv.x | tv.y | tv.z | tv.w;
 #pragma unroll
             for (int i = 0; i < 4; ++i) st[i] = -(int32_t)t[i] - 1;
             if (any_h) {                                 // rare: an occupied voxel; its row was left in state[] by k_trace
@@ -939,7 +942,7 @@ __global__ __launch_bounds__(ENC_T) void k_encode(const ScanParams P, uint32_t t
                 uint32_t cd[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) cd[i] = st[i] >= 0 ? 0xffffu : min(t[i], 0xffffu);
-                *reinterpret_cast<uint2 *>(code16 + L0) = make_uint2(cd[0] | (cd[1] << 16), cd[2] | (cd[3] << 16));
+                if (code16) *reinterpret_cast<uint2 *>(code16 + L0) = make_uint2(cd[0] | (cd[1] << 16), cd[2] | (cd[3] << 16));   // (nullptr: no k_fuse4 will read this slot)
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) if (sx0 + i < (uint32_t)xy) state[L0 + i] = st[i];
@@ -1767,6 +1770,226 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         height[(size_t)sy * P.hs + sx] = hval;
         inferred[(size_t)sy * P.hs + sx] =
             (zf != INT_MAX) ? ((double)zf + P.origin[2]) * P.z_res : -1000.0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_encfuse: k_encode + k_fuse1 in ONE pass, for mappers with a ONE-slot ring (buffer_size = 1: the headline 256^3
+// config, c1, c2), launched right behind k_trace (gvom_capi.hip, "eager fusion").  It reads the scan's accumulators
+// once and writes
+//   * the ring slot exactly as k_encode does (state + compact rows; gvom.py:1154-1168, 1303-1329) and zeroes the
+//     accumulators -- a later combine without a new scan, the debug reads and the statistics still find the slot;
+//   * the fusion of that slot with the previous fused map (gvom.py:943-968 for the one slot, :972-997, :910-912),
+//     fused state / rows / tile tags, as k_fuse1 does;
+//   * the column tails height / inferred height (gvom.py:525-554).
+// The two-pass form reads the accumulators, writes the slot's states, reads them back with the previous map's and
+// writes the fused ones (72.5 + 56.9 MB in two launches on the 256^3 grid); here the slot's states never come back.
+// The scan's window IS the fused window (the fused frame is the newest slot's, gvom.py:184), so only the previous
+// map needs the shifted-window test.
+//
+// Workgroup = a QUAD COLUMN BLOCK: 16 sx x 4 storage rows (sy = 4Q .. 4Q+3) x all z, NW waves.  Lane (zl = lane >> 4,
+// p = (lane >> 2) & 3, r = lane & 3) owns the 4 voxels sx = 16 bx + 4 p .. + 3 of row 4Q + r at level 4 (it NW + w) + zl:
+// its quarter of a 4x4 accumulator patch line (a wave instruction = 4 levels x 4 whole lines = 4 x 256 B), 16 bytes
+// of every state array.  A lane owns its 4 COLUMNS for all the levels its wave visits: the column tails are
+// lane-private minima, combined over zl and over the waves once, at the end.  Four workgroups share a 64-voxel tile,
+// so a tile that is live in a source is written and stamped whole by each of them (never "only if it has content").
+// The two workgroups that share the 128-byte lines of the state arrays get neighbouring dispatch slots of ONE XCD
+// (block ids 8 apart; speed only).
+// ------------------------------------------------------------------------------------------
+#define ENCFUSE_MAXIT 8                                    // wave iterations whose tile tags are fetched together
+__global__ __launch_bounds__(512) void k_encfuse(
+    const ScanParams P, const FuseParams F, const MapDesc prev, uint32_t *hit, uint32_t *total, uint32_t *mh,
+    int32_t *state, uint4 *crows, const uint32_t *__restrict__ stags, int32_t *fstate, uint4 *frows, uint32_t *ftags,
+    uint32_t *blockcounts, double *height, double *inferred, uint32_t *counters, unsigned long long *host_flag, uint32_t seq)
+{
+    __shared__ unsigned long long s_zh[8][WAVE];            // per wave and column: min of (window z << 32 | min-height bits) over occupied voxels
+    __shared__ uint32_t s_zf[8][WAVE];                      // per wave and column: lowest observed-free window z
+    __shared__ uint32_t s_cnt[8];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // k_trace has completed: {seq, any-in-grid} to the spinning host, as k_encode's first thread does
+        const uint32_t any = counters[GVOM_CNT_INGRID] ? 0x80000000u : 0u;
+        counters[GVOM_CNT_INGRID] = 0;
+        __hip_atomic_store(host_flag, ((unsigned long long)seq << 32) | any, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nw = (int)(blockDim.x >> 6);
+    const int xy = P.xy, zs = P.zs, nseg = P.nseg;
+    const uint32_t nbx = (uint32_t)xy >> 4;
+    // dispatch slot -> column block: ids b and b + 8 share an XCD (observed round-robin placement), so the two blocks
+    // that split a 32-sx run (the 128-byte lines of state / fstate) are ids 8 apart
+    uint32_t M = blockIdx.x;
+    if ((gridDim.x & 15u) == 0u) { const uint32_t slot = M >> 3, xcd = M & 7u; M = ((slot >> 1) << 4) + (xcd << 1) + (slot & 1u); }
+    const uint32_t bx = M % nbx, Q = M / nbx;
+    const int zl = lane >> 4, p4 = (lane >> 2) & 3, r = lane & 3;
+    const uint32_t sx0 = bx * 16u + (uint32_t)p4 * 4u, sy = Q * 4u + (uint32_t)r;
+    const uint32_t seg = sx0 >> 6;
+    const int y = wrap_sub((int)sy, F.om[1], xy);
+    const bool has_prev = F.has_prev != 0;
+    const int dpx = has_prev ? prev.d[0] : 0, dpy = has_prev ? prev.d[1] : 0, dpz = has_prev ? prev.d[2] : 0;
+    uint32_t okp = 0;                                       // bit i: the previous map's window contains column i of this lane
+    {
+        const bool yp = has_prev && y + dpy >= 0 && y + dpy < xy;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int xw = wrap_sub((int)sx0 + i, F.om[0], xy);
+            if (yp && xw + dpx >= 0 && xw + dpx < xy) okp |= 1u << i;
+        }
+    }
+    // (no previous map: its pointers are null -- the unconditional dummy loads below then read the slot's arrays)
+    const gptr_i32 sp = has_prev ? (gptr_i32)prev.state : (gptr_i32)state;
+    const gptr_u32 ptags = has_prev ? (gptr_u32)prev.tags : (gptr_u32)stags;
+    const gptr_v4u prows = has_prev ? (gptr_v4u)prev.rows : (gptr_v4u)crows;
+    const int niter = (zs + 4 * nw - 1) / (4 * nw);         // wave iterations (4 levels each)
+    // every wave numbers its occupied voxels inside a static range of the fused compact rows (as k_fuse1)
+    const uint32_t rbase = (M * (uint32_t)nw + (uint32_t)w) * (uint32_t)(niter * 256);
+    uint32_t running = 0;
+    unsigned long long zh[4];
+    uint32_t zf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { zh[i] = ((unsigned long long)INT_MAX << 32) | 0x3f800000ull; zf[i] = (uint32_t)INT_MAX; }
+
+    for (int it0 = 0; it0 < niter; it0 += ENCFUSE_MAXIT) {
+        // tile tags of up to ENCFUSE_MAXIT iterations: lane l < 16 the scan's tag of (level l >> 2, row l & 3), lanes
+        // 16..31 the previous map's; all fetched before the first use
+        uint32_t tv_[ENCFUSE_MAXIT];
+#pragma unroll
+        for (int k = 0; k < ENCFUSE_MAXIT; ++k) {
+            const int szt = ((it0 + k) * nw + w) * 4 + ((lane >> 2) & 3);
+            const bool okt = it0 + k < niter && lane < 32 && szt < zs && (lane < 16 || has_prev);
+            const uint32_t ti = ((Q * 4u + (uint32_t)(lane & 3)) * (uint32_t)zs + (uint32_t)(okt ? szt : 0)) * (uint32_t)nseg + seg;
+            tv_[k] = okt ? (lane < 16 ? stags[ti] : ptags[ti]) : 0u;
+        }
+        // iteration k's mask in lane k: bits 0..15 scan-live (level, row), bits 16..31 the previous map's
+        uint32_t lmv = 0u;
+#pragma unroll
+        for (int k = 0; k < ENCFUSE_MAXIT; ++k) {
+            const uint32_t b_ = (uint32_t)__ballot(it0 + k < niter && lane < 32 && tv_[k] != 0u && tv_[k] == (lane < 16 ? P.epoch : prev.epoch));
+            if (lane == k) lmv = b_;
+        }
+        const int kend = min(ENCFUSE_MAXIT, niter - it0);
+#pragma unroll 1
+        for (int k = 0; k < kend; ++k) {
+            const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)lmv, k);
+            if (m == 0u) continue;                           // wave-uniform: the 4 levels are dead in both sources
+            const int sz = ((it0 + k) * nw + w) * 4 + zl;
+            const bool zok = sz < zs;
+            const bool live_s = zok && ((m >> (zl * 4 + r)) & 1u);
+            const bool live_p = zok && ((m >> (16 + zl * 4 + r)) & 1u);
+            const uint32_t A0 = acc_idx((int)sx0, (int)sy, zok ? sz : 0, zs, P.sxq);
+            const uint32_t L0 = (sy * (uint32_t)zs + (uint32_t)(zok ? sz : 0)) * (uint32_t)xy + sx0;
+            // unconditional 16-byte loads (a dead tile reads a valid dummy address): all in flight together
+            const v4u hv = *(gptr_v4u)(hit + (live_s ? A0 : (uint32_t)(4 * lane)));
+            const v4u tv = *(gptr_v4u)(total + (live_s ? A0 : (uint32_t)(4 * lane)));
+            const v4i pv = *(gptr_v4i)(sp + (live_p ? L0 : (uint32_t)(4 * lane)));
+            const int zw = wrap_sub(zok ? sz : 0, F.om[2], zs);
+            const bool zp_in = live_p && zw + dpz >= 0 && zw + dpz < zs;
+            const uint32_t h[4] = {hv.x, hv.y, hv.z, hv.w};
+            const uint32_t t[4] = {tv.x + hv.x, tv.y + hv.y, tv.z + hv.z, tv.w + hv.w};   // passes + the endpoints' own count (endpoint_commit)
+            const int b[4] = {pv.x, pv.y, pv.z, pv.w};
+            const uint32_t any_h = live_s ? (h[0] | h[1] | h[2] | h[3]) : 0u;
+            const uint32_t any_t = live_s ? (tv.x | tv.y | tv.z | tv.w) : 0u;
+            int st[4], c[4], stp[4];
+            uint32_t occ = 0, socc = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                st[i] = live_s ? -(int32_t)t[i] - 1 : -1;    // gvom.py:1160 (occupied voxels: their row, below)
+                if (live_s && h[i] > 0u) socc |= 1u << i;
+                stp[i] = (zp_in && ((okp >> i) & 1u)) ? b[i] : -1;
+                c[i] = -1;
+                if ((socc >> i) & 1u) occ |= 1u << i;                                       // gvom.py:963
+                else if (st[i] < -1) c[i] = add_free(c[i], st[i] + 1);                      // gvom.py:967
+                if (!((occ >> i) & 1u)) {
+                    if (stp[i] >= 0 && c[i] >= -11) occ |= 1u << i;                         // gvom.py:992
+                    else if (stp[i] < -1) c[i] = add_free(c[i], stp[i] + 1);                // gvom.py:996
+                }
+            }
+            if (__builtin_amdgcn_readfirstlane((int)(__ballot(occ != 0u) != 0ull))) {       // rare: occupied voxels in these 4 levels
+                // everything an occupied voxel needs, fetched before the first use: the row k_trace's endpoint blocks left in
+                // the slot's state, the min-height accumulator, the previous map's row
+                int32_t rows[4];
+                v4u rp[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    rows[i] = state[L0 + (((socc >> i) & 1u) ? (uint32_t)i : 0u)];
+                    rp[i] = prows[(((occ >> i) & 1u) && stp[i] >= 0) ? (uint32_t)stp[i] : 0u];
+                }
+                const v4u mv = *(gptr_v4u)(mh + (socc ? A0 : (uint32_t)(4 * lane)));
+                const uint32_t mm_[4] = {mv.x, mv.y, mv.z, mv.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool o = (occ >> i) & 1u;
+                    const unsigned long long bm = __ballot(o);
+                    if (o) {
+                        uint32_t hh = 0, tt = 0, mn = 0x3f800000u;
+                        if ((socc >> i) & 1u) {                                              // the slot's own row (k_encode's move, gvom.py:1164-1168)
+                            const uint32_t mbits = 0x3f800000u - mm_[i];
+                            crows[rows[i]] = make_uint4(h[i], t[i], mbits, 0u);
+                            st[i] = rows[i];
+                            hh += h[i]; tt += t[i]; mn = min(mn, mbits);                     // gvom.py:910-912
+                        }
+                        if (stp[i] >= 0) { hh += rp[i].x; tt += rp[i].y; mn = min(mn, rp[i].z); }
+                        const uint32_t row = rbase + running + (uint32_t)__popcll(bm & lanemask_lt());
+                        frows[row] = make_uint4(hh, tt, mn, 0u);
+                        c[i] = (int32_t)row;
+                        zh[i] = min(zh[i], ((unsigned long long)(uint32_t)zw << 32) | mn);  // lowest occupied level wins
+                    }
+                    running += (uint32_t)__popcll(bm);
+                }
+            }
+            if (live_s) {
+                *reinterpret_cast<int4 *>(state + L0) = make_int4(st[0], st[1], st[2], st[3]);
+                if (any_t) *reinterpret_cast<uint4 *>(total + A0) = make_uint4(0, 0, 0, 0);
+                if (any_h) {
+                    *reinterpret_cast<uint4 *>(hit + A0) = make_uint4(0, 0, 0, 0);
+                    *reinterpret_cast<uint4 *>(mh + A0) = make_uint4(0, 0, 0, 0);
+                }
+            }
+            if (live_s || live_p) {
+                *reinterpret_cast<int4 *>(fstate + L0) = make_int4(c[0], c[1], c[2], c[3]);
+                if ((sx0 & 63u) == 0u) ftags[(sy * (uint32_t)zs + (uint32_t)sz) * (uint32_t)nseg + seg] = F.epoch;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (!((occ >> i) & 1u) && c[i] < -1) zf[i] = min(zf[i], (uint32_t)zw);  // gvom.py:551
+            }
+        }
+    }
+
+    // ---- column tails: over the 4 level groups of the wave (lanes l, l ^ 16, l ^ 32, l ^ 48), then over the waves
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+            const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)zh[i], o), hi = (uint32_t)__shfl_xor((int)(uint32_t)(zh[i] >> 32), o);
+            zh[i] = min(zh[i], ((unsigned long long)hi << 32) | lo);
+            zf[i] = min(zf[i], (uint32_t)__shfl_xor((int)zf[i], o));
+        }
+    }
+    if (zl == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { s_zh[w][r * 16 + p4 * 4 + i] = zh[i]; s_zf[w][r * 16 + p4 * 4 + i] = zf[i]; }
+    }
+    if (lane == 0) s_cnt[w] = running;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int k = 0; k < nw; ++k) tot += s_cnt[k];
+        blockcounts[M] = tot;
+    }
+    if (w == 0) {                                            // lane = column: row 4Q + (lane >> 4), sx = 16 bx + (lane & 15)
+        const int csx = (int)(bx * 16u) + (lane & 15), csy = (int)(Q * 4u) + (lane >> 4);
+        unsigned long long zhm = ((unsigned long long)INT_MAX << 32) | 0x3f800000ull;
+        uint32_t zfm = (uint32_t)INT_MAX;
+        for (int k = 0; k < nw; ++k) { zhm = min(zhm, s_zh[k][lane]); zfm = min(zfm, s_zf[k][lane]); }
+        const int x = wrap_sub(csx, F.om[0], xy), yy = wrap_sub(csy, F.om[1], xy);
+        const int zo = (int)(zhm >> 32), zfi = (int)zfm;
+        double hval = -1000.0;
+        const double xp = ((F.origin[0] + (double)x) * F.xy_res) - F.ego[0];
+        const double yp = ((F.origin[1] + (double)yy) * F.xy_res) - F.ego[1];
+        if (xp * xp + yp * yp <= F.radius2) hval = F.ego[2] - F.ground_to_lidar_height;          // gvom.py:531-534
+        if (zo != INT_MAX) hval = (((double)__uint_as_float((uint32_t)zhm) + (double)zo) + F.origin[2]) * F.z_res;   // gvom.py:536-540
+        height[(size_t)csy * F.hs + csx] = hval;
+        inferred[(size_t)csy * F.hs + csx] = (zfi != INT_MAX) ? ((double)zfi + F.origin[2]) * F.z_res : -1000.0;   // gvom.py:544-554
     }
 }
 
@@ -2836,6 +3059,30 @@ hipError_t gvom_launch_fuse(hipStream_t s, const FuseParams &P, const FuseDescs 
         if (mem) FUSE_LAUNCH(k_fuse<false, true>); else FUSE_LAUNCH(k_fuse<false, false>);
     }
 #undef FUSE_LAUNCH
+    return hipGetLastError();
+}
+
+// k_encfuse (one-slot rings; the host has checked xy % 16 == 0, z_size >= 4, the whole grid on this handle): grid = one
+// workgroup per 16-sx x 4-row column block, up to 8 waves of 4 levels per iteration.  Returns the number of workgroups
+// (= entries of blockcounts written) in *nblocks and the fused compact rows the launch may number in *row_cap.
+void gvom_encfuse_shape(int xy, int zs, int *nw, int *nblocks, size_t *row_cap)
+{
+    int w = (zs + 3) / 4;
+    if (w > 8) w = 8;
+    if (w < 1) w = 1;
+    const int niter = (zs + 4 * w - 1) / (4 * w);
+    *nw = w; *nblocks = (xy / 16) * (xy / 4);
+    *row_cap = (size_t)*nblocks * (size_t)w * (size_t)niter * 256;
+}
+hipError_t gvom_launch_encfuse(hipStream_t s, const ScanParams &P, const FuseParams &F, const MapDesc &prev, uint32_t *hit,
+                               uint32_t *total, uint32_t *mh, int32_t *state, uint4 *crows, const uint32_t *stags,
+                               int32_t *fstate, uint4 *frows, uint32_t *ftags, uint32_t *blockcounts, double *height,
+                               double *inferred, uint32_t *counters, unsigned long long *host_flag, uint32_t seq)
+{
+    int nw, nblocks; size_t cap;
+    gvom_encfuse_shape(P.xy, P.zs, &nw, &nblocks, &cap);
+    hipLaunchKernelGGL(k_encfuse, dim3((unsigned)nblocks), dim3(64u * (unsigned)nw), 0, s, P, F, prev, hit, total, mh, state, crows,
+                       stags, fstate, frows, ftags, blockcounts, height, inferred, counters, host_flag, seq);
     return hipGetLastError();
 }
 

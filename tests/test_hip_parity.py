@@ -1070,6 +1070,64 @@ def test_one_slot_fusion_kernel_against_the_oracle_and_the_general_kernel(gvom_m
         assert np.array_equal(gd[j], gd4[j]) and np.array_equal(np.asarray(wd[j]), gd[j]), j
 
 
+@pytest.mark.parametrize("grid", [(64, 32), (32, 8), (128, 256), (48, 20), (16, 4), (64, 70)])
+def test_eager_fusion_of_one_slot_rings_equals_the_two_pass_form_and_the_oracle(gvom_mod, grid):
+    """Eager fusion (buffer_size = 1): the scan launches k_encfuse behind k_trace -- slot encoding AND its fusion with the
+    previous map in one pass over the accumulators, into spare buffers -- and combine_maps adopts the result iff nothing
+    changed in between; otherwise the combine fuses the encoded slot with k_fuse1 as before.  Every call order must give the
+    reference's results: a scan behind a scan (speculation dropped, the slot still correctly encoded), two combines behind one
+    scan (the second re-fuses the slot), rejected scans (no return in the grid: ring untouched, but the ego moves), debug
+    reads between a scan and its combine (they show the LAST combine's maps), a moving window with decaying voxels.  The
+    mapper with the automatic policy, one forced eager, one with eager off and the oracle are recorded step by step (scan
+    slots, fused maps densely, all 2-D maps, counts, debug maps) and compared; z sizes that are no multiple of the kernel's
+    4-level groups and grids of a single column block included."""
+    xy, zs = grid
+    params = (0.4, 0.2, xy, zs, 1, 0.5, 0.5, 0.5, 0.3, 2.0, 2.0, 1.0, 1, 1)
+    rng = np.random.default_rng(xy * 13 + zs)
+
+    def cloud(k, ego, dtype):
+        n = 6000
+        ground = np.stack([rng.uniform(-0.18 * xy, 0.18 * xy, n) + ego[0], rng.uniform(-0.18 * xy, 0.18 * xy, n) + ego[1],
+                           rng.normal(-0.5, 0.12, n) + ego[2]], axis=1)
+        wall = np.stack([np.full(500, 2.6 + 0.4 * (k % 2)) + ego[0], rng.uniform(-2, 2, 500) + ego[1], rng.uniform(-0.6, 0.6, 500) + ego[2]], axis=1)
+        return np.concatenate([ground, wall], 0).astype(dtype)
+    far = np.full((50, 3), 1.0e4)                               # no return in the grid: rejected (gvom.py:148-150)
+    steps, k = [], 0
+    for kind in "sc sc ssc cc s rc sc rsc c ssssc sc sc".replace(" ", ""):
+        if kind == "c":
+            steps.append(("combine",))
+            continue
+        ego = (0.45 * k, -0.25 * k, 0.04 * k)
+        steps.append(("scan", far if kind == "r" else cloud(k, ego, np.float32 if k % 2 else np.float64), ego,
+                      scenarios.rot_z(0.01 * k, (0.0, 0.0, 0.0)) if k % 3 == 0 and kind != "r" else None))
+        k += 1
+    sc = {"params": params, "steps": steps}
+
+    def knob(v):
+        def make(*p):
+            g = gvom_mod.Gvom(*p)
+            g.set_tuning("eager", v)
+            made.append(g)
+            return g
+        return make
+    made = []
+    want = scenarios.run_and_record(oracle.OracleGvom, sc)
+    recs = [scenarios.run_and_record(knob(v), sc) for v in (-1, 1, 0)]
+    for got in recs:
+        assert compare_records(got, want, float_tol=1e-5) > 50
+    for key in recs[2]:                                         # eager on / off: bit-identical, floats included
+        for other in recs[:2]:
+            a, b = np.asarray(recs[2][key]), np.asarray(other[key])
+            assert a.shape == b.shape and (np.array_equal(a, b, equal_nan=True) if a.dtype.kind in "fiub" else True), key
+    auto, forced, off = made
+    n_comb = sum(1 for st in steps if st[0] == "combine")
+    assert off.get_tuning("eager_adopted") == 0 and off.get_tuning("eager_dropped") == 0
+    assert 0 < forced.get_tuning("eager_adopted") < n_comb and forced.get_tuning("eager_dropped") > 0
+    # the automatic policy stops speculating after three wasted fusions in a row ("ssssc") and comes back
+    assert 0 < auto.get_tuning("eager_adopted") <= forced.get_tuning("eager_adopted")
+    assert auto.get_tuning("eager_dropped") <= forced.get_tuning("eager_dropped")
+
+
 @pytest.mark.parametrize("grid", [(32, 16, 20), (30, 12, 24), (16, 300, 18), (32, 16, 40)])
 def test_long_rings_read_their_descriptors_from_memory(gvom_mod, grid):
     """More than 17 fusion sources (ring slots + previous map) no longer fit the kernel arguments: the

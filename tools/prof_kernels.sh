@@ -1,6 +1,6 @@
 #!/bin/bash
 export TMPDIR=/tmp; cd /tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-/root/repo}
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/pf -- python3 $R/tools/run_steps.py m256 200 "$@" > $R/gpurun_out/pf.log 2>&1
 f=$(find $R/gpurun_out/pf -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY'
