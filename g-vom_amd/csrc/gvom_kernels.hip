@@ -1797,7 +1797,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 // (block ids 8 apart; speed only).
 // ------------------------------------------------------------------------------------------
 #define ENCFUSE_MAXIT 8                                    // wave iterations whose tile tags are fetched together
-__global__ __launch_bounds__(512) void k_encfuse(
+#define ENCFUSE_LIST 128                                   // per wave: occupied voxels listed before they are settled
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_encfuse(
     const ScanParams P, const FuseParams F, const MapDesc prev, uint32_t *hit, uint32_t *total, uint32_t *mh,
     int32_t *state, uint4 *crows, const uint32_t *__restrict__ stags, int32_t *fstate, uint4 *frows, uint32_t *ftags,
     uint32_t *blockcounts, double *height, double *inferred, uint32_t *counters, unsigned long long *host_flag, uint32_t seq)
@@ -1805,6 +1806,10 @@ __global__ __launch_bounds__(512) void k_encfuse(
     __shared__ unsigned long long s_zh[8][WAVE];            // per wave and column: min of (window z << 32 | min-height bits) over occupied voxels
     __shared__ uint32_t s_zf[8][WAVE];                      // per wave and column: lowest observed-free window z
     __shared__ uint32_t s_cnt[8];
+    // per wave: the occupied voxels of the levels in hand, one entry each -- storage voxel, accumulator index, the scan's hit and
+    // total there, the previous map's state, {window z | column << 10 | occupied in the scan << 16}
+    __shared__ uint32_t s_eL[8][ENCFUSE_LIST], s_eA[8][ENCFUSE_LIST], s_eh[8][ENCFUSE_LIST], s_et[8][ENCFUSE_LIST], s_em[8][ENCFUSE_LIST];
+    __shared__ int32_t s_ep[8][ENCFUSE_LIST];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         // k_trace has completed: {seq, any-in-grid} to the spinning host, as k_encode's first thread does
         const uint32_t any = counters[GVOM_CNT_INGRID] ? 0x80000000u : 0u;
@@ -1824,6 +1829,7 @@ __global__ __launch_bounds__(512) void k_encfuse(
     const int zl = lane >> 4, p4 = (lane >> 2) & 3, r = lane & 3;
     const uint32_t sx0 = bx * 16u + (uint32_t)p4 * 4u, sy = Q * 4u + (uint32_t)r;
     const uint32_t seg = sx0 >> 6;
+    const uint32_t col0 = (uint32_t)(r * 16 + p4 * 4);      // this lane's first column inside the block (row-major 4 x 16)
     const int y = wrap_sub((int)sy, F.om[1], xy);
     const bool has_prev = F.has_prev != 0;
     const int dpx = has_prev ? prev.d[0] : 0, dpy = has_prev ? prev.d[1] : 0, dpz = has_prev ? prev.d[2] : 0;
@@ -1843,11 +1849,42 @@ __global__ __launch_bounds__(512) void k_encfuse(
     const int niter = (zs + 4 * nw - 1) / (4 * nw);         // wave iterations (4 levels each)
     // every wave numbers its occupied voxels inside a static range of the fused compact rows (as k_fuse1)
     const uint32_t rbase = (M * (uint32_t)nw + (uint32_t)w) * (uint32_t)(niter * 256);
-    uint32_t running = 0;
-    unsigned long long zh[4];
-    uint32_t zf[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { zh[i] = ((unsigned long long)INT_MAX << 32) | 0x3f800000ull; zf[i] = (uint32_t)INT_MAX; }
+    uint32_t running = 0, n = 0;
+    uint32_t zf[4] = {(uint32_t)INT_MAX, (uint32_t)INT_MAX, (uint32_t)INT_MAX, (uint32_t)INT_MAX};
+    s_zh[w][lane] = ((unsigned long long)INT_MAX << 32) | 0x3f800000ull;      // wave-private until the tail
+    // the occupied voxels listed so far, one lane each: the slot's row (k_trace's endpoint blocks left it in the slot's state),
+    // the min-height accumulator and the previous map's row in ONE round trip; then the slot's compact row (k_encode's move,
+    // gvom.py:1164-1168, 1303-1329), the fused row (gvom.py:910-912) and the fused state
+    auto emit = [&]() {
+        for (uint32_t base = 0; base < n; base += WAVE) {
+            const uint32_t e = base + (uint32_t)lane;
+            const bool on = e < n;
+            const uint32_t ei = on ? e : 0u;
+            const uint32_t L = s_eL[w][ei], A = s_eA[w][ei], h_ = s_eh[w][ei], t_ = s_et[w][ei], meta = s_em[w][ei];
+            const int stp = on ? s_ep[w][ei] : -1;
+            const bool so = on && ((meta >> 16) & 1u);
+            const int32_t row_s = state[so ? L : 0u];
+            const uint32_t mraw = mh[so ? A : 0u];
+            const v4u rp = prows[stp >= 0 ? (uint32_t)stp : 0u];
+            uint32_t hh = 0, tt = 0, mn = 0x3f800000u;
+            if (so) {
+                const uint32_t mbits = 0x3f800000u - mraw;
+                crows[row_s] = make_uint4(h_, t_, mbits, 0u);
+                mh[A] = 0u;                                    // (hit and total are zeroed with the whole line quarter, below)
+                hh += h_; tt += t_; mn = min(mn, mbits);       // gvom.py:910-912
+            }
+            if (stp >= 0) { hh += rp.x; tt += rp.y; mn = min(mn, rp.z); }
+            const unsigned long long ob = __ballot(on);
+            if (on) {
+                const uint32_t row = rbase + running + (uint32_t)__popcll(ob & lanemask_lt());
+                frows[row] = make_uint4(hh, tt, mn, 0u);
+                fstate[L] = (int32_t)row;
+                atomicMin(&s_zh[w][(meta >> 10) & 63u], ((unsigned long long)(meta & 1023u) << 32) | mn);   // lowest occupied level wins
+            }
+            running += (uint32_t)__popcll(ob);
+        }
+        n = 0;
+    };
 
     for (int it0 = 0; it0 < niter; it0 += ENCFUSE_MAXIT) {
         // tile tags of up to ENCFUSE_MAXIT iterations: lane l < 16 the scan's tag of (level l >> 2, row l & 3), lanes
@@ -1893,7 +1930,7 @@ __global__ __launch_bounds__(512) void k_encfuse(
             uint32_t occ = 0, socc = 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                st[i] = live_s ? -(int32_t)t[i] - 1 : -1;    // gvom.py:1160 (occupied voxels: their row, below)
+                st[i] = live_s ? -(int32_t)t[i] - 1 : -1;    // gvom.py:1160 (occupied voxels keep the row k_trace left there)
                 if (live_s && h[i] > 0u) socc |= 1u << i;
                 stp[i] = (zp_in && ((okp >> i) & 1u)) ? b[i] : -1;
                 c[i] = -1;
@@ -1904,70 +1941,51 @@ __global__ __launch_bounds__(512) void k_encfuse(
                     else if (stp[i] < -1) c[i] = add_free(c[i], stp[i] + 1);                // gvom.py:996
                 }
             }
-            if (__builtin_amdgcn_readfirstlane((int)(__ballot(occ != 0u) != 0ull))) {       // rare: occupied voxels in these 4 levels
-                // everything an occupied voxel needs, fetched before the first use: the row k_trace's endpoint blocks left in
-                // the slot's state, the min-height accumulator, the previous map's row
-                int32_t rows[4];
-                v4u rp[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    rows[i] = state[L0 + (((socc >> i) & 1u) ? (uint32_t)i : 0u)];
-                    rp[i] = prows[(((occ >> i) & 1u) && stp[i] >= 0) ? (uint32_t)stp[i] : 0u];
-                }
-                const v4u mv = *(gptr_v4u)(mh + (socc ? A0 : (uint32_t)(4 * lane)));
-                const uint32_t mm_[4] = {mv.x, mv.y, mv.z, mv.w};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const bool o = (occ >> i) & 1u;
-                    const unsigned long long bm = __ballot(o);
-                    if (o) {
-                        uint32_t hh = 0, tt = 0, mn = 0x3f800000u;
-                        if ((socc >> i) & 1u) {                                              // the slot's own row (k_encode's move, gvom.py:1164-1168)
-                            const uint32_t mbits = 0x3f800000u - mm_[i];
-                            crows[rows[i]] = make_uint4(h[i], t[i], mbits, 0u);
-                            st[i] = rows[i];
-                            hh += h[i]; tt += t[i]; mn = min(mn, mbits);                     // gvom.py:910-912
-                        }
-                        if (stp[i] >= 0) { hh += rp[i].x; tt += rp[i].y; mn = min(mn, rp[i].z); }
-                        const uint32_t row = rbase + running + (uint32_t)__popcll(bm & lanemask_lt());
-                        frows[row] = make_uint4(hh, tt, mn, 0u);
-                        c[i] = (int32_t)row;
-                        zh[i] = min(zh[i], ((unsigned long long)(uint32_t)zw << 32) | mn);  // lowest occupied level wins
-                    }
-                    running += (uint32_t)__popcll(bm);
-                }
-            }
             if (live_s) {
-                *reinterpret_cast<int4 *>(state + L0) = make_int4(st[0], st[1], st[2], st[3]);
-                if (any_t) *reinterpret_cast<uint4 *>(total + A0) = make_uint4(0, 0, 0, 0);
-                if (any_h) {
-                    *reinterpret_cast<uint4 *>(hit + A0) = make_uint4(0, 0, 0, 0);
-                    *reinterpret_cast<uint4 *>(mh + A0) = make_uint4(0, 0, 0, 0);
+                if (socc == 0u) *reinterpret_cast<int4 *>(state + L0) = make_int4(st[0], st[1], st[2], st[3]);
+                else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) if (!((socc >> i) & 1u)) state[L0 + i] = st[i];
                 }
+                if (any_t) *reinterpret_cast<uint4 *>(total + A0) = make_uint4(0, 0, 0, 0);
+                if (any_h) *reinterpret_cast<uint4 *>(hit + A0) = make_uint4(0, 0, 0, 0);
             }
             if (live_s || live_p) {
+                // (an occupied voxel's word is overwritten with its row by emit(): same wave, later in program order)
                 *reinterpret_cast<int4 *>(fstate + L0) = make_int4(c[0], c[1], c[2], c[3]);
                 if ((sx0 & 63u) == 0u) ftags[(sy * (uint32_t)zs + (uint32_t)sz) * (uint32_t)nseg + seg] = F.epoch;
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     if (!((occ >> i) & 1u) && c[i] < -1) zf[i] = min(zf[i], (uint32_t)zw);  // gvom.py:551
             }
+            if (__builtin_amdgcn_readfirstlane((int)(__ballot(occ != 0u) != 0ull))) {       // rare: occupied voxels in these 4 levels
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool o = (occ >> i) & 1u;
+                    const unsigned long long bm = __ballot(o);
+                    if (o) {
+                        const uint32_t at = n + (uint32_t)__popcll(bm & lanemask_lt());
+                        s_eL[w][at] = L0 + (uint32_t)i; s_eA[w][at] = A0 + (uint32_t)i; s_eh[w][at] = h[i]; s_et[w][at] = t[i];
+                        s_ep[w][at] = stp[i];
+                        s_em[w][at] = (uint32_t)zw | ((col0 + (uint32_t)i) << 10) | (((socc >> i) & 1u) << 16);
+                    }
+                    n += (uint32_t)__popcll(bm);
+                    if (n > ENCFUSE_LIST - WAVE) emit();       // the next batch (<= 64 voxels) might not fit
+                }
+            }
         }
     }
+    if (n) emit();
 
     // ---- column tails: over the 4 level groups of the wave (lanes l, l ^ 16, l ^ 32, l ^ 48), then over the waves
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int o = 16; o <= 32; o <<= 1) {
-            const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)zh[i], o), hi = (uint32_t)__shfl_xor((int)(uint32_t)(zh[i] >> 32), o);
-            zh[i] = min(zh[i], ((unsigned long long)hi << 32) | lo);
-            zf[i] = min(zf[i], (uint32_t)__shfl_xor((int)zf[i], o));
-        }
+        zf[i] = min(zf[i], (uint32_t)__shfl_xor((int)zf[i], 16));
+        zf[i] = min(zf[i], (uint32_t)__shfl_xor((int)zf[i], 32));
     }
     if (zl == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { s_zh[w][r * 16 + p4 * 4 + i] = zh[i]; s_zf[w][r * 16 + p4 * 4 + i] = zf[i]; }
+        for (int i = 0; i < 4; ++i) s_zf[w][col0 + i] = zf[i];
     }
     if (lane == 0) s_cnt[w] = running;
     __syncthreads();

@@ -8,4 +8,4 @@ tail -15 $O/pytest.txt
 [ $rc -ne 0 ] && exit $rc
 python3 tools/ab_knob.py m256 300 8 eager=0 eager=1 > $O/ab_m256.txt 2>&1; cat $O/ab_m256.txt
 python3 tools/ab_knob.py c2 300 8 eager=0 eager=1 > $O/ab_c2.txt 2>&1; cat $O/ab_c2.txt
-python3 tools/run_steps.py m256 300 stage > $O/steps_m256.txt 2>&1; cat $O/steps_m256.txt
+bash tools/prof_kernels.sh > $O/kernels_m256.txt 2>&1; cat $O/kernels_m256.txt
