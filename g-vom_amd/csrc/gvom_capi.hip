@@ -143,6 +143,7 @@ struct gvom_handle {
     int spec_nxt = 0, spec_slot = 0, spec_blocks = 0;
     uint32_t spec_epoch = 0;
     int64_t spec_origin[3] = {0, 0, 0};
+    int tune_encfuse = 0;                               // gvom_set_tuning "encfuse": A/B of k_encfuse's shape (low 4 bits: waves per block, bit 4: no XCD pairing)
     int tune_eager = -1;                                // gvom_set_tuning "eager": 0 off, 1 always, -1 automatic (off after 3 wasted in a row)
     int eager_waste = 0;                                // speculations dropped in a row (saturates at 4)
     int eager_stat[2] = {0, 0};                         // adopted / dropped since creation (gvom_get_tuning "eager_adopted" / "eager_dropped")
@@ -720,6 +721,7 @@ int eager_launch(gvom_handle *h, const ScanParams &P, Slot &st, const int64_t or
     FuseParams FP;
     fill_fuse_frame(h, origin, FP);
     FP.nslots = 1; FP.has_prev = prev ? 1 : 0;
+    FP.nz = h->tune_encfuse & 15; FP.cpw = (h->tune_encfuse >> 4) & 1;      // A/B knob (waves per column block, XCD pairing off)
     MapDesc pd;
     memset(&pd, 0, sizeof pd);
     if (prev) {
@@ -2153,6 +2155,7 @@ VIS int gvom_set_tuning(gvom_t *h, const char *name, int value)
     else if (!strcmp(name, "interleave")) h->tune_ilv = value;
     else if (!strcmp(name, "flag_kernel")) h->tune_flag_kernel = value;
     else if (!strcmp(name, "fuse1")) h->tune_fuse1 = value;
+    else if (!strcmp(name, "encfuse")) h->tune_encfuse = value;
     else if (!strcmp(name, "eager")) { h->tune_eager = value; h->eager_waste = 0; }
     else if (!strcmp(name, "churn")) h->tune_churn = value;
     else if (!strcmp(name, "exported")) h->exported = value != 0;       // (set by the peer transport, gvom_comm.hip)

@@ -1824,7 +1824,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     // dispatch slot -> column block: ids b and b + 8 share an XCD (observed round-robin placement), so the two blocks
     // that split a 32-sx run (the 128-byte lines of state / fstate) are ids 8 apart
     uint32_t M = blockIdx.x;
-    if ((gridDim.x & 15u) == 0u) { const uint32_t slot = M >> 3, xcd = M & 7u; M = ((slot >> 1) << 4) + (xcd << 1) + (slot & 1u); }
+    if ((gridDim.x & 15u) == 0u && !(F.cpw & 1)) { const uint32_t slot = M >> 3, xcd = M & 7u; M = ((slot >> 1) << 4) + (xcd << 1) + (slot & 1u); }
     const uint32_t bx = M % nbx, Q = M / nbx;
     const int zl = lane >> 4, p4 = (lane >> 2) & 3, r = lane & 3;
     const uint32_t sx0 = bx * 16u + (uint32_t)p4 * 4u, sy = Q * 4u + (uint32_t)r;
@@ -3081,12 +3081,14 @@ hipError_t gvom_launch_fuse(hipStream_t s, const FuseParams &P, const FuseDescs 
 }
 
 // k_encfuse (one-slot rings; the host has checked xy % 16 == 0, z_size >= 4, the whole grid on this handle): grid = one
-// workgroup per 16-sx x 4-row column block, up to 8 waves of 4 levels per iteration.  Returns the number of workgroups
+// workgroup per 16-sx x 4-row column block, up to 4 waves of 4 levels per iteration.  Returns the number of workgroups
 // (= entries of blockcounts written) in *nblocks and the fused compact rows the launch may number in *row_cap.
 void gvom_encfuse_shape(int xy, int zs, int *nw, int *nblocks, size_t *row_cap)
 {
+    // 4 waves per block (measured against 8 / 2: m256 98.9 / 100.2 / 102.2 us per step, c2 87.1 / 91.1 / 88.4): at 70 VGPRs a
+    // SIMD holds 7 waves, i.e. 7 four-wave blocks per CU but only 3 eight-wave ones
     int w = (zs + 3) / 4;
-    if (w > 8) w = 8;
+    if (w > 4) w = 4;
     if (w < 1) w = 1;
     const int niter = (zs + 4 * w - 1) / (4 * w);
     *nw = w; *nblocks = (xy / 16) * (xy / 4);
@@ -3099,6 +3101,7 @@ hipError_t gvom_launch_encfuse(hipStream_t s, const ScanParams &P, const FusePar
 {
     int nw, nblocks; size_t cap;
     gvom_encfuse_shape(P.xy, P.zs, &nw, &nblocks, &cap);
+    if (F.nz > 0 && F.nz <= nw) nw = F.nz;              // (A/B knob "encfuse": fewer waves per column block; rows stay inside the range of the default shape)
     hipLaunchKernelGGL(k_encfuse, dim3((unsigned)nblocks), dim3(64u * (unsigned)nw), 0, s, P, F, prev, hit, total, mh, state, crows,
                        stags, fstate, frows, ftags, blockcounts, height, inferred, counters, host_flag, seq);
     return hipGetLastError();
