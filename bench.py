@@ -48,6 +48,14 @@ HBM_PEAK_GBS = 8000.0       # MI355X spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6
 VALU_ISSUE_RATE = 1.2288e12  # wave64 VALU instructions / s: 1024 SIMDs x 2.4 GHz / 2 cycles (MI355X_MICROARCH.md:54,473)
 MIN_TIMED_S = 0.5
 METRIC = "M points/sec (process_pointcloud + combine_maps, 256^3 voxel grid); map Hz beside it"
+
+
+def metric_for(name, grid=None):
+    """BASELINE.json's metric, naming the grid the line was measured on (m256 IS the 256^3 grid the metric is quoted on;
+    the other configs are reported under their own grid, never under the 256^3 label)."""
+    if name == "m256" or not grid:
+        return METRIC
+    return "M points/sec (process_pointcloud + combine_maps, %dx%dx%d voxel grid: BASELINE config %s); map Hz beside it" % (grid[0], grid[1], grid[2], name)
 DTYPE = "int32 atomics + f32 ray state + f64 compares/maps"
 
 
@@ -565,6 +573,9 @@ def step_roofline(alg, res, config):
     one_slot = config in synth.CONFIGS and synth.CONFIGS[config][0][4] == 1
     fuse = (pmc_traffic("k_fuse1", config) if one_slot else None) or pmc_traffic("k_fuse4", config)
     parts = [pmc_traffic(k, config) for k in ("k_trace", "k_encode")] + [fuse, pmc_traffic("k_map2d", config)]
+    if one_slot and res.get("stage_ms", {}).get("fuse") == 0.0:
+        # eager fusion: ONE kernel (k_encfuse) encodes the slot and fuses it, right behind k_trace
+        parts = [pmc_traffic(k, config) for k in ("k_trace", "k_encfuse", "k_map2d")]
     if all(parts):
         meas = sum(p["bytes_per_launch"] for p in parts)
     return {"algorithmic_bytes": a, "frac_algorithmic": a / t / 1e9 / HBM_PEAK_GBS,
@@ -585,6 +596,11 @@ def roofline_of(alg, stages, profiled="m256"):
     except (ImportError, KeyError):
         pass
     ms = {s: v["median"] for s, v in stages.items()}
+    if config and ms.get("fuse") == 0.0 and ms.get("encode"):
+        # one-slot rings with eager fusion: the "encode" stage is k_encfuse = the slot's encoding AND its fusion (the combine
+        # launches k_map2d only): its algorithmic bytes are both stages'
+        kern["encode"] = "k_encfuse"
+        alg = dict(alg, encode=alg["encode"] + alg["fuse"], fuse=0)
     dom = max(ms, key=lambda s: ms[s])
     achieved = alg[dom] / (ms[dom] * 1e-3) / 1e9
     traf = pmc_traffic(kern[dom], config) if config else None
@@ -607,7 +623,9 @@ def roofline_of(alg, stages, profiled="m256"):
             stage_gbs[s] = t["bytes_per_launch"] / (ms[s] * 1e-3) / 1e9
     req = (traf or {}).get("atomic_requests_per_launch")
     return {"bound": "hbm", "kernel": kern[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": (traf or {}).get("bytes_per_launch"), "traffic_detail": traf,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": (traf or {}).get("bytes_per_launch"),
+            "traffic_source": ("profiles/%s (committed PMC passes of this command; NOT measured by this run)" % traf["source"]) if traf else None,
+            "traffic_detail": traf,
             "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": ms[dom],
             "launch_ms_spread": {k: stages[dom][k] for k in ("p10", "p90", "samples")},
             "valu": valu,
@@ -656,7 +674,7 @@ def run_single(args):
     args.steps = steps
     alg, stages, params, scans = extra
     out = {
-        "metric": METRIC, "value": res["value"], "unit": "M points/s",
+        "metric": metric_for(name, res["grid"]), "value": res["value"], "unit": "M points/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
         "config": {"workload": synth.CONFIGS[name][2], "name": name, "points_per_scan": res["points_per_scan"],
@@ -693,8 +711,12 @@ def run_single(args):
                                       "of the reference, off by default here because it is not on the north-star path")
     if not args.no_extra and name == "m256":
         out["configs"] = {}
-        for other, poses in (("c2", 8), ("c3", 8), ("m256b8", 8)):
-            r, _ = run_config(hip, other, 100, 30, poses, False)
+        # (c4 / c5: BASELINE's multi-GPU configs on this ONE GPU, short device-resident runs -- their paced 20 Hz streams and
+        # sharded forms are `--config c4|c5 [--gpus N] --offered-hz 20`)
+        for other, poses, nsteps, nwarm in (("c2", 8, 100, 30), ("c3", 8, 100, 30), ("m256b8", 8, 100, 30), ("c4", 2, 40, 10), ("c5", 1, 20, 6)):
+            if getattr(args, "no_big", False) and other in ("c4", "c5"):
+                continue
+            r, _ = run_config(hip, other, nsteps, nwarm, poses, False)
             out["configs"][other] = r
     if args.offered_hz > 0:
         out["stream"] = stream_single(name, args.offered_hz, args.ticks, poses)
@@ -751,6 +773,7 @@ def main():
     ap.add_argument("--config", default="m256", choices=["c1", "c2", "c3", "m256", "m256b8", "c4", "c5"])
     ap.add_argument("--poses", type=int, default=8, help="distinct sensor poses cycled through (0.2 m apart)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-big", action="store_true", help="skip the c4 / c5 ride-along runs of the default line")
     ap.add_argument("--no-extra", action="store_true", help="skip the short runs of the other configs")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--offered-hz", type=float, default=0.0,

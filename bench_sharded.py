@@ -287,7 +287,7 @@ def run(args):
         achieved = (trace_alg["bytes"] / (tr_ms * 1e-3) / 1e9) if (trace_alg and tr_ms) else None
         worst = max(table, key=lambda r: r[2])
         out = {
-            "metric": bench.METRIC, "value": n_total * steps / med / 1e6, "unit": "M points/s",
+            "metric": bench.metric_for(name, list(params[2:3]) * 2 + [params[3]]), "value": n_total * steps / med / 1e6, "unit": "M points/s",
             "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": med / steps * 1e3, "higher_is_better": True,
             "scaling": "weak" if per_rank == 1 and not big else "strong",

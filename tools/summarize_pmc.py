@@ -70,7 +70,7 @@ hit, _ = counter_avgs("pmc_TCC_HIT_sum", "TCC_HIT_sum")
 miss, _ = counter_avgs("pmc_TCC_MISS_sum", "TCC_MISS_sum")
 # which calibration applies to which kernel's dominant access width
 width = {"k_trace": ("read4", "write4"), "k_encode": ("read16", "write16"), "k_minh": ("read4", "write4"),
-         "k_fuse": ("read4", "write4"), "k_fuse4": ("read16", "write16"), "k_map2d": ("read4", "write4")}
+         "k_fuse": ("read4", "write4"), "k_fuse4": ("read16", "write16"), "k_fuse1": ("read16", "write16"), "k_encfuse": ("read16", "write16"), "k_map2d": ("read4", "write4")}
 kern = {}
 for k in sorted(set(fetch) | set(write)):
     if not k.startswith("k_"):
