@@ -148,6 +148,7 @@ struct gvom_handle {
     int eager_waste = 0;                                // speculations dropped in a row (saturates at 4)
     int eager_stat[2] = {0, 0};                         // adopted / dropped since creation (gvom_get_tuning "eager_adopted" / "eager_dropped")
     bool last_scan_spec = false;                        // the last accepted scan went through k_encfuse
+    bool solo_encoded = false;                          // a sharded handle of ONE rank: gvom_shard_scan_local has already encoded the scan (nothing to wait for)
     bool fresh_scan = false;                            // a scan has been committed and no combine has looked at it yet
 
     double *hmaps = nullptr;                            // [sy][3][sx]: height | inferred height | positive density
@@ -845,7 +846,11 @@ int scan_launch(gvom_handle *h, std::unique_lock<std::mutex> &lk, const void *de
                                       h->stats ? (uint32_t *)st.rowvox.p : nullptr);
     if (le != hipSuccess) { scan_abort(h); HIPCHK(h, le); }
     if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
-    if (shard_local) {
+    // (a sharded map of ONE rank has no other ranks' rows: nothing to pack, no counts to publish and to wait for -- the scan
+    // is encoded right behind the trace, as on an unsharded handle, and gvom_shard_scan_merge only commits it)
+    const bool solo = shard_local && h->world == 1;
+    h->solo_encoded = solo;
+    if (shard_local && !solo) {
         // sharded map: the ray passes in other ranks' rows are packed for their owners; the counts go
         // to host-mapped memory (the caller sizes the exchange with them); k_encode follows in
         // scan_merge, once the other ranks' contributions have been added
@@ -1403,8 +1408,8 @@ VIS int gvom_shard_scan_local(gvom_t *h, const void *xyz, int on_device, int64_t
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(h->mu);
     for (int d = 0; d < h->world; ++d) {
-        if (send_quads) send_quads[d] = (int64_t)h->x_host[d];
-        if (send_eps) send_eps[d] = (int64_t)h->x_host[h->world + d];
+        if (send_quads) send_quads[d] = h->solo_encoded ? 0 : (int64_t)h->x_host[d];
+        if (send_eps) send_eps[d] = h->solo_encoded ? 0 : (int64_t)h->x_host[h->world + d];
     }
     if (any_ingrid) *any_ingrid = h->pending_any ? 1 : 0;
     return GVOM_OK;
@@ -1433,7 +1438,7 @@ VIS int gvom_shard_stats_counts(gvom_t *h, int64_t *send_returns)
 {
     if (!h || !h->sharded || !send_returns) return GVOM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
-    for (int d = 0; d < h->world; ++d) send_returns[d] = (h->stats && h->pending) ? (int64_t)h->x_host[2 * h->world + 2 + d] : 0;
+    for (int d = 0; d < h->world; ++d) send_returns[d] = (h->stats && h->pending && !h->solo_encoded) ? (int64_t)h->x_host[2 * h->world + 2 + d] : 0;
     return GVOM_OK;
 }
 
@@ -1493,6 +1498,11 @@ VIS int gvom_shard_scan_merge(gvom_t *h, const int64_t *recv_quads, const int64_
     std::lock_guard<std::mutex> lk(h->mu);
     if (!h->pending) return GVOM_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
+    if (h->solo_encoded) {                                 // one rank: gvom_shard_scan_local has encoded the scan already
+        h->solo_encoded = false;
+        scan_commit(h, accept != 0);
+        return GVOM_OK;
+    }
     Slot &st = h->slots[h->staging];
     const ScanParams &P = h->pending_P;
     int64_t tot_eps = 0;
@@ -1829,9 +1839,14 @@ VIS int gvom_combine_map2d_into(gvom_t *h, double origin_world[3], void *pinned_
     HIPCHK(h, hipSetDevice(h->device));
     char *dev = nullptr;
     HIPCHK(h, hipHostGetDevicePointer((void **)&dev, pinned_out, 0));
-    int rc = map2d_impl(h, true, false, dev, true);
+    // completion as in the unsharded combine: k_map2d's last workgroup stores a flag the host spins on (a stream
+    // synchronisation notices the end of the stream several microseconds later); the count was published by k_posdens
+    std::unique_lock<std::mutex> ulk(h->mu, std::adopt_lock);
+    const uint32_t done_seq = ++h->combine_seq;
+    int rc = map2d_impl(h, true, false, dev, true, nullptr, nullptr, done_seq);
+    if (rc == GVOM_OK) rc = finish_combine(h, ulk, done_seq);
+    ulk.release();                                         // (the lock_guard above still owns the mutex)
     if (rc) return rc;
-    if ((rc = finish_combine(h))) return rc;
     if (origin_world) {
         const Fused &F = h->fused[h->cur];
         origin_world[0] = (double)F.origin[0] * h->prm.xy_resolution;

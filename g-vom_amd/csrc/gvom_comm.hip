@@ -229,6 +229,7 @@ struct gvom_comm {
     Segment *seg = nullptr;
     std::string shm_name, err;
     uint64_t calls = 0;                        // host exchanges so far
+    std::vector<int64_t> scan_table;           // gvom_comm_process_pointcloud: every rank's counts of the scan in hand
     // rendezvous / host-exchange patience: the ranks of a job start seconds to minutes apart on a cold box
     // (first import of the interpreter's packages); GVOM_COMM_TIMEOUT_S overrides
     double timeout_s = 600.0;
@@ -970,6 +971,7 @@ static int allgather_rows_impl(gvom_comm_t *c, gvom_t *h)
         if (se != hipSuccess) { c->err = std::string("hipStreamSynchronize failed: ") + hipGetErrorString(se); return GVOM_ERR_HIP; }
         return rb;
     }
+    if (c->world == 1) return GVOM_OK;                     // (one rank: its rows are all the rows)
     if (!c->nccl) { c->err = "communicator without RCCL"; return GVOM_ERR_INVALID; }
     NCCLCHK(c, c->rccl.AllGather((char *)ptr + share * c->rank, ptr, share, ncclUint8, c->nccl, (hipStream_t)gvom_stream(h)));
     return GVOM_OK;
@@ -1024,6 +1026,64 @@ VIS int gvom_comm_before_combine(gvom_comm_t *c)
     int rc = GVOM_OK;
     for (int p = 0; p < c->world && rc == GVOM_OK; ++p)
         if (p != c->rank) rc = peer_wait(c, p, c->seg->flags[p].pulled_rows, c->rows_x, "pulling the previous combine's rows");
+    return rc;
+}
+
+// ONE sharded scan, natively: what ShardedGvom.process_pointcloud does call by call from Python (before_scan, scan_local, the
+// host exchange of the counts, recv_reserve, the device exchange, scan_merge), for handles without per-voxel statistics.
+// Every rank calls it with ITS share of the cloud.  out = {the scan was accepted (some rank saw a return in the grid,
+// gvom.py:147-150), returns of all ranks, bytes this rank sent, bytes it received}.
+VIS int gvom_comm_process_pointcloud(gvom_comm_t *c, gvom_t *h, const void *xyz, int on_device, int64_t n, int64_t row_stride_bytes,
+                                     int dtype, const double ego[3], const double *transform_4x4, int64_t out[4])
+{
+    if (!c || !h || !out) return GVOM_ERR_INVALID;
+    const int W = c->world, me = c->rank;
+    if (W > GVOM_COMM_MAX_RANKS) return GVOM_ERR_INVALID;
+    int rc = gvom_comm_before_scan(c);
+    if (rc) return rc;
+    int64_t mine[2 * GVOM_COMM_MAX_RANKS + 2], sq[GVOM_COMM_MAX_RANKS], se[GVOM_COMM_MAX_RANKS];
+    int any = 0;
+    if ((rc = gvom_shard_scan_local(h, xyz, on_device, n, row_stride_bytes, dtype, ego, transform_4x4, sq, se, &any))) {
+        c->err = std::string("gvom_shard_scan_local failed: ") + gvom_last_error(h);
+        if (c->seg && W > 1) c->seg->poison.store((uint32_t)me + 1u, std::memory_order_release);   // the others must not wait for this rank
+        return rc;
+    }
+    for (int d = 0; d < W; ++d) { mine[d] = sq[d]; mine[W + d] = se[d]; }
+    mine[2 * W] = any; mine[2 * W + 1] = n;
+    const int k = 2 * W + 2;
+    std::vector<int64_t> &table = c->scan_table;
+    table.resize((size_t)k * W);
+    if ((rc = gvom_comm_exchange_host(c, mine, k, table.data()))) return rc;
+    int64_t rq[GVOM_COMM_MAX_RANKS], re[GVOM_COMM_MAX_RANKS], accept = 0, total_n = 0, sent = 0, got = 0;
+    for (int s_ = 0; s_ < W; ++s_) {
+        const int64_t *row = table.data() + (size_t)s_ * k;
+        rq[s_] = s_ != me ? row[me] : 0;
+        re[s_] = s_ != me ? row[W + me] : 0;
+        accept |= row[2 * W] != 0;
+        total_n += row[2 * W + 1];
+        got += 1028 * rq[s_] + 8 * re[s_];
+    }
+    sq[me] = 0; se[me] = 0;
+    for (int d = 0; d < W; ++d) sent += 1028 * sq[d] + 8 * se[d];
+    if ((rc = gvom_shard_recv_reserve(h, re))) { c->err = std::string("gvom_shard_recv_reserve failed: ") + gvom_last_error(h); return rc; }
+    if ((rc = gvom_comm_exchange_scan(c, h, sq, se, rq, re))) return rc;
+    if ((rc = gvom_shard_scan_merge(h, rq, re, accept ? 1 : 0))) { c->err = std::string("gvom_shard_scan_merge failed: ") + gvom_last_error(h); return rc; }
+    out[0] = accept; out[1] = total_n; out[2] = sent; out[3] = got;
+    return GVOM_OK;
+}
+
+// ONE sharded combine, natively (before_combine, the slab's fusion, the all-gather of the height rows, the 2-D maps into the
+// pinned buffer): returns GVOM_EMPTY_BUFFER as gvom_combine_fuse does.
+VIS int gvom_comm_combine_maps_into(gvom_comm_t *c, gvom_t *h, double origin_world[3], void *pinned_out)
+{
+    if (!c || !h || !pinned_out) return GVOM_ERR_INVALID;
+    int rc = gvom_comm_before_combine(c);
+    if (rc) return rc;
+    rc = gvom_combine_fuse(h, nullptr);
+    if (rc == GVOM_EMPTY_BUFFER) return rc;
+    if (rc) { c->err = std::string("gvom_combine_fuse failed: ") + gvom_last_error(h); return rc; }
+    if ((rc = gvom_comm_allgather_rows(c, h))) return rc;
+    if ((rc = gvom_combine_map2d_into(h, origin_world, pinned_out))) c->err = std::string("gvom_combine_map2d_into failed: ") + gvom_last_error(h);
     return rc;
 }
 

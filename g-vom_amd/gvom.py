@@ -116,6 +116,8 @@ ABI = [
                                      ctypes.POINTER(_I64)]),
     ("gvom_comm_exchange_stats", _I, [_P, _P, ctypes.POINTER(_I64), ctypes.POINTER(_I64), _I]),
     ("gvom_comm_allgather_rows", _I, [_P, _P]),
+    ("gvom_comm_process_pointcloud", _I, [_P, _P, _P, _I, ctypes.c_int64, ctypes.c_int64, _I, _P, _P, _P]),
+    ("gvom_comm_combine_maps_into", _I, [_P, _P, _P, _P]),
     ("gvom_comm_rank", _I, [_P]),
     ("gvom_comm_world", _I, [_P]),
     ("gvom_comm_last_error", ctypes.c_char_p, [_P]),
@@ -147,7 +149,7 @@ ABI = [
 ]
 
 
-ABI_VERSION = 6          # include/gvom_hip.h GVOM_ABI_VERSION this binding was written against
+ABI_VERSION = 7          # include/gvom_hip.h GVOM_ABI_VERSION this binding was written against
 
 
 def load_library(path=None):
@@ -794,7 +796,7 @@ class Gvom(object):
         return dict(zip(STAGE_NAMES, [float(v) for v in ms]))
 
     def set_tuning(self, name, value):
-        """Performance knobs that never change a result: "segs", "period", "ep_row", "prio", "interleave" (include/gvom_hip.h)."""
+        """Performance knobs that never change a result: "segs", "period", "ep_row", "prio", "interleave", "eager" (include/gvom_hip.h)."""
         self._check(self._lib.gvom_set_tuning(self._h, name.encode(), int(value)))
 
     def get_tuning(self, name):

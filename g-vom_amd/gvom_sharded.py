@@ -191,6 +191,41 @@ class RcclComm(object):
         self._check(self.lib.gvom_comm_exchange_host(self.c, _vec(values), k, out))
         return [list(out[r * k:(r + 1) * k]) for r in range(self.world)]
 
+    # a whole scan / combine in ONE library call (ShardedGvom takes these when the communicator has them: the call-by-call
+    # orchestration from Python cost ~25 us per step, profiles/r4_bench_sharded_w1_m256.json against r5's)
+    def scan_native(self, backend, pointcloud, ego, tf):
+        g = backend.g
+        on_device = isinstance(pointcloud, tuple)
+        if on_device:
+            dptr, n, dt = pointcloud
+            code = 0 if np.dtype(dt) == np.float32 else 1
+            stride, src = (12 if code == 0 else 24), ctypes.c_void_p(int(dptr))
+        else:
+            pc, n, stride, code = g._prepare_cloud(pointcloud)
+            src = _gvom._ptr(pc) if n else None
+        t = None
+        if tf is not None:
+            t = np.ascontiguousarray(np.asarray(tf, dtype=np.float64))
+            if t.shape != (4, 4):
+                raise ValueError("transform must be 4x4")
+        ego_c = (ctypes.c_double * 3)(float(ego[0]), float(ego[1]), float(ego[2]))
+        out = (ctypes.c_int64 * 4)()
+        g.ego_position = ego
+        self._check(self.lib.gvom_comm_process_pointcloud(self.c, backend.h, src, 1 if on_device else 0, int(n), stride, code, ego_c,
+                                                          _gvom._ptr(t), out))
+        backend.dtype_code = code
+        return bool(out[0]), int(out[1]), (int(out[2]), int(out[3]))
+
+    def combine_native(self, backend):
+        lib, c = self.lib, self.c
+        rc, out = backend.g._combine_into(lambda h, origin, ptr: self._combine_rc(lib.gvom_comm_combine_maps_into(c, h, origin, ptr)))
+        return rc, out
+
+    def _combine_rc(self, rc):
+        if rc not in (0, _gvom.GVOM_EMPTY_BUFFER):
+            self._check(rc)
+        return rc
+
     def barrier(self):
         self._check(self.lib.gvom_comm_barrier(self.c))
 
@@ -366,6 +401,14 @@ class ShardedGvom(object):
         tuple for a share already in HBM); n may differ between ranks."""
         self.ego_position = ego_position
         W, me = self.world, self.rank
+        if hasattr(self.comm, "scan_native") and not getattr(self.b, "has_stats", False) and isinstance(self.b, HipShardBackend):
+            accept, total_n, self.last_exchange_bytes = self.comm.scan_native(self.b, pointcloud, ego_position, transform)
+            if me == 0:
+                if total_n == 0:
+                    print("[WARNING] Processing an empty pointcloud, nothing will happen!")
+                elif not accept:
+                    print("[WARNING] The pointcloud points don't overlap with any voxels, nothing will happen!")
+            return None
         getattr(self.comm, "before_scan", _nothing)()                # (a transport whose peers may still be reading this rank's send regions)
         send_q, send_e, any_, n = self.b.scan_local(pointcloud, ego_position, transform)
         # one host-side exchange: what every rank packed for every other rank, who saw a return in
@@ -404,6 +447,14 @@ class ShardedGvom(object):
         return self.b.g.make_debug_voxel_map()
 
     def combine_maps(self):
+        if hasattr(self.comm, "combine_native") and isinstance(self.b, HipShardBackend):
+            rc, out = self.comm.combine_native(self.b)
+            if rc == _gvom.GVOM_EMPTY_BUFFER:
+                if self.rank == 0:
+                    print("[WARNING] The map buffer is empty, nothing will happen!")
+                return None
+            self._cells_dirty = True
+            return out
         getattr(self.comm, "before_combine", _nothing)()             # (... or this rank's rows of the previous combine)
         rc = self.b.combine_fuse()
         if rc == _gvom.GVOM_EMPTY_BUFFER:

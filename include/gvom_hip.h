@@ -26,7 +26,9 @@
 extern "C" {
 #endif
 
-#define GVOM_ABI_VERSION 6   /* 6: sub-cloud interleave of the trace ("interleave" knob, automatic by a layout probe), gvom_get_tuning;
+#define GVOM_ABI_VERSION 7   /* 7: eager fusion of one-slot rings ("eager" knob, gvom_get_tuning "eager_adopted" / "eager_dropped"); a sharded scan /
+                              *    combine as ONE native call (gvom_comm_process_pointcloud, gvom_comm_combine_maps_into);
+                              * 6: sub-cloud interleave of the trace ("interleave" knob, automatic by a layout probe), gvom_get_tuning;
                               *    peer transport absorbs refused exports / imports (gvom_shard_renew_region, gvom_comm_peer_renewed), gvom_comm_info;
                               * 5: second transport between ranks (peer copies: gvom_comm_create2, gvom_comm_transport),
                               *    gvom_alloc_generation;
@@ -282,6 +284,15 @@ int  gvom_comm_exchange_scan(gvom_comm_t *c, gvom_t *h, const int64_t *send_quad
 int  gvom_comm_exchange_stats(gvom_comm_t *c, gvom_t *h, const int64_t *send_returns, const int64_t *recv_returns,
                               int bytes_per_return);
 int  gvom_comm_allgather_rows(gvom_comm_t *c, gvom_t *h);
+/* A whole sharded scan / combine in ONE call (handles without per-voxel statistics): the sequences documented above --
+ * gvom_comm_before_scan, gvom_shard_scan_local, the host exchange of the counts, gvom_shard_recv_reserve,
+ * gvom_comm_exchange_scan, gvom_shard_scan_merge; gvom_comm_before_combine, gvom_combine_fuse, gvom_comm_allgather_rows,
+ * gvom_combine_map2d_into -- run natively, every rank calling with ITS share of the cloud (n may be 0).
+ * out = {accepted (some rank saw a return in the grid, gvom.py:147-150), returns of all ranks, bytes this rank sent, received}.
+ * gvom_comm_combine_maps_into returns GVOM_EMPTY_BUFFER while the ring is empty (gvom.py:179-181). */
+int  gvom_comm_process_pointcloud(gvom_comm_t *c, gvom_t *h, const void *xyz, int on_device, int64_t n, int64_t row_stride_bytes,
+                                  int dtype, const double ego[3], const double *transform_4x4, int64_t out[4]);
+int  gvom_comm_combine_maps_into(gvom_comm_t *c, gvom_t *h, double origin_world[3], void *pinned_out);
 int  gvom_comm_rank(gvom_comm_t *c);
 int  gvom_comm_world(gvom_comm_t *c);
 const char *gvom_comm_last_error(gvom_comm_t *c);
@@ -354,6 +365,15 @@ int gvom_host_timing(gvom_t *h, double us[8]);
  * one-wave probe kernel in front of the trace looks for that structure (64 sampled returns per candidate K <= 4) on the second
  * cloud of a length and every 32nd after it, and the following clouds of that length are traced accordingly; clouds whose
  * length changes from scan to scan are never probed; 1: off.  Only WHO traces which return changes, never a result.
+ * "eager": the EAGER FUSION of one-slot rings (buffer_size 1, unsharded, no statistics, xy_size % 16 == 0).  The scan launches
+ * ONE kernel behind the trace that encodes the ring slot AND fuses it with the previous fused map (the work of the scan's
+ * encode pass and of the next combine's fusion, in one pass over the scan's accumulators), into spare buffers -- speculating
+ * that the next call is gvom_combine_maps*, the reference node's pattern (gvom_ros.py:82-115: one combine per scan).  That
+ * call adopts the result iff no scan came in between; otherwise it is dropped and the combine fuses the encoded slot as
+ * before.  -1 (default): automatic -- off after three dropped speculations in a row, on again once combines follow scans;
+ * 1: always; 0: never.  gvom_get_tuning "eager_adopted" / "eager_dropped": how often either happened.
+ * "encfuse" (A/B of that kernel's shape: low 4 bits waves per column block, bit 4 no XCD pairing), "fuse1" (1: one-slot
+ * fusions through the general kernel), "flag_kernel" (1: round 3's completion-flag kernel).
  * "epoch_bias" (test hook) advances the 32-bit tile-epoch counter, e.g. to just below its wrap. */
 int gvom_set_tuning(gvom_t *h, const char *name, int value);
 /* The value the LAST scan ran with ("segs", "period", "ep_row", "prio", "interleave": what automatic resolved to). */
