@@ -545,13 +545,16 @@ def stream_single(name, hz, ticks, poses):
         except Exception as e:                          # pragma: no cover
             err.append(e)
 
-    ts = [threading.Thread(target=lidar), threading.Thread(target=timer)]
+    ts = [threading.Thread(target=lidar, daemon=True), threading.Thread(target=timer, daemon=True)]
     for t in ts:
         t.start()
     for t in ts:
         t.join(ticks * period + 120)
     if err:
         raise err[0]
+    if any(t.is_alive() for t in ts) or len(lat) != ticks:
+        # (a stalled thread still holds `g`: report it instead of computing percentiles of a partial list)
+        raise RuntimeError("paced two-thread stream stalled: %d of %d ticks completed" % (len(lat), ticks))
     out["two_threads"] = {"latency_ms": {"p50": _pct(lat, 0.5) * 1e3, "p95": _pct(lat, 0.95) * 1e3, "p99": _pct(lat, 0.99) * 1e3,
                                          "max": max(lat) * 1e3},
                           "deadline_misses": sum(1 for v in lat if v > period),

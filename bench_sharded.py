@@ -267,9 +267,9 @@ def run(args):
             share, ego = host_shares[kk % poses]
             sh.process_pointcloud(share, ego)
             return sh.combine_maps()
-        t0 = max(r[0] for r in comm.exchange_host([int((time.perf_counter() + 0.25) * 1e9)])) * 1e-9
-        for kk in range(3):
+        for kk in range(3):                                 # warm ticks FIRST, then the ranks agree on the schedule's start
             tick(kk)
+        t0 = max(r[0] for r in comm.exchange_host([int((time.perf_counter() + 0.25) * 1e9)])) * 1e-9
         stream = bench.paced_stream(tick, args.offered_hz, args.ticks, t0=t0, warm=0)
         rank_rows = comm.exchange_host([int(stream["latency_ms"][q] * 1e3) for q in ("p50", "p95", "p99", "max")] + [stream["deadline_misses"]])
         stream["per_rank"] = [{"rank": r, "latency_us_p50_p95_p99_max": list(row[:4]), "deadline_misses": row[4]} for r, row in enumerate(rank_rows)]

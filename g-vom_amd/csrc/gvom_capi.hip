@@ -91,6 +91,7 @@ struct gvom_handle {
     uint64_t alloc_gen = 0;                             // changes whenever a send region of this handle is re-allocated
     uint64_t handle_gen = 0;                            // this handle's own number (its fixed allocations)
     bool exported = false;                              // a transport has exported this handle's send regions to other processes
+    bool holds_pooled = false;                          // some region of this handle came out of the process-wide pool (a peer may still have it mapped)
     std::vector<Buf> retired;                           // outgrown / replaced exported regions (possibly still mapped by peers), with their sizes
     uint64_t fixed_gen[3] = {0, 0, 0};                  // generations of the fixed exported allocations: send ids, send quads, height-map rows
     // rank exchange of a sharded map (world > 1): send / receive regions, indexed by peer rank
@@ -267,13 +268,16 @@ void pool_put(void *p, size_t bytes, uint64_t gen)
     }
 }
 // an exportable allocation of exactly `bytes` (a multiple of 2 MiB): a parked one, or a fresh one
-hipError_t pool_get(size_t bytes, void **p, uint64_t *gen)
+// (*reused: the region came out of the pool, i.e. some peer may STILL have it mapped: its next owner must park it again
+// whether or not it exports anything itself -- ADVICE r4)
+hipError_t pool_get(size_t bytes, void **p, uint64_t *gen, bool *reused = nullptr)
 {
     {
         std::lock_guard<std::mutex> lk(g_pool.m);
         for (size_t k = 0; k < g_pool.v.size(); ++k)
             if (g_pool.v[k].bytes == bytes) {
                 *p = g_pool.v[k].p; *gen = g_pool.v[k].gen;
+                if (reused) *reused = true;
                 g_pool.bytes -= bytes;
                 g_pool.v.erase(g_pool.v.begin() + (long)k);
                 return hipSuccess;
@@ -295,7 +299,7 @@ int ensure(gvom_handle *h, Buf &b, size_t bytes)
     if (b.p && exported) { h->retired.push_back(b); b.p = nullptr; }
     if (b.p) HIPCHK(h, hipFree(b.p));
     b.p = nullptr; b.bytes = 0;
-    if (exported) HIPCHK(h, pool_get(want, &b.p, &b.gen));
+    if (exported) HIPCHK(h, pool_get(want, &b.p, &b.gen, &h->holds_pooled));
     else { HIPCHK(h, hipMalloc(&b.p, want)); b.gen = ++g_alloc_generation; }
     b.bytes = want;
     if (&b == &h->x_send_eps || &b == &h->x_send_sp) h->alloc_gen = b.gen;   // (see gvom_alloc_generation)
@@ -530,7 +534,7 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, b
         CK(hipMalloc((void **)&h->hmaps2, h->cells2d * 24));
     }
     h->hs = 3 * xy;
-    if (sharded) CK(pool_get(exportable_size(h->cells2d * 24), (void **)&h->hmaps, &h->fixed_gen[2]));
+    if (sharded) CK(pool_get(exportable_size(h->cells2d * 24), (void **)&h->hmaps, &h->fixed_gen[2], &h->holds_pooled));
     else CK(hipMalloc((void **)&h->hmaps, h->cells2d * 24));
     h->height = h->hmaps; h->inferred = h->hmaps + xy;
     double **maps[4] = {&h->slope_x, &h->slope_y, &h->rough, &h->guessed};
@@ -544,8 +548,8 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, b
         // rank exchange regions (DESIGN.md "Multi-GPU"): a quad = 4 storage rows x 64 sx at one sz
         h->x_Q = (size_t)(xy / 4) * zs * h->nseg;
         h->x_myQ = h->x_Q / world;
-        CK(pool_get(exportable_size(h->x_Q * 4), (void **)&h->x_send_ids, &h->fixed_gen[0]));
-        CK(pool_get(exportable_size(h->x_Q * 1024), &h->x_send_pay, &h->fixed_gen[1]));
+        CK(pool_get(exportable_size(h->x_Q * 4), (void **)&h->x_send_ids, &h->fixed_gen[0], &h->holds_pooled));
+        CK(pool_get(exportable_size(h->x_Q * 1024), &h->x_send_pay, &h->fixed_gen[1], &h->holds_pooled));
         CK(hipMalloc((void **)&h->x_recv_ids, h->x_Q * 4));
         CK(hipMalloc(&h->x_recv_pay, h->x_Q * 1024));
         CK(hipMalloc((void **)&h->x_qcnt, (size_t)world * 64));
@@ -1326,7 +1330,7 @@ VIS void gvom_destroy(gvom_t *h)
     // to the process-wide pool (see pool_put), the others back to the allocator
     auto park = [&](void *ptr, size_t bytes, uint64_t gen) {
         if (!ptr) return;
-        if (h->exported) pool_put(ptr, bytes, gen); else hipFree(ptr);
+        if (h->exported || h->holds_pooled) pool_put(ptr, bytes, gen); else hipFree(ptr);
     };
     for (Buf &r : h->retired) park(r.p, r.bytes, r.gen);
     if (h->sharded) {

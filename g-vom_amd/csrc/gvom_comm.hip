@@ -216,7 +216,6 @@ struct gvom_comm {
     int transport = GVOM_TRANSPORT_RCCL;       // the one in use (never AUTO)
     Rccl rccl;
     ncclComm_t nccl = nullptr;
-    uint64_t seen_gen[GVOM_COMM_MAX_RANKS][GVOM_PEER_KINDS] = {};   // the exports as of the last exchange (every rank's, every kind)
     uint64_t recover_round = 0;                // rounds of the import recovery so far (the same on every rank)
     void *src_all[GVOM_COMM_MAX_RANKS][GVOM_PEER_KINDS] = {};       // scratch of one exchange: where each source's export is mapped
     bool need_all[GVOM_COMM_MAX_RANKS][GVOM_PEER_KINDS] = {};
@@ -422,21 +421,18 @@ int peer_source(gvom_comm *c, int s, int kind, void **src, bool *refused = nullp
 
 struct PeerPull { int kind, recv_which; int64_t unit; const int64_t *recv_counts; const int64_t *send_counts; };
 
-// Host-synchronised exchanges, after the barrier that made the exports visible: every rank opens what it needs
-// (src[s][k] for need[s][k]).  An open the HSA runtime REFUSES is absorbed here: the rank says so in the segment, the owner
-// of the allocation moves the region into a fresh one and exports that, and everybody tries again -- collectively (every
-// rank passes the same barriers: rounds happen only in exchanges in which some export is new, which all ranks see alike),
-// up to three rounds.  republish(kind): the caller's way to export `kind` again from a fresh allocation.
+// After the barrier that made the exports visible: every rank opens what it needs (src[s][k] for need[s][k]).  An open the HSA
+// runtime REFUSES is absorbed here: the rank says so in the segment, the owner of the allocation moves the region into a fresh
+// one and exports that, and everybody tries again -- up to three rounds.  Whether a round is needed is decided COLLECTIVELY:
+// every rank brings "an open of mine was refused" to one host exchange and every rank sees the OR (round 4 let each rank
+// decide from the export generations it had seen: a rank that opened an OLD export for the first time -- three or more
+// ranks, a source that had nothing for it in the earlier scans -- failed alone while the others went on to the next barrier;
+// ADVICE r4).  One more ~1 us host barrier per exchange of the peer transport; both of its forms (host-synchronised and
+// asynchronous) come through here.  republish(kind): the caller's way to export `kind` again from a fresh allocation.
 template <typename Republish>
 int peer_open_all(gvom_comm *c, const int *kinds, int nk, const bool (*need)[GVOM_PEER_KINDS], void *(*src)[GVOM_PEER_KINDS],
                   Republish republish)
 {
-    bool newgen = false;
-    for (int s = 0; s < c->world; ++s)
-        for (int k = 0; k < GVOM_PEER_KINDS; ++k) {
-            const uint64_t g = c->seg->exports[s][k].generation;
-            if (g != c->seen_gen[s][k]) { newgen = true; c->seen_gen[s][k] = g; }
-        }
     for (int round = 0; ; ++round) {
         const uint64_t tag = ++c->recover_round;
         bool mine_failed = false;
@@ -456,26 +452,19 @@ int peer_open_all(gvom_comm *c, const int *kinds, int nk, const bool (*need)[GVO
                 }
             }
         }
-        if (!newgen) {                                                 // (nothing new: every source was mapped before)
-            if (mine_failed) { c->err = first_err; return GVOM_ERR_HIP; }
-            return GVOM_OK;
-        }
-        int rc = gvom_comm_barrier(c);                                 // the refusals of this round are on the table
+        // the refusals of this round are on the table, and every rank learns whether there were any
+        int64_t mine = mine_failed ? 1 : 0, all[GVOM_COMM_MAX_RANKS];
+        int rc = gvom_comm_exchange_host(c, &mine, 1, all);
         if (rc) return rc;
-        bool any = false, me = false;
-        for (int s = 0; s < c->world; ++s)
-            for (int i = 0; i < nk; ++i)
-                if (c->seg->import_failed[s][kinds[i]].load(std::memory_order_acquire) == tag) { any = true; if (s == c->rank) me = true; }
+        bool any = false;
+        for (int r = 0; r < c->world; ++r) any = any || all[r] != 0;
         if (!any) return GVOM_OK;
         if (round >= 3) { c->err = first_err.empty() ? "a peer could not open an exported region (three fresh allocations tried)" : first_err; return GVOM_ERR_HIP; }
-        if (me)
-            for (int i = 0; i < nk; ++i)
-                if (c->seg->import_failed[c->rank][kinds[i]].load(std::memory_order_acquire) == tag && (rc = republish(kinds[i]))) break;
+        for (int i = 0; i < nk; ++i)
+            if (c->seg->import_failed[c->rank][kinds[i]].load(std::memory_order_acquire) == tag && (rc = republish(kinds[i]))) break;
         const int rb = gvom_comm_barrier(c);                           // the fresh exports are visible
         if (rc) return rc;
         if (rb) return rb;
-        for (int s = 0; s < c->world; ++s)
-            for (int k = 0; k < GVOM_PEER_KINDS; ++k) c->seen_gen[s][k] = c->seg->exports[s][k].generation;
     }
 }
 
@@ -495,7 +484,7 @@ int peer_pull(gvom_comm *c, gvom_t *h, hipStream_t st, const PeerPull *pulls, in
     if (rc) return rc;
     auto &src_all = c->src_all;
     auto &need_all = c->need_all;
-    if (!async) {
+    {
         int kinds[GVOM_PEER_KINDS];
         for (int s = 0; s < c->world; ++s)
             for (int k = 0; k < n_pulls; ++k) {
@@ -522,8 +511,7 @@ int peer_pull(gvom_comm *c, gvom_t *h, hipStream_t st, const PeerPull *pulls, in
                 rc = GVOM_ERR_INVALID;
                 break;
             }
-            if (async) { if ((rc = peer_source(c, s, pulls[k].kind, &src))) break; }
-            else src = src_all[s][pulls[k].kind];
+            src = src_all[s][pulls[k].kind];
             const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, st);
             if (e != hipSuccess) { c->err = std::string("hipMemcpyAsync (peer copy) failed: ") + hipGetErrorString(e); rc = GVOM_ERR_HIP; break; }
             c->peer_bytes += bytes; ++c->peer_copies;
@@ -940,11 +928,20 @@ static int allgather_rows_impl(gvom_comm_t *c, gvom_t *h)
             const uint64_t x = ++c->rows_x;
             if ((rc = peer_flag(c, st, &c->seg->flags[c->rank].rows_ready, x))) return rc;
             if ((rc = gvom_comm_barrier(c))) return rc;                // (exports visible)
+            {
+                const int kind4 = 4;
+                for (int s = 0; s < c->world; ++s) { c->need_all[s][4] = s != c->rank; c->src_all[s][4] = nullptr; }
+                if ((rc = peer_open_all(c, &kind4, 1, c->need_all, c->src_all, [&](int) { return peer_publish(c, h, 4, nullptr, true); }))) return rc;
+                // (this rank's own rows may lie in a fresh allocation now: a renewal waits for the stream, so rows_ready below
+                // would be stale -- publish it again behind the move)
+                void *p2 = nullptr;
+                if (gvom_device_buffer(h, GVOM_BUF_HEIGHT_MAPS, &p2, &bytes, &row)) { c->err = "height-map rows missing"; return GVOM_ERR_INVALID; }
+                if (p2 != ptr) { ptr = p2; if ((rc = peer_flag(c, st, &c->seg->flags[c->rank].rows_ready, x))) return rc; }
+            }
             for (int s = 0; s < c->world; ++s) {
-                void *src = nullptr;
                 if (s == c->rank) continue;
                 if ((rc = peer_wait(c, s, c->seg->flags[s].rows_ready, x, "its rows of the combine"))) return rc;
-                if ((rc = peer_source(c, s, 4, &src))) return rc;
+                void *src = c->src_all[s][4];
                 HIPCHK_C(c, hipMemcpyAsync((char *)ptr + share * s, src, share, hipMemcpyDefault, st));
                 c->peer_bytes += share; ++c->peer_copies;
             }

@@ -730,8 +730,9 @@ def test_sub_cloud_interleave_leaves_results_unchanged(gvom_mod):
 
 
 def test_layout_probe_finds_interleaved_sensors_and_nothing_else(gvom_mod):
-    """Automatic interleave (the default): a probe inside k_trace looks at every cloud and the NEXT cloud of as many returns is
-    traced accordingly (clouds whose length changes from scan to scan are never probed).  It must find the 4 sensors of the c4 cloud (and the sensor groups of a 16-sensor one), must not find
+    """Automatic interleave (the default): a one-wave probe kernel in front of k_trace looks at the second cloud of a length (and
+    every 32nd after it) and the NEXT clouds of as many returns are traced accordingly (clouds whose length changes from scan to
+    scan are never probed).  It must find the 4 sensors of the c4 cloud (and the sensor groups of a 16-sensor one), must not find
     structure in a single sensor's scan or in random points, forgets its answer when the cloud's length changes -- and whatever
     it answers, the slots equal those of a mapper with the interleave switched off."""
     p4, multi = synth.config_inputs("c4", n_scans=2)

@@ -211,17 +211,22 @@ def test_peer_transport_with_a_new_exported_region_every_scan(monkeypatch):
     assert text.count("105 combines equal the unsharded mapper's") == 4, text[-3000:]
 
 
-@pytest.mark.parametrize("fault,world", [("export:2,rank:1", 2), ("import:3,rank:0", 2), ("export:1", 4), ("import:2", 4)])
-def test_peer_transport_absorbs_a_refused_export_or_import(monkeypatch, fault, world):
+@pytest.mark.parametrize("fault,world,asynchronous", [("export:2,rank:1", 2, False), ("import:3,rank:0", 2, False), ("export:1", 4, False),
+                                                      ("import:2", 4, False), ("import:5,rank:2", 4, False), ("import:7,rank:3", 4, False),
+                                                      ("import:2", 4, True), ("export:2,rank:1", 2, True), ("import:6,rank:1", 4, True)])
+def test_peer_transport_absorbs_a_refused_export_or_import(monkeypatch, fault, world, asynchronous):
     """hipIpcGetMemHandle / hipIpcOpenMemHandle can refuse an allocation (profiles/r3_peer_churn.txt).  The library, not the
     test harness, absorbs it: the refused region moves into a fresh allocation which is exported instead (a refused OPEN is
     reported through the segment, its owner does the same, every rank tries again -- collectively, inside the exchange).
     Test hook GVOM_TEST_IPC_REFUSE: the N-th export / import of a process (of one rank, or of every rank) is answered with the
-    runtime's refusal.  The run must end with the unsharded mapper's maps, no restart, and say how many regions it renewed."""
+    runtime's refusal.  The run must end with the unsharded mapper's maps, no restart, and say how many regions it renewed.
+    Late refusals (the 5th / 7th import of one rank: an export that has been on the table for several exchanges, opened for the
+    first time by this rank -- ADVICE r4: whether a recovery round is needed is decided collectively, not from the export
+    generations a rank has seen) and the asynchronous form of the transport (GVOM_PEER_ASYNC=1) take the same path."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import shard_procs
     monkeypatch.setenv("GVOM_TEST_IPC_REFUSE", fault)
-    ok, text = shard_procs.launch(world, "peer", False)
+    ok, text = shard_procs.launch(world, "peer", False, asynchronous=asynchronous)
     assert ok, text[-3000:]
     assert text.count("combines equal the unsharded mapper's") == world, text[-3000:]
     import re
