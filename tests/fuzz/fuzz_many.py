@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Runs tests/test_hip_parity.py::_fuzz_case for a range of seeds on the GPU box and reports the
-seeds whose HIP records differ from the oracle.  Usage: tests/fuzz/fuzz_many.py <first> <count> [stats] [ilv=K] [p2]
+seeds whose HIP records differ from the oracle.  Usage: tests/fuzz/fuzz_many.py <first> <count> [stats] [ilv=K] [p2] [eager]
 (ilv=K: the HIP mapper traces with the sub-cloud interleave forced to K -- a permutation of who traces which return; it applies
 to the scans whose length K divides; p2: grid sizes snapped to powers of two, z_size <= xy_size -- the grids on which k_trace takes
 its mask-wrap and no-window-test step bodies)"""
@@ -31,6 +31,10 @@ for seed in range(first, first + count):
         xy2 = 1 << max(2, int(round(np.log2(max(params[2], 4)))))
         zs2 = min(xy2, 1 << max(0, int(round(np.log2(max(params[3], 1))))))
         params = params[:2] + (xy2, zs2) + params[4:]
+    if "eager" in sys.argv[3:]:
+        # one-slot rings on grids the eager fusion takes (buffer_size 1, xy_size % 16 == 0, z_size >= 4): scans with and without
+        # a combine behind them, rejected and empty scans, moving windows -- k_encfuse, its adoption and its fall-backs
+        params = params[:2] + (16 * max(1, min(4, round(params[2] / 16))), max(4, params[3]), 1) + params[5:]
     sc = {"params": params, "steps": steps}
     try:
         with contextlib.redirect_stdout(io.StringIO()):
