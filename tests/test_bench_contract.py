@@ -26,6 +26,22 @@ def test_roofline_object_has_the_contract_keys():
     json.dumps(r)
     rp = bench.roofline_of(alg, stages, profiled=True)                # committed m256 passes
     assert rp["traffic"] and rp["valu"] and rp["valu"]["insts_per_launch"] > 1e6
+    # the line says where `traffic` comes from: a committed PMC pass, not this run
+    assert rp["traffic_source"].startswith("profiles/") and "NOT measured by this run" in rp["traffic_source"] and r["traffic_source"] is None
+    # one-slot rings with the eager fusion: the scan's second kernel is k_encfuse (encode + fusion), the combine has no fusion stage
+    eager = dict(stages, fuse={"median": 0.0, "p10": 0.0, "p90": 0.0, "samples": 20}, encode=dict(stages["encode"], median=0.045))
+    re_ = bench.roofline_of(alg, eager, profiled="m256")
+    assert re_["kernel"] == "k_encfuse" and re_["algorithmic_bytes_per_launch"] == alg["encode"] + alg["fuse"]
+    assert re_["traffic_detail"]["source"].startswith("r5_") or re_["traffic"] is None
+
+
+def test_metric_names_the_grid_the_line_ran_on():
+    """m256 IS the 256^3 grid BASELINE.json's metric is quoted on; any other config says its own grid (VERDICT r4 item 11:
+    sharded c4 / c5 lines used to say "256^3 voxel grid")."""
+    import bench
+    assert bench.metric_for("m256", [256, 256, 256]) == bench.METRIC and "256^3" in bench.METRIC
+    m = bench.metric_for("c4", [512, 512, 128])
+    assert "512x512x128" in m and "256^3" not in m and "BASELINE config c4" in m
 
 
 def _bench(argv, env_extra=None, timeout=300):
