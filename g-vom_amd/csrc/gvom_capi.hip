@@ -385,7 +385,10 @@ void fill_scan_params(const gvom_handle *h, const int64_t origin[3], const doubl
         // m256 and c3: 12 = 16)
         P.lc_period = h->tune_period > 0 ? h->tune_period : (many ? 12 : 16);
         if (P.lc_period > 32) P.lc_period = 32;          // the line cache is direct-mapped with 64 entries
-        P.ep_row = h->tune_ep_row >= -1 ? h->tune_ep_row : 0;  // endpoint blocks first: their atomics retire under the walk (-1: inside segment 0's waves)
+        // endpoint blocks first: their atomics retire under the walk; clouds with plenty of returns (several dispatch rounds
+        // anyway) do the endpoint work inside segment 0's waves instead (-1): one wave and one load of the returns less per
+        // bundle (r5, ep_row 0 / -1: c4 615.6 / 605.6 us per step, c5 2297 / 2052; c3 145.9 / 148.0 and m256 98.2 / 98.1 keep the row)
+        P.ep_row = h->tune_ep_row >= -1 ? h->tune_ep_row : (many ? -1 : 0);
         if (P.ep_row > P.nsegs) P.ep_row = P.nsegs;
         // issue priority by remaining work (k_trace, prio_by_remaining): steps per priority level.  Measured, off / 4 / 8 / 16:
         // m256 40.1 / 40.1 / 39.0 / 40.4 us, c2 39.2 / - / 36.7 / -, c3 70.6 / - / 68.2 / -, c4 unchanged
