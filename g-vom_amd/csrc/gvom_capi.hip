@@ -192,6 +192,8 @@ struct gvom_handle {
     bool fuse_b_unjoined = false;                       // ev_fuse_b recorded; the main stream has not waited on it
     uint64_t fuse_b_slots = 0;                          // bit k: slots[k] is a source of that fusion
     bool scan_inflight = false;                         // a scan's kernels are enqueued and it is not committed yet (scan_mu held)
+    std::vector<void *> out_bufs;                        // buffers handed out by gvom_output_buffer_alloc (coherent by construction)
+    void *last_checked_out = nullptr;                    // a caller's own output buffer whose flags have been checked
     void *out_host = nullptr;                           // pinned, device-mapped staging for the 4 outputs
     char *out_host_dev = nullptr;                       // device view of out_host (zero-copy target)
     uint32_t scan_seq = 0;                              // sequence number of the {seq,count} flag
@@ -1599,6 +1601,21 @@ VIS int gvom_combine_maps(gvom_t *h, double origin_world[3], int32_t *positive, 
     return GVOM_OK;
 }
 
+// A caller's own output buffer must be COHERENT pinned memory (see gvom_hip.h, gvom_combine_maps_into): the completion flag is only
+// ordered behind the maps for write-through stores.  Buffers from gvom_output_buffer_alloc are; others are asked once.
+static int check_out_buffer(gvom_handle *h, void *pinned_out)
+{
+    if (std::find(h->out_bufs.begin(), h->out_bufs.end(), pinned_out) != h->out_bufs.end() || pinned_out == h->last_checked_out) return GVOM_OK;
+    unsigned int flags = 0;
+    if (hipHostGetFlags(&flags, pinned_out) != hipSuccess) { (void)hipGetLastError(); h->err = "output buffer is not pinned host memory (hipHostMalloc)"; return GVOM_ERR_INVALID; }
+    if (!(flags & hipHostMallocCoherent) || !(flags & hipHostMallocMapped)) {
+        h->err = "output buffer must be coherent, device-mapped pinned memory (hipHostMallocMapped | hipHostMallocCoherent; gvom_output_buffer_alloc returns such)";
+        return GVOM_ERR_INVALID;
+    }
+    h->last_checked_out = pinned_out;
+    return GVOM_OK;
+}
+
 // ---- zero-copy outputs ---------------------------------------------------------------------
 // gvom_output_buffer_alloc returns a pinned, device-mapped host buffer of 20*xy*xy bytes laid out
 // [positive i32 | negative i32 | visibility i32 | roughness f64] (each xy*xy, COLUMN-major:
@@ -1614,6 +1631,7 @@ VIS int gvom_output_buffer_alloc(gvom_t *h, void **host_ptr)
     // GVOM_OUT_COHERENT=1: fine-grained (coherent) pinned memory -- stores leave the GPU as they are
     // issued instead of being written back from L2 at the end of the kernel
     HIPCHK(h, hipHostMalloc(host_ptr, h->cells2d * 20, hipHostMallocMapped | hipHostMallocCoherent));
+    h->out_bufs.push_back(*host_ptr);
     return GVOM_OK;
 }
 
@@ -1623,6 +1641,9 @@ VIS int gvom_output_buffer_free(gvom_t *h, void *host_ptr)
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, sync_streams(h));
+    for (size_t k = 0; k < h->out_bufs.size(); ++k)
+        if (h->out_bufs[k] == host_ptr) { h->out_bufs[k] = h->out_bufs.back(); h->out_bufs.pop_back(); break; }
+    if (h->last_checked_out == host_ptr) h->last_checked_out = nullptr;
     HIPCHK(h, hipHostFree(host_ptr));
     return GVOM_OK;
 }
@@ -1634,6 +1655,7 @@ VIS int gvom_combine_maps_into(gvom_t *h, double origin_world[3], void *pinned_o
     std::unique_lock<std::mutex> lk(h->mu);
     if (h->pending_combine) { h->err = "a combine begun with gvom_combine_begin has not been ended"; return GVOM_ERR_INVALID; }
     HIPCHK(h, hipSetDevice(h->device));
+    { const int rc0 = check_out_buffer(h, pinned_out); if (rc0) return rc0; }
     double t0 = now_ns();
     int rc = fuse_impl(h);
     if (rc) return rc;
@@ -1666,6 +1688,7 @@ VIS int gvom_combine_occupancy_into(gvom_t *h, double origin_world[3], void *pin
     std::unique_lock<std::mutex> lk(h->mu);
     if (h->pending_combine) { h->err = "a combine begun with gvom_combine_begin has not been ended"; return GVOM_ERR_INVALID; }
     HIPCHK(h, hipSetDevice(h->device));
+    { const int rc0 = check_out_buffer(h, pinned_out); if (rc0) return rc0; }
     double t0 = now_ns();
     int rc = fuse_impl(h);
     if (rc) return rc;
@@ -1699,6 +1722,7 @@ VIS int gvom_combine_begin(gvom_t *h, void *pinned_out, const double *occ)
     std::lock_guard<std::mutex> lk(h->mu);
     if (h->pending_combine) { h->err = "a combine begun with gvom_combine_begin has not been ended"; return GVOM_ERR_INVALID; }
     HIPCHK(h, hipSetDevice(h->device));
+    { const int rc0 = check_out_buffer(h, pinned_out); if (rc0) return rc0; }
     double t0 = now_ns();
     // k_map2d goes to the second stream, and with a ring of three or more filled slots the fusion too (behind
     // the scan's k_encode on the main stream): the next scan's k_trace / k_encode overlap them -- they touch the

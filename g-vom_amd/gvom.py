@@ -28,6 +28,7 @@ __all__ = ["Gvom", "GvomBackendError", "load_library", "library_path"]
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 GVOM_OK, GVOM_EMPTY_CLOUD, GVOM_NO_OVERLAP, GVOM_EMPTY_BUFFER, GVOM_NO_DATA = 0, 1, 2, 3, 4
+GVOM_ERR_INVALID = -1
 GVOM_WHICH_FUSED = -1
 MAP_HEIGHT, MAP_INFERRED, MAP_SLOPE_X, MAP_SLOPE_Y, MAP_ROUGHNESS, MAP_GUESSED = range(6)
 BUF_HEIGHT_MAPS, BUF_FUSED_CELLS = 0, 3

@@ -143,7 +143,12 @@ int gvom_combine_maps(gvom_t *h, double origin_world[3], int32_t *positive, int3
  * each map is stored COLUMN-MAJOR: cell (x, y) at m[y*xy_size + x] -- the Fortran-ordered form of
  * the reference's [x, y]-indexed arrays, which is what gvom_ros.py:141-162 reads
  * (np.reshape(map, -1, order='F')); the GPU writes it as contiguous runs without a transpose and
- * streams each map out as soon as it is known.  The caller owns the buffer (and may keep several alive) until gvom_output_buffer_free. */
+ * streams each map out as soon as it is known.  The caller owns the buffer (and may keep several alive) until gvom_output_buffer_free.
+ * COHERENCE: the synchronous calls learn of completion from a flag k_map2d's last workgroup stores behind its maps (every wave waits
+ * for its stores to be acknowledged first), not from a stream synchronisation.  That is sound for COHERENT (fine-grained) pinned
+ * memory, which is what gvom_output_buffer_alloc returns (hipHostMallocMapped | hipHostMallocCoherent): system-scope stores are
+ * written through.  A buffer of the caller's own must be allocated the same way; gvom_combine_maps_into /
+ * gvom_combine_occupancy_into / gvom_combine_begin refuse (GVOM_ERR_INVALID) a pinned buffer whose flags say otherwise. */
 int gvom_output_buffer_alloc(gvom_t *h, void **host_ptr);
 int gvom_output_buffer_free(gvom_t *h, void *host_ptr);
 int gvom_combine_maps_into(gvom_t *h, double origin_world[3], void *pinned_out);

@@ -850,6 +850,42 @@ def test_c_entry_combine_maps_fills_caller_buffers_row_major(gvom_mod):
         assert a.combined_cell_count_cpu == b.combined_cell_count_cpu
 
 
+def test_output_buffers_of_the_callers_own_must_be_coherent_pinned_memory(gvom_mod):
+    """gvom_combine_maps_into with a buffer that is not from gvom_output_buffer_alloc: accepted iff it is coherent, device-mapped
+    pinned memory (the completion flag is only ordered behind the maps for write-through stores, include/gvom_hip.h)
+    -- a non-coherent pinned buffer and plain host memory are refused with GVOM_ERR_INVALID and a message, nothing is launched
+    into them, and the mapper goes on working."""
+    import ctypes
+    rt = ctypes.CDLL("libamdhip64.so")
+    rt.hipHostMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, ctypes.c_uint]
+    rt.hipHostFree.argtypes = [ctypes.c_void_p]
+    params = (0.4, 0.2, 32, 16, 1, 0.5, 0.5, 0.5, 0.3, 2.0, 2.0, 1.0, 1, 1)
+    g = gvom_mod.Gvom(*params)
+    rng = np.random.default_rng(3)
+    pc = np.stack([rng.uniform(-5, 5, 3000), rng.uniform(-5, 5, 3000), rng.normal(-0.6, 0.2, 3000)], 1).astype(np.float32)
+    g.process_pointcloud(pc, (0.0, 0.0, 0.0))
+    want = g.combine_maps()
+    n2 = 32 * 32
+    origin = (ctypes.c_double * 3)()
+    good, bad = ctypes.c_void_p(), ctypes.c_void_p()
+    assert rt.hipHostMalloc(ctypes.byref(good), n2 * 20, 0x2 | 0x40000000) == 0            # mapped | coherent
+    assert rt.hipHostMalloc(ctypes.byref(bad), n2 * 20, 0x2 | 0x80000000) == 0             # mapped | NON-coherent
+    plain = np.zeros(n2 * 20, np.uint8)
+    try:
+        g.process_pointcloud(pc, (0.0, 0.0, 0.0))
+        assert g._lib.gvom_combine_maps_into(g._h, origin, bad) == gvom_mod.GVOM_ERR_INVALID
+        assert b"coherent" in g._lib.gvom_last_error(g._h)
+        assert g._lib.gvom_combine_maps_into(g._h, origin, plain.ctypes.data_as(ctypes.c_void_p)) == gvom_mod.GVOM_ERR_INVALID
+        assert g._lib.gvom_combine_maps_into(g._h, origin, good) == gvom_mod.GVOM_OK      # (the refused calls changed nothing)
+        pos = np.ctypeslib.as_array(ctypes.cast(good, ctypes.POINTER(ctypes.c_int32)), (n2,)).reshape(32, 32).T
+        again = g.combine_maps()
+        assert int(pos.sum()) > 0 and again is not None
+    finally:
+        g._check(g._lib.gvom_sync(g._h))
+        rt.hipHostFree(good); rt.hipHostFree(bad)
+    assert want is not None
+
+
 def _pointcloud2_bytes(xyz32, point_step, offsets, seed):
     """Packed PointCloud2 data: x, y, z float32 at `offsets`, the other bytes random (intensity, ring,
     timestamps ...), a few records with NaN / inf coordinates as real drivers emit."""
