@@ -222,13 +222,16 @@ def test_asynchronous_combine_with_several_scans_before_its_end(gvom_mod):
             assert np.array_equal(ad[j], bd[j]), (slot, j)
 
 
-def test_scans_from_a_second_thread_while_a_combine_waits(gvom_mod):
+@pytest.mark.parametrize("buffer_size", [3, 1])
+def test_scans_from_a_second_thread_while_a_combine_waits(gvom_mod, buffer_size):
     """The ROS node calls process_pointcloud and combine_maps from two callback threads
     (gvom_ros.py:44-51).  combine_maps waits for its maps with the handle released, so scans keep being
     accepted; no call is lost, nothing deadlocks, and once both threads are done the map is the one a
-    sequential run of the same scans gives (the fusion only depends on the scans in the ring)."""
+    sequential run of the same scans gives (the fusion only depends on the scans in the ring).
+    buffer_size 1: the eager fusion's speculations are adopted or dropped as the two threads' calls happen to
+    interleave (a scan entering while a combine waits, a combine entering while a scan waits for its trace)."""
     import threading
-    params = (0.4, 0.2, 64, 32, 3, 0.5, 0.5, 0.5, 0.3, 2.0, 4.0, 1.0, 1, 1)
+    params = (0.4, 0.2, 64, 32, buffer_size, 0.5, 0.5, 0.5, 0.3, 2.0, 4.0, 1.0, 1, 1)
     rng = np.random.default_rng(12)
     scans = []
     for k in range(40):
@@ -257,6 +260,10 @@ def test_scans_from_a_second_thread_while_a_combine_waits(gvom_mod):
     t1.start(); t2.start(); t1.join(60); t2.join(60)
     assert not t1.is_alive() and not t2.is_alive() and not errors, errors
     assert combines[0] > 0
+    if buffer_size == 1:
+        assert g.get_tuning("eager_adopted") + g.get_tuning("eager_dropped") > 0
+        # a quiet epilogue on both mappers: scan, combine, combine -- the first adopts a speculation, the second re-fuses the slot
+        g.combine_maps()
     for pc, ego in scans:
         ref.process_pointcloud(pc, ego)
     # the previous fused map enters a combine (gvom.py:972-997), so only ring contents are compared
