@@ -1799,7 +1799,9 @@ VIS int gvom_combine_fuse(gvom_t *h, int64_t *local_cells)
     HIPCHK(h, hipSetDevice(h->device));
     int rc = fuse_impl(h);
     if (rc) return rc;
-    if ((rc = posdens_impl(h))) return rc;                // third row of the height buffer + the cell count
+    // third row of the height buffer + the cell count -- unless this rank holds every row (a sharded map of ONE rank): nothing
+    // is gathered then, and k_map2d computes the densities of its own cells and publishes the count, as on an unsharded handle
+    if (!(h->sharded && h->world == 1) && (rc = posdens_impl(h))) return rc;
     if (h->sharded) {                                     // no host wait: the count stays on the device (GVOM_BUF_FUSED_CELLS)
         if (local_cells) *local_cells = -1;
         return GVOM_OK;
@@ -1874,7 +1876,8 @@ VIS int gvom_combine_map2d_into(gvom_t *h, double origin_world[3], void *pinned_
     // synchronisation notices the end of the stream several microseconds later); the count was published by k_posdens
     std::unique_lock<std::mutex> ulk(h->mu, std::adopt_lock);
     const uint32_t done_seq = ++h->combine_seq;
-    int rc = map2d_impl(h, true, false, dev, true, nullptr, nullptr, done_seq);
+    const bool solo = h->sharded && h->world == 1;       // (every row is this rank's: no gathered densities, see gvom_combine_fuse)
+    int rc = map2d_impl(h, !solo, solo, dev, true, nullptr, nullptr, done_seq);
     if (rc == GVOM_OK) rc = finish_combine(h, ulk, done_seq);
     ulk.release();                                         // (the lock_guard above still owns the mutex)
     if (rc) return rc;
