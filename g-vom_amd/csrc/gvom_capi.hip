@@ -144,6 +144,13 @@ struct gvom_handle {
     int spec_nxt = 0, spec_slot = 0, spec_blocks = 0;
     uint32_t spec_epoch = 0;
     int64_t spec_origin[3] = {0, 0, 0};
+    // DIRECTIONAL ORDER of unordered clouds (k_dirbin_*, ScanParams::perm): "dirsort" 1 always, -1 never, 0 automatic -- when the
+    // layout probe found no spatial order in the previous cloud of this length (BASELINE c1's 50,000 random points: k_trace 65 -> 16 us)
+    int tune_dirsort = 0;
+    Buf dir_keys, dir_perm;                             // uint16 key / uint32 position -> return, per return
+    uint32_t *dir_hist = nullptr;                       // [3][GVOM_DIRBINS]: two histograms (alternating, zero between uses) + the bins' cursors
+    uint32_t dir_flip = 0;
+    int last_dirsort = 0;                               // gvom_get_tuning "dirsort": the last scan ran in directional order
     int tune_encfuse = 0;                               // gvom_set_tuning "encfuse": A/B of k_encfuse's shape (low 4 bits: waves per block, bit 4: no XCD pairing)
     int tune_eager = -1;                                // gvom_set_tuning "eager": 0 off, 1 always, -1 automatic (off after 3 wasted in a row)
     int eager_waste = 0;                                // speculations dropped in a row (saturates at 4)
@@ -522,6 +529,8 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, b
         CK(hipMalloc((void **)&h->fused[k].tags, h->ntiles * 4));
         CK(hipMemsetAsync(h->fused[k].tags, 0, h->ntiles * 4, h->stream));
     }
+    CK(hipMalloc((void **)&h->dir_hist, 3 * GVOM_DIRBINS * 4));
+    CK(hipMemsetAsync(h->dir_hist, 0, 3 * GVOM_DIRBINS * 4, h->stream));
     CK(hipMalloc((void **)&h->counters, GVOM_CNT_WORDS * 4));
     CK(hipHostMalloc((void **)&h->counters_host, 64, hipHostMallocMapped | hipHostMallocCoherent));
     CK(hipHostGetDevicePointer((void **)&h->counters_host_dev, h->counters_host, 0));
@@ -847,6 +856,27 @@ int scan_launch(gvom_handle *h, std::unique_lock<std::mutex> &lk, const void *de
             if (le != hipSuccess) { scan_abort(h); HIPCHK(h, le); }
         }
         h->last_n = n;
+    }
+    P.perm = nullptr;
+    {   // directional order: forced, or the probe's verdict on the previous cloud of this length ("scattered", bit 3 of its answer)
+        bool sort = h->tune_dirsort == 1;
+        if (h->tune_dirsort == 0 && h->tune_ilv == 0 && h->counters_host) {
+            const unsigned long long w = *(volatile unsigned long long *)(h->counters_host + 8);
+            sort = (int64_t)(w >> 8) == n && ((w >> 3) & 1ull) != 0;
+        }
+        h->last_dirsort = 0;
+        if (sort && n >= 256 && n < (1ll << 31)) {
+            if ((rc = ensure(h, h->dir_keys, (size_t)n * 2)) || (rc = ensure(h, h->dir_perm, (size_t)n * 4))) return rc;
+            uint32_t *hist = h->dir_hist + (h->dir_flip & 1u) * GVOM_DIRBINS, *next = h->dir_hist + ((h->dir_flip + 1u) & 1u) * GVOM_DIRBINS;
+            ++h->dir_flip;
+            le = gvom_launch_dirbin(h->stream, P, dtype, dev_pts, stride_elems, n, (uint16_t *)h->dir_keys.p, hist, next,
+                                    h->dir_hist + 2 * GVOM_DIRBINS, (uint32_t *)h->dir_perm.p);
+            if (le != hipSuccess) { scan_abort(h); HIPCHK(h, le); }
+            P.perm = (const uint32_t *)h->dir_perm.p;
+            P.ilv_lg = 0; P.ilv_len = n;
+            h->last_dirsort = 1;
+            h->last_knobs[4] = 1;
+        }
     }
     le = gvom_launch_trace(h->stream, P, X, dtype, big, dev_pts, stride_elems, n,
                                       h->stats ? wpts.p : nullptr, h->hit, h->total, h->mh, st.state,
@@ -1349,7 +1379,7 @@ VIS void gvom_destroy(gvom_t *h)
     if (h->x_host) hipHostFree(h->x_host);
     for (auto &s : h->slots) { hipFree(s.state); hipFree(s.code16); hipFree(s.tags); fb(s.crows); fb(s.metrics); fb(s.base); fb(s.rowvox); }
     for (auto &f : h->fused) { hipFree(f.state); hipFree(f.tags); fb(f.rows); fb(f.metrics); }
-    fb(h->in_pts); fb(h->world_pts[0]); fb(h->world_pts[1]); fb(h->tl);
+    fb(h->in_pts); fb(h->world_pts[0]); fb(h->world_pts[1]); fb(h->tl); fb(h->dir_keys); fb(h->dir_perm); hipFree(h->dir_hist);
     hipFree(h->counters); if (h->counters_host) hipHostFree(h->counters_host);
     hipFree(h->descs_dev); if (h->descs_host) hipHostFree(h->descs_host);
     hipFree(h->blockcounts); hipFree(h->blockcounts2); hipFree(h->hmaps2);
@@ -2205,6 +2235,7 @@ VIS int gvom_set_tuning(gvom_t *h, const char *name, int value)
     else if (!strcmp(name, "flag_kernel")) h->tune_flag_kernel = value;
     else if (!strcmp(name, "fuse1")) h->tune_fuse1 = value;
     else if (!strcmp(name, "encfuse")) h->tune_encfuse = value;
+    else if (!strcmp(name, "dirsort")) h->tune_dirsort = value;
     else if (!strcmp(name, "eager")) { h->tune_eager = value; h->eager_waste = 0; }
     else if (!strcmp(name, "churn")) h->tune_churn = value;
     else if (!strcmp(name, "exported")) h->exported = value != 0;       // (set by the peer transport, gvom_comm.hip)
@@ -2221,6 +2252,7 @@ VIS int gvom_get_tuning(gvom_t *h, const char *name, int *value)
     static const char *const names[5] = {"segs", "period", "ep_row", "prio", "interleave"};
     for (int k = 0; k < 5; ++k)
         if (!strcmp(name, names[k])) { *value = h->last_knobs[k]; return GVOM_OK; }
+    if (!strcmp(name, "dirsort")) { *value = h->last_dirsort; return GVOM_OK; }
     if (!strcmp(name, "eager_adopted")) { *value = h->eager_stat[0]; return GVOM_OK; }
     if (!strcmp(name, "eager_dropped")) { *value = h->eager_stat[1]; return GVOM_OK; }
     return GVOM_ERR_INVALID;

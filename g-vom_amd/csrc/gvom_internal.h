@@ -77,6 +77,9 @@ struct ScanParams {
                           //   neighbours sit in neighbouring lanes of ONE wave (merged steps, shared accumulator lines).  A
                           //   permutation of who traces which return: it cannot change a result.
     long   ilv_len;       // returns per sub-cloud (n / K; n % K == 0 or ilv_lg = 0)
+    const uint32_t *perm; // k_trace: nullptr, or the DIRECTIONAL ORDER of an unordered cloud (k_dirbin_*): position p takes return perm[p].
+                          //   A wave's 64 rays then point the same way (one of 1536 direction bins) and share accumulator lines; as with
+                          //   the interleave, only WHO traces which return changes
     int    f32_sqrt;      // GVOM_FLAG_CUDA_F32_SQRT: ray_length = sqrtf(f32 sum) (real Numba-CUDA typing, gvom.py:1109)
     int    sxq;           // accumulator layout: 4x4 (x,y) patches per row of patches = ceil(xy/4) + padding
     uint32_t epoch;       // this scan's tile epoch
@@ -183,6 +186,11 @@ hipError_t gvom_launch_encode(hipStream_t s, const ScanParams &P, uint32_t *hit,
 hipError_t gvom_launch_layout_probe(hipStream_t s, const ScanParams &P, int dtype, const void *pts, int64_t stride_elems, int64_t n,
                                     int max_lg, unsigned long long *host_word);
 hipError_t gvom_launch_publish_seq(hipStream_t s, unsigned long long *host_flag, uint32_t seq);
+// directional order of an unordered cloud: keys[n] (scratch), hist / cursor: GVOM_DIRBINS counters each (hist zero on entry, zeroed
+// again for the next use on exit: the caller alternates two), perm[n] out
+#define GVOM_DIRBINS 1536      // 6 cube faces x 16 x 16
+hipError_t gvom_launch_dirbin(hipStream_t s, const ScanParams &P, int dtype, const void *pts, int64_t stride_elems, int64_t n,
+                              uint16_t *keys, uint32_t *hist, uint32_t *hist_next, uint32_t *cursor, uint32_t *perm);
 hipError_t gvom_launch_fuse(hipStream_t s, const FuseParams &P, const FuseDescs &KD,
                             const MapDesc *descs_dev, int32_t *fstate, uint4 *frows,
                             uint32_t *ftags, uint32_t *blockcounts, double *height, double *inferred);

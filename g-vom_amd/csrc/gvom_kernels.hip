@@ -558,7 +558,8 @@ __device__ __forceinline__ void trace_item(const ScanParams &P, const ShardExcha
     const long pos = bundle * 64 + lane;
     const bool live = pos < n;
     // sub-cloud interleave (ScanParams::ilv_lg): which return this lane takes
-    const long i = P.ilv_lg ? (pos & ((1L << P.ilv_lg) - 1)) * P.ilv_len + (pos >> P.ilv_lg) : pos;
+    // ... or, for a cloud in no spatial order, the return the directional order puts here (ScanParams::perm)
+    const long i = P.perm ? (live ? (long)P.perm[pos] : pos) : (P.ilv_lg ? (pos & ((1L << P.ilv_lg) - 1)) * P.ilv_len + (pos >> P.ilv_lg) : pos);
     T x = 0, y = 0, z = 0;
     if (live) load_return(P, in, stride, i, x, y, z);
     const T d2 = (x * x + y * y) + z * z;
@@ -2983,6 +2984,120 @@ hipError_t gvom_launch_encode(hipStream_t s, const ScanParams &P, uint32_t *hit,
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// Directional order of an UNORDERED cloud (BASELINE config c1: 50,000 uniformly random points; any cloud that has been
+// shuffled, merged or filtered out of its sensor order).  k_trace's cost follows the accumulator lines a 64-ray bundle touches per
+// step: consecutive returns of a rotating lidar are neighbours in space, 64 random returns are not (c1: k_trace 65 us in the
+// order given, 15.6 us with the same returns ordered by direction -- tools/c1_sort_probe.py).  A counting sort by direction bin
+// seen from the sensor -- 6 cube faces x 16 x 16 cells in Morton order, 1536 bins of ~5.6 degrees -- in two launches:
+//   k_dirbin_hist     key of every return (float arithmetic: the order need not be exact) + per-block LDS histogram -> global
+//   k_dirbin_scatter  every block scans the 1536 counts itself (no scan launch), reserves its share of each bin with one global
+//                     atomic per non-empty bin and block, and writes perm[position] = return
+// The order inside a bin is whatever the atomics give: k_trace's results do not depend on who traces which return.
+// ------------------------------------------------------------------------------------------
+// (DIRBIN_ITEMS returns per thread, 256 threads per block: 1 for clouds up to 131 k returns -- both kernels are latency chains,
+// and 25 blocks of 8 returns per thread took 8.4 + 7.7 us on c1's 50,000 points -- 2 up to 524 k, 8 above)
+template <typename T>
+__device__ __forceinline__ uint32_t dirbin_key(const ScanParams &P, const T *__restrict__ in, long stride, long i)
+{
+    T x, y, z;
+    load_return(P, in, stride, i, x, y, z);
+    const float ux = (float)x * P.rinv[0] - P.pt0[0], uy = (float)y * P.rinv[0] - P.pt0[1], uz = (float)z * P.rinv[1] - P.pt0[2];
+    const float ax = fabsf(ux), ay = fabsf(uy), az = fabsf(uz);
+    uint32_t face;
+    float a, u, v;
+    if (ax >= ay && ax >= az) { face = ux < 0.0f ? 1u : 0u; a = ax; u = uy; v = uz; }
+    else if (ay >= az) { face = uy < 0.0f ? 3u : 2u; a = ay; u = uz; v = ux; }
+    else { face = uz < 0.0f ? 5u : 4u; a = az; u = ux; v = uy; }
+    if (!(a > 0.0f) || !(a < INFINITY)) return 0u;         // the sensor's own position, NaN, inf: anywhere
+    const uint32_t qu = (uint32_t)min(15, max(0, (int)((u / a + 1.0f) * 8.0f)));
+    const uint32_t qv = (uint32_t)min(15, max(0, (int)((v / a + 1.0f) * 8.0f)));
+    // Morton order of the face's 16 x 16 cells: bins that follow each other point in neighbouring directions
+    auto part = [](uint32_t t) { t = (t | (t << 2)) & 0x33u; return (t | (t << 1)) & 0x55u; };
+    return face * 256u + (part(qu) | (part(qv) << 1));
+}
+template <typename T, int DIRBIN_ITEMS>
+__global__ __launch_bounds__(256) void k_dirbin_hist(const ScanParams P, const T *__restrict__ in, long stride, long n, uint16_t *keys,
+                                                     uint32_t *hist, uint32_t *cursor)
+{
+    __shared__ uint32_t s_h[GVOM_DIRBINS];
+    for (int b = threadIdx.x; b < GVOM_DIRBINS; b += 256) s_h[b] = 0u;
+    if (blockIdx.x == 0) for (int b = threadIdx.x; b < GVOM_DIRBINS; b += 256) cursor[b] = 0u;      // (nobody reads it before k_dirbin_scatter)
+    __syncthreads();
+    const long base = (long)blockIdx.x * (256 * DIRBIN_ITEMS);
+#pragma unroll
+    for (int k = 0; k < DIRBIN_ITEMS; ++k) {
+        const long i = base + k * 256 + threadIdx.x;
+        if (i < n) {
+            const uint32_t key = dirbin_key(P, in, stride, i);
+            keys[i] = (uint16_t)key;
+            atomicAdd(&s_h[key], 1u);
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < GVOM_DIRBINS; b += 256) { const uint32_t c = s_h[b]; if (c) atomicAdd(&hist[b], c); }
+}
+template <int DIRBIN_ITEMS>
+__global__ __launch_bounds__(256) void k_dirbin_scatter(long n, const uint16_t *__restrict__ keys, const uint32_t *__restrict__ hist,
+                                                        uint32_t *hist_next, uint32_t *cursor, uint32_t *perm)
+{
+    __shared__ uint32_t s_start[GVOM_DIRBINS];             // first position of every bin (exclusive prefix of the counts), then this block's share
+    __shared__ uint32_t s_cnt[GVOM_DIRBINS];               // this block's returns per bin, then its running fill
+    __shared__ uint32_t s_part[256];
+    // exclusive prefix of the 1536 counts: 6 consecutive bins per thread, then a scan over the 256 partial sums
+    uint32_t c6[6], acc = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { c6[k] = hist[threadIdx.x * 6 + k]; acc += c6[k]; s_cnt[threadIdx.x * 6 + k] = 0u; }
+    s_part[threadIdx.x] = acc;
+    if (blockIdx.x == 0) for (int k = 0; k < 6; ++k) hist_next[threadIdx.x * 6 + k] = 0u;          // the other histogram, for the next cloud
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const uint32_t v = threadIdx.x >= (unsigned)o ? s_part[threadIdx.x - o] : 0u;
+        __syncthreads();
+        s_part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_part[threadIdx.x] - acc;               // exclusive
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { s_start[threadIdx.x * 6 + k] = run; run += c6[k]; }
+    __syncthreads();
+    const long base = (long)blockIdx.x * (256 * DIRBIN_ITEMS);
+    uint32_t key[DIRBIN_ITEMS], rank[DIRBIN_ITEMS];
+#pragma unroll
+    for (int k = 0; k < DIRBIN_ITEMS; ++k) {
+        const long i = base + k * 256 + threadIdx.x;
+        key[k] = i < n ? (uint32_t)keys[i] : 0xffffu;
+        rank[k] = key[k] != 0xffffu ? atomicAdd(&s_cnt[key[k]], 1u) : 0u;                          // my place among the block's returns of the bin
+    }
+    __syncthreads();
+    // one global atomic per non-empty bin of the block reserves its share of the bin
+    for (int b = threadIdx.x; b < GVOM_DIRBINS; b += 256) {
+        const uint32_t c = s_cnt[b];
+        if (c) s_start[b] += atomicAdd(&cursor[b], c);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < DIRBIN_ITEMS; ++k) {
+        const long i = base + k * 256 + threadIdx.x;
+        if (key[k] != 0xffffu) perm[s_start[key[k]] + rank[k]] = (uint32_t)i;
+    }
+}
+hipError_t gvom_launch_dirbin(hipStream_t s, const ScanParams &P, int dtype, const void *pts, int64_t stride_elems, int64_t n,
+                              uint16_t *keys, uint32_t *hist, uint32_t *hist_next, uint32_t *cursor, uint32_t *perm)
+{
+    if (n <= 0) return hipSuccess;
+#define DIRBIN_LAUNCH(IT)                                                                                                      \
+    do {                                                                                                                       \
+        const unsigned blocks = (unsigned)((n + 256 * IT - 1) / (256 * IT));                                                   \
+        if (dtype == 0) hipLaunchKernelGGL((k_dirbin_hist<float, IT>), dim3(blocks), dim3(256), 0, s, P, (const float *)pts, (long)stride_elems, (long)n, keys, hist, cursor); \
+        else hipLaunchKernelGGL((k_dirbin_hist<double, IT>), dim3(blocks), dim3(256), 0, s, P, (const double *)pts, (long)stride_elems, (long)n, keys, hist, cursor);          \
+        hipLaunchKernelGGL((k_dirbin_scatter<IT>), dim3(blocks), dim3(256), 0, s, (long)n, keys, hist, hist_next, cursor, perm);  \
+    } while (0)
+    if (n <= 131072) DIRBIN_LAUNCH(1); else if (n <= 524288) DIRBIN_LAUNCH(2); else DIRBIN_LAUNCH(8);
+#undef DIRBIN_LAUNCH
+    return hipGetLastError();
+}
+
 // one store of `seq` into host-mapped memory: launched behind the last kernel of a call, it tells the
 // spinning host that everything before it on the stream has completed (lower latency than an event wait)
 // Layout probe (ONE wave, a launch of its own in front of k_trace -- on the first cloud of a new length and every 32nd scan
@@ -2998,6 +3113,27 @@ __global__ __launch_bounds__(64) void k_layout_probe(const ScanParams P, const T
 {
     const int lane = threadIdx.x;
     int best = 0;
+    // is the cloud in ANY spatial order?  64 samples: a return and its successor point more than ~6 degrees apart in most of
+    // them (a rotating lidar's neighbours are a fraction of a degree apart) -> "scattered" (bit 3 of the answer): the next clouds
+    // of this length are traced in directional order (k_dirbin_*)
+    int scattered = 0;
+    if (n >= 128) {
+        const long q = (n / 64) * lane + n / 128;            // q + 1 < n
+        float d0[3] = {0.0f, 0.0f, 0.0f}, e = 0.0f;
+        bool good = true;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            T x, y, z;
+            load_return(P, in, stride, q + k, x, y, z);
+            const float ux = (float)x * P.rinv[0] - P.pt0[0], uy = (float)y * P.rinv[0] - P.pt0[1], uz = (float)z * P.rinv[1] - P.pt0[2];
+            const float r = sqrtf((ux * ux + uy * uy) + uz * uz);
+            good = good && r > 0.0f && r < INFINITY;
+            const float dx = ux / r, dy = uy / r, dz = uz / r;
+            if (k == 0) { d0[0] = dx; d0[1] = dy; d0[2] = dz; }
+            else { const float a = dx - d0[0], b = dy - d0[1], c = dz - d0[2]; e = (a * a + b * b) + c * c; }
+        }
+        if (__popcll(lanes(good && e > 0.01f)) >= 48) scattered = 1;
+    }
     for (int lg = 1; lg <= max_lg; ++lg) {
         const long K = 1L << lg;
         if (n % K != 0 || n / K < 4096) break;
@@ -3021,7 +3157,7 @@ __global__ __launch_bounds__(64) void k_layout_probe(const ScanParams P, const T
         if (__popcll(lanes(pass)) >= 56) best = lg;
     }
     if (lane == 0)
-        __hip_atomic_store(host_word, ((unsigned long long)n << 8) | (unsigned long long)best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(host_word, ((unsigned long long)n << 8) | (unsigned long long)(best | (scattered << 3)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 hipError_t gvom_launch_layout_probe(hipStream_t s, const ScanParams &P, int dtype, const void *pts, int64_t stride_elems, int64_t n,
                                     int max_lg, unsigned long long *host_word)

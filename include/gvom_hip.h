@@ -377,6 +377,13 @@ int gvom_host_timing(gvom_t *h, double us[8]);
  * call adopts the result iff no scan came in between; otherwise it is dropped and the combine fuses the encoded slot as
  * before.  -1 (default): automatic -- off after three dropped speculations in a row, on again once combines follow scans;
  * 1: always; 0: never.  gvom_get_tuning "eager_adopted" / "eager_dropped": how often either happened.
+ * "dirsort": the DIRECTIONAL ORDER of clouds that are in no spatial order (BASELINE config c1's uniformly random points; any cloud
+ * shuffled, merged or filtered out of its sensor order).  The trace's cost follows the accumulator lines a 64-ray bundle touches per
+ * step, and 64 random returns touch 64; a counting sort by direction bin seen from the sensor (two small kernels in front of the
+ * trace: 6 cube faces x 16 x 16 cells) gives every wave 64 rays that point the same way: c1's trace 65 -> 16 us + 15 us of sorting.
+ * 0 (default): automatic -- the layout probe also looks whether a return and its successor point more than ~6 degrees apart in
+ * most of 64 samples, and the following clouds of that length are then traced in directional order; 1: always; -1: never.
+ * gvom_get_tuning("dirsort"): whether the last scan was.  Only WHO traces which return changes, never a result.
  * "encfuse" (A/B of that kernel's shape: low 4 bits waves per column block, bit 4 no XCD pairing), "fuse1" (1: one-slot
  * fusions through the general kernel), "flag_kernel" (1: round 3's completion-flag kernel).
  * "epoch_bias" (test hook) advances the 32-bit tile-epoch counter, e.g. to just below its wrap. */

@@ -765,6 +765,52 @@ def test_layout_probe_finds_interleaved_sensors_and_nothing_else(gvom_mod):
         assert used == [1, 1, want, 1], (used, want)
 
 
+def test_directional_order_of_unordered_clouds_leaves_results_unchanged(gvom_mod):
+    """Clouds in no spatial order (BASELINE c1: uniformly random points) are traced in DIRECTIONAL order: a counting sort by
+    direction bin seen from the sensor (k_dirbin_*: 6 cube faces x 16 x 16 cells) in front of k_trace, so that a wave's 64 rays
+    share accumulator lines -- gvom_set_tuning("dirsort", 1) forces it, -1 forbids it, 0 (default) takes the layout probe's
+    verdict on the previous cloud of the same length.  A permutation of who traces which return: scan slots, fused maps and
+    returned maps are bit-identical with and without it -- random clouds, float64 + transform, ragged lengths, non-finite and
+    far-away returns, clouds below the sort's minimum, a one-slot ring (eager fusion) and a ring of three; and the probe
+    finds c1's cloud scattered and a lidar's scan ordered."""
+    params1, scans1 = synth.config_inputs("c1")
+    rng = np.random.default_rng(4)
+    c1 = scans1[0][0]
+    odd = np.concatenate([c1[:12345].astype(np.float32), np.array([[np.nan, 0, 0], [np.inf, 1, 1], [1e9, -1e9, 3.0], [0.3, -0.2, 0.1]], np.float32)], 0)
+    tiny = c1[:100].astype(np.float32)
+    cases = [(params1, [(c1, scans1[0][1], None), (c1[::-1].copy(), (0.7, -0.2, 0.1), scenarios.rot_z(0.2, (0.1, 0.0, 0.0))), (odd, (0.3, -0.2, 0.1), None), (tiny, (0.3, -0.2, 0.1), None)]),
+             (params1[:4] + (3,) + params1[5:], [(c1[:30000].astype(np.float32), (0.2 * k, 0.1 * k, 0.0), None) for k in range(4)])]
+    for params, clouds in cases:
+        rec = {}
+        for mode in (-1, 1):
+            g = gvom_mod.Gvom(*params)
+            g.set_tuning("dirsort", mode)
+            out = []
+            for pc, ego, tf in clouds:
+                g.process_pointcloud(pc, ego, tf)
+                assert g.get_tuning("dirsort") == (1 if mode == 1 and pc.shape[0] >= 256 else 0)
+                b = g.last_buffer_index
+                out.append(scenarios.dense_from_compact(scenarios.host(g.index_buffer[b]), scenarios.host(g.hit_count_buffer[b]),
+                                                        scenarios.host(g.total_count_buffer[b]), scenarios.host(g.min_height_buffer[b])))
+                out.append(g.combine_maps())
+                out.append(g.read_dense(gvom_mod.GVOM_WHICH_FUSED))
+            rec[mode] = out
+        for a, b in zip(rec[-1], rec[1]):
+            for x, y in zip(a, b):
+                assert np.array_equal(np.asarray(x), np.asarray(y), equal_nan=True)
+    # the probe: c1's cloud is scattered (the third scan of that length runs sorted), an OS1-64 scan is not
+    g = gvom_mod.Gvom(*params1)
+    seen = []
+    for k in range(4):
+        g.process_pointcloud(c1, scans1[0][1]); seen.append(g.get_tuning("dirsort"))
+    assert seen[0] == 0 and seen[-1] == 1, seen
+    p2, lidar = synth.config_inputs("c2", n_scans=1)
+    g2 = gvom_mod.Gvom(*p2)
+    for k in range(4):
+        g2.process_pointcloud(*lidar[0])
+        assert g2.get_tuning("dirsort") == 0
+
+
 @pytest.mark.parametrize("occ_params", [(50, -10, 0), (12.5, -6.0, 1.5)])
 def test_combine_maps_occupancy_matches_node_postprocessing(gvom_mod, occ_params):
     """combine_maps_occupancy() == the ROS node's numpy post-processing
