@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Runs tests/test_hip_parity.py::_fuzz_case for a range of seeds on the GPU box and reports the
-seeds whose HIP records differ from the oracle.  Usage: tests/fuzz/fuzz_many.py <first> <count> [stats] [ilv=K] [p2] [eager]
+seeds whose HIP records differ from the oracle.  Usage: tests/fuzz/fuzz_many.py <first> <count> [stats] [ilv=K] [p2] [eager] [dirsort]
 (ilv=K: the HIP mapper traces with the sub-cloud interleave forced to K -- a permutation of who traces which return; it applies
 to the scans whose length K divides; p2: grid sizes snapped to powers of two, z_size <= xy_size -- the grids on which k_trace takes
 its mask-wrap and no-window-test step bodies)"""
@@ -23,6 +23,8 @@ def hip_mapper(*p):
     g = gvom.Gvom(*p, voxel_statistics=True) if stats else gvom.Gvom(*p)
     if ilv:
         g.set_tuning("interleave", ilv[0])
+    if "dirsort" in sys.argv[3:]:
+        g.set_tuning("dirsort", 1)          # every scan of >= 256 returns traced in directional order (k_dirbin_*)
     return g
 bad = []
 for seed in range(first, first + count):

@@ -11,6 +11,7 @@ for W in ${@:-many mid shard stats}; do
     shard1) run python3 tests/fuzz/fuzz_shard.py 70000 3000 ;;
     stats) run python3 tests/fuzz/fuzz_many.py 5000 300 stats ;;
     p2)    run python3 tests/fuzz/fuzz_many.py 20000 2000 p2; run python3 tests/fuzz/fuzz_many.py 20000 1000 p2 ilv=2 ;;
+    dirsort) run python3 tests/fuzz/fuzz_many.py 60000 2000 dirsort; run python3 tests/fuzz/fuzz_many.py 62000 500 dirsort stats ;;
     eager) run python3 tests/fuzz/fuzz_many.py 40000 3000 eager ;;
     ilv)   run python3 tests/fuzz/fuzz_many.py 9000 1500 ilv=2; run python3 tests/fuzz/fuzz_many.py 9000 1500 ilv=4 ;;
   esac
