@@ -859,22 +859,22 @@ int scan_launch(gvom_handle *h, std::unique_lock<std::mutex> &lk, const void *de
     }
     P.perm = nullptr;
     {   // directional order: forced, or the probe's verdict on the previous cloud of this length ("scattered", bit 3 of its answer)
-        bool sort = h->tune_dirsort == 1;
+        int sort = h->tune_dirsort == 1 || h->tune_dirsort == 2 ? h->tune_dirsort : 0;   // 1: cube cells, 2: elevation rows
         if (h->tune_dirsort == 0 && h->tune_ilv == 0 && h->counters_host) {
             const unsigned long long w = *(volatile unsigned long long *)(h->counters_host + 8);
-            sort = (int64_t)(w >> 8) == n && ((w >> 3) & 1ull) != 0;
+            if ((int64_t)(w >> 8) == n) sort = (int)((w >> 3) & 3ull);
         }
         h->last_dirsort = 0;
         if (sort && n >= 256 && n < (1ll << 31)) {
             if ((rc = ensure(h, h->dir_keys, (size_t)n * 2)) || (rc = ensure(h, h->dir_perm, (size_t)n * 4))) return rc;
             uint32_t *hist = h->dir_hist + (h->dir_flip & 1u) * GVOM_DIRBINS, *next = h->dir_hist + ((h->dir_flip + 1u) & 1u) * GVOM_DIRBINS;
             ++h->dir_flip;
-            le = gvom_launch_dirbin(h->stream, P, dtype, dev_pts, stride_elems, n, (uint16_t *)h->dir_keys.p, hist, next,
+            le = gvom_launch_dirbin(h->stream, P, sort == 2 ? 2 : 1, dtype, dev_pts, stride_elems, n, (uint16_t *)h->dir_keys.p, hist, next,
                                     h->dir_hist + 2 * GVOM_DIRBINS, (uint32_t *)h->dir_perm.p);
             if (le != hipSuccess) { scan_abort(h); HIPCHK(h, le); }
             P.perm = (const uint32_t *)h->dir_perm.p;
             P.ilv_lg = 0; P.ilv_len = n;
-            h->last_dirsort = 1;
+            h->last_dirsort = sort == 2 ? 2 : 1;
             h->last_knobs[4] = 1;
         }
     }

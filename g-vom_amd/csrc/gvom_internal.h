@@ -188,8 +188,8 @@ hipError_t gvom_launch_layout_probe(hipStream_t s, const ScanParams &P, int dtyp
 hipError_t gvom_launch_publish_seq(hipStream_t s, unsigned long long *host_flag, uint32_t seq);
 // directional order of an unordered cloud: keys[n] (scratch), hist / cursor: GVOM_DIRBINS counters each (hist zero on entry, zeroed
 // again for the next use on exit: the caller alternates two), perm[n] out
-#define GVOM_DIRBINS 1536      // 6 cube faces x 16 x 16
-hipError_t gvom_launch_dirbin(hipStream_t s, const ScanParams &P, int dtype, const void *pts, int64_t stride_elems, int64_t n,
+#define GVOM_DIRBINS 8192      // mode 1: 6 cube faces x 16 x 16 (1536 used); mode 2: 256 sin(elevation) rows x 32 azimuth sectors
+hipError_t gvom_launch_dirbin(hipStream_t s, const ScanParams &P, int mode, int dtype, const void *pts, int64_t stride_elems, int64_t n,
                               uint16_t *keys, uint32_t *hist, uint32_t *hist_next, uint32_t *cursor, uint32_t *perm);
 hipError_t gvom_launch_fuse(hipStream_t s, const FuseParams &P, const FuseDescs &KD,
                             const MapDesc *descs_dev, int32_t *fstate, uint4 *frows,

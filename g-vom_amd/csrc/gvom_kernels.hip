@@ -2985,71 +2985,83 @@ hipError_t gvom_launch_encode(hipStream_t s, const ScanParams &P, uint32_t *hit,
 }
 
 // ------------------------------------------------------------------------------------------
-// Directional order of an UNORDERED cloud (BASELINE config c1: 50,000 uniformly random points; any cloud that has been
-// shuffled, merged or filtered out of its sensor order).  k_trace's cost follows the accumulator lines a 64-ray bundle touches per
-// step: consecutive returns of a rotating lidar are neighbours in space, 64 random returns are not (c1: k_trace 65 us in the
-// order given, 15.6 us with the same returns ordered by direction -- tools/c1_sort_probe.py).  A counting sort by direction bin
-// seen from the sensor -- 6 cube faces x 16 x 16 cells in Morton order, 1536 bins of ~5.6 degrees -- in two launches:
+// Directional order of a cloud whose OWN order does not suit the trace.  k_trace's cost follows the accumulator lines (4 x 4 voxels
+// at one level) a bundle of 64 consecutive returns touches per step: a rotating lidar's beam-major rows (64 azimuths of one beam: a
+// horizontal fan) are ideal; 64 random returns (BASELINE config c1; any shuffled, merged, filtered cloud) touch 64 lines -- c1:
+// k_trace 65 us as given, 15.6 us with the same returns ordered by direction (tools/c1_sort_probe.py) -- and an azimuth-major
+// ("firing order") organised cloud makes every bundle a VERTICAL fan: 280 us for the scan the beam-major order traces in 37
+// (tools/bundle_shape_probe.py).  A counting sort by direction bin seen from the sensor, two launches in front of the trace:
+//   mode 1 (no spatial order)   6 cube faces x 16 x 16 cells in Morton order: 1536 bins of ~5.6 degrees
+//   mode 2 (vertical fans)      256 rows of sin(elevation) x 32 azimuth sectors, row-major: inside a cell the returns keep (roughly)
+//                               the order they came in, which for a firing-order cloud is increasing azimuth -- the beam-major
+//                               fans come back (tools/sphere_sort_probe.py: 37-43 us)
 //   k_dirbin_hist     key of every return (float arithmetic: the order need not be exact) + per-block LDS histogram -> global
-//   k_dirbin_scatter  every block scans the 1536 counts itself (no scan launch), reserves its share of each bin with one global
-//                     atomic per non-empty bin and block, and writes perm[position] = return
-// The order inside a bin is whatever the atomics give: k_trace's results do not depend on who traces which return.
+//   k_dirbin_scatter  every block scans the counts itself (no scan launch), reserves its share of each bin with one global atomic
+//                     per non-empty bin and block, and writes perm[position] = return
+// k_trace's results do not depend on who traces which return.
+// (DIRBIN_ITEMS returns per thread, 256 threads per block: 1 for clouds up to 131 k returns -- both kernels are latency chains -- 2
+// up to 524 k, 8 above)
 // ------------------------------------------------------------------------------------------
-// (DIRBIN_ITEMS returns per thread, 256 threads per block: 1 for clouds up to 131 k returns -- both kernels are latency chains,
-// and 25 blocks of 8 returns per thread took 8.4 + 7.7 us on c1's 50,000 points -- 2 up to 524 k, 8 above)
 template <typename T>
-__device__ __forceinline__ uint32_t dirbin_key(const ScanParams &P, const T *__restrict__ in, long stride, long i)
+__device__ __forceinline__ uint32_t dirbin_key(const ScanParams &P, int mode, const T *__restrict__ in, long stride, long i)
 {
     T x, y, z;
     load_return(P, in, stride, i, x, y, z);
     const float ux = (float)x * P.rinv[0] - P.pt0[0], uy = (float)y * P.rinv[0] - P.pt0[1], uz = (float)z * P.rinv[1] - P.pt0[2];
+    if (mode == 2) {
+        const float r = sqrtf((ux * ux + uy * uy) + uz * uz);
+        if (!(r > 0.0f) || !(r < INFINITY)) return 0u;     // the sensor's own position, NaN, inf: anywhere
+        const uint32_t row = (uint32_t)min(255, max(0, (int)((uz / r + 1.0f) * 128.0f)));
+        const uint32_t sec = (uint32_t)min(31, max(0, (int)((atan2f(uy, ux) + 3.14159265f) * (32.0f / 6.2831853f))));
+        return row * 32u + sec;
+    }
     const float ax = fabsf(ux), ay = fabsf(uy), az = fabsf(uz);
     uint32_t face;
     float a, u, v;
     if (ax >= ay && ax >= az) { face = ux < 0.0f ? 1u : 0u; a = ax; u = uy; v = uz; }
     else if (ay >= az) { face = uy < 0.0f ? 3u : 2u; a = ay; u = uz; v = ux; }
     else { face = uz < 0.0f ? 5u : 4u; a = az; u = ux; v = uy; }
-    if (!(a > 0.0f) || !(a < INFINITY)) return 0u;         // the sensor's own position, NaN, inf: anywhere
+    if (!(a > 0.0f) || !(a < INFINITY)) return 0u;
     const uint32_t qu = (uint32_t)min(15, max(0, (int)((u / a + 1.0f) * 8.0f)));
     const uint32_t qv = (uint32_t)min(15, max(0, (int)((v / a + 1.0f) * 8.0f)));
     // Morton order of the face's 16 x 16 cells: bins that follow each other point in neighbouring directions
     auto part = [](uint32_t t) { t = (t | (t << 2)) & 0x33u; return (t | (t << 1)) & 0x55u; };
     return face * 256u + (part(qu) | (part(qv) << 1));
 }
-template <typename T, int DIRBIN_ITEMS>
-__global__ __launch_bounds__(256) void k_dirbin_hist(const ScanParams P, const T *__restrict__ in, long stride, long n, uint16_t *keys,
+template <typename T, int DIRBIN_ITEMS, int NBINS>
+__global__ __launch_bounds__(256) void k_dirbin_hist(const ScanParams P, int mode, const T *__restrict__ in, long stride, long n, uint16_t *keys,
                                                      uint32_t *hist, uint32_t *cursor)
 {
-    __shared__ uint32_t s_h[GVOM_DIRBINS];
-    for (int b = threadIdx.x; b < GVOM_DIRBINS; b += 256) s_h[b] = 0u;
-    if (blockIdx.x == 0) for (int b = threadIdx.x; b < GVOM_DIRBINS; b += 256) cursor[b] = 0u;      // (nobody reads it before k_dirbin_scatter)
+    __shared__ uint32_t s_h[NBINS];
+    for (int b = threadIdx.x; b < NBINS; b += 256) s_h[b] = 0u;
+    if (blockIdx.x == 0) for (int b = threadIdx.x; b < NBINS; b += 256) cursor[b] = 0u;      // (nobody reads it before k_dirbin_scatter)
     __syncthreads();
     const long base = (long)blockIdx.x * (256 * DIRBIN_ITEMS);
 #pragma unroll
     for (int k = 0; k < DIRBIN_ITEMS; ++k) {
         const long i = base + k * 256 + threadIdx.x;
         if (i < n) {
-            const uint32_t key = dirbin_key(P, in, stride, i);
+            const uint32_t key = dirbin_key(P, mode, in, stride, i);
             keys[i] = (uint16_t)key;
             atomicAdd(&s_h[key], 1u);
         }
     }
     __syncthreads();
-    for (int b = threadIdx.x; b < GVOM_DIRBINS; b += 256) { const uint32_t c = s_h[b]; if (c) atomicAdd(&hist[b], c); }
+    for (int b = threadIdx.x; b < NBINS; b += 256) { const uint32_t c = s_h[b]; if (c) atomicAdd(&hist[b], c); }
 }
-template <int DIRBIN_ITEMS>
+template <int DIRBIN_ITEMS, int NBINS>
 __global__ __launch_bounds__(256) void k_dirbin_scatter(long n, const uint16_t *__restrict__ keys, const uint32_t *__restrict__ hist,
                                                         uint32_t *hist_next, uint32_t *cursor, uint32_t *perm)
 {
-    __shared__ uint32_t s_start[GVOM_DIRBINS];             // first position of every bin (exclusive prefix of the counts), then this block's share
-    __shared__ uint32_t s_cnt[GVOM_DIRBINS];               // this block's returns per bin, then its running fill
+    constexpr int BPT = NBINS / 256;               // consecutive bins per thread of the prefix
+    __shared__ uint32_t s_start[NBINS];             // first position of every bin (exclusive prefix of the counts), then this block's share
+    __shared__ uint32_t s_cnt[NBINS];               // this block's returns per bin
     __shared__ uint32_t s_part[256];
-    // exclusive prefix of the 1536 counts: 6 consecutive bins per thread, then a scan over the 256 partial sums
-    uint32_t c6[6], acc = 0;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) { c6[k] = hist[threadIdx.x * 6 + k]; acc += c6[k]; s_cnt[threadIdx.x * 6 + k] = 0u; }
+    uint32_t acc = 0;
+    for (int k = 0; k < BPT; ++k) { const uint32_t c = hist[threadIdx.x * BPT + k]; s_start[threadIdx.x * BPT + k] = c; acc += c; s_cnt[threadIdx.x * BPT + k] = 0u; }
     s_part[threadIdx.x] = acc;
-    if (blockIdx.x == 0) for (int k = 0; k < 6; ++k) hist_next[threadIdx.x * 6 + k] = 0u;          // the other histogram, for the next cloud
+    // the other histogram, for the next cloud: ALL of it (the next cloud may be sorted in the other mode, with more bins)
+    if (blockIdx.x == 0) for (int k = threadIdx.x; k < GVOM_DIRBINS; k += 256) hist_next[k] = 0u;
     __syncthreads();
     for (int o = 1; o < 256; o <<= 1) {
         const uint32_t v = threadIdx.x >= (unsigned)o ? s_part[threadIdx.x - o] : 0u;
@@ -3058,8 +3070,7 @@ __global__ __launch_bounds__(256) void k_dirbin_scatter(long n, const uint16_t *
         __syncthreads();
     }
     uint32_t run = s_part[threadIdx.x] - acc;               // exclusive
-#pragma unroll
-    for (int k = 0; k < 6; ++k) { s_start[threadIdx.x * 6 + k] = run; run += c6[k]; }
+    for (int k = 0; k < BPT; ++k) { const uint32_t c = s_start[threadIdx.x * BPT + k]; s_start[threadIdx.x * BPT + k] = run; run += c; }
     __syncthreads();
     const long base = (long)blockIdx.x * (256 * DIRBIN_ITEMS);
     uint32_t key[DIRBIN_ITEMS], rank[DIRBIN_ITEMS];
@@ -3071,7 +3082,7 @@ __global__ __launch_bounds__(256) void k_dirbin_scatter(long n, const uint16_t *
     }
     __syncthreads();
     // one global atomic per non-empty bin of the block reserves its share of the bin
-    for (int b = threadIdx.x; b < GVOM_DIRBINS; b += 256) {
+    for (int b = threadIdx.x; b < NBINS; b += 256) {
         const uint32_t c = s_cnt[b];
         if (c) s_start[b] += atomicAdd(&cursor[b], c);
     }
@@ -3082,18 +3093,20 @@ __global__ __launch_bounds__(256) void k_dirbin_scatter(long n, const uint16_t *
         if (key[k] != 0xffffu) perm[s_start[key[k]] + rank[k]] = (uint32_t)i;
     }
 }
-hipError_t gvom_launch_dirbin(hipStream_t s, const ScanParams &P, int dtype, const void *pts, int64_t stride_elems, int64_t n,
+hipError_t gvom_launch_dirbin(hipStream_t s, const ScanParams &P, int mode, int dtype, const void *pts, int64_t stride_elems, int64_t n,
                               uint16_t *keys, uint32_t *hist, uint32_t *hist_next, uint32_t *cursor, uint32_t *perm)
 {
     if (n <= 0) return hipSuccess;
-#define DIRBIN_LAUNCH(IT)                                                                                                      \
+#define DIRBIN_LAUNCH(IT, NB)                                                                                                  \
     do {                                                                                                                       \
         const unsigned blocks = (unsigned)((n + 256 * IT - 1) / (256 * IT));                                                   \
-        if (dtype == 0) hipLaunchKernelGGL((k_dirbin_hist<float, IT>), dim3(blocks), dim3(256), 0, s, P, (const float *)pts, (long)stride_elems, (long)n, keys, hist, cursor); \
-        else hipLaunchKernelGGL((k_dirbin_hist<double, IT>), dim3(blocks), dim3(256), 0, s, P, (const double *)pts, (long)stride_elems, (long)n, keys, hist, cursor);          \
-        hipLaunchKernelGGL((k_dirbin_scatter<IT>), dim3(blocks), dim3(256), 0, s, (long)n, keys, hist, hist_next, cursor, perm);  \
+        if (dtype == 0) hipLaunchKernelGGL((k_dirbin_hist<float, IT, NB>), dim3(blocks), dim3(256), 0, s, P, mode, (const float *)pts, (long)stride_elems, (long)n, keys, hist, cursor); \
+        else hipLaunchKernelGGL((k_dirbin_hist<double, IT, NB>), dim3(blocks), dim3(256), 0, s, P, mode, (const double *)pts, (long)stride_elems, (long)n, keys, hist, cursor);          \
+        hipLaunchKernelGGL((k_dirbin_scatter<IT, NB>), dim3(blocks), dim3(256), 0, s, (long)n, keys, hist, hist_next, cursor, perm);  \
     } while (0)
-    if (n <= 131072) DIRBIN_LAUNCH(1); else if (n <= 524288) DIRBIN_LAUNCH(2); else DIRBIN_LAUNCH(8);
+    // (mode 2's 8192 bins cost every block a scan of their own: 2048 returns per block whatever the cloud's size)
+    if (mode == 2) DIRBIN_LAUNCH(8, 8192);
+    else if (n <= 131072) DIRBIN_LAUNCH(1, 1536); else if (n <= 524288) DIRBIN_LAUNCH(2, 1536); else DIRBIN_LAUNCH(8, 1536);
 #undef DIRBIN_LAUNCH
     return hipGetLastError();
 }
@@ -3113,26 +3126,32 @@ __global__ __launch_bounds__(64) void k_layout_probe(const ScanParams P, const T
 {
     const int lane = threadIdx.x;
     int best = 0;
-    // is the cloud in ANY spatial order?  64 samples: a return and its successor point more than ~6 degrees apart in most of
-    // them (a rotating lidar's neighbours are a fraction of a degree apart) -> "scattered" (bit 3 of the answer): the next clouds
-    // of this length are traced in directional order (k_dirbin_*)
+    // Does the cloud's order suit the trace?  k_trace's cost follows the accumulator lines (4 x 4 voxels at ONE level) a bundle of 64
+    // consecutive returns touches per step.  64 samples say "scattered" (bit 3 of the answer: the next clouds of this length are
+    // traced in directional order, k_dirbin_*) when in most of them
+    //   * a return and its successor point more than ~6 degrees apart (no spatial order at all: BASELINE c1's random points), or
+    //   * a return and the one 63 places behind it differ by more than ~3 degrees in ELEVATION: a bundle is a vertical fan -- an
+    //     azimuth-major ("firing order") organised cloud, every beam of one azimuth behind one another: 280 us for the cloud the
+    //     beam-major order traces in 37 (tools/bundle_shape_probe.py); a rotating lidar's beam-major rows have neither property.
     int scattered = 0;
-    if (n >= 128) {
-        const long q = (n / 64) * lane + n / 128;            // q + 1 < n
-        float d0[3] = {0.0f, 0.0f, 0.0f}, e = 0.0f;
+    if (n >= 8192) {
+        const long q = (n / 64) * lane + n / 128;            // q + 63 < n
+        float d0[3] = {0.0f, 0.0f, 0.0f}, e1 = 0.0f, ez = 0.0f;
         bool good = true;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < 3; ++k) {
             T x, y, z;
-            load_return(P, in, stride, q + k, x, y, z);
+            load_return(P, in, stride, q + (k == 0 ? 0 : (k == 1 ? 1 : 63)), x, y, z);
             const float ux = (float)x * P.rinv[0] - P.pt0[0], uy = (float)y * P.rinv[0] - P.pt0[1], uz = (float)z * P.rinv[1] - P.pt0[2];
             const float r = sqrtf((ux * ux + uy * uy) + uz * uz);
             good = good && r > 0.0f && r < INFINITY;
             const float dx = ux / r, dy = uy / r, dz = uz / r;
             if (k == 0) { d0[0] = dx; d0[1] = dy; d0[2] = dz; }
-            else { const float a = dx - d0[0], b = dy - d0[1], c = dz - d0[2]; e = (a * a + b * b) + c * c; }
+            else if (k == 1) { const float a = dx - d0[0], b = dy - d0[1], c = dz - d0[2]; e1 = (a * a + b * b) + c * c; }
+            else ez = fabsf(dz - d0[2]);
         }
-        if (__popcll(lanes(good && e > 0.01f)) >= 48) scattered = 1;
+        if (__popcll(lanes(good && e1 > 0.01f)) >= 48) scattered = 1;            // no spatial order: cube cells (bit 3)
+        else if (__popcll(lanes(good && ez > 0.05f)) >= 48) scattered = 2;       // vertical fans: elevation rows (bit 4)
     }
     for (int lg = 1; lg <= max_lg; ++lg) {
         const long K = 1L << lg;

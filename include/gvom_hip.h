@@ -381,9 +381,13 @@ int gvom_host_timing(gvom_t *h, double us[8]);
  * shuffled, merged or filtered out of its sensor order).  The trace's cost follows the accumulator lines a 64-ray bundle touches per
  * step, and 64 random returns touch 64; a counting sort by direction bin seen from the sensor (two small kernels in front of the
  * trace: 6 cube faces x 16 x 16 cells) gives every wave 64 rays that point the same way: c1's trace 65 -> 16 us + 15 us of sorting.
- * 0 (default): automatic -- the layout probe also looks whether a return and its successor point more than ~6 degrees apart in
- * most of 64 samples, and the following clouds of that length are then traced in directional order; 1: always; -1: never.
- * gvom_get_tuning("dirsort"): whether the last scan was.  Only WHO traces which return changes, never a result.
+ * The same remedy serves organised clouds in azimuth-major ("firing") order, whose bundles are VERTICAL fans (the scan the
+ * beam-major order traces in 37 us takes 280): they are sorted by (sin-elevation row, azimuth sector) -- 256 x 32 bins -- inside
+ * which the returns keep the order they came in, and the beam-major fans come back (43 us + the sort).
+ * 0 (default): automatic -- the layout probe also looks, in 64 samples, whether a return and its successor point more than ~6
+ * degrees apart (mode 1: cube cells) or a return and the one 63 places behind it differ by more than ~3 degrees in elevation
+ * (mode 2: elevation rows), and the following clouds of that length are traced accordingly; 1 / 2: always, in that mode; -1: never.
+ * gvom_get_tuning("dirsort"): the mode the last scan ran in (0: the cloud's own order).  Only WHO traces which return changes.
  * "encfuse" (A/B of that kernel's shape: low 4 bits waves per column block, bit 4 no XCD pairing), "fuse1" (1: one-slot
  * fusions through the general kernel), "flag_kernel" (1: round 3's completion-flag kernel).
  * "epoch_bias" (test hook) advances the 32-bit tile-epoch counter, e.g. to just below its wrap. */

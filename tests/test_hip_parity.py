@@ -767,9 +767,10 @@ def test_layout_probe_finds_interleaved_sensors_and_nothing_else(gvom_mod):
 
 def test_directional_order_of_unordered_clouds_leaves_results_unchanged(gvom_mod):
     """Clouds in no spatial order (BASELINE c1: uniformly random points) are traced in DIRECTIONAL order: a counting sort by
-    direction bin seen from the sensor (k_dirbin_*: 6 cube faces x 16 x 16 cells) in front of k_trace, so that a wave's 64 rays
-    share accumulator lines -- gvom_set_tuning("dirsort", 1) forces it, -1 forbids it, 0 (default) takes the layout probe's
-    verdict on the previous cloud of the same length.  A permutation of who traces which return: scan slots, fused maps and
+    direction bin seen from the sensor (k_dirbin_*: 6 cube faces x 16 x 16 cells, or 256 elevation rows x 32 azimuth sectors for
+    clouds whose bundles are vertical fans) in front of k_trace, so that a wave's 64 rays share accumulator lines --
+    gvom_set_tuning("dirsort", 1 | 2) forces a mode, -1 forbids it, 0 (default) takes the layout probe's verdict on the previous
+    cloud of the same length.  A permutation of who traces which return: scan slots, fused maps and
     returned maps are bit-identical with and without it -- random clouds, float64 + transform, ragged lengths, non-finite and
     far-away returns, clouds below the sort's minimum, a one-slot ring (eager fusion) and a ring of three; and the probe
     finds c1's cloud scattered and a lidar's scan ordered."""
@@ -782,22 +783,23 @@ def test_directional_order_of_unordered_clouds_leaves_results_unchanged(gvom_mod
              (params1[:4] + (3,) + params1[5:], [(c1[:30000].astype(np.float32), (0.2 * k, 0.1 * k, 0.0), None) for k in range(4)])]
     for params, clouds in cases:
         rec = {}
-        for mode in (-1, 1):
+        for mode in (-1, 1, 2):                             # off / cube cells / elevation rows
             g = gvom_mod.Gvom(*params)
             g.set_tuning("dirsort", mode)
             out = []
             for pc, ego, tf in clouds:
                 g.process_pointcloud(pc, ego, tf)
-                assert g.get_tuning("dirsort") == (1 if mode == 1 and pc.shape[0] >= 256 else 0)
+                assert g.get_tuning("dirsort") == (mode if mode > 0 and pc.shape[0] >= 256 else 0)
                 b = g.last_buffer_index
                 out.append(scenarios.dense_from_compact(scenarios.host(g.index_buffer[b]), scenarios.host(g.hit_count_buffer[b]),
                                                         scenarios.host(g.total_count_buffer[b]), scenarios.host(g.min_height_buffer[b])))
                 out.append(g.combine_maps())
                 out.append(g.read_dense(gvom_mod.GVOM_WHICH_FUSED))
             rec[mode] = out
-        for a, b in zip(rec[-1], rec[1]):
-            for x, y in zip(a, b):
-                assert np.array_equal(np.asarray(x), np.asarray(y), equal_nan=True)
+        for other in (1, 2):
+            for a, b in zip(rec[-1], rec[other]):
+                for x, y in zip(a, b):
+                    assert np.array_equal(np.asarray(x), np.asarray(y), equal_nan=True)
     # the probe: c1's cloud is scattered (the third scan of that length runs sorted), an OS1-64 scan is not
     g = gvom_mod.Gvom(*params1)
     seen = []
@@ -809,6 +811,18 @@ def test_directional_order_of_unordered_clouds_leaves_results_unchanged(gvom_mod
     for k in range(4):
         g2.process_pointcloud(*lidar[0])
         assert g2.get_tuning("dirsort") == 0
+    # ... and the SAME scan in azimuth-major ("firing") order -- every beam of one azimuth behind one another, a bundle a vertical
+    # fan -- is re-ordered as well, with the beam-major scan's maps
+    pc, ego, tf = lidar[0]
+    firing = np.ascontiguousarray(pc.reshape(64, 2048, 3).transpose(1, 0, 2).reshape(-1, 3))
+    g3 = gvom_mod.Gvom(*p2)
+    seen = []
+    for k in range(4):
+        g3.process_pointcloud(firing, ego, tf); seen.append(g3.get_tuning("dirsort"))
+    assert seen[0] == 0 and seen[-1] == 2, seen             # (elevation rows: the beam-major fans come back)
+    a, b = g2.combine_maps(), g3.combine_maps()
+    for i in range(5):
+        assert np.array_equal(a[i], b[i], equal_nan=True), i
 
 
 @pytest.mark.parametrize("occ_params", [(50, -10, 0), (12.5, -6.0, 1.5)])
