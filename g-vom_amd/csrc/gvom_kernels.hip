@@ -3059,17 +3059,17 @@ __global__ __launch_bounds__(256) void k_dirbin_scatter(long n, const uint16_t *
     __shared__ uint32_t s_part[256];
     uint32_t acc = 0;
     for (int k = 0; k < BPT; ++k) { const uint32_t c = hist[threadIdx.x * BPT + k]; s_start[threadIdx.x * BPT + k] = c; acc += c; s_cnt[threadIdx.x * BPT + k] = 0u; }
-    s_part[threadIdx.x] = acc;
     // the other histogram, for the next cloud: ALL of it (the next cloud may be sorted in the other mode, with more bins)
     if (blockIdx.x == 0) for (int k = threadIdx.x; k < GVOM_DIRBINS; k += 256) hist_next[k] = 0u;
+    // inclusive scan of the 256 partial sums: inside each wave by shuffles, the four waves' totals through LDS (one barrier)
+    uint32_t inc = acc;
+    const int ln = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)inc, o); if (ln >= o) inc += v; }
+    if (ln == 63) s_part[threadIdx.x >> 6] = inc;
     __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {
-        const uint32_t v = threadIdx.x >= (unsigned)o ? s_part[threadIdx.x - o] : 0u;
-        __syncthreads();
-        s_part[threadIdx.x] += v;
-        __syncthreads();
-    }
-    uint32_t run = s_part[threadIdx.x] - acc;               // exclusive
+    for (int wv = 0; wv < (int)(threadIdx.x >> 6); ++wv) inc += s_part[wv];
+    uint32_t run = inc - acc;                               // exclusive
     for (int k = 0; k < BPT; ++k) { const uint32_t c = s_start[threadIdx.x * BPT + k]; s_start[threadIdx.x * BPT + k] = run; run += c; }
     __syncthreads();
     const long base = (long)blockIdx.x * (256 * DIRBIN_ITEMS);
