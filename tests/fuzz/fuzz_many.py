@@ -23,8 +23,9 @@ def hip_mapper(*p):
     g = gvom.Gvom(*p, voxel_statistics=True) if stats else gvom.Gvom(*p)
     if ilv:
         g.set_tuning("interleave", ilv[0])
-    if "dirsort" in sys.argv[3:]:
-        g.set_tuning("dirsort", 1)          # every scan of >= 256 returns traced in directional order (k_dirbin_*)
+    for a_ in sys.argv[3:]:
+        if a_.startswith("dirsort"):         # every scan of >= 256 returns traced in directional order (k_dirbin_*); dirsort=2: elevation rows
+            g.set_tuning("dirsort", int(a_[8:]) if a_.startswith("dirsort=") else 1)
     return g
 bad = []
 for seed in range(first, first + count):
