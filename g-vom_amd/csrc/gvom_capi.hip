@@ -84,6 +84,7 @@ struct gvom_handle {
     int tune_ilv = 0;                                   // gvom_set_tuning "interleave": sub-clouds per cloud (0: automatic, 1: off)
     int last_knobs[5] = {0, 0, 0, 0, 1};                // gvom_get_tuning: segs, period, ep_row, prio, interleave of the last scan
     int64_t last_n = -1;                                // returns of the previous scan
+    uint32_t probe_var_age = 0;                         // scans of changing length since the probe last ran
     int64_t probe_n = -1; uint32_t probe_age = 0;       // layout probe (k_layout_probe): the length it last looked at, scans since
     int tune_fuse1 = 0;                                 // gvom_set_tuning "fuse1": 1 = the one-slot fusion through k_fuse4 as well (A/B)
     int tune_flag_kernel = 0;                           // gvom_set_tuning "flag_kernel": 1 = the combine's completion flag from a kernel of its own (round 3's form)
@@ -850,8 +851,13 @@ int scan_launch(gvom_handle *h, std::unique_lock<std::mutex> &lk, const void *de
         // returns hands over a different length every scan -- its sub-clouds do not start at multiples of n / K, nothing to find,
         // nothing to pay), on the second cloud of a length and every 32nd scan after it; in front of k_trace (the caller may
         // free the cloud as soon as this call has returned, i.e. once k_trace is done); its answer serves LATER scans
-        if (n == h->last_n && (n != h->probe_n || ++h->probe_age >= 32)) {
-            h->probe_n = n; h->probe_age = 0;
+        // A stream whose length CHANGES from scan to scan (invalid returns dropped) is looked at every 8th scan all the same -- for the
+        // "is this order any good for the trace" half of the answer only, which does not depend on the exact length
+        const bool stable = n == h->last_n && (n != h->probe_n || ++h->probe_age >= 32);
+        const bool varying = n != h->last_n && ++h->probe_var_age >= 8;
+        if (stable || varying) {
+            if (stable) { h->probe_n = n; h->probe_age = 0; }
+            h->probe_var_age = 0;
             le = gvom_launch_layout_probe(h->stream, P, dtype, dev_pts, stride_elems, n, 2, (unsigned long long *)(h->counters_host_dev + 8));
             if (le != hipSuccess) { scan_abort(h); HIPCHK(h, le); }
         }
@@ -862,7 +868,9 @@ int scan_launch(gvom_handle *h, std::unique_lock<std::mutex> &lk, const void *de
         int sort = h->tune_dirsort == 1 || h->tune_dirsort == 2 ? h->tune_dirsort : 0;   // 1: cube cells, 2: elevation rows
         if (h->tune_dirsort == 0 && h->tune_ilv == 0 && h->counters_host) {
             const unsigned long long w = *(volatile unsigned long long *)(h->counters_host + 8);
-            if ((int64_t)(w >> 8) == n) sort = (int)((w >> 3) & 3ull);
+            const int64_t np_ = (int64_t)(w >> 8);
+            // (the verdict on a cloud of about this length -- within a quarter -- holds for this one)
+            if (np_ > 0 && (np_ == n || (n > np_ - np_ / 4 && n < np_ + np_ / 4))) sort = (int)((w >> 3) & 3ull);
         }
         h->last_dirsort = 0;
         if (sort && n >= 256 && n < (1ll << 31)) {

@@ -369,7 +369,7 @@ int gvom_host_timing(gvom_t *h, double us[8]);
  * 512^2 x 128, 4 x 262,144 returns: 11.5 M -> 4.1 M memory-side atomic requests, 549 -> 355 us).  0 (default): automatic -- a
  * one-wave probe kernel in front of the trace looks for that structure (64 sampled returns per candidate K <= 4) on the second
  * cloud of a length and every 32nd after it, and the following clouds of that length are traced accordingly; clouds whose
- * length changes from scan to scan are never probed; 1: off.  Only WHO traces which return changes, never a result.
+ * length changes from scan to scan are not looked at for sub-clouds (they are probed every 8th scan for the "dirsort" verdict only); 1: off.  Only WHO traces which return changes, never a result.
  * "eager": the EAGER FUSION of one-slot rings (buffer_size 1, unsharded, no statistics, xy_size % 16 == 0).  The scan launches
  * ONE kernel behind the trace that encodes the ring slot AND fuses it with the previous fused map (the work of the scan's
  * encode pass and of the next combine's fusion, in one pass over the scan's accumulators), into spare buffers -- speculating

@@ -739,7 +739,7 @@ def test_sub_cloud_interleave_leaves_results_unchanged(gvom_mod):
 def test_layout_probe_finds_interleaved_sensors_and_nothing_else(gvom_mod):
     """Automatic interleave (the default): a one-wave probe kernel in front of k_trace looks at the second cloud of a length (and
     every 32nd after it) and the NEXT clouds of as many returns are traced accordingly (clouds whose length changes from scan to
-    scan are never probed).  It must find the 4 sensors of the c4 cloud (and the sensor groups of a 16-sensor one), must not find
+    scan are not looked at for sub-clouds).  It must find the 4 sensors of the c4 cloud (and the sensor groups of a 16-sensor one), must not find
     structure in a single sensor's scan or in random points, forgets its answer when the cloud's length changes -- and whatever
     it answers, the slots equal those of a mapper with the interleave switched off."""
     p4, multi = synth.config_inputs("c4", n_scans=2)
@@ -806,6 +806,12 @@ def test_directional_order_of_unordered_clouds_leaves_results_unchanged(gvom_mod
     for k in range(4):
         g.process_pointcloud(c1, scans1[0][1]); seen.append(g.get_tuning("dirsort"))
     assert seen[0] == 0 and seen[-1] == 1, seen
+    # a stream of unordered clouds whose length changes every scan (invalid returns dropped) is probed every 8th scan and sorted too
+    gv = gvom_mod.Gvom(*params1)
+    seen = []
+    for k in range(20):
+        gv.process_pointcloud(c1[:45000 + 137 * k], scans1[0][1]); seen.append(gv.get_tuning("dirsort"))
+    assert seen[0] == 0 and seen[-1] == 1 and sum(seen) >= 8, seen
     p2, lidar = synth.config_inputs("c2", n_scans=1)
     g2 = gvom_mod.Gvom(*p2)
     for k in range(4):
