@@ -14,6 +14,12 @@
 //     call under tests/shard_procs.py's churn hook): an allocation is exported ONCE and a mapping
 //     opened ONCE (both kept until the communicator goes), exported regions are whole multiples of 2 MiB, and a region a
 //     peer may have mapped is never given back to the allocator while the process lives (gvom_capi.hip);
+//   * device data, third transport (GVOM_TRANSPORT_LOOPBACK): RCCL LOOPBACK -- the ranks are THREADS of one process that share
+//     one GPU (RCCL refuses two ranks of ONE communicator on one device), each with a 1-rank communicator of its own; what
+//     the RCCL transport moves with ncclSend on the sender and ncclRecv on the receiver, the RECEIVER moves with
+//     ncclSend(peer's send region, self) + ncclRecv(own receive region, self) in one group on its handle's stream, through the
+//     same group / capacity-check / byte-count code (WireGroup below), and the combine ends in the in-place ncclAllGather.
+//     It exists so that a one-GPU box executes the RCCL calls, byte counts and stream ordering of the product path;
 //   * host data: the ranks are the processes of ONE node, so the small per-scan vectors (counts,
 //     in-grid flags) and the ncclUniqueId travel through a POSIX shared-memory segment
 //     (/dev/shm/<name>): ~1 us, no GPU involved.  Double-buffered slots, sequence numbers, C11 atomics.
@@ -104,6 +110,11 @@ struct PeerExport {                            // one exported region of one ran
     uint64_t offset[GVOM_COMM_MAX_RANKS];      // byte offset, inside the allocation, of the part meant for rank d
 };
 
+struct LoopRegion {                            // loopback transport: one rank's regions of one kind
+    uint64_t ptr[GVOM_COMM_MAX_RANKS];         // device address of the part meant for rank d (0: nothing)
+    uint64_t cap[GVOM_COMM_MAX_RANKS];         // its capacity in bytes
+};
+
 struct Segment {                               // the shared-memory rendezvous of one communicator
     std::atomic<uint32_t> magic;               // set last by rank 0
     uint32_t world;
@@ -128,6 +139,9 @@ struct Segment {                               // the shared-memory rendezvous o
     // recovery of refused imports: import_failed[s][kind] = the recovery round in which some rank could not open rank s's
     // export `kind` (written between two barriers, read after the second: every rank sees the same table)
     std::atomic<uint64_t> import_failed[GVOM_COMM_MAX_RANKS][GVOM_PEER_KINDS];
+    // loopback transport (the ranks are threads of ONE process): loop[s][kind] = where rank s holds what it has of `kind` for
+    // every destination, as plain device addresses (written by s between two barriers, read by the receivers behind the second)
+    LoopRegion loop[GVOM_COMM_MAX_RANKS][GVOM_PEER_KINDS];
 };
 
 inline double now_s() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + t.tv_nsec * 1e-9; }
@@ -220,6 +234,7 @@ struct gvom_comm {
     void *src_all[GVOM_COMM_MAX_RANKS][GVOM_PEER_KINDS] = {};       // scratch of one exchange: where each source's export is mapped
     bool need_all[GVOM_COMM_MAX_RANKS][GVOM_PEER_KINDS] = {};
     uint64_t peer_bytes = 0, peer_copies = 0;  // pulled so far (diagnostics)
+    uint64_t wire_ops = 0, wire_bytes = 0, wire_groups = 0, wire_allgathers = 0;   // RCCL calls issued so far (ncclSend + ncclRecv, their bytes, groups, all-gathers)
     uint64_t export_seq = 0, peer_open_retries = 0, peer_renewed = 0;
     // asynchronous form of the peer transport (no host wait for the GPU inside an exchange)
     bool async = false, registered = false;
@@ -253,6 +268,117 @@ namespace {
             return GVOM_ERR_HIP;                                                               \
         }                                                                                      \
     } while (0)
+
+// ---- one grouped RCCL point-to-point exchange on a handle's stream -----------------------------------
+// The RCCL transport (peers = the other ranks of the communicator) and the loopback transport (peer = this rank itself, the
+// source a same-process peer's send region) issue their transfers through this one object: zero-byte transfers are skipped,
+// regions of the handle are capacity-checked against the announced byte count, counts travel as size_t bytes of ncclUint8,
+// and a group that has been opened is closed on every path (an open group stays with the thread).
+struct WireGroup {
+    gvom_comm *c;
+    hipStream_t st;
+    int rc = GVOM_OK;
+    bool open = false;
+    int begin()
+    {
+        const ncclResult_t r = c->rccl.GroupStart();
+        if (r != ncclSuccess) { c->err = std::string("ncclGroupStart failed: ") + c->rccl.GetErrorString(r); return rc = GVOM_ERR_HIP; }
+        open = true;
+        return GVOM_OK;
+    }
+    void fail(int code, const char *why) { if (rc == GVOM_OK) { rc = code; c->err = why; } }
+    // the part of region `which` of handle h that belongs to rank p, if it can hold `bytes`
+    void *region(gvom_t *h, int which, int p, size_t bytes)
+    {
+        void *ptr = nullptr;
+        int64_t cap = 0;
+        if (gvom_shard_buffer(h, which, p, &ptr, &cap) || !ptr || (int64_t)bytes > cap) {
+            fail(GVOM_ERR_INVALID, "exchange region missing or smaller than the announced count");
+            return nullptr;
+        }
+        return ptr;
+    }
+    void wire(bool send, void *ptr, size_t bytes, int peer)
+    {
+        if (rc != GVOM_OK || bytes == 0 || !ptr) return;
+        const ncclResult_t r = send ? c->rccl.Send(ptr, bytes, ncclUint8, peer, c->nccl, st) : c->rccl.Recv(ptr, bytes, ncclUint8, peer, c->nccl, st);
+        if (r != ncclSuccess) { c->err = std::string(send ? "ncclSend" : "ncclRecv") + " failed: " + c->rccl.GetErrorString(r); rc = GVOM_ERR_HIP; return; }
+        ++c->wire_ops; c->wire_bytes += bytes;
+    }
+    // a transfer out of / into this handle's own region
+    void xfer(bool send, gvom_t *h, int which, int p, size_t bytes, int peer)
+    {
+        if (rc != GVOM_OK || bytes == 0) return;
+        wire(send, region(h, which, p, bytes), bytes, peer);
+    }
+    int end()
+    {
+        if (!open) return rc;
+        open = false;
+        ++c->wire_groups;
+        const ncclResult_t ge = c->rccl.GroupEnd();
+        if (rc != GVOM_OK) return rc;
+        if (ge != ncclSuccess) { c->err = std::string("ncclGroupEnd failed: ") + c->rccl.GetErrorString(ge); return rc = GVOM_ERR_HIP; }
+        return GVOM_OK;
+    }
+};
+
+// ---- loopback transport -----------------------------------------------------------------------------
+struct LoopPull { int kind, send_which, recv_which; int64_t unit; const int64_t *recv_counts; const int64_t *send_counts; };
+
+// where this rank holds what it has of `kind` for every other rank (between two barriers' worth of quiet, as peer_publish)
+int loop_publish(gvom_comm *c, gvom_t *h, int kind, int send_which, const int64_t *counts)
+{
+    LoopRegion &e = c->seg->loop[c->rank][kind];
+    for (int d = 0; d < c->world; ++d) {
+        e.ptr[d] = 0; e.cap[d] = 0;
+        if (d == c->rank || counts[d] <= 0) continue;
+        void *ptr = nullptr;
+        int64_t cap = 0;
+        if (gvom_shard_buffer(h, send_which, d, &ptr, &cap) || !ptr) { c->err = "send region missing"; return GVOM_ERR_INVALID; }
+        e.ptr[d] = (uint64_t)(uintptr_t)ptr; e.cap[d] = (uint64_t)cap;
+    }
+    return GVOM_OK;
+}
+int loop_same_process(gvom_comm *c)
+{
+    const int64_t me = (int64_t)getpid();
+    for (int r = 0; r < c->world; ++r)
+        if (c->seg->rank_pid[r] != me) { c->err = "loopback transport: rank " + std::to_string(r) + " is not a thread of this process"; return GVOM_ERR_INVALID; }
+    return GVOM_OK;
+}
+// One exchange over RCCL loopback: the senders' regions are published and complete; barrier; every rank moves what the others
+// hold for it -- ncclSend(their region, self) + ncclRecv(its own region, self), one group on ITS handle's stream, in front of
+// the kernels that consume the data -- and waits for the group; barrier (the senders may repack).
+int loop_pull(gvom_comm *c, gvom_t *h, hipStream_t st, const LoopPull *pulls, int n_pulls)
+{
+    HIPCHK_C(c, hipStreamSynchronize(st));                             // what the others read of me is complete
+    int rc = gvom_comm_barrier(c);
+    if (rc) return rc;
+    rc = loop_same_process(c);
+    WireGroup g{c, st};
+    if (rc == GVOM_OK) g.begin();
+    for (int s = 0; s < c->world && g.open && g.rc == GVOM_OK; ++s) {
+        if (s == c->rank) continue;
+        for (int k = 0; k < n_pulls && g.rc == GVOM_OK; ++k) {
+            const int64_t cnt = pulls[k].recv_counts[s];
+            if (cnt < 0) { g.fail(GVOM_ERR_INVALID, "negative count"); break; }
+            if (cnt == 0) continue;
+            const size_t bytes = (size_t)cnt * (size_t)pulls[k].unit;
+            const LoopRegion &e = c->seg->loop[s][pulls[k].kind];
+            if (!e.ptr[c->rank] || bytes > e.cap[c->rank]) { g.fail(GVOM_ERR_INVALID, "a peer announced more than its send region holds"); break; }
+            g.wire(true, (void *)(uintptr_t)e.ptr[c->rank], bytes, 0);
+            g.xfer(false, h, pulls[k].recv_which, s, bytes, 0);
+        }
+    }
+    if (rc == GVOM_OK) rc = g.end();
+    // (even a failed rank passes the second barrier: the others would wait for it for ever)
+    const hipError_t se = hipStreamSynchronize(st);
+    const int rb = gvom_comm_barrier(c);
+    if (rc) return rc;
+    if (se != hipSuccess) { c->err = std::string("hipStreamSynchronize failed: ") + hipGetErrorString(se); return GVOM_ERR_HIP; }
+    return rb;
+}
 
 // ---- peer transport -------------------------------------------------------------------------------
 __global__ void k_comm_flag(unsigned long long *p, unsigned long long v)
@@ -545,12 +671,13 @@ extern "C" {
 VIS int gvom_comm_create2(int rank, int world, int device, const char *name, int transport, gvom_comm_t **out)
 {
     if (!out || !name || world < 1 || world > GVOM_COMM_MAX_RANKS || rank < 0 || rank >= world) return GVOM_ERR_INVALID;
-    if (transport != GVOM_TRANSPORT_RCCL && transport != GVOM_TRANSPORT_PEER && transport != GVOM_TRANSPORT_AUTO) return GVOM_ERR_INVALID;
+    if (transport != GVOM_TRANSPORT_RCCL && transport != GVOM_TRANSPORT_PEER && transport != GVOM_TRANSPORT_AUTO && transport != GVOM_TRANSPORT_LOOPBACK) return GVOM_ERR_INVALID;
     *out = nullptr;
     gvom_comm *c = new gvom_comm();
     c->rank = rank; c->world = world; c->device = device;
-    c->transport = transport == GVOM_TRANSPORT_PEER ? GVOM_TRANSPORT_PEER : GVOM_TRANSPORT_RCCL;
+    c->transport = transport == GVOM_TRANSPORT_AUTO ? GVOM_TRANSPORT_RCCL : transport;
     const bool want_rccl = transport != GVOM_TRANSPORT_PEER, may_fall_back = transport == GVOM_TRANSPORT_AUTO;
+    const bool loopback = transport == GVOM_TRANSPORT_LOOPBACK;       // every rank a 1-rank communicator of its own
     bool rccl_ok = want_rccl;                                          // (this rank's view)
     c->shm_name = std::string("/") + name;
     if (const char *t = getenv("GVOM_COMM_TIMEOUT_S")) { const double v = atof(t); if (v > 0.0) c->timeout_s = v; }
@@ -592,7 +719,7 @@ VIS int gvom_comm_create2(int rank, int world, int device, const char *name, int
         c->seg->created_s = wall_s();
         c->seg->creator_pid = (int64_t)getpid();
         c->seg->creator_start = proc_start_time((int64_t)getpid());
-        if (!host_only && rccl_ok && c->rccl.GetUniqueId(&c->seg->id) != ncclSuccess) {
+        if (!host_only && rccl_ok && !loopback && c->rccl.GetUniqueId(&c->seg->id) != ncclSuccess) {
             if (!may_fall_back) return fail("ncclGetUniqueId failed", GVOM_ERR_HIP);
             rccl_ok = false;
         }
@@ -659,7 +786,13 @@ VIS int gvom_comm_create2(int rank, int world, int device, const char *name, int
             memcpy(&id, &c->seg->id, sizeof id);
             ncclResult_t r = ncclSuccess;
             std::string why;
-            if (!may_fall_back) {
+            if (loopback) {
+                // (the ranks are threads of one process on one device: their communicators are made one after the other)
+                static std::mutex init_mu;
+                std::lock_guard<std::mutex> lk(init_mu);
+                r = c->rccl.GetUniqueId(&id);
+                if (r == ncclSuccess) r = c->rccl.CommInitRank(&c->nccl, 1, id, 0);
+            } else if (!may_fall_back) {
                 r = c->rccl.CommInitRank(&c->nccl, world, id, rank);
             } else {
                 // AUTO: ncclCommInitRank is a collective that can also HANG (a rank that failed early leaves the others
@@ -829,35 +962,28 @@ static int exchange_scan_impl(gvom_comm_t *c, gvom_t *h, const int64_t *send_qua
         return peer_pull(c, h, st, pulls, 3, &c->seg->flags[c->rank].pulled_scan, c->scan_x);
     }
     if (!c->nccl) { c->err = "communicator without RCCL"; return GVOM_ERR_INVALID; }
-    NCCLCHK(c, c->rccl.GroupStart());
-    // (inside the group every failure path must still close it: an open group stays with the thread)
-    int rc = GVOM_OK;
-    auto xfer = [&](bool send, int which, int p, size_t bytes) {
-        if (rc != GVOM_OK || bytes == 0) return;
-        void *ptr = nullptr;
-        int64_t cap = 0;
-        if (gvom_shard_buffer(h, which, p, &ptr, &cap) || (int64_t)bytes > cap) {
-            c->err = "exchange region missing or smaller than the announced count";
-            rc = GVOM_ERR_INVALID;
-            return;
-        }
-        const ncclResult_t r = send ? c->rccl.Send(ptr, bytes, ncclUint8, p, c->nccl, st) : c->rccl.Recv(ptr, bytes, ncclUint8, p, c->nccl, st);
-        if (r != ncclSuccess) { c->err = std::string(send ? "ncclSend" : "ncclRecv") + " failed: " + c->rccl.GetErrorString(r); rc = GVOM_ERR_HIP; }
-    };
-    for (int p = 0; p < c->world; ++p) {
-        if (p == c->rank) continue;
-        if (send_quads[p] < 0 || send_eps[p] < 0 || recv_quads[p] < 0 || recv_eps[p] < 0) { c->err = "negative count"; rc = GVOM_ERR_INVALID; break; }
-        xfer(true, GVOM_XBUF_SEND_IDS, p, (size_t)send_quads[p] * 4);
-        xfer(true, GVOM_XBUF_SEND_QUADS, p, (size_t)send_quads[p] * 1024);
-        xfer(true, GVOM_XBUF_SEND_EPS, p, (size_t)send_eps[p] * 8);
-        xfer(false, GVOM_XBUF_RECV_IDS, p, (size_t)recv_quads[p] * 4);
-        xfer(false, GVOM_XBUF_RECV_QUADS, p, (size_t)recv_quads[p] * 1024);
-        xfer(false, GVOM_XBUF_RECV_EPS, p, (size_t)recv_eps[p] * 8);
+    if (c->transport == GVOM_TRANSPORT_LOOPBACK) {
+        int rc = GVOM_OK;
+        for (int k = 0; k < 3 && rc == GVOM_OK; ++k) rc = loop_publish(c, h, k, region_of_kind[k], k < 2 ? send_quads : send_eps);
+        if (rc) return rc;
+        const LoopPull pulls[3] = {{0, GVOM_XBUF_SEND_IDS, GVOM_XBUF_RECV_IDS, 4, recv_quads, send_quads},
+                                   {1, GVOM_XBUF_SEND_QUADS, GVOM_XBUF_RECV_QUADS, 1024, recv_quads, send_quads},
+                                   {2, GVOM_XBUF_SEND_EPS, GVOM_XBUF_RECV_EPS, 8, recv_eps, send_eps}};
+        return loop_pull(c, h, st, pulls, 3);
     }
-    const ncclResult_t ge = c->rccl.GroupEnd();
-    if (rc != GVOM_OK) return rc;
-    if (ge != ncclSuccess) { c->err = std::string("ncclGroupEnd failed: ") + c->rccl.GetErrorString(ge); return GVOM_ERR_HIP; }
-    return GVOM_OK;
+    WireGroup g{c, st};
+    if (g.begin()) return g.rc;
+    for (int p = 0; p < c->world && g.rc == GVOM_OK; ++p) {
+        if (p == c->rank) continue;
+        if (send_quads[p] < 0 || send_eps[p] < 0 || recv_quads[p] < 0 || recv_eps[p] < 0) { g.fail(GVOM_ERR_INVALID, "negative count"); break; }
+        g.xfer(true, h, GVOM_XBUF_SEND_IDS, p, (size_t)send_quads[p] * 4, p);
+        g.xfer(true, h, GVOM_XBUF_SEND_QUADS, p, (size_t)send_quads[p] * 1024, p);
+        g.xfer(true, h, GVOM_XBUF_SEND_EPS, p, (size_t)send_eps[p] * 8, p);
+        g.xfer(false, h, GVOM_XBUF_RECV_IDS, p, (size_t)recv_quads[p] * 4, p);
+        g.xfer(false, h, GVOM_XBUF_RECV_QUADS, p, (size_t)recv_quads[p] * 1024, p);
+        g.xfer(false, h, GVOM_XBUF_RECV_EPS, p, (size_t)recv_eps[p] * 8, p);
+    }
+    return g.end();
 }
 
 // Statistics handles: the returns every other rank needs of this one (gvom_shard_stats_counts) -> their receive
@@ -878,30 +1004,21 @@ static int exchange_stats_impl(gvom_comm_t *c, gvom_t *h, const int64_t *send_re
         return peer_pull(c, h, st, &pull, 1, &c->seg->flags[c->rank].pulled_stats, c->stats_x);
     }
     if (!c->nccl) { c->err = "communicator without RCCL"; return GVOM_ERR_INVALID; }
-    NCCLCHK(c, c->rccl.GroupStart());
-    int rc = GVOM_OK;
-    for (int p = 0; p < c->world && rc == GVOM_OK; ++p) {
-        if (p == c->rank) continue;
-        for (int dir = 0; dir < 2 && rc == GVOM_OK; ++dir) {
-            const int64_t cnt = dir == 0 ? send_returns[p] : recv_returns[p];
-            if (cnt < 0) { c->err = "negative count"; rc = GVOM_ERR_INVALID; break; }
-            if (cnt == 0) continue;
-            void *ptr = nullptr;
-            int64_t cap = 0;
-            const size_t bytes = (size_t)cnt * (size_t)bytes_per_return;
-            if (gvom_shard_buffer(h, dir == 0 ? GVOM_XBUF_SEND_RETURNS : GVOM_XBUF_RECV_RETURNS, p, &ptr, &cap) || (int64_t)bytes > cap) {
-                c->err = "statistics exchange region missing or smaller than the announced count";
-                rc = GVOM_ERR_INVALID;
-                break;
-            }
-            const ncclResult_t r = dir == 0 ? c->rccl.Send(ptr, bytes, ncclUint8, p, c->nccl, st) : c->rccl.Recv(ptr, bytes, ncclUint8, p, c->nccl, st);
-            if (r != ncclSuccess) { c->err = std::string("ncclSend/Recv failed: ") + c->rccl.GetErrorString(r); rc = GVOM_ERR_HIP; }
-        }
+    if (c->transport == GVOM_TRANSPORT_LOOPBACK) {
+        const int rc = loop_publish(c, h, 3, GVOM_XBUF_SEND_RETURNS, send_returns);
+        if (rc) return rc;
+        const LoopPull pull = {3, GVOM_XBUF_SEND_RETURNS, GVOM_XBUF_RECV_RETURNS, bytes_per_return, recv_returns, send_returns};
+        return loop_pull(c, h, st, &pull, 1);
     }
-    const ncclResult_t ge = c->rccl.GroupEnd();
-    if (rc != GVOM_OK) return rc;
-    if (ge != ncclSuccess) { c->err = std::string("ncclGroupEnd failed: ") + c->rccl.GetErrorString(ge); return GVOM_ERR_HIP; }
-    return GVOM_OK;
+    WireGroup g{c, st};
+    if (g.begin()) return g.rc;
+    for (int p = 0; p < c->world && g.rc == GVOM_OK; ++p) {
+        if (p == c->rank) continue;
+        if (send_returns[p] < 0 || recv_returns[p] < 0) { g.fail(GVOM_ERR_INVALID, "negative count"); break; }
+        g.xfer(true, h, GVOM_XBUF_SEND_RETURNS, p, (size_t)send_returns[p] * (size_t)bytes_per_return, p);
+        g.xfer(false, h, GVOM_XBUF_RECV_RETURNS, p, (size_t)recv_returns[p] * (size_t)bytes_per_return, p);
+    }
+    return g.end();
 }
 
 // The combine's exchange: in-place all-gather of the handle's [height | inferred height | positive
@@ -968,9 +1085,42 @@ static int allgather_rows_impl(gvom_comm_t *c, gvom_t *h)
         if (se != hipSuccess) { c->err = std::string("hipStreamSynchronize failed: ") + hipGetErrorString(se); return GVOM_ERR_HIP; }
         return rb;
     }
+    if (c->transport == GVOM_TRANSPORT_LOOPBACK) {
+        // every rank offers ITS rows and moves the others' into the same place of its own buffer with ncclSend / ncclRecv to
+        // itself (one group on its handle's stream); then the in-place all-gather of its 1-rank communicator over its own
+        // share: the product's call with the product's arguments, complete before k_map2d by stream order
+        if (!c->nccl) { c->err = "communicator without RCCL"; return GVOM_ERR_INVALID; }
+        hipStream_t st = (hipStream_t)gvom_stream(h);
+        LoopRegion &e = c->seg->loop[c->rank][4];
+        for (int d = 0; d < c->world; ++d) { e.ptr[d] = (uint64_t)(uintptr_t)((char *)ptr + share * c->rank); e.cap[d] = share; }
+        HIPCHK_C(c, hipStreamSynchronize(st));                         // my rows are complete
+        if ((rc = gvom_comm_barrier(c))) return rc;
+        rc = loop_same_process(c);
+        WireGroup g{c, st};
+        if (rc == GVOM_OK) g.begin();
+        for (int s = 0; s < c->world && g.open && g.rc == GVOM_OK; ++s) {
+            if (s == c->rank) continue;
+            const LoopRegion &o = c->seg->loop[s][4];
+            if (!o.ptr[c->rank] || o.cap[c->rank] != share) { g.fail(GVOM_ERR_INVALID, "the ranks' height-map rows differ in size"); break; }
+            g.wire(true, (void *)(uintptr_t)o.ptr[c->rank], share, 0);
+            g.wire(false, (char *)ptr + share * s, share, 0);
+        }
+        if (rc == GVOM_OK) rc = g.end();
+        if (rc == GVOM_OK) {
+            const ncclResult_t r = c->rccl.AllGather((char *)ptr + share * c->rank, (char *)ptr + share * c->rank, share, ncclUint8, c->nccl, st);
+            if (r != ncclSuccess) { c->err = std::string("ncclAllGather failed: ") + c->rccl.GetErrorString(r); rc = GVOM_ERR_HIP; }
+            else ++c->wire_allgathers;
+        }
+        const hipError_t se = hipStreamSynchronize(st);                // nobody's next fusion rewrites its rows before everyone has pulled
+        const int rb = gvom_comm_barrier(c);
+        if (rc) return rc;
+        if (se != hipSuccess) { c->err = std::string("hipStreamSynchronize failed: ") + hipGetErrorString(se); return GVOM_ERR_HIP; }
+        return rb;
+    }
     if (c->world == 1) return GVOM_OK;                     // (one rank: its rows are all the rows)
     if (!c->nccl) { c->err = "communicator without RCCL"; return GVOM_ERR_INVALID; }
     NCCLCHK(c, c->rccl.AllGather((char *)ptr + share * c->rank, ptr, share, ncclUint8, c->nccl, (hipStream_t)gvom_stream(h)));
+    ++c->wire_allgathers;
     return GVOM_OK;
 }
 
@@ -1089,6 +1239,23 @@ VIS int gvom_comm_peer_stats(gvom_comm_t *c, int64_t out[4])
 {
     if (!c || !out) return GVOM_ERR_INVALID;
     out[0] = (int64_t)c->peer_bytes; out[1] = (int64_t)c->peer_copies; out[2] = (int64_t)c->export_seq; out[3] = (int64_t)c->peer_open_retries;
+    return GVOM_OK;
+}
+
+// RCCL calls this rank has issued: {ncclSend + ncclRecv calls, their bytes, groups closed, ncclAllGather calls}
+VIS int gvom_comm_wire_stats(gvom_comm_t *c, int64_t out[4])
+{
+    if (!c || !out) return GVOM_ERR_INVALID;
+    out[0] = (int64_t)c->wire_ops; out[1] = (int64_t)c->wire_bytes; out[2] = (int64_t)c->wire_groups; out[3] = (int64_t)c->wire_allgathers;
+    return GVOM_OK;
+}
+
+// A rank that cannot go on (its caller failed outside the library) says so: the others' next wait ends with an error naming it
+// instead of lasting GVOM_COMM_TIMEOUT_S.  The communicator stays broken.
+VIS int gvom_comm_abort(gvom_comm_t *c)
+{
+    if (!c || !c->seg) return GVOM_ERR_INVALID;
+    c->seg->poison.store((uint32_t)c->rank + 1u, std::memory_order_release);
     return GVOM_OK;
 }
 

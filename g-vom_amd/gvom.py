@@ -109,6 +109,8 @@ ABI = [
     ("gvom_comm_peer_stats", _I, [_P, ctypes.POINTER(_I64)]),
     ("gvom_comm_peer_renewed", _I64, [_P]),
     ("gvom_comm_info", _I, [_P, ctypes.POINTER(_I64), ctypes.c_char_p, ctypes.c_size_t]),
+    ("gvom_comm_wire_stats", _I, [_P, ctypes.POINTER(_I64)]),
+    ("gvom_comm_abort", _I, [_P]),
     ("gvom_shard_renew_region", _I, [_P, _I]),
     ("gvom_comm_destroy", None, [_P]),
     ("gvom_comm_exchange_host", _I, [_P, ctypes.POINTER(_I64), _I, ctypes.POINTER(_I64)]),
@@ -150,7 +152,7 @@ ABI = [
 ]
 
 
-ABI_VERSION = 7          # include/gvom_hip.h GVOM_ABI_VERSION this binding was written against
+ABI_VERSION = 8          # include/gvom_hip.h GVOM_ABI_VERSION this binding was written against
 
 
 def load_library(path=None):

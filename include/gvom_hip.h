@@ -26,7 +26,8 @@
 extern "C" {
 #endif
 
-#define GVOM_ABI_VERSION 7   /* 7: eager fusion of one-slot rings ("eager" knob, gvom_get_tuning "eager_adopted" / "eager_dropped"); a sharded scan /
+#define GVOM_ABI_VERSION 8   /* 8: RCCL loopback transport (GVOM_TRANSPORT_LOOPBACK), gvom_comm_wire_stats, gvom_comm_abort;
+                              * 7: eager fusion of one-slot rings ("eager" knob, gvom_get_tuning "eager_adopted" / "eager_dropped"); a sharded scan /
                               *    combine as ONE native call (gvom_comm_process_pointcloud, gvom_comm_combine_maps_into);
                               * 6: sub-cloud interleave of the trace ("interleave" knob, automatic by a layout probe), gvom_get_tuning;
                               *    peer transport absorbs refused exports / imports (gvom_shard_renew_region, gvom_comm_peer_renewed), gvom_comm_info;
@@ -250,7 +251,7 @@ int  gvom_comm_create(int rank, int world, int device, const char *name, gvom_co
  *       this is the transport a one-GPU box can run several rank processes with);
  * AUTO  RCCL; if librccl cannot be loaded, or ncclCommInitRank fails on any rank or does not return within
  *       GVOM_RCCL_INIT_TIMEOUT_S (default 90 s after the last rank has arrived), every rank uses PEER.
- * gvom_comm_transport: the transport in use (GVOM_TRANSPORT_RCCL or GVOM_TRANSPORT_PEER).
+ * gvom_comm_transport: the transport in use (GVOM_TRANSPORT_RCCL, GVOM_TRANSPORT_PEER or GVOM_TRANSPORT_LOOPBACK).
  * Failure semantics: a rank whose device exchange failed marks the communicator (for every rank) as broken, and a rank
  * whose process has gone is noticed by whoever waits for it next: the others' next gvom_comm_exchange_host / _barrier
  * returns GVOM_ERR_HIP with a message naming the rank instead of waiting GVOM_COMM_TIMEOUT_S.  A broken communicator stays
@@ -258,6 +259,14 @@ int  gvom_comm_create(int rank, int world, int device, const char *name, gvom_co
 #define GVOM_TRANSPORT_RCCL 0
 #define GVOM_TRANSPORT_PEER 1
 #define GVOM_TRANSPORT_AUTO 2
+/* LOOPBACK  RCCL on a box with ONE GPU: the ranks are threads of one process that share the device (RCCL refuses two ranks of
+ *       one communicator on one device), each with a 1-rank communicator of its own.  What RCCL moves with ncclSend on the
+ *       sender and ncclRecv on the receiver, the RECEIVER moves with ncclSend(the peer's send region, itself) +
+ *       ncclRecv(its receive region, itself) in one group on its handle's stream -- same group handling, capacity checks,
+ *       ncclUint8 byte counts and position in front of the unpack kernels as GVOM_TRANSPORT_RCCL -- bracketed by two host
+ *       barriers; the combine's rows the same way, followed by the in-place ncclAllGather of the 1-rank communicator.
+ *       All ranks must live in one process (plain device addresses travel through the segment). */
+#define GVOM_TRANSPORT_LOOPBACK 3
 int  gvom_comm_create2(int rank, int world, int device, const char *name, int transport, gvom_comm_t **out);
 int  gvom_comm_transport(gvom_comm_t *c);
 /* Peer transport, asynchronous form (GVOM_PEER_ASYNC=1 on every rank, and every rank able to register the segment with HIP;
@@ -281,6 +290,10 @@ int64_t gvom_comm_peer_renewed(gvom_comm_t *c);
 /* What the communicator itself knows of the job: out = {ranks in RCCL's communicator (ncclCommCount; -1 without RCCL), this
  * rank's number there (ncclCommUserRank), HIP device, transport in use}; busid (optional): the device's PCI bus id. */
 int  gvom_comm_info(gvom_comm_t *c, int64_t out[4], char *busid, size_t busid_len);
+/* RCCL calls this rank has issued so far: {ncclSend + ncclRecv calls, their bytes, groups closed, ncclAllGather calls} */
+int  gvom_comm_wire_stats(gvom_comm_t *c, int64_t out[4]);
+/* A rank whose caller cannot go on marks the communicator broken for every rank (see "Failure semantics" above). */
+int  gvom_comm_abort(gvom_comm_t *c);
 void gvom_comm_destroy(gvom_comm_t *c);
 int  gvom_comm_exchange_host(gvom_comm_t *c, const int64_t *mine, int k, int64_t *all);
 int  gvom_comm_barrier(gvom_comm_t *c);

@@ -3,7 +3,8 @@
 tests/shard_threads.py): every rank contributes its own sensor's scan (weak scaling: world x returns
 into ONE map); the rows each rank owns of the scan slot and of the fused map, and every rank's
 returned 2-D maps, must equal the unsharded handle's fed with the concatenated cloud.
-Usage: tests/fuzz/shard_big.py <config: c2|c4|c5> <worlds, e.g. 4,8> [scans] [buffer]"""
+Usage: tests/fuzz/shard_big.py <config: c2|c4|c5> <worlds, e.g. 4,8> [scans] [buffer] [threads|loopback]
+(loopback: the product's communicator over RCCL instead of the thread double; prints the RCCL calls it issued)"""
 import os, sys, io, contextlib
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -26,6 +27,7 @@ def main():
     worlds = [int(w) for w in sys.argv[2].split(",")] if len(sys.argv) > 2 else [4, 8]
     n_scans = int(sys.argv[3]) if len(sys.argv) > 3 else 3
     buffer = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+    transport = sys.argv[5] if len(sys.argv) > 5 and sys.argv[5] != "threads" else None
     xy, zs, beams = GRIDS[cfg]
     params = (0.2, 0.2, xy, zs, buffer) + synth.REF_TAIL
     scene = synth.make_scene(2)
@@ -66,11 +68,18 @@ def main():
                         if not np.array_equal(a, c):
                             nbad += 1
                             print("MISMATCH world %d rank %d %s %s: %d voxels" % (W, r, "slot" if which != gvom.GVOM_WHICH_FUSED else "fused", nm, int(np.sum(a != c))))
+            if transport:
+                wire[r] = sh.comm.wire_stats()
             return nbad
 
+        wire = [None] * W
         with contextlib.redirect_stdout(sys.stderr):
-            res = run_ranks(W, params, body)
+            res = run_ranks(W, params, body, transport=transport)
         bad += sum(res)
+        if transport:
+            print("%s world %d over %s: RCCL calls per rank %s" % (cfg, W, transport, wire))
+            if not all(w["p2p_calls"] > 0 and w["allgathers"] == n_scans for w in wire):
+                bad += 1
         print("%s world %d: %d returns per scan, %d scans checked" % (cfg, W, sum(s.shape[0] for s in scans[0][0]), n_scans))
     print("shard_big: %d mismatches" % bad)
     sys.exit(1 if bad else 0)

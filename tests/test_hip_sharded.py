@@ -18,8 +18,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_sharded_map_equals_single_handle_over_a_moving_window(world):
+@pytest.mark.parametrize("world,transport", [(2, None), (4, None), (2, "loopback"), (4, "loopback")])
+def test_sharded_map_equals_single_handle_over_a_moving_window(world, transport):
+    """transport None: the thread double (device copies); "loopback": the product's communicator over RCCL -- every rank a
+    1-rank communicator, grouped ncclSend / ncclRecv to itself on the receiving handle's stream in front of k_unpack_*, the
+    in-place ncclAllGather in front of k_map2d, the library's one-call scan and combine (csrc/gvom_comm.hip)."""
     import gvom
     import synth
     from shard_threads import run_ranks
@@ -50,14 +53,22 @@ def test_sharded_map_equals_single_handle_over_a_moving_window(world):
                 assert a.dtype == b.dtype and np.array_equal(a, b)
             assert sh.combined_cell_count_cpu == wcnt
             assert sh.b.g.buffer_index == wbuf
+        if transport == "loopback":
+            assert sh.comm.transport == "loopback" and sh.comm.info()["rccl_comm_count"] == 1
+            w = sh.comm.wire_stats()
+            # every scan's exchange is one group (the rejected scan's too), every combine one more and one all-gather; a combine
+            # moves every other rank's rows with one ncclSend + one ncclRecv, an accepted scan at least its quads or endpoints
+            assert w["groups"] == 2 * len(steps) and w["allgathers"] == len(steps), w
+            assert w["p2p_calls"] >= 2 * (world - 1) * (len(steps) + 4) and w["p2p_bytes"] > (1 << 20), w
         return True
 
     with contextlib.redirect_stdout(io.StringIO()):
-        assert run_ranks(world, params, body) == [True] * world
+        assert run_ranks(world, params, body, transport=transport) == [True] * world
 
 
-@pytest.mark.parametrize("world,dtype", [(2, np.float32), (4, np.float32), (4, np.float64)])
-def test_sharded_voxel_statistics_equal_the_unsharded_handle(world, dtype):
+@pytest.mark.parametrize("world,dtype,transport", [(2, np.float32, None), (4, np.float32, None), (4, np.float64, None),
+                                                   (4, np.float64, "loopback")])
+def test_sharded_voxel_statistics_equal_the_unsharded_handle(world, dtype, transport):
     """SURVEY 8f rank 2 on a sharded map ("absent on sharded handles"): with voxel_statistics=True every rank
     also receives the returns whose 27-voxel neighbourhood reaches into its rows, and make_debug_voxel_map() returns the
     rank's own voxels.  The ranks' rows together must be the unsharded mapper's debug cloud -- positions, hit counts and
@@ -95,7 +106,7 @@ def test_sharded_voxel_statistics_equal_the_unsharded_handle(world, dtype):
             parts.append(np.array(sh.make_debug_voxel_map(), copy=True))
         return parts
 
-    parts = run_ranks(world, params, body, voxel_statistics=True)
+    parts = run_ranks(world, params, body, transport=transport, voxel_statistics=True)
     for k, (_, wcloud) in enumerate(want):
         got = np.concatenate([parts[r][k] for r in range(world)], 0)
         assert got.shape == wcloud.shape, (k, got.shape, wcloud.shape)
@@ -105,13 +116,15 @@ def test_sharded_voxel_statistics_equal_the_unsharded_handle(world, dtype):
         np.testing.assert_allclose(g[:, 5:], w[:, 5:], rtol=1e-4, atol=2e-5, err_msg="step %d: eigenvalue columns" % k)
 
 
-@pytest.mark.parametrize("cfg,worlds,scans,buffer", [("c2", "4,8", "3", "1"), ("c4", "4", "6", "4")])
-def test_sharded_map_at_full_size(cfg, worlds, scans, buffer):
+@pytest.mark.parametrize("cfg,worlds,scans,buffer,transport", [("c2", "4,8", "3", "1", "threads"), ("c4", "4", "6", "4", "threads"),
+                                                               ("c4", "2,4", "4", "4", "loopback")])
+def test_sharded_map_at_full_size(cfg, worlds, scans, buffer, transport):
     """tests/fuzz/shard_big.py: the weak-scaling clouds of the bench on the c2 grid (4 and 8 ranks x
     131,072 returns) and BASELINE c4 at its own settings (512 x 512 x 128, buffer 4, 4 ranks x 262,144 returns, six
     scans of a moving window: the ring wraps and evicts): slots, fused map and returned maps of every rank equal the
-    unsharded handle's."""
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", "shard_big.py"), cfg, worlds, scans, buffer],
+    unsharded handle's.  "loopback": c4's clouds through the product's communicator over RCCL (2 and 4 ranks: 262,144 /
+    524,288 returns per rank, quads by the ten thousand per exchange)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", "shard_big.py"), cfg, worlds, scans, buffer, transport],
                          capture_output=True, text=True, timeout=1200)
     assert out.returncode == 0, (out.stdout + out.stderr)[-2000:]
     assert "shard_big: 0 mismatches" in out.stdout

@@ -29,6 +29,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in ("tests", "tests/golden", "tests/fuzz", "g-vom_amd", ""):
     sys.path.insert(0, os.path.join(ROOT, p))
 import gvom_sharded          # noqa: E402
+import shard_threads         # noqa: E402
 import fuzz_shard            # noqa: E402
 
 
@@ -41,9 +42,9 @@ def patch_transport(legacy, backlog):
     if backlog:
         for b in big:
             assert rt.hipMalloc(ctypes.byref(b), nbig) == 0
-    stream_copy = gvom_sharded.ThreadComm._copy
-    stream_drain = gvom_sharded.ThreadComm._drain
-    stream_allgather = gvom_sharded.ThreadComm.allgather_rows
+    stream_copy = shard_threads.ThreadComm._copy
+    stream_drain = shard_threads.ThreadComm._drain
+    stream_allgather = shard_threads.ThreadComm.allgather_rows
     import threading
     tl = threading.local()
 
@@ -73,9 +74,9 @@ def patch_transport(legacy, backlog):
         finally:
             tl.gather = False
 
-    gvom_sharded.ThreadComm._copy = copy
-    gvom_sharded.ThreadComm._drain = drain
-    gvom_sharded.ThreadComm.allgather_rows = allgather
+    shard_threads.ThreadComm._copy = copy
+    shard_threads.ThreadComm._drain = drain
+    shard_threads.ThreadComm.allgather_rows = allgather
 
 
 def main():
