@@ -45,6 +45,8 @@ for p in (ROOT, os.path.join(ROOT, "g-vom_amd")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0       # MI355X spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+PCIE_PEAK_GBS = 64.0        # host link, one direction: PCIe Gen5 x16 (32 GT/s x 16 lanes, 128b/130b); 42-48 GB/s is what
+                            # k_map2d's write-through stores into pinned host memory reach (profiles/r4_experiments.txt)
 VALU_ISSUE_RATE = 1.2288e12  # wave64 VALU instructions / s: 1024 SIMDs x 2.4 GHz / 2 cycles (MI355X_MICROARCH.md:54,473)
 MIN_TIMED_S = 0.5
 METRIC = "M points/sec (process_pointcloud + combine_maps, 256^3 voxel grid); map Hz beside it"
@@ -233,6 +235,32 @@ def _newest_profile(pattern, kernel, config="m256"):
     return None, None
 
 
+_LIB_SHA = {}
+
+
+def loaded_library_sha():
+    """sha256 of the libgvom_hip.so this process loads (hipcc's output is reproducible: the sha names the sources)."""
+    import hashlib
+    import gvom
+    path = gvom.library_path()
+    if path not in _LIB_SHA:
+        h = hashlib.sha256()
+        with open(path, "rb") as f:
+            for chunk in iter(lambda: f.read(1 << 20), b""):
+                h.update(chunk)
+        _LIB_SHA[path] = h.hexdigest()
+    return _LIB_SHA[path]
+
+
+def profile_library(source):
+    """the library identity a committed counter summary was taken on ({"lib_sha256", "git_head", ...}; None: not recorded --
+    summaries older than round 6)"""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", source))).get("library")
+    except Exception:
+        return None
+
+
 def pmc_traffic(kernel, config="m256"):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*_traffic.json:
     separate FETCH_SIZE / WRITE_SIZE passes, corrected with the factors calibrated on known-byte
@@ -376,14 +404,20 @@ def run_config(hip, name, steps, warmup, poses, full):
     b6, k = timed_blocks(step_async_occ, k, steps, 0.2)
     pend[0].result()
     out["value_async_occupancy_api"] = n_pts * steps / _median(b6) / 1e6
-    out["host_us"] = g.host_timing()
+    if os.environ.get("GVOM_HOST_TIMING"):                 # (the library only keeps these times when asked to)
+        out["host_us"] = g.host_timing()
+    # which path the timed steps took (results never depend on it; speed does): eager fusion adopted by the combines, the
+    # cloud traced in its own order (dirsort 0) with how many sub-clouds interleaved
+    out["fast_path"] = {"eager_adopted": g.get_tuning("eager_adopted"), "eager_dropped": g.get_tuning("eager_dropped"),
+                        "dirsort": g.get_tuning("dirsort"), "interleave": g.get_tuning("interleave")}
     # exact integer accounting for the roofline (algorithmic bytes), AFTER the timed regions:
     # the dense read-back allocates and frees 16*V bytes
     stats = g.scan_stats()
     V = params[2] * params[2] * params[3]
     P = 12 if scans[0][0].dtype == np.float32 else 24
     filled = min(warmup + steps, params[4])
-    alg = {"trace": n_pts * P + 4 * (stats["sum_hit"] + stats["sum_total"]),
+    # (4 * N_in: one f32 min per in-grid return, SURVEY 8d -- N_in = sum_hit: every in-grid return adds 1 to its voxel's hit)
+    alg = {"trace": n_pts * P + 4 * (stats["sum_hit"] + stats["sum_total"]) + 4 * stats["sum_hit"],
            "encode": 20 * V + 4 * stats["sum_hit"],
            "fuse": 4 * V * (filled + 1) + 4 * V + 4 * V,
            "map2d": 68 * params[2] * params[2]}
@@ -587,9 +621,11 @@ def step_roofline(alg, res, config):
                     "+ 4*V*(S+L) + 8*V + 68*xy^2 (SURVEY 8d); measured = PMC HBM bytes of the four kernels (profiles/)"}
 
 
-def roofline_of(alg, stages, profiled="m256"):
+def roofline_of(alg, stages, profiled="m256", xy=None, lib_sha=None):
     """profiled: the config whose committed counter passes (profiles/) apply -- a config without passes of its own gets
-    null counter-derived fields rather than another workload's numbers (False / None: no counters at all)."""
+    null counter-derived fields rather than another workload's numbers (False / None: no counters at all).
+    xy: the grid's width (adds the host-link ceiling of k_map2d); lib_sha: sha256 of the library this run loaded (the line then
+    says whether the committed counters were taken on the same one)."""
     config = profiled if isinstance(profiled, str) else ("m256" if profiled else None)
     kern = {"trace": "k_trace", "encode": "k_encode", "fuse": "k_fuse4", "map2d": "k_map2d"}
     try:
@@ -625,9 +661,24 @@ def roofline_of(alg, stages, profiled="m256"):
         if t and ms.get(s):
             stage_gbs[s] = t["bytes_per_launch"] / (ms[s] * 1e-3) / 1e9
     req = (traf or {}).get("atomic_requests_per_launch")
+    plib = profile_library(traf["source"]) if traf else None
+    traffic_sha = (plib or {}).get("lib_sha256")
+    pcie = None
+    if xy and ms.get("map2d"):
+        # k_map2d IS host-link time: its four returned maps (3 x int32 + 1 x f64 = 20 B per cell) are stored straight into
+        # pinned host memory; its HBM traffic is a few MB (0.03 of the HBM peak)
+        b = 20.0 * xy * xy
+        pcie = {"bound": "pcie", "kernel": "k_map2d", "bytes_to_host": b, "stage_ms": ms["map2d"],
+                "achieved": b / (ms["map2d"] * 1e-3) / 1e9, "peak": PCIE_PEAK_GBS, "unit": "GB/s",
+                "frac": b / (ms["map2d"] * 1e-3) / 1e9 / PCIE_PEAK_GBS,
+                "note": "20 B per cell over the host link / the stage's HIP-event time / PCIe Gen5 x16's 64 GB/s"}
     return {"bound": "hbm", "kernel": kern[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": (traf or {}).get("bytes_per_launch"),
             "traffic_source": ("profiles/%s (committed PMC passes of this command; NOT measured by this run)" % traf["source"]) if traf else None,
+            "lib_sha": lib_sha, "traffic_lib_sha": traffic_sha, "traffic_git_head": (plib or {}).get("git_head"),
+            # the committed counters belong to ANOTHER library than the one measured here (or do not say which)
+            "traffic_stale": (traffic_sha != lib_sha) if (traf and lib_sha) else None,
+            "pcie": pcie,
             "traffic_detail": traf,
             "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": ms[dom],
             "launch_ms_spread": {k: stages[dom][k] for k in ("p10", "p90", "samples")},
@@ -698,10 +749,12 @@ def run_single(args):
                            "(the node's two callbacks, gvom_ros.py:61-62, 113-115), both free-running (_paced: one combine per new scan); "
                            "value_async_combine: combine_maps_async() (extension), the next scan traced while the maps "
                            "of the pending combine are stored to host memory -- same maps, one step later",
-        "stage_ms": res["stage_ms"], "host_us": res["host_us"],
+        "stage_ms": res["stage_ms"], "fast_path": res["fast_path"],
         "sum_hit": res["sum_hit"], "sum_total": res["sum_total"], "cells": res["cells"],
-        "roofline": roofline_of(alg, stages, profiled=name),
+        "roofline": roofline_of(alg, stages, profiled=name, xy=params[2], lib_sha=loaded_library_sha()),
     }
+    if "host_us" in res:
+        out["host_us"] = res["host_us"]
     out["roofline"]["step"] = step_roofline(alg, res, name)
     for key in ("value_ros_two_threads", "scans_per_s_ros_two_threads", "maps_per_s_ros_two_threads"):
         out[key] = res[key]
@@ -722,7 +775,12 @@ def run_single(args):
             r, _ = run_config(hip, other, nsteps, nwarm, poses, False)
             out["configs"][other] = r
     if args.offered_hz > 0:
-        out["stream"] = stream_single(name, args.offered_hz, args.ticks, poses)
+        out["stream"] = dict(stream_single(name, args.offered_hz, args.ticks, poses), config=name)
+    elif not args.no_extra and name == "m256" and not getattr(args, "no_big", False):
+        # BASELINE.json config 5 as it is quoted -- "4 M-pt multi-sensor stream at 20 Hz, sustained throughput" -- on this ONE GPU:
+        # 200 ticks (10 s) of host-resident 4,194,304-point clouds handed over at 20 Hz, upload inside
+        out["stream"] = dict(stream_single("c5", 20.0, 200, 1), config="c5",
+                             grid=list(synth.CONFIGS["c5"][0][2:4]), workload=synth.CONFIGS["c5"][2])
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(params, scans, args.cpu_budget)
     return out

@@ -752,7 +752,7 @@ int eager_launch(gvom_handle *h, const ScanParams &P, Slot &st, const int64_t or
         pd.epoch = prev->epoch; pd.tags = prev->tags;
     }
     int nw, nblocks; size_t row_cap;
-    gvom_encfuse_shape(p.xy_size, p.z_size, &nw, &nblocks, &row_cap);
+    gvom_encfuse_shape(p.xy_size, p.z_size, FP.nz, &nw, &nblocks, &row_cap);
     if (row_cap >= 2147483648ull) { h->err = "fused row space exceeds 31 bits"; return GVOM_ERR_CAPACITY; }
     int rc;
     if ((rc = ensure(h, F.rows, row_cap * 16))) return rc;
@@ -846,6 +846,10 @@ int scan_launch(gvom_handle *h, std::unique_lock<std::mutex> &lk, const void *de
     }
 #endif
     hipError_t le = hipSuccess;
+    // the layout probe's LAST answer, read before this scan's probe is launched: every kernel of the earlier scans has completed
+    // (their process_pointcloud returned behind k_trace), so which scan starts to sort is deterministic (read behind
+    // the launch, scan k or k + 1 saw the new verdict depending on how fast the probe ran)
+    const unsigned long long probe_word = h->counters_host ? *(volatile unsigned long long *)(h->counters_host + 8) : 0ull;
     if (h->tune_ilv == 0 && n >= 8192) {
         // layout probe: only for clouds whose length is STABLE (the same as the previous scan's: a node that drops invalid
         // returns hands over a different length every scan -- its sub-clouds do not start at multiples of n / K, nothing to find,
@@ -867,7 +871,7 @@ int scan_launch(gvom_handle *h, std::unique_lock<std::mutex> &lk, const void *de
     {   // directional order: forced, or the probe's verdict on the previous cloud of this length ("scattered", bit 3 of its answer)
         int sort = h->tune_dirsort == 1 || h->tune_dirsort == 2 ? h->tune_dirsort : 0;   // 1: cube cells, 2: elevation rows
         if (h->tune_dirsort == 0 && h->tune_ilv == 0 && h->counters_host) {
-            const unsigned long long w = *(volatile unsigned long long *)(h->counters_host + 8);
+            const unsigned long long w = probe_word;
             const int64_t np_ = (int64_t)(w >> 8);
             // (the verdict on a cloud of about this length -- within a quarter -- holds for this one)
             if (np_ > 0 && (np_ == n || (n > np_ - np_ / 4 && n < np_ + np_ / 4))) sort = (int)((w >> 3) & 3ull);
@@ -1905,19 +1909,18 @@ VIS int gvom_device_buffer(gvom_t *h, int which, void **ptr, int64_t *bytes, int
 VIS int gvom_combine_map2d_into(gvom_t *h, double origin_world[3], void *pinned_out)
 {
     if (!h || !pinned_out) return GVOM_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::unique_lock<std::mutex> lk(h->mu);              // (ONE lock object: finish_combine releases it while the host spins)
     if (!h->has_combined) return GVOM_NO_DATA;
     HIPCHK(h, hipSetDevice(h->device));
+    { const int rc0 = check_out_buffer(h, pinned_out); if (rc0) return rc0; }   // (the completion flag is only sound for coherent pinned memory)
     char *dev = nullptr;
     HIPCHK(h, hipHostGetDevicePointer((void **)&dev, pinned_out, 0));
     // completion as in the unsharded combine: k_map2d's last workgroup stores a flag the host spins on (a stream
     // synchronisation notices the end of the stream several microseconds later); the count was published by k_posdens
-    std::unique_lock<std::mutex> ulk(h->mu, std::adopt_lock);
     const uint32_t done_seq = ++h->combine_seq;
     const bool solo = h->sharded && h->world == 1;       // (every row is this rank's: no gathered densities, see gvom_combine_fuse)
     int rc = map2d_impl(h, !solo, solo, dev, true, nullptr, nullptr, done_seq);
-    if (rc == GVOM_OK) rc = finish_combine(h, ulk, done_seq);
-    ulk.release();                                         // (the lock_guard above still owns the mutex)
+    if (rc == GVOM_OK) rc = finish_combine(h, lk, done_seq);
     if (rc) return rc;
     if (origin_world) {
         const Fused &F = h->fused[h->cur];

@@ -194,7 +194,7 @@ hipError_t gvom_launch_dirbin(hipStream_t s, const ScanParams &P, int mode, int 
 hipError_t gvom_launch_fuse(hipStream_t s, const FuseParams &P, const FuseDescs &KD,
                             const MapDesc *descs_dev, int32_t *fstate, uint4 *frows,
                             uint32_t *ftags, uint32_t *blockcounts, double *height, double *inferred);
-void gvom_encfuse_shape(int xy, int zs, int *nw, int *nblocks, size_t *row_cap);
+void gvom_encfuse_shape(int xy, int zs, int nw_override, int *nw, int *nblocks, size_t *row_cap);
 hipError_t gvom_launch_encfuse(hipStream_t s, const ScanParams &P, const FuseParams &F, const MapDesc &prev, uint32_t *hit,
                                uint32_t *total, uint32_t *mh, int32_t *state, uint4 *crows, const uint32_t *stags,
                                int32_t *fstate, uint4 *frows, uint32_t *ftags, uint32_t *blockcounts, double *height,

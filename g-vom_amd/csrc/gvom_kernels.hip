@@ -24,6 +24,13 @@
 #include "gvom_internal.h"
 #include <limits.h>
 
+// Written for ONE target: 64-wide waves, 160 KB of LDS per workgroup (k_dirbin_scatter<., 8192> alone declares 65 KB of static
+// LDS), v_cvt_flr_i32_f32, DPP wave shifts, the memory side's merging of same-line atomics.  Any other --offload-arch is a
+// build error here, not a launch failure later.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libgvom_hip.so is written for gfx950 (MI355X) only: build with --offload-arch=gfx950"
+#endif
+
 #define WAVE 64
 
 // Pointers read out of a descriptor table are generic ("flat") to the compiler; these casts tell
@@ -1857,6 +1864,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     // the min-height accumulator and the previous map's row in ONE round trip; then the slot's compact row (k_encode's move,
     // gvom.py:1164-1168, 1303-1329), the fused row (gvom.py:910-912) and the fused state
     auto emit = [&]() {
+        // (the lists were written by other lanes of this wave: their LDS stores are made visible to the whole wave first)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         for (uint32_t base = 0; base < n; base += WAVE) {
             const uint32_t e = base + (uint32_t)lane;
             const bool on = e < n;
@@ -1885,6 +1895,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
             running += (uint32_t)__popcll(ob);
         }
         n = 0;
+        __builtin_amdgcn_wave_barrier();                       // (nobody refills the lists before every lane has read its entry)
     };
 
     for (int it0 = 0; it0 < niter; it0 += ENCFUSE_MAXIT) {
@@ -1952,8 +1963,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
                 if (any_h) *reinterpret_cast<uint4 *>(hit + A0) = make_uint4(0, 0, 0, 0);
             }
             if (live_s || live_p) {
-                // (an occupied voxel's word is overwritten with its row by emit(): same wave, later in program order)
-                *reinterpret_cast<int4 *>(fstate + L0) = make_int4(c[0], c[1], c[2], c[3]);
+                // (an occupied voxel's word belongs to emit(), where ANOTHER lane stores the voxel's row: the owner never writes
+                // it, so no ordering between two lanes' stores to one address is relied on -- ADVICE r5)
+                if (occ == 0u) *reinterpret_cast<int4 *>(fstate + L0) = make_int4(c[0], c[1], c[2], c[3]);
+                else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) if (!((occ >> i) & 1u)) fstate[L0 + i] = c[i];
+                }
                 if ((sx0 & 63u) == 0u) ftags[(sy * (uint32_t)zs + (uint32_t)sz) * (uint32_t)nseg + seg] = F.epoch;
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -3239,13 +3255,17 @@ hipError_t gvom_launch_fuse(hipStream_t s, const FuseParams &P, const FuseDescs 
 // k_encfuse (one-slot rings; the host has checked xy % 16 == 0, z_size >= 4, the whole grid on this handle): grid = one
 // workgroup per 16-sx x 4-row column block, up to 4 waves of 4 levels per iteration.  Returns the number of workgroups
 // (= entries of blockcounts written) in *nblocks and the fused compact rows the launch may number in *row_cap.
-void gvom_encfuse_shape(int xy, int zs, int *nw, int *nblocks, size_t *row_cap)
+// nw_override (A/B knob "encfuse", 0: none): fewer waves per column block; the row range follows the shape that is
+// LAUNCHED -- a wave numbers rows from (block * nw + wave) * niter * 256, and nw' * ceil(zs / 4 nw') can exceed the default
+// shape's product (z_size 16: 4 x 1 = 4 against 3 x 2 = 6).
+void gvom_encfuse_shape(int xy, int zs, int nw_override, int *nw, int *nblocks, size_t *row_cap)
 {
     // 4 waves per block (measured against 8 / 2: m256 98.9 / 100.2 / 102.2 us per step, c2 87.1 / 91.1 / 88.4): at 70 VGPRs a
     // SIMD holds 7 waves, i.e. 7 four-wave blocks per CU but only 3 eight-wave ones
     int w = (zs + 3) / 4;
     if (w > 4) w = 4;
     if (w < 1) w = 1;
+    if (nw_override > 0 && nw_override <= w) w = nw_override;
     const int niter = (zs + 4 * w - 1) / (4 * w);
     *nw = w; *nblocks = (xy / 16) * (xy / 4);
     *row_cap = (size_t)*nblocks * (size_t)w * (size_t)niter * 256;
@@ -3256,8 +3276,7 @@ hipError_t gvom_launch_encfuse(hipStream_t s, const ScanParams &P, const FusePar
                                double *inferred, uint32_t *counters, unsigned long long *host_flag, uint32_t seq)
 {
     int nw, nblocks; size_t cap;
-    gvom_encfuse_shape(P.xy, P.zs, &nw, &nblocks, &cap);
-    if (F.nz > 0 && F.nz <= nw) nw = F.nz;              // (A/B knob "encfuse": fewer waves per column block; rows stay inside the range of the default shape)
+    gvom_encfuse_shape(P.xy, P.zs, F.nz, &nw, &nblocks, &cap);   // (F.nz: A/B knob "encfuse"; the caller sized the fused rows with the same call)
     hipLaunchKernelGGL(k_encfuse, dim3((unsigned)nblocks), dim3(64u * (unsigned)nw), 0, s, P, F, prev, hit, total, mh, state, crows,
                        stags, fstate, frows, ftags, blockcounts, height, inferred, counters, host_flag, seq);
     return hipGetLastError();

@@ -149,7 +149,8 @@ int gvom_combine_maps(gvom_t *h, double origin_world[3], int32_t *positive, int3
  * for its stores to be acknowledged first), not from a stream synchronisation.  That is sound for COHERENT (fine-grained) pinned
  * memory, which is what gvom_output_buffer_alloc returns (hipHostMallocMapped | hipHostMallocCoherent): system-scope stores are
  * written through.  A buffer of the caller's own must be allocated the same way; gvom_combine_maps_into /
- * gvom_combine_occupancy_into / gvom_combine_begin refuse (GVOM_ERR_INVALID) a pinned buffer whose flags say otherwise. */
+ * gvom_combine_occupancy_into / gvom_combine_begin / gvom_combine_map2d_into (and gvom_comm_combine_maps_into through it)
+ * refuse (GVOM_ERR_INVALID) a pinned buffer whose flags say otherwise. */
 int gvom_output_buffer_alloc(gvom_t *h, void **host_ptr);
 int gvom_output_buffer_free(gvom_t *h, void *host_ptr);
 int gvom_combine_maps_into(gvom_t *h, double origin_world[3], void *pinned_out);

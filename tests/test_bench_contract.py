@@ -32,7 +32,19 @@ def test_roofline_object_has_the_contract_keys():
     eager = dict(stages, fuse={"median": 0.0, "p10": 0.0, "p90": 0.0, "samples": 20}, encode=dict(stages["encode"], median=0.045))
     re_ = bench.roofline_of(alg, eager, profiled="m256")
     assert re_["kernel"] == "k_encfuse" and re_["algorithmic_bytes_per_launch"] == alg["encode"] + alg["fuse"]
-    assert re_["traffic_detail"]["source"].startswith("r5_") or re_["traffic"] is None
+    assert re_["traffic_detail"]["source"].startswith(("r5_", "r6_")) or re_["traffic"] is None
+    # evidence hygiene: the line names the library it measured and the one the committed counters were
+    # taken on, and says when they differ; k_map2d gets its own ceiling, the host link
+    for key in ("lib_sha", "traffic_lib_sha", "traffic_stale", "pcie"):
+        assert key in rp, key
+    assert rp["lib_sha"] is None and rp["traffic_stale"] is None and rp["pcie"] is None    # (nothing loaded, no grid given)
+    rs = bench.roofline_of(alg, stages, profiled="m256", xy=256, lib_sha="0" * 64)
+    assert rs["traffic_stale"] is True and rs["lib_sha"] == "0" * 64                       # no committed pass was taken on THAT library
+    assert rs["pcie"]["bound"] == "pcie" and rs["pcie"]["kernel"] == "k_map2d" and rs["pcie"]["bytes_to_host"] == 20 * 256 * 256
+    assert abs(rs["pcie"]["frac"] - 20 * 256 * 256 / 0.032e-3 / 1e9 / bench.PCIE_PEAK_GBS) < 1e-9
+    same = rs["traffic_lib_sha"]
+    if same:                                                                                # (summaries of round 6 on carry the identity)
+        assert bench.roofline_of(alg, stages, profiled="m256", xy=256, lib_sha=same)["traffic_stale"] is False
 
 
 def test_metric_names_the_grid_the_line_ran_on():
@@ -114,7 +126,20 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and 0 < r["frac"] < 1 and r["peak"] == 8000.0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
-    # a report, not a bound (no assert on an absolute time or rate under -m gpu)
+    # the counters in the line say which library they belong to, and whether it is the one that ran
+    import hashlib
+    sys.path.insert(0, os.path.join(ROOT, "g-vom_amd"))
+    import gvom
+    assert r["lib_sha"] == hashlib.sha256(open(gvom.library_path(), "rb").read()).hexdigest()
+    assert r["traffic_stale"] == (r["traffic_lib_sha"] != r["lib_sha"]) and 0 < r["pcie"]["frac"] < 1
+    assert r["algorithmic_bytes_per_launch"] == 131072 * 12 + 4 * (2 * d["sum_hit"] + d["sum_total"]) or r["kernel"] != "k_trace"
+    # the fast path is the one that ran: the combines adopted the eager fusion, the organised cloud was traced in its
+    # own order; and ONE loose, box-independent guard on the rate -- a GPU step slower than five one-thread CPU steps is a
+    # regression on any box (the measured ratio is ~3000)
+    fp = d["fast_path"]
+    assert fp["eager_adopted"] >= d["steps"] and fp["dirsort"] == 0, fp           # (the two-thread legs may drop speculations; the timed blocks adopt every one)
+    assert d["value"] > 5.0 * c["value"], (d["value"], c["value"])
+    # otherwise a report, not a bound (no assert on an absolute time or rate under -m gpu)
     print("bench: %.1f M points/s, %.4f ms/step, k_trace frac %.3f, cpu %.3f M points/s"
           % (d["value"], d["ms_per_step"], r["frac"], c["value"]))
 

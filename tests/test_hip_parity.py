@@ -1238,6 +1238,45 @@ def test_eager_fusion_of_one_slot_rings_equals_the_two_pass_form_and_the_oracle(
     assert auto.get_tuning("eager_dropped") <= forced.get_tuning("eager_dropped")
 
 
+@pytest.mark.parametrize("zs", [16, 32, 70])
+def test_eager_fusion_shape_knob_numbers_its_rows_inside_what_was_allocated(gvom_mod, zs):
+    """gvom_set_tuning("encfuse", 1..3): fewer waves per column block.  A wave numbers its fused rows from
+    (block * waves + wave) * iterations * 256, and waves' * ceil(z / 4 waves') can EXCEED the default shape's product
+    (z 16: 4 x 1 against 3 x 2; z 32: 4 x 2 against 3 x 3) -- the row buffer is sized from the shape that is launched
+    (it was sized from the default one and k_encfuse wrote past its end).  Dense scans (most voxels occupied near
+    the sensor, so high row numbers are really written), a moving window, every shape against the default and the oracle."""
+    xy = 64
+    params = (0.4, 0.2, xy, zs, 1, 0.5, 0.5, 0.5, 0.3, 2.0, 2.0, 1.0, 1, 1)
+    rng = np.random.default_rng(900 + zs)
+    steps = []
+    for k in range(4):
+        ego = (0.45 * k, -0.25 * k, 0.04 * k)
+        n = 60000
+        pc = np.stack([rng.uniform(-0.19 * xy, 0.19 * xy, n) + ego[0], rng.uniform(-0.19 * xy, 0.19 * xy, n) + ego[1],
+                       rng.uniform(-0.09 * zs, 0.09 * zs, n) + ego[2]], axis=1).astype(np.float32)
+        steps += [("scan", pc, ego, None), ("combine",)]
+    sc = {"params": params, "steps": steps}
+    want = scenarios.run_and_record(oracle.OracleGvom, sc)
+
+    def knob(v):
+        def make(*p):
+            g = gvom_mod.Gvom(*p)
+            g.set_tuning("eager", 1)
+            g.set_tuning("encfuse", v)
+            made.append(g)
+            return g
+        return make
+    made = []
+    recs = [scenarios.run_and_record(knob(v), sc) for v in (0, 1, 2, 3, 16 + 3)]
+    for got in recs:
+        assert compare_records(got, want, float_tol=1e-5) > 20
+    for key in recs[0]:
+        for other in recs[1:]:
+            a, b = np.asarray(recs[0][key]), np.asarray(other[key])
+            assert a.shape == b.shape and (np.array_equal(a, b, equal_nan=True) if a.dtype.kind in "fiub" else True), key
+    assert all(g.get_tuning("eager_adopted") == 4 for g in made)
+
+
 @pytest.mark.parametrize("grid", [(32, 16, 20), (30, 12, 24), (16, 300, 18), (32, 16, 40)])
 def test_long_rings_read_their_descriptors_from_memory(gvom_mod, grid):
     """More than 17 fusion sources (ring slots + previous map) no longer fit the kernel arguments: the

@@ -82,7 +82,9 @@ for k in sorted(set(fetch) | set(write)):
                "FETCH_SIZE_KiB": fetch.get(k), "WRITE_SIZE_KiB": write.get(k),
                "TCC_EA0_ATOMIC_sum": atom.get(k), "TCC_HIT_sum": hit.get(k), "TCC_MISS_sum": miss.get(k),
                "fetch_bytes_corrected": fb, "write_bytes_corrected": wb, "hbm_bytes_corrected": fb + wb}
-out = {"tag": tag, "calibration_factors": factors, "calibration_raw": calib, "kernels": kern,
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import lib_identity  # noqa: E402
+out = {"tag": tag, "library": lib_identity.identity(), "calibration_factors": factors, "calibration_raw": calib, "kernels": kern,
        "note": "FETCH_SIZE/WRITE_SIZE in KiB as reported; corrected = raw*1024*factor, factor measured "
                "with tools/pmc_calib (1 GiB known-byte kernels) in the same session"}
 os.makedirs(os.path.join(root, "profiles"), exist_ok=True)

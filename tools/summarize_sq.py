@@ -14,7 +14,9 @@ dur = {}
 for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         dur[short(r["Name"])] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3}
-res = {"command": cmd, "unit": "per launch (mean over launches); SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* in quad-cycles",
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import lib_identity  # noqa: E402
+res = {"command": cmd, "library": lib_identity.identity(), "unit": "per launch (mean over launches); SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* in quad-cycles",
        "kernels": {}}
 for k, cs in acc.items():
     if not k.startswith("k_"):
