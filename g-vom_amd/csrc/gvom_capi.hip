@@ -46,6 +46,7 @@ struct Slot {                                  // one scan in sparse form
     int64_t count = 0;
     bool filled = false;
     bool has_code16 = false;                   // the last encode wrote the 16-bit codes (k_fuse4 may read this slot)
+    bool has_metrics = false;                  // the scan computed its per-voxel statistics (metrics / base / rowvox are this scan's)
     bool stats_valid = false;
     gvom_scan_stats stats = {0, 0, 0, 0};
 };
@@ -59,6 +60,7 @@ struct Fused {
     int64_t origin[3] = {0, 0, 0};
     int64_t count = 0;                         // rows on THIS rank
     bool valid = false;
+    bool has_metrics = false;                  // k_fuse_stats merged the statistics of this map (every source had its own)
 };
 
 }  // namespace
@@ -217,7 +219,13 @@ struct gvom_handle {
     double host_ns[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // host-side phase timing (GVOM_HOST_TIMING)
     long host_calls = 0;
     bool host_timing = false;
-    bool stats = false;                                 // per-voxel statistics enabled (gvom_params.reserved0 bit 0)
+    bool stats = false;                                 // per-voxel statistics computed by the NEXT scan / merged by the next fusion
+    // ON DEMAND (GVOM_FLAG_STATISTICS_ON_DEMAND): the statistics start ON -- the reference computes them in every scan and
+    // combine (gvom.py:159, 276-284) and its node reads them every tick (gvom_ros.py:171) -- and go OFF when three combines
+    // in a row went by without anybody reading them (gvom_debug_voxel_map*, gvom_read_rows, gvom_gather_metrics); a later read
+    // finds no data and switches them ON again for the scans that follow
+    bool stats_auto = false;
+    int stats_idle = 0;                                 // combines since the statistics were last read
     int acc_pad = 7, sxq = 0;                           // accumulator row pitch (lines) = ceil(xy/4) + acc_pad
     bool profiling = false;
     hipEvent_t ev[8] = {nullptr};
@@ -456,8 +464,10 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, b
     h->device = device_id;
     h->rank = rank; h->world = world; h->sharded = sharded;
     h->stats = (params->reserved0 & GVOM_FLAG_VOXEL_STATISTICS) != 0;
+    h->stats_auto = !h->stats && !sharded && (params->reserved0 & GVOM_FLAG_STATISTICS_ON_DEMAND) != 0;
+    if (h->stats_auto) h->stats = true;
     h->f32_sqrt = (params->reserved0 & GVOM_FLAG_CUDA_F32_SQRT) != 0;
-    if (const char *v = getenv("GVOM_VOXEL_STATISTICS")) h->stats = atoi(v) != 0;
+    if (const char *v = getenv("GVOM_VOXEL_STATISTICS")) { h->stats = atoi(v) != 0; h->stats_auto = false; }
     // sharded statistics send a return to the ranks that own the first and the last row of its neighbourhood: the
     // neighbourhood (2 xy_eigen_dist + 1 rows) must not reach over a whole slab
     if (sharded && h->stats && world > 1 && 2 * params->xy_eigen_dist + 1 > params->xy_size / world) { delete h; return GVOM_ERR_INVALID; }
@@ -543,7 +553,7 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, b
     CK(hipMalloc((void **)&h->blockcounts, (size_t)(h->fuse_blocks > 0 ? h->fuse_blocks : 1) * 4));
     CK(hipMemsetAsync(h->blockcounts, 0, (size_t)(h->fuse_blocks > 0 ? h->fuse_blocks : 1) * 4, h->stream));
     h->cnt_blocks = h->fuse_blocks;
-    if (!sharded && params->buffer_size == 1 && !h->stats && xy % 16 == 0 && zs >= 4) {       // eager fusion possible
+    if (!sharded && params->buffer_size == 1 && (!h->stats || h->stats_auto) && xy % 16 == 0 && zs >= 4) {       // eager fusion possible
         CK(hipMalloc((void **)&h->blockcounts2, (size_t)(h->fuse_blocks > 0 ? h->fuse_blocks : 1) * 4));
         CK(hipMemsetAsync(h->blockcounts2, 0, (size_t)(h->fuse_blocks > 0 ? h->fuse_blocks : 1) * 4, h->stream));
         CK(hipMalloc((void **)&h->hmaps2, h->cells2d * 24));
@@ -584,6 +594,14 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, b
 #undef CK
     *out = h;
     return GVOM_OK;
+}
+
+// Somebody reads the per-voxel statistics: a handle that computes them ON DEMAND keeps doing so, or starts again (the caller of
+// this read finds no data; the scans that follow carry statistics, and the fused map does once every ring slot does).
+static void stats_demand(gvom_handle *h)
+{
+    h->stats_idle = 0;
+    if (h->stats_auto && !h->stats) h->stats = true;
 }
 
 // A failed scan must not leak into the next one: k_trace may already have added to the dense
@@ -790,6 +808,7 @@ int scan_launch(gvom_handle *h, std::unique_lock<std::mutex> &lk, const void *de
     if (h->fuse_b_unjoined && ((h->fuse_b_slots >> h->staging) & 1ull)) HIPCHK(h, join_fuse_stream(h));
     st.epoch = ++h->epoch;                                 // tiles stamped by this scan
     P.epoch = st.epoch;
+    st.has_metrics = h->stats;
     h->scan_inflight = true;
     const size_t esz = dtype == GVOM_DTYPE_F32 ? 4 : 8;
     // compact rows are indexed by return (the row of an occupied voxel = the index of one of its returns)
@@ -820,10 +839,12 @@ int scan_launch(gvom_handle *h, std::unique_lock<std::mutex> &lk, const void *de
     ShardExchange X;
     X.ep_send = nullptr; X.ep_cnt = nullptr; X.ep_cap = 0; X.sp_send = nullptr; X.sp_cnt = nullptr;
     if (h->sharded) {
+#ifdef GVOM_HOOKS
         if (h->tune_churn > 0 && h->x_send_eps.p) {            // test hook (gvom_set_tuning "churn"): a fresh allocation every scan
             h->retired.push_back(h->x_send_eps);                 // (as a region that grows: retired, not freed)
             h->x_send_eps.p = nullptr; h->x_send_eps.bytes = 0;
         }
+#endif
         if ((rc = ensure(h, h->x_send_eps, (size_t)h->world * (size_t)(n > 0 ? n : 1) * 8))) return rc;
         h->x_ep_cap = n > 0 ? n : 1;
         X.ep_send = (uint2 *)h->x_send_eps.p; X.ep_cnt = h->x_ecnt; X.ep_cap = (long)h->x_ep_cap;
@@ -929,7 +950,7 @@ int scan_launch(gvom_handle *h, std::unique_lock<std::mutex> &lk, const void *de
         return GVOM_OK;
     }
     // one-slot rings: encode + fuse in one pass, speculating that combine_maps comes next (see gvom_handle::hmaps2)
-    const bool eager = h->hmaps2 && h->tune_eager != 0 && (h->tune_eager == 1 || h->eager_waste < 3) && !gvom_diag_env("GVOM_TRACE_DEBUG");
+    const bool eager = h->hmaps2 && !h->stats && h->tune_eager != 0 && (h->tune_eager == 1 || h->eager_waste < 3) && !gvom_diag_env("GVOM_TRACE_DEBUG");
     h->last_scan_spec = false;
     if (eager) {
         if ((rc = eager_launch(h, P, st, origin, seq))) { scan_abort(h); return rc; }
@@ -1121,6 +1142,7 @@ int fuse_impl(gvom_handle *h, hipStream_t on = nullptr)
         S.origin[0] = h->spec_origin[0]; S.origin[1] = h->spec_origin[1]; S.origin[2] = h->spec_origin[2];
         S.epoch = h->spec_epoch;
         S.valid = true;
+        S.has_metrics = false;
         std::swap(h->hmaps, h->hmaps2);
         h->height = h->hmaps; h->inferred = h->hmaps + h->prm.xy_size;
         std::swap(h->blockcounts, h->blockcounts2);
@@ -1149,6 +1171,13 @@ int fuse_impl(gvom_handle *h, hipStream_t on = nullptr)
     fill_fuse_frame(h, F.origin, P);
     int ns = 0;
     bool all_codes = true;
+    // statistics on demand: three combines in a row that nobody read the statistics of -> the scans stop computing them
+    if (h->stats_auto && h->stats && ++h->stats_idle > 3) h->stats = false;
+    // this fusion merges the statistics iff every slot of the ring carries its own; a previous map WITHOUT them (the
+    // statistics were switched on again after a pause) contributes none (k_fuse_stats skips a source without metrics): the
+    // statistics restart from the ring
+    bool fstats = h->stats;
+    for (int i = 0; i < p.buffer_size && fstats; ++i) { const Slot &s = h->slots[h->ring[i]]; if (s.filled && !s.has_metrics) fstats = false; }
     for (int i = 0; i < p.buffer_size; ++i) {                          // slot order, gvom.py:198
         const Slot &s = h->slots[h->ring[i]];
         if (!s.filled) continue;
@@ -1157,7 +1186,7 @@ int fuse_impl(gvom_handle *h, hipStream_t on = nullptr)
         d.d[0] = clamp_delta(F.origin[0] - s.origin[0], p.xy_size);
         d.d[1] = clamp_delta(F.origin[1] - s.origin[1], p.xy_size);
         d.d[2] = clamp_delta(F.origin[2] - s.origin[2], p.z_size);
-        d.epoch = s.epoch; d.tags = s.tags; d.metrics = h->stats ? s.metrics.p : nullptr;
+        d.epoch = s.epoch; d.tags = s.tags; d.metrics = fstats ? s.metrics.p : nullptr;
         d.code16 = s.code16;
         all_codes = all_codes && s.has_code16;
     }
@@ -1169,7 +1198,7 @@ int fuse_impl(gvom_handle *h, hipStream_t on = nullptr)
         d.d[0] = clamp_delta(F.origin[0] - prev->origin[0], p.xy_size);
         d.d[1] = clamp_delta(F.origin[1] - prev->origin[1], p.xy_size);
         d.d[2] = clamp_delta(F.origin[2] - prev->origin[2], p.z_size);
-        d.epoch = prev->epoch; d.tags = prev->tags; d.metrics = h->stats ? prev->metrics.p : nullptr;
+        d.epoch = prev->epoch; d.tags = prev->tags; d.metrics = (fstats && prev->has_metrics) ? prev->metrics.p : nullptr;
         d.code16 = nullptr;
     }
     P.nz = choose_nz(p.z_size, &P.zc, &P.cpw);
@@ -1189,11 +1218,12 @@ int fuse_impl(gvom_handle *h, hipStream_t on = nullptr)
     if (row_cap >= 2147483648ull) { h->err = "fused row space exceeds 31 bits"; return GVOM_ERR_CAPACITY; }
     int rc;
     if ((rc = ensure(h, F.rows, row_cap * 16))) return rc;
-    if (h->stats && (rc = ensure(h, F.metrics, row_cap * 40))) return rc;
+    if (fstats && (rc = ensure(h, F.metrics, row_cap * 40))) return rc;
+    F.has_metrics = fstats;
     const int nsrc = ns + (prev ? 1 : 0);
     // the previous k_fuse_stats reads (as its "previous map") the fused buffer this fusion writes, and the descriptor
     // table this call refills
-    if (h->stats && h->fs_pending) HIPCHK(h, hipStreamWaitEvent(fs, h->ev_fsdone, 0));
+    if (h->fs_pending) HIPCHK(h, hipStreamWaitEvent(fs, h->ev_fsdone, 0));
     FuseDescs KD;
     const MapDesc *descs_mem = nullptr;
     if (nsrc <= GVOM_KARG_DESCS) {
@@ -1208,7 +1238,7 @@ int fuse_impl(gvom_handle *h, hipStream_t on = nullptr)
                                F.tags, h->blockcounts,
                                h->height, h->inferred));
     if (h->profiling) { HIPCHK(h, hipEventRecord(h->ev[5], fs)); h->ev_fuse = true; }
-    if (h->stats) {                                      // beside k_map2d, behind this fusion and the scans' statistics
+    if (fstats) {                                        // beside k_map2d, behind this fusion and the scans' statistics
         HIPCHK(h, hipEventRecord(h->ev_fz_s, fs));
         HIPCHK(h, hipStreamWaitEvent(h->stream_s, h->ev_fz_s, 0));
         HIPCHK(h, gvom_launch_fuse_stats(h->stream_s, P, KD, descs_mem, F.state, F.tags, (float *)F.metrics.p));
@@ -2037,16 +2067,16 @@ VIS int gvom_gather_metrics(gvom_t *h, int which, const int32_t *rows, int64_t n
 {
     if (!h || !rows || !out || n < 0) return GVOM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
-    if (!h->stats) return GVOM_NO_DATA;
+    stats_demand(h);
     HIPCHK(h, hipSetDevice(h->device));
     const void *src; int f64;
     if (which == GVOM_WHICH_FUSED) {
-        if (!h->has_combined) return GVOM_NO_DATA;
+        if (!h->has_combined || !h->fused[h->cur].has_metrics) return GVOM_NO_DATA;
         src = h->fused[h->cur].metrics.p; f64 = 0;
     } else {
         if (which < 0 || which >= h->prm.buffer_size) return GVOM_ERR_INVALID;
         const Slot &sl = h->slots[h->ring[which]];
-        if (!sl.filled) return GVOM_NO_DATA;
+        if (!sl.filled || !sl.has_metrics) return GVOM_NO_DATA;
         src = sl.metrics.p; f64 = 1;
     }
     if (n == 0) return GVOM_OK;
@@ -2140,7 +2170,8 @@ VIS int gvom_debug_voxel_eigen(gvom_t *h, float *out, float *eigen, int64_t max_
 {
     if (!h || !out || max_rows < 0) return GVOM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
-    if (!h->has_combined || !h->stats) return GVOM_NO_DATA;
+    stats_demand(h);
+    if (!h->has_combined || !h->fused[h->cur].has_metrics) return GVOM_NO_DATA;
     HIPCHK(h, hipSetDevice(h->device));
     const gvom_params &p = h->prm;
     const Fused &F = h->fused[h->cur];
@@ -2248,10 +2279,12 @@ VIS int gvom_set_tuning(gvom_t *h, const char *name, int value)
     else if (!strcmp(name, "encfuse")) h->tune_encfuse = value;
     else if (!strcmp(name, "dirsort")) h->tune_dirsort = value;
     else if (!strcmp(name, "eager")) { h->tune_eager = value; h->eager_waste = 0; }
-    else if (!strcmp(name, "churn")) h->tune_churn = value;
     else if (!strcmp(name, "exported")) h->exported = value != 0;       // (set by the peer transport, gvom_comm.hip)
-
-    else if (!strcmp(name, "epoch_bias")) h->epoch += (uint32_t)value;   // test hook: advances the tile-epoch counter (towards its wrap)
+#ifdef GVOM_HOOKS
+    // test hooks (include/gvom_hip_test.h; lib/libgvom_hip_test.so only)
+    else if (!strcmp(name, "churn")) h->tune_churn = value;             // a fresh endpoint send region every scan
+    else if (!strcmp(name, "epoch_bias")) h->epoch += (uint32_t)value;   // advances the tile-epoch counter (towards its wrap)
+#endif
     else return GVOM_ERR_INVALID;
     return GVOM_OK;
 }

@@ -53,6 +53,9 @@
 #include <unistd.h>
 
 #define VIS __attribute__((visibility("default")))
+#if defined(GVOM_DIAG) || defined(GVOM_TEST_HOOKS)
+#define GVOM_HOOKS 1                           // (as gvom_internal.h: the test hooks of include/gvom_hip_test.h)
+#endif
 #define GVOM_COMM_MAX_RANKS 64
 #define GVOM_COMM_MAX_VALUES 208          // int64 values per rank and exchange (statistics handles exchange 3 * ranks + 3)
 static_assert(GVOM_COMM_MAX_VALUES >= 3 * GVOM_COMM_MAX_RANKS + 4, "a communicator of GVOM_COMM_MAX_RANKS ranks must be able to exchange its counts");
@@ -210,12 +213,14 @@ struct PeerOwn {                               // an allocation this process has
 static std::mutex g_ipc_mu;
 static std::vector<PeerImport> g_imports;
 static std::vector<PeerOwn> g_own;
-// test hook: GVOM_TEST_IPC_REFUSE="export:N" / "import:N" [",rank:R"] -- the N-th export (import) this process attempts is
-// answered as the HSA runtime answers when it refuses (every repetition of it too), so that the recovery below runs
+// test hook (lib/libgvom_hip_test.so only; include/gvom_hip_test.h): GVOM_TEST_IPC_REFUSE="export:N" / "import:N" [",rank:R"] -- the
+// N-th export (import) this process attempts is answered as the HSA runtime answers when it refuses (every repetition of it
+// too), so that the recovery below runs.  The production library has no such switch: nothing is ever injected.
 struct IpcFault { int export_n = 0, import_n = 0, rank = -1; std::atomic<int> exports{0}, imports{0}; bool parsed = false; };
 static IpcFault g_fault;
 static void parse_fault()
 {
+#ifdef GVOM_HOOKS
     if (g_fault.parsed) return;
     g_fault.parsed = true;
     const char *e = getenv("GVOM_TEST_IPC_REFUSE");
@@ -223,6 +228,7 @@ static void parse_fault()
     if (const char *p = strstr(e, "export:")) g_fault.export_n = atoi(p + 7);
     if (const char *p = strstr(e, "import:")) g_fault.import_n = atoi(p + 7);
     if (const char *p = strstr(e, "rank:")) g_fault.rank = atoi(p + 5);
+#endif
 }
 
 struct gvom_comm {

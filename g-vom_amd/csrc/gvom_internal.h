@@ -25,6 +25,12 @@
 // reads no environment variable that can change a result.
 #include <stdlib.h>
 #include <string.h>
+// TEST HOOKS (include/gvom_hip_test.h: the "epoch_bias" and "churn" knobs, the GVOM_TEST_IPC_REFUSE fault injector) exist only
+// in lib/libgvom_hip_test.so (make test-lib, -DGVOM_TEST_HOOKS: the production kernels + the hooks) and in the diagnostic
+// build; the production library does not contain them.
+#if defined(GVOM_DIAG) || defined(GVOM_TEST_HOOKS)
+#define GVOM_HOOKS 1
+#endif
 #ifdef GVOM_DIAG
 #define GVOM_DBG(P, bits) ((P).dbg & (bits))
 static inline int gvom_diag_env(const char *name) { const char *v = getenv(name); return v ? atoi(v) : 0; }

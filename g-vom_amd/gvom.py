@@ -18,6 +18,7 @@ There is NO CPU fallback: importing works anywhere, but constructing `Gvom` rais
 `GvomBackendError` if libgvom_hip.so is missing or no gfx950 device is visible.
 """
 import ctypes
+import math
 import os
 import threading
 
@@ -305,12 +306,26 @@ class _PendingMaps(object):
 
 
 class Gvom(object):
-    """A class to convert lidar pointclouds into a cost map (reference gvom.py:12-27)."""
+    """A class to convert lidar pointclouds into a cost map (reference gvom.py:12-27).
+
+    The 14 positional arguments are the reference's (gvom.py:29-31).  Keyword arguments of this implementation:
+      device            HIP device of the map (default 0)
+      voxel_statistics  the per-voxel mean / covariance path behind make_debug_voxel_map (gvom.py:159, 276-284, 363-378).
+                        None (default): ON DEMAND -- it runs from the first scan on, as in the reference, for as long as somebody
+                        reads it (make_debug_voxel_map, metrics_buffer, combined_metrics, voxels_eigenvalues: the unchanged
+                        node does every tick, gvom_ros.py:171); three combines in a row without a read switch it off (the
+                        scans then cost what the north-star path costs), a later read returns None once and switches it on
+                        again for the scans that follow.  True: always.  False: never (make_debug_voxel_map returns None).
+      c_order           False (default): combine_maps returns the four maps as FORTRAN-ordered views of pinned host memory the
+                        GPU has written -- same [x, y] indexing, shapes, dtypes and values as the reference's arrays; its
+                        caller flattens them with order='F' (gvom_ros.py:141-162), which is then a no-copy reshape.  True:
+                        C-contiguous arrays of their own, as the reference's copy_to_host() returns (gvom.py:352-354).
+      cuda_f32_sqrt     the typing a real CUDA device gives gvom.py:1109."""
 
     def __init__(self, xy_resolution, z_resolution, xy_size, z_size, buffer_size, min_distance,
                  positive_obstacle_threshold, negative_obstacle_threshold, slope_obstacle_threshold,
                  robot_height, robot_radius, ground_to_lidar_height, xy_eigen_dist, z_eigen_dist,
-                 device=0, voxel_statistics=False, cuda_f32_sqrt=False, _shard=None):
+                 device=0, voxel_statistics=None, cuda_f32_sqrt=False, c_order=False, _shard=None, _library=None):
         self.xy_resolution = xy_resolution
         self.z_resolution = z_resolution
         self.xy_size = xy_size
@@ -330,12 +345,20 @@ class Gvom(object):
         self.threads_per_block = 256
         self.threads_per_block_3D = (8, 8, 4)
         self.threads_per_block_2D = (16, 16)
+        self.blocks = math.ceil(self.voxel_count / self.threads_per_block)          # gvom.py:94
         self.ego_position = [0, 0, 0]
+        # reference attributes that guard ITS buffers (gvom.py:65-67, 96) or hold a placeholder (gvom.py:54): inert here -- the
+        # library serialises per handle with its own mutex -- but present, for callers that touch them
+        self.semaphores = [threading.Semaphore() for _ in range(int(buffer_size))]
+        self.ego_semaphore = threading.Semaphore()
+        self.metrics = _DeviceArrayView(lambda: np.array([[3, 2]]))
+        self._c_order = bool(c_order)
 
-        self._lib = load_library()
+        self._lib = load_library(_library)
         self._h = ctypes.c_void_p()
+        stat_flags = 4 if (voxel_statistics is None and _shard is None) else (1 if voxel_statistics else 0)
         prm = GvomParams(float(xy_resolution), float(z_resolution), int(xy_size), int(z_size),
-                         int(buffer_size), (1 if voxel_statistics else 0) | (2 if cuda_f32_sqrt else 0), float(min_distance),
+                         int(buffer_size), stat_flags | (2 if cuda_f32_sqrt else 0), float(min_distance),
                          float(positive_obstacle_threshold), float(negative_obstacle_threshold),
                          float(slope_obstacle_threshold), float(robot_height), float(robot_radius),
                          float(ground_to_lidar_height), int(xy_eigen_dist), int(z_eigen_dist))
@@ -470,7 +493,16 @@ class Gvom(object):
         """Combines all maps in the buffer and processes the resultant map into 2D maps
         (reference gvom.py:177-354).  Returns None or (origin_world f64[3], positive i32[xy,xy],
         negative i32[xy,xy], roughness f64[xy,xy], visibility i32[xy,xy])."""
-        rc, out = self._combine_into(self._lib.gvom_combine_maps_into)
+        if self._c_order:
+            xy = self.xy_size
+            origin = np.zeros(3, np.float64)
+            positive, negative, visibility = (np.empty((xy, xy), np.int32) for _ in range(3))
+            roughness = np.empty((xy, xy), np.float64)
+            rc = self._check(self._lib.gvom_combine_maps(self._h, _ptr(origin), _ptr(positive), _ptr(negative), _ptr(roughness),
+                                                         _ptr(visibility)))
+            out = (origin, positive, negative, roughness, visibility)
+        else:
+            rc, out = self._combine_into(self._lib.gvom_combine_maps_into)
         if rc == GVOM_EMPTY_BUFFER:
             print("[WARNING] The map buffer is empty, nothing will happen!")
             return None
@@ -581,9 +613,9 @@ class Gvom(object):
         return out.astype(bool)
 
     def make_debug_voxel_map(self):
-        """float32[Cc, 8] rows {x, y, z, hit/total, hit, l0-l1, l1-l2, l2} (reference gvom.py:363-378)
-        when the mapper was created with voxel_statistics=True (or GVOM_VOXEL_STATISTICS=1); else
-        None, which the reference's caller tolerates (gvom_ros.py:171-172)."""
+        """float32[Cc, 8] rows {x, y, z, hit/total, hit, l0-l1, l1-l2, l2} (reference gvom.py:363-378) while the mapper
+        computes the per-voxel statistics (voxel_statistics: by default for as long as this is called); else None, which
+        the reference's caller tolerates (gvom_ros.py:171-172) -- and which switches them on again for the scans that follow."""
         n = self.combined_cell_count_cpu
         if n is None:
             print("No data")

@@ -77,6 +77,14 @@ typedef struct gvom_params {
                                         * 858-909, 1333-1378) that feeds only make_debug_voxel_map; off by
                                         * default: it is not on the north-star path and costs scan time.
                                         * The environment variable GVOM_VOXEL_STATISTICS=0/1 overrides. */
+#define GVOM_FLAG_STATISTICS_ON_DEMAND 4 /* (unsharded handles, ignored with GVOM_FLAG_VOXEL_STATISTICS) the per-voxel path runs
+                                        * WHILE SOMEBODY READS IT: it starts on -- the reference computes it in every scan and
+                                        * combine and its node reads it every tick (gvom_ros.py:171) -- goes off when three
+                                        * combines in a row passed without a call of gvom_debug_voxel_map / _eigen /
+                                        * gvom_gather_metrics, and comes back with the next such call: that call returns
+                                        * GVOM_NO_DATA, the scans that follow carry statistics again, and the fused map has them
+                                        * once every ring slot does (they then restart from the ring: what the map had merged
+                                        * before the pause is not in them).  g-vom_amd/gvom.py's default. */
 #define GVOM_FLAG_CUDA_F32_SQRT    2   /* ray_length = sqrt(f32 sum) evaluated in float32, as Numba types
                                         * math.sqrt(float32) when it compiles gvom.py:1109 for a real CUDA device
                                         * (SURVEY App. A.2).  Default (flag clear): the float64 square root of
@@ -327,7 +335,8 @@ int gvom_get_occupancy(gvom_t *h, uint8_t *out_xyz);
 /* Gvom.make_debug_voxel_map (gvom.py:363-378; kernels :1333-1378 eigenvalues, :454-473): one row of
  * 8 float32 per occupied fused voxel {x, y, z, hit/total, hit, l0-l1, l1-l2, l2}; row order is
  * unspecified (as in the reference).  *rows = number of occupied voxels; at most max_rows are written.
- * GVOM_NO_DATA unless the handle was created with GVOM_FLAG_VOXEL_STATISTICS and has combined. */
+ * GVOM_NO_DATA unless the handle computes the per-voxel statistics (GVOM_FLAG_VOXEL_STATISTICS / _ON_DEMAND), has combined and the
+ * fused map carries them. */
 int gvom_debug_voxel_map(gvom_t *h, float *out, int64_t max_rows, int64_t *rows);
 /* The same with the three eigenvalues of every row (reference attribute voxels_eigenvalues,
  * gvom.py:1333-1378): eigen[row][3] = {l0, l1, l2}, row for row with `out`. */
@@ -404,7 +413,7 @@ int gvom_host_timing(gvom_t *h, double us[8]);
  * gvom_get_tuning("dirsort"): the mode the last scan ran in (0: the cloud's own order).  Only WHO traces which return changes.
  * "encfuse" (A/B of that kernel's shape: low 4 bits waves per column block, bit 4 no XCD pairing), "fuse1" (1: one-slot
  * fusions through the general kernel), "flag_kernel" (1: round 3's completion-flag kernel).
- * "epoch_bias" (test hook) advances the 32-bit tile-epoch counter, e.g. to just below its wrap. */
+ * (Test hooks are not part of this library: include/gvom_hip_test.h, lib/libgvom_hip_test.so.) */
 int gvom_set_tuning(gvom_t *h, const char *name, int value);
 /* The value the LAST scan ran with ("segs", "period", "ep_row", "prio", "interleave": what automatic resolved to). */
 int gvom_get_tuning(gvom_t *h, const char *name, int *value);

@@ -4,6 +4,7 @@ reference's surface and fails loudly -- never silently falls back -- when the GP
 import inspect
 import os
 import re
+import subprocess
 
 import numpy as np
 import pytest
@@ -56,6 +57,40 @@ def test_constructor_signature_matches_reference():
     sig = inspect.signature(gvom.Gvom.process_pointcloud)
     assert list(sig.parameters)[1:] == ["pointcloud", "ego_position", "transform"]
     assert sig.parameters["transform"].default is None
+    # keyword extensions come behind the reference's 14 and default to its behaviour: statistics for as long as somebody reads
+    # them (None), Fortran-ordered views of the GPU's own output unless c_order is asked for
+    extra = {p.name: p.default for p in list(inspect.signature(gvom.Gvom.__init__).parameters.values())[15:]}
+    assert extra["voxel_statistics"] is None and extra["c_order"] is False and extra["device"] == 0
+    # the reference object's remaining attributes (gvom.py:54, 65-67, 94, 96) are set by the constructor
+    src = inspect.getsource(gvom.Gvom.__init__)
+    for attr in ("self.semaphores", "self.ego_semaphore", "self.metrics", "self.blocks"):
+        assert attr in src, attr
+
+
+def test_test_hooks_live_in_the_test_library_only():
+    """"epoch_bias", "churn" and the GVOM_TEST_IPC_REFUSE fault injector are documented in
+    include/gvom_hip_test.h and compiled into lib/libgvom_hip_test.so (-DGVOM_TEST_HOOKS: the production sources + the hooks);
+    the production library contains none of the three strings, exports exactly the same symbols, and its public header does
+    not mention them."""
+    pkg = os.path.join(ROOT, "g-vom_amd")
+    build = subprocess.run(["make", "-C", pkg, "lib/libgvom_hip.so", "lib/libgvom_hip_test.so"], capture_output=True, text=True, timeout=900)
+    assert build.returncode == 0, build.stderr[-2000:]
+    prod, test = os.path.join(pkg, "lib", "libgvom_hip.so"), os.path.join(pkg, "lib", "libgvom_hip_test.so")
+    blob_p, blob_t = open(prod, "rb").read(), open(test, "rb").read()
+    for hook in (b"GVOM_TEST_IPC_REFUSE", b"epoch_bias", b"churn"):
+        assert hook not in blob_p, hook
+        assert hook in blob_t, hook
+
+    def exported(path):
+        nm = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True)
+        return {ln.split()[-1] for ln in nm.stdout.splitlines() if " T " in ln and ln.split()[-1].startswith("gvom_")}
+    assert exported(prod) == exported(test) and len(exported(prod)) >= 60
+    public = open(os.path.join(ROOT, "include", "gvom_hip.h")).read()
+    for word in ("GVOM_TEST_IPC_REFUSE", "epoch_bias", "\"churn\""):
+        assert word not in public, word
+    hooks = open(os.path.join(ROOT, "include", "gvom_hip_test.h")).read()
+    for word in ("GVOM_TEST_IPC_REFUSE", "epoch_bias", "churn"):
+        assert word in hooks
 
 
 def test_no_silent_cpu_fallback():

@@ -16,6 +16,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TEST_LIB = os.path.join(ROOT, "g-vom_amd", "lib", "libgvom_hip_test.so")     # production sources + the three test hooks
 
 
 @pytest.mark.parametrize("world,transport", [(2, None), (4, None), (2, "loopback"), (4, "loopback")])
@@ -218,6 +219,7 @@ def test_peer_transport_with_a_new_exported_region_every_scan(monkeypatch):
     them this run ends in differing maps or a refused hipIpc call (profiles/r3_peer_churn.txt); four rank processes, 105 scans."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import shard_procs
+    monkeypatch.setenv("GVOM_HIP_LIBRARY", TEST_LIB)           # ("churn" is a test hook: include/gvom_hip_test.h)
     monkeypatch.setenv("GVOM_TEST_CHURN", "1")
     ok, text = shard_procs.launch(4, "peer", False, repeat=15)
     assert ok, text[-3000:]
@@ -238,6 +240,7 @@ def test_peer_transport_absorbs_a_refused_export_or_import(monkeypatch, fault, w
     generations a rank has seen) and the asynchronous form of the transport (GVOM_PEER_ASYNC=1) take the same path."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import shard_procs
+    monkeypatch.setenv("GVOM_HIP_LIBRARY", TEST_LIB)           # (the fault injector is a test hook: include/gvom_hip_test.h)
     monkeypatch.setenv("GVOM_TEST_IPC_REFUSE", fault)
     ok, text = shard_procs.launch(world, "peer", False, asynchronous=asynchronous)
     assert ok, text[-3000:]
@@ -245,6 +248,19 @@ def test_peer_transport_absorbs_a_refused_export_or_import(monkeypatch, fault, w
     import re
     renewed = [int(m) for m in re.findall(r"'renewed_regions': (\d+)", text)]
     assert len(renewed) == world and sum(renewed) >= 1, text[-3000:]
+
+
+def test_production_library_ignores_the_fault_injector(monkeypatch):
+    """GVOM_TEST_IPC_REFUSE is read by lib/libgvom_hip_test.so only: under the production library the same environment renews
+    nothing (no refusal is injected) and the run is an ordinary one."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import re
+    import shard_procs
+    monkeypatch.setenv("GVOM_TEST_IPC_REFUSE", "export:1")
+    ok, text = shard_procs.launch(2, "peer", False)
+    assert ok, text[-3000:]
+    renewed = [int(m) for m in re.findall(r"'renewed_regions': (\d+)", text)]
+    assert len(renewed) == 2 and sum(renewed) == 0, text[-3000:]
 
 
 def test_auto_transport_falls_back_to_peer_copies_when_rccl_cannot_start():
