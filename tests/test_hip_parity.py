@@ -107,7 +107,6 @@ def test_voxel_statistics_run_on_demand(gvom_mod):
     same_cloud(a, w, False)
     a, w, n = step(11, True)
     same_cloud(a, w, False)
-    assert np.isfinite(a).all()
 
 
 def test_hip_voxel_statistics_match_oracle_c2(gvom_mod):
