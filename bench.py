@@ -212,7 +212,7 @@ def cpu_baseline(params, scans, budget_s=20.0):
             "ms_per_step": e1 / s1 * 1e3, "ms_per_step_all_cores": en / sn * 1e3}
 
 
-_CONFIG_TAGS = ("c1", "c2", "c3", "c4", "c5", "m256b8")
+_CONFIG_TAGS = ("c1", "c2", "c3", "c4", "c5", "m256b8", "m256_d10", "m256_d25", "m256_d40")
 
 
 def _newest_profile(pattern, kernel, config="m256"):
@@ -326,7 +326,10 @@ def run_config(hip, name, steps, warmup, poses, full):
     params, scans = synth.config_inputs(name, n_scans=max(1, poses))
     g = gvom.Gvom(*params, device=0)
     dev = [(hip.to_device(pc), pc.shape[0], pc.dtype, ego, tf) for (pc, ego, tf) in scans]
-    n_pts = scans[0][0].shape[0]
+    lengths = [pc.shape[0] for (pc, _, _) in scans]
+    # (clouds of a node that drops invalid returns differ in length from scan to scan: points per step = their mean over the poses,
+    # which the timed blocks cycle through)
+    n_pts = lengths[0] if len(set(lengths)) == 1 else sum(lengths) / float(len(lengths))
 
     def step(k):
         d, n, dt, ego, tf = dev[k % len(dev)]
@@ -337,13 +340,15 @@ def run_config(hip, name, steps, warmup, poses, full):
         step(k)
     blocks, k = timed_blocks(step, warmup, steps, MIN_TIMED_S if full else 0.1)
     med = _median(blocks)
-    out = {"workload": synth.CONFIGS[name][2], "points_per_scan": n_pts, "grid": [params[2], params[2], params[3]],
+    out = {"workload": synth.CONFIGS[name][2], "points_per_scan": n_pts, "points_per_scan_range": [min(lengths), max(lengths)],
+           "grid": [params[2], params[2], params[3]],
            "buffer_size": params[4], "poses": len(scans), "steps": steps, "blocks": len(blocks),
            "ms_per_step": med / steps * 1e3, "ms_per_step_min": min(blocks) / steps * 1e3,
            "ms_per_step_max": max(blocks) / steps * 1e3, "value": n_pts * steps / med / 1e6, "map_hz": steps / med}
     stages = stage_samples(g, step, k, 40 if full else 20)
     out["stage_ms"] = {s: v["median"] for s, v in stages.items()}
     if not full:
+        out["fast_path"] = {"eager_adopted": g.get_tuning("eager_adopted"), "dirsort": g.get_tuning("dirsort"), "interleave": g.get_tuning("interleave")}
         del g
         return out, None
     out["stage_ms_spread"] = stages
@@ -769,7 +774,10 @@ def run_single(args):
         out["configs"] = {}
         # (c4 / c5: BASELINE's multi-GPU configs on this ONE GPU, short device-resident runs -- their paced 20 Hz streams and
         # sharded forms are `--config c4|c5 [--gpus N] --offered-hz 20`)
-        for other, poses, nsteps, nwarm in (("c2", 8, 100, 30), ("c3", 8, 100, 30), ("m256b8", 8, 100, 30), ("c4", 2, 40, 10), ("c5", 1, 20, 6)):
+        # (m256_d*: what a real node delivers -- non-uniform beam elevations, 10 / 25 / 40 % of the returns dropped before the call,
+        # a different length every scan: the layout probe's verdicts and the trace's speed on such clouds)
+        for other, poses, nsteps, nwarm in (("c2", 8, 100, 30), ("c3", 8, 100, 30), ("m256b8", 8, 100, 30), ("m256_d10", 8, 96, 32),
+                                            ("m256_d25", 8, 96, 32), ("m256_d40", 8, 96, 32), ("c4", 2, 40, 10), ("c5", 1, 20, 6)):
             if getattr(args, "no_big", False) and other in ("c4", "c5"):
                 continue
             r, _ = run_config(hip, other, nsteps, nwarm, poses, False)
@@ -831,7 +839,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--config", default="m256", choices=["c1", "c2", "c3", "m256", "m256b8", "c4", "c5"])
+    ap.add_argument("--config", default="m256", choices=["c1", "c2", "c3", "m256", "m256b8", "c4", "c5", "m256_d10", "m256_d25", "m256_d40"])
     ap.add_argument("--poses", type=int, default=8, help="distinct sensor poses cycled through (0.2 m apart)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-big", action="store_true", help="skip the c4 / c5 ride-along runs of the default line")

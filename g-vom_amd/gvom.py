@@ -320,12 +320,15 @@ class Gvom(object):
                         GPU has written -- same [x, y] indexing, shapes, dtypes and values as the reference's arrays; its
                         caller flattens them with order='F' (gvom_ros.py:141-162), which is then a no-copy reshape.  True:
                         C-contiguous arrays of their own, as the reference's copy_to_host() returns (gvom.py:352-354).
-      cuda_f32_sqrt     the typing a real CUDA device gives gvom.py:1109."""
+      numba_cuda_typing the types Numba infers for a REAL CUDA device where they differ from its simulator's (which the golden
+                        fixtures were recorded under): ray_length = sqrt(float32) in float32, slope / ray_length in float32,
+                        the loop bound from that float32 (gvom.py:1109-1114, 1127; profiles/numba_cuda_typing.txt, INTEGRATION.md
+                        section 5).  cuda_f32_sqrt: the name this switch had before round 6."""
 
     def __init__(self, xy_resolution, z_resolution, xy_size, z_size, buffer_size, min_distance,
                  positive_obstacle_threshold, negative_obstacle_threshold, slope_obstacle_threshold,
                  robot_height, robot_radius, ground_to_lidar_height, xy_eigen_dist, z_eigen_dist,
-                 device=0, voxel_statistics=None, cuda_f32_sqrt=False, c_order=False, _shard=None, _library=None):
+                 device=0, voxel_statistics=None, numba_cuda_typing=False, c_order=False, _shard=None, _library=None, cuda_f32_sqrt=None):
         self.xy_resolution = xy_resolution
         self.z_resolution = z_resolution
         self.xy_size = xy_size
@@ -353,12 +356,14 @@ class Gvom(object):
         self.ego_semaphore = threading.Semaphore()
         self.metrics = _DeviceArrayView(lambda: np.array([[3, 2]]))
         self._c_order = bool(c_order)
+        if cuda_f32_sqrt is not None:
+            numba_cuda_typing = bool(cuda_f32_sqrt)
 
         self._lib = load_library(_library)
         self._h = ctypes.c_void_p()
         stat_flags = 4 if (voxel_statistics is None and _shard is None) else (1 if voxel_statistics else 0)
         prm = GvomParams(float(xy_resolution), float(z_resolution), int(xy_size), int(z_size),
-                         int(buffer_size), stat_flags | (2 if cuda_f32_sqrt else 0), float(min_distance),
+                         int(buffer_size), stat_flags | (2 if numba_cuda_typing else 0), float(min_distance),
                          float(positive_obstacle_threshold), float(negative_obstacle_threshold),
                          float(slope_obstacle_threshold), float(robot_height), float(robot_radius),
                          float(ground_to_lidar_height), int(xy_eigen_dist), int(z_eigen_dist))

@@ -37,16 +37,55 @@ def _ray_box(o, d, box):
     return np.where(hit, tmin, np.inf)
 
 
+def os1_like_elevations(beams, seed=7):
+    """Beam elevations (degrees) of a REAL multi-beam lidar rather than a uniform comb: denser around the horizon (a
+    "gradient" beam configuration), every beam off its nominal angle by a fixed calibration error of up to +-0.25 deg --
+    no two neighbouring beams are the same distance apart."""
+    u = np.linspace(-1.0, 1.0, beams)
+    el = 22.5 * np.sign(u) * np.abs(u) ** 1.6
+    el += np.random.default_rng(seed).uniform(-0.25, 0.25, beams)
+    return np.sort(el)
+
+
+def os1_like_azimuth_offsets(beams):
+    """Per-beam azimuth offsets (radians): the beams of such a sensor sit in four staggered columns, ~ +-3 deg apart."""
+    return np.deg2rad(np.array([-3.1, -1.0, 1.0, 3.1])[np.arange(beams) % 4])
+
+
+def drop_returns(cloud, fraction, seed):
+    """What a real node hands over (gvom_ros.py:108: ros_numpy's xyz array has the invalid returns REMOVED): `fraction` of the
+    returns taken out before the call -- half of them in bursts of 8..64 consecutive returns of a beam (glass, absorbers, the
+    robot's own body), half singly -- the order of the survivors kept.  The length differs from scan to scan (seed)."""
+    n = cloud.shape[0]
+    rng = np.random.default_rng(5000 + seed)
+    keep = np.ones(n, bool)
+    target = int(fraction * n)
+    removed = 0
+    while removed < target // 2:
+        a = int(rng.integers(0, n))
+        ln = int(rng.integers(8, 65))
+        seg = keep[a:a + ln]
+        removed += int(seg.sum())
+        seg[:] = False
+    rest = target - int((~keep).sum())
+    if rest > 0:
+        alive = np.flatnonzero(keep)
+        keep[rng.choice(alive, size=min(rest, alive.size), replace=False)] = False
+    return np.ascontiguousarray(cloud[keep])
+
+
 def lidar_scan(scene, beams=64, azimuths=2048, sensor=(0.0, 0.0, 0.0), yaw=0.0, noise_seed=0,
-               dtype=np.float32, frame="world"):
+               dtype=np.float32, frame="world", elevations_deg=None, azimuth_offsets=None):
     """Returns an (beams*azimuths, 3) cloud, beam-major.  frame="world": points in the world
     frame (transform=None); frame="sensor": points in the sensor frame, use with
-    `sensor_transform(sensor, yaw)`."""
+    `sensor_transform(sensor, yaw)`.  elevations_deg / azimuth_offsets: per-beam elevations and azimuth offsets of a real
+    sensor (os1_like_*) instead of the uniform comb."""
     o = np.asarray(sensor, np.float64)
-    el = np.deg2rad(np.linspace(-22.5, 22.5, beams))
+    el = np.deg2rad(np.linspace(-22.5, 22.5, beams) if elevations_deg is None else np.asarray(elevations_deg, np.float64))
     az = 2.0 * np.pi * np.arange(azimuths) / azimuths + yaw
+    az2 = az[None, :] + (0.0 if azimuth_offsets is None else np.asarray(azimuth_offsets, np.float64)[:, None])
     ce, se = np.cos(el)[:, None], np.sin(el)[:, None]
-    d = np.stack([ce * np.cos(az)[None, :], ce * np.sin(az)[None, :], se * np.ones_like(az)[None, :]],
+    d = np.stack([ce * np.cos(az2), ce * np.sin(az2), se * np.ones_like(az2)],
                  axis=-1).reshape(-1, 3)
     n = d.shape[0]
     rng = np.random.default_rng(1000 + noise_seed)
@@ -122,6 +161,11 @@ CONFIGS = {
     "c4": ((0.2, 0.2, 512, 128, 4) + REF_TAIL, 128, "512x512x128 @0.2 m, 4 x OS1-128 = 1,048,576-pt cloud, buffer=4"),
     "c5": ((0.2, 0.2, 1024, 128, 8) + REF_TAIL, 128, "1024x1024x128 @0.2 m, 16 x OS1-128 = 4,194,304-pt cloud per tick, buffer=8"),
 }
+# what a real node delivers: the metric grid, an OS1-64-like sensor with NON-UNIFORM beam elevations and
+# staggered beam columns, 10 / 25 / 40 % of the returns removed before the call, a different length every scan
+for _pct in (10, 25, 40):
+    CONFIGS["m256_d%d" % _pct] = (CONFIGS["m256"][0], 64, "256x256x256 @0.2 m (metric grid), OS1-64-like scan with non-uniform beam "
+                                  "elevations, %d %% of the 131,072 returns dropped before the call (length varies per scan), buffer=1" % _pct)
 SENSORS = {"c4": 4, "c5": 16}
 
 
@@ -143,6 +187,15 @@ def config_inputs(name, n_scans=1, dtype=np.float32):
                           sensor, None))
         return params, scans
     scene = make_scene(2)
+    if name.startswith("m256_d"):
+        frac = int(name[6:]) / 100.0
+        el, azo = os1_like_elevations(beams), os1_like_azimuth_offsets(beams)
+        for k in range(n_scans):
+            sensor = (0.2 * k, 0.0, 0.0)
+            full = lidar_scan(scene, beams=beams, sensor=sensor, noise_seed=k, dtype=dtype, elevations_deg=el, azimuth_offsets=azo)
+            # (the fraction itself wanders by a tenth from scan to scan, as a scene's share of invalid returns does)
+            scans.append((drop_returns(full, frac * (0.9 + 0.2 * ((k * 37) % 11) / 10.0), k), sensor, None))
+        return params, scans
     for k in range(n_scans):
         sensor = (0.2 * k, 0.0, 0.0)
         scans.append((lidar_scan(scene, beams=beams, sensor=sensor, noise_seed=k, dtype=dtype),

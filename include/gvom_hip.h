@@ -85,10 +85,16 @@ typedef struct gvom_params {
                                         * GVOM_NO_DATA, the scans that follow carry statistics again, and the fused map has them
                                         * once every ring slot does (they then restart from the ring: what the map had merged
                                         * before the pause is not in them).  g-vom_amd/gvom.py's default. */
-#define GVOM_FLAG_CUDA_F32_SQRT    2   /* ray_length = sqrt(f32 sum) evaluated in float32, as Numba types
-                                        * math.sqrt(float32) when it compiles gvom.py:1109 for a real CUDA device
-                                        * (SURVEY App. A.2).  Default (flag clear): the float64 square root of
-                                        * Numba's simulator, which is what the golden fixtures were generated with. */
+#define GVOM_FLAG_NUMBA_CUDA_TYPING 2  /* the types Numba 0.54.1 infers for a REAL CUDA device where they differ from its simulator's
+                                        * (profiles/numba_cuda_typing.txt: its type inference with the CUDA target's typing context
+                                        * over gvom.py:1060-1150, 1303-1329): ray_length = math.sqrt(float32) is
+                                        * float32 (gvom.py:1109), slope[k] / ray_length is float32 / float32 (:1112-1114) and the loop
+                                        * bound is that float32 minus 1 in float64 (:1127) -- every other difference (math.floor
+                                        * giving float64, the voxel index carried as float64) is value-neutral.  Default (flag
+                                        * clear): the float64 square root of Numba's simulator, which is what the golden fixtures
+                                        * were generated with.  What NO flag reproduces: NVVM's default contraction of a*b + c into
+                                        * FMAs on a real device (code generation, not typing; unpinnable without one). */
+#define GVOM_FLAG_CUDA_F32_SQRT    GVOM_FLAG_NUMBA_CUDA_TYPING   /* (its name before ABI 8) */
 
 /* Ring-buffer bookkeeping visible on the reference object (gvom.py:56-58,172-175). */
 typedef struct gvom_state {

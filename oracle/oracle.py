@@ -191,10 +191,10 @@ class OracleGvom:
     def __init__(self, xy_resolution, z_resolution, xy_size, z_size, buffer_size, min_distance,
                  positive_obstacle_threshold, negative_obstacle_threshold, slope_obstacle_threshold,
                  robot_height, robot_radius, ground_to_lidar_height, xy_eigen_dist, z_eigen_dist,
-                 voxel_statistics=False, cuda_f32_sqrt=False):
+                 voxel_statistics=False, cuda_f32_sqrt=False, numba_cuda_typing=None, c_order=False):
         # cuda_f32_sqrt: ray_length = sqrt(float32) evaluated in float32, as Numba types gvom.py:1109 for a
         # real CUDA device; default = the simulator's float64 square root (the fixtures)
-        self.cuda_f32_sqrt = cuda_f32_sqrt
+        self.cuda_f32_sqrt = bool(cuda_f32_sqrt if numba_cuda_typing is None else numba_cuda_typing)   # (numba_cuda_typing: the switch's name since round 6)
         # voxel_statistics: also restate the per-voxel mean/covariance/eigenvalue path (SURVEY 8f
         # rank 2: gvom.py:1172-1299, 858-909, 1333-1378, 363-378).  Off by default so that the
         # timed CPU baseline covers the same work as the GPU hot path.

@@ -824,6 +824,32 @@ def test_layout_probe_finds_interleaved_sensors_and_nothing_else(gvom_mod):
         assert used == [1, 1, want, 1], (used, want)
 
 
+@pytest.mark.parametrize("pct", [10, 25, 40])
+def test_layout_probe_is_stable_on_the_clouds_a_real_node_delivers(gvom_mod, pct):
+    """synth m256_d*: an OS1-64-like sensor with non-uniform beam elevations and staggered beam columns, 10 / 25 / 40 % of its
+    returns removed BEFORE the call (what ros_numpy's xyz array is, gvom_ros.py:108), the length changing with every scan.  The
+    layout probe (every 8th scan of a stream of changing lengths) must keep ONE verdict for the stream -- the survivors are still in
+    beam-major order, which the trace takes as it is: no directional sort, no sub-cloud interleave, and above all no flapping
+    between modes on consecutive scans (each flip would change the trace's cost by a factor; results never change).  Not a
+    timing test.  The maps of the stream equal those of the same clouds traced in forced directional order."""
+    params, scans = synth.config_inputs("m256_d%d" % pct, n_scans=12)
+    params = params[:3] + (64,) + params[4:]                   # (a flatter grid: the same rays, a quicker test)
+    g, f = gvom_mod.Gvom(*params), gvom_mod.Gvom(*params)
+    f.set_tuning("dirsort", 2)
+    assert len({pc.shape[0] for pc, _, _ in scans}) > 6
+    modes, ilv = [], []
+    for k in range(60):
+        pc, ego, tf = scans[k % len(scans)]
+        g.process_pointcloud(pc, ego, tf); f.process_pointcloud(pc, ego, tf)
+        modes.append(g.get_tuning("dirsort")); ilv.append(g.get_tuning("interleave"))
+        if k % 6 == 5:
+            for a, b in zip(g.combine_maps(), f.combine_maps()):
+                assert np.array_equal(a, b)
+    assert f.get_tuning("dirsort") == 2
+    assert sum(1 for a, b in zip(modes, modes[1:]) if a != b) == 0 and modes[-1] == 0, modes
+    assert set(ilv) == {1}, ilv
+
+
 def test_directional_order_of_unordered_clouds_leaves_results_unchanged(gvom_mod):
     """Clouds in no spatial order (BASELINE c1: uniformly random points) are traced in DIRECTIONAL order: a counting sort by
     direction bin seen from the sensor (k_dirbin_*: 6 cube faces x 16 x 16 cells, or 256 elevation rows x 32 azimuth sectors for
@@ -1366,11 +1392,15 @@ def test_long_rings_read_their_descriptors_from_memory(gvom_mod, grid):
 
 
 def test_cuda_f32_sqrt_flag(gvom_mod):
-    """GVOM_FLAG_CUDA_F32_SQRT: real Numba-CUDA types math.sqrt(float32) as float32
-    (gvom.py:1109-1114); the simulator -- and therefore the fixtures and the default -- takes the float64
-    square root.  Two returns, found by search, whose rays mark different voxels under the two typings;
-    the HIP path follows the oracle in both modes (this mode has no reference-generated vector: the
-    simulator cannot produce one)."""
+    """numba_cuda_typing=True (GVOM_FLAG_NUMBA_CUDA_TYPING; its name before round 6: cuda_f32_sqrt): the types Numba infers for
+    a real CUDA device where they differ from the simulator's -- profiles/numba_cuda_typing.txt, generated by
+    tests/golden/numba_typing_probe.py from Numba 0.54.1's own type inference (CUDA typing context) over the unmodified
+    reference: ray_length = math.sqrt(float32) -> float32 (gvom.py:1109), slope / ray_length in float32 (:1112-1114), the loop
+    bound from that float32 (:1127); every other difference in the table is value-neutral.  The simulator -- and therefore the
+    fixtures and the default -- takes the float64 square root.  Two returns, found by search, whose rays mark different
+    voxels under the two typings; the HIP path follows the oracle in both modes, on them, on a random cloud and on the 40 seeds
+    of the edge-case fuzz (this mode has no reference-generated VECTOR: the simulator cannot produce one, and no CUDA device is
+    here -- what is pinned is the typing table)."""
     params = (0.2, 0.2, 64, 32, 1, 0.5, 0.5, 0.5, 0.3, 2.0, 4.0, 1.0, 1, 1)
     ego = (0.013, -0.027, 0.004)
     rays = np.array([[4.66099739074707, -5.127684116363525, -0.5784711241722107],
@@ -1380,8 +1410,8 @@ def test_cuda_f32_sqrt_flag(gvom_mod):
     dense = {}
     for flag in (False, True):
         for pc, tag in ((rays, "rays"), (cloud, "cloud")):
-            g = gvom_mod.Gvom(*params, cuda_f32_sqrt=flag)
-            w = oracle.OracleGvom(*params, cuda_f32_sqrt=flag)
+            g = gvom_mod.Gvom(*params, numba_cuda_typing=flag)
+            w = oracle.OracleGvom(*params, numba_cuda_typing=flag)
             g.process_pointcloud(pc, ego); w.process_pointcloud(pc.copy(), ego)
             gd = g.read_dense(0)
             wd = scenarios.dense_from_compact(w.index_buffer[0], w.hit_count_buffer[0], w.total_count_buffer[0], w.min_height_buffer[0])
@@ -1389,6 +1419,18 @@ def test_cuda_f32_sqrt_flag(gvom_mod):
                 assert np.array_equal(np.asarray(wd[j]), gd[j]), (flag, tag, j)
             dense[(flag, tag)] = gd[0].copy()
     assert not np.array_equal(dense[(False, "rays")], dense[(True, "rays")])
+    assert gvom_mod.Gvom(*params, cuda_f32_sqrt=True).read_dense(0) is None                        # (the old keyword still binds)
+    differ = 0
+    for seed in range(40):
+        fparams, steps = _fuzz_case(1000 + seed)
+        sc = {"params": fparams, "steps": steps}
+        want = scenarios.run_and_record(lambda *p: oracle.OracleGvom(*p, numba_cuda_typing=True), sc)
+        got = scenarios.run_and_record(lambda *p: gvom_mod.Gvom(*p, numba_cuda_typing=True), sc)
+        assert compare_records(got, want, float_tol=1e-5) > 3, seed
+        plain = scenarios.run_and_record(oracle.OracleGvom, sc)
+        differ += any(k in plain and not np.array_equal(np.asarray(plain[k]), np.asarray(want[k]), equal_nan=True)
+                      for k in want if k.endswith(("slot_total", "fused_total")))
+    print("numba_cuda_typing: %d of 40 fuzz seeds mark other voxels than the simulator's typing" % differ)
 
 
 def test_long_run_moving_window_matches_oracle(gvom_mod):
