@@ -155,6 +155,8 @@ struct gvom_handle {
     uint32_t dir_flip = 0;
     int last_dirsort = 0;                               // gvom_get_tuning "dirsort": the last scan ran in directional order
     int tune_encfuse = 0;                               // gvom_set_tuning "encfuse": A/B of k_encfuse's shape (low 4 bits: waves per block, bit 4: no XCD pairing)
+    int tune_fastdiv = -1;                              // gvom_set_tuning "fastdiv": 0 = IEEE divides by the resolutions in k_trace, else the verified reciprocal form
+    int fastdiv_ok = 0;                                 // bit 0 / 1: div_by_res() verified for xy_resolution / z_resolution (verify_fastdiv)
     int tune_eager = -1;                                // gvom_set_tuning "eager": 0 off, 1 always, -1 automatic (off after 3 wasted in a row)
     int eager_waste = 0;                                // speculations dropped in a row (saturates at 4)
     int eager_stat[2] = {0, 0};                         // adopted / dropped since creation (gvom_get_tuning "eager_adopted" / "eager_dropped")
@@ -361,6 +363,8 @@ void fill_scan_params(const gvom_handle *h, const int64_t origin[3], const doubl
     P.pt0[1] = (float)(h->ego[1] / p.xy_resolution);
     P.pt0[2] = (float)(h->ego[2] / p.z_resolution);
     P.rinv[0] = (float)(1.0 / p.xy_resolution); P.rinv[1] = (float)(1.0 / p.z_resolution);
+    P.drcp[0] = 1.0 / p.xy_resolution; P.drcp[1] = 1.0 / p.z_resolution;
+    P.fastdiv = h->tune_fastdiv == 0 ? 0 : h->fastdiv_ok;
     for (int k = 0; k < 3; ++k) {
         const int64_t size = k < 2 ? p.xy_size : p.z_size;
         const bool small = origin[k] > -(1ll << 18) && origin[k] < (1ll << 18) && size >= 5;
@@ -441,6 +445,36 @@ void fill_scan_params(const gvom_handle *h, const int64_t origin[3], const doubl
     P.epoch = 0;
 }
 
+// div_by_res() (gvom_kernels.hip) replaces (double)x / d, x a float32, by two fused multiply-adds around r = RN(1 / d).  It is
+// used for a divisor only after this check: every float32 significand (2^23 of them: the rounding of the quotient depends on
+// nothing else, see there) through the same three operations, against the divide.  ~30 ms per divisor, once per process.
+__attribute__((target("fma"))) static bool verify_fastdiv_all(double d, double r)
+{
+    for (uint32_t m = 0; m < (1u << 23); ++m) {
+        const uint32_t bits = 0x3f800000u | m;
+        float xf;
+        memcpy(&xf, &bits, 4);
+        const double x = (double)xf;
+        const double q = x * r;
+        const double e = __builtin_fma(-q, d, x);
+        const double q2 = __builtin_fma(e, r, q);
+        if (q2 != x / d) return false;
+    }
+    return true;
+}
+static bool verify_fastdiv(double d)
+{
+    static std::mutex mu;
+    static std::vector<std::pair<double, bool>> known;
+    if (!(d > 0x1p-64 && d < 0x1p64)) return false;        // (also NaN: no float32 coordinate over or underflows anything for such a d)
+    if (!__builtin_cpu_supports("fma")) return false;      // (no hardware fma on this host to check with: the divide stays)
+    std::lock_guard<std::mutex> lk(mu);
+    for (const auto &k : known) if (k.first == d) return k.second;
+    const bool ok = verify_fastdiv_all(d, 1.0 / d);
+    known.emplace_back(d, ok);
+    return ok;
+}
+
 int create_impl(const gvom_params *params, int device_id, int rank, int world, bool sharded, gvom_t **out)
 {
     if (!params || !out) return GVOM_ERR_INVALID;
@@ -467,6 +501,7 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, b
     h->stats_auto = !h->stats && !sharded && (params->reserved0 & GVOM_FLAG_STATISTICS_ON_DEMAND) != 0;
     if (h->stats_auto) h->stats = true;
     h->f32_sqrt = (params->reserved0 & GVOM_FLAG_CUDA_F32_SQRT) != 0;
+    h->fastdiv_ok = (verify_fastdiv(params->xy_resolution) ? 1 : 0) | (verify_fastdiv(params->z_resolution) ? 2 : 0);
     if (const char *v = getenv("GVOM_VOXEL_STATISTICS")) { h->stats = atoi(v) != 0; h->stats_auto = false; }
     // sharded statistics send a return to the ranks that own the first and the last row of its neighbourhood: the
     // neighbourhood (2 xy_eigen_dist + 1 rows) must not reach over a whole slab
@@ -2278,6 +2313,7 @@ VIS int gvom_set_tuning(gvom_t *h, const char *name, int value)
     else if (!strcmp(name, "fuse1")) h->tune_fuse1 = value;
     else if (!strcmp(name, "encfuse")) h->tune_encfuse = value;
     else if (!strcmp(name, "dirsort")) h->tune_dirsort = value;
+    else if (!strcmp(name, "fastdiv")) h->tune_fastdiv = value;
     else if (!strcmp(name, "eager")) { h->tune_eager = value; h->eager_waste = 0; }
     else if (!strcmp(name, "exported")) h->exported = value != 0;       // (set by the peer transport, gvom_comm.hip)
 #ifdef GVOM_HOOKS
@@ -2299,6 +2335,7 @@ VIS int gvom_get_tuning(gvom_t *h, const char *name, int *value)
     if (!strcmp(name, "dirsort")) { *value = h->last_dirsort; return GVOM_OK; }
     if (!strcmp(name, "eager_adopted")) { *value = h->eager_stat[0]; return GVOM_OK; }
     if (!strcmp(name, "eager_dropped")) { *value = h->eager_stat[1]; return GVOM_OK; }
+    if (!strcmp(name, "fastdiv")) { *value = h->tune_fastdiv == 0 ? 0 : h->fastdiv_ok; return GVOM_OK; }   // bit 0 / 1: xy / z resolution divided by reciprocal
     return GVOM_ERR_INVALID;
 }
 

@@ -64,6 +64,8 @@ struct ScanParams {
     double tf[12];        // rows 0..2 of the 4x4 (gvom.py:1044-1052)
     float  pt0[3];        // (float)(ego / res)  (gvom.py:1097-1099)
     float  rinv[2];       // (float)(1 / xy_res), (float)(1 / z_res): k_trace's conservative early-exit estimate only
+    double drcp[2];       // RN(1 / xy_res), RN(1 / z_res) for div_by_res(): the EXACT quotient of a float32 coordinate without a divide
+    int    fastdiv;       // bit 0 / 1: the host has verified drcp[0] / drcp[1] over all 2^23 float32 significands (gvom_create)
     float  win_lo[3], win_hi[3];   // k_trace: the window shrunk by 2 voxels, in voxel coordinates (origin + 2 .. origin + size - 2): a run
                           //   of steps between two positions inside it needs no window test.  lo > hi (never true) when |origin| >= 2^18
     int    has_tf;

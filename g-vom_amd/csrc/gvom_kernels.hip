@@ -229,6 +229,29 @@ __device__ __forceinline__ uint32_t ray_steps(double lim, double step_len, doubl
     return n;
 }
 
+// (double)x / d for a FLOAT32 coordinate x and a wave-uniform divisor d (xy_res, z_res), bit for bit, without the divide
+// (an IEEE f64 division is ~15 instructions on gfx950: v_div_scale x2, v_rcp_f64, four Newton v_fma_f64, v_div_fmas,
+// v_div_fixup ...): with r = RN(1 / d) from the host, q = x * r is within an ulp of the quotient, e = fma(-q, d, x) is its
+// EXACT residual and fma(e, r, q) the correctly rounded quotient (Markstein's correction step).  Whether that holds for a
+// given d is not taken from a theorem but CHECKED: rounding depends on the significands only (scaling x by a power of two
+// scales q, e and the result exactly; no float32 x brings any of them near the ends of the f64 range for 2^-64 < d < 2^64), and
+// a float32 has 2^23 significands -- gvom_create tries them all against the divide (verify_fastdiv, once per divisor and
+// process) and clears the bit in P.fastdiv if one differs.  Zeros and non-finite x keep x * r, which is the quotient there
+// (signed zero, inf, NaN).  Explicit fma() calls are not subject to -ffp-contract=off.  T = double (clouds handed over in
+// float64): the IEEE divide, always.
+template <typename T>
+__device__ __forceinline__ double div_by_res(T x, double d, double r, bool fast)
+{
+    if (sizeof(T) == 4 && fast) {
+        const double xd = (double)x;
+        const double q = xd * r;
+        const double e = __builtin_fma(-q, d, xd);
+        const double q2 = __builtin_fma(e, r, q);
+        return (fabs(xd) < INFINITY && xd != 0.0) ? q2 : q;
+    }
+    return (double)x / d;
+}
+
 // Endpoint voxel of one return (gvom.py:1070-1086): storage index L, accumulator index A, storage row
 // sy, and its min-height sample (gvom.py:1303-1329).
 struct Endpoint { bool ingrid; uint32_t L, A, mbits; int sy; };
@@ -238,9 +261,9 @@ __device__ __forceinline__ Endpoint endpoint_of(const ScanParams &P, bool pass, 
     Endpoint E;
     E.ingrid = false; E.L = 0; E.A = 0; E.mbits = 0; E.sy = 0;
     if (pass) {
-        const double fx = floor((double)x / P.xy_res - P.origin[0]);
-        const double fy = floor((double)y / P.xy_res - P.origin[1]);
-        const double az = (double)z / P.z_res - P.origin[2];
+        const double fx = floor(div_by_res<T>(x, P.xy_res, P.drcp[0], P.fastdiv & 1) - P.origin[0]);
+        const double fy = floor(div_by_res<T>(y, P.xy_res, P.drcp[0], P.fastdiv & 1) - P.origin[1]);
+        const double az = div_by_res<T>(z, P.z_res, P.drcp[1], P.fastdiv & 2) - P.origin[2];
         const double fz = floor(az);
         if (fx >= 0.0 && fx < (double)P.xy && fy >= 0.0 && fy < (double)P.xy && fz >= 0.0 && fz < (double)P.zs) {
             E.ingrid = true;
@@ -296,9 +319,9 @@ struct RaySetup { float incx, incy, incz; double step_len, inv_step, lim; bool f
 template <typename T>
 __device__ __forceinline__ RaySetup ray_setup(const ScanParams &P, T x, T y, T z)
 {
-    const float e0 = (float)((double)x / P.xy_res);
-    const float e1 = (float)((double)y / P.xy_res);
-    const float e2 = (float)((double)z / P.z_res);
+    const float e0 = (float)div_by_res<T>(x, P.xy_res, P.drcp[0], P.fastdiv & 1);
+    const float e1 = (float)div_by_res<T>(y, P.xy_res, P.drcp[0], P.fastdiv & 1);
+    const float e2 = (float)div_by_res<T>(z, P.z_res, P.drcp[1], P.fastdiv & 2);
     float s0 = e0 - P.pt0[0], s1 = e1 - P.pt0[1], s2 = e2 - P.pt0[2];
     const float ss = (s0 * s0 + s1 * s1) + s2 * s2;
     // math.sqrt -> f64; GVOM_FLAG_CUDA_F32_SQRT: sqrt of the f32 sum in f32, as real
@@ -634,8 +657,15 @@ __device__ __forceinline__ void trace_item(const ScanParams &P, const ShardExcha
         endpoint_commit(P, lane, i, mine, E.L, E.A, E.mbits, hit, total, mh, state, tags, stat_sums, stat_base, stat_rowvox);
         if (P.ep_row >= 0) { TL_MARK(P, widx, 2); return; }
     }
-    const int seg = P.ep_row >= 0 ? row - (row > P.ep_row ? 1 : 0) : row;
-    const uint32_t j0 = (uint32_t)P.seg_start[seg];
+    int seg = P.ep_row >= 0 ? row - (row > P.ep_row ? 1 : 0) : row;
+    uint32_t j0 = 0;
+#ifdef GVOM_DIAG
+    // diagnostic build, GVOM_TRACE_DEBUG bits 8..11 = k: k EXTRA dispatch rows whose waves all die at the early-exit test below
+    // (what a (row, bundle) wave that cannot walk costs: the launch slot, the load of its returns, the test)
+    if (seg >= P.nsegs) { seg = P.nsegs; j0 = 0x3ffffff0u; }
+    else
+#endif
+    j0 = (uint32_t)P.seg_start[seg];
     if (P.prio_div > 0) __builtin_amdgcn_s_setprio(3);   // set-up and replay: everything is still in front of this wave
     // ---- later segments: leave before the f64 set-up when no ray of the wave can still be running ----
     // After j0 steps `length` is >= j0 * (1 - 2^-22) (every step adds |1 / sd| with |sd| <= 1 + 2^-23),
@@ -2938,7 +2968,7 @@ hipError_t gvom_launch_trace(hipStream_t s, const ScanParams &P, const ShardExch
 {
     if (n <= 0) return hipSuccess;
 #define TRACE_LAUNCH(TT, BB, WW)                                                                             \
-    hipLaunchKernelGGL((k_trace<TT, BB, WW>), dim3((unsigned)((n + 64 * WW - 1) / (64 * WW)), (unsigned)P.nsegs + (P.ep_row >= 0 ? 1u : 0u)), dim3(64 * WW), 0, s, P, X, (const TT *)pts, \
+    hipLaunchKernelGGL((k_trace<TT, BB, WW>), dim3((unsigned)((n + 64 * WW - 1) / (64 * WW)), (unsigned)P.nsegs + (P.ep_row >= 0 ? 1u : 0u) + ((unsigned)GVOM_DBG(P, 0xF00) >> 8)), dim3(64 * WW), 0, s, P, X, (const TT *)pts, \
                        (long)stride_elems, (long)n, (TT *)world, hit, total, mh, state, tags, counters,     \
                        stat_sums, stat_base, stat_rowvox)
     // 8 waves per workgroup (measured on m256: 1 / 2 / 4 / 8 / 16 waves -> 47.4 / 44.6 / 41.7 / 40.5 / 42.8 us)

@@ -417,6 +417,11 @@ int gvom_host_timing(gvom_t *h, double us[8]);
  * degrees apart (mode 1: cube cells) or a return and the one 63 places behind it differ by more than ~3 degrees in elevation
  * (mode 2: elevation rows), and the following clouds of that length are traced accordingly; 1 / 2: always, in that mode; -1: never.
  * gvom_get_tuning("dirsort"): the mode the last scan ran in (0: the cloud's own order).  Only WHO traces which return changes.
+ * "fastdiv": k_trace divides every float32 coordinate by xy_resolution / z_resolution (gvom.py:1072-1080, 1101-1103); with the
+ * reciprocal r = RN(1 / d), q = x * r, e = fma(-q, d, x), fma(e, r, q) IS the IEEE quotient for every float32 x iff it is for the
+ * 2^23 float32 significands, which gvom_create checks on the host for both resolutions (once per value and process); a
+ * resolution that fails the check, float64 clouds and hosts without hardware fma keep the divide.  -1 (default): use it where
+ * verified; 0: always divide.  gvom_get_tuning("fastdiv"): bit 0 / 1 = in use for xy_resolution / z_resolution.
  * "encfuse" (A/B of that kernel's shape: low 4 bits waves per column block, bit 4 no XCD pairing), "fuse1" (1: one-slot
  * fusions through the general kernel), "flag_kernel" (1: round 3's completion-flag kernel).
  * (Test hooks are not part of this library: include/gvom_hip_test.h, lib/libgvom_hip_test.so.) */

@@ -734,6 +734,51 @@ def test_trace_far_origin_uses_f64_lookup(gvom_mod):
     assert compare_records(got, want, float_tol=1e-5) > 10
 
 
+@pytest.mark.parametrize("res", [(0.2, 0.2), (0.4, 0.2), (0.1, 0.1), (1.0 / 3.0, 0.07), (0.25, 0.5), (1.0, 1.0), (0.3, 0.15), (0.123456789, 0.987654321)])
+def test_division_by_the_resolution_through_the_verified_reciprocal(gvom_mod, res):
+    """k_trace divides every float32 coordinate by xy_resolution / z_resolution (gvom.py:1072-1080, 1101-1103).  The library does
+    it with the host's r = RN(1 / d) and two fused multiply-adds (q = x r; e = fma(-q, d, x); fma(e, r, q)) after gvom_create
+    has checked on the host that this IS the IEEE quotient for all 2^23 float32 significands -- the rounding depends on nothing
+    else -- and with the divide otherwise ("fastdiv" knob 0: always the divide).  Both forms and the oracle (which divides) on
+    clouds that sit on the edges: returns on voxel faces (quotients that are integers, or one ulp off), huge, tiny, denormal,
+    zero, negative-zero and non-finite coordinates, an ego off the origin; float64 clouds take the divide in either setting."""
+    xy_res, z_res = res
+    params = (xy_res, z_res, 48, 24, 1, 0.0, 0.5, 0.5, 0.3, 2.0, 2.0, 1.0, 1, 1)
+    rng = np.random.default_rng(int(xy_res * 1e6) + 17)
+    half = np.array([24 * xy_res, 24 * xy_res, 12 * z_res])
+    steps = []
+    for k in range(3):
+        ego = tuple(float(v) for v in rng.uniform(-2, 2, 3) * np.array([1, 1, 0.1]))
+        n = 20000
+        body = rng.uniform(-1.3, 1.3, (n, 3)) * half + np.array(ego)
+        faces = np.round(rng.uniform(-1, 1, (4000, 3)) * half / np.array([xy_res, xy_res, z_res])) * np.array([xy_res, xy_res, z_res])
+        near = faces * (1.0 + rng.choice([-1, 1], (4000, 1)) * 2.0 ** -rng.integers(18, 25, (4000, 1)))   # an ulp or so off a face
+        odd = np.array([[0.0, 0.0, 0.0], [-0.0, 0.0, -0.0], [1e-42, -1e-42, 1e-45], [3e38, 1.0, 1.0], [-3e38, 3e38, -3e38],
+                        [np.inf, 0.5, 0.5], [0.5, -np.inf, 0.5], [np.nan, 0.5, 0.5], [1e-20, 1e-30, -1e-38]])
+        pc = np.concatenate([body, faces, near, odd], 0).astype(np.float32 if k < 2 else np.float64)
+        steps += [("scan", pc, ego, None), ("combine",)]
+    sc = {"params": params, "steps": steps}
+    want = scenarios.run_and_record(oracle.OracleGvom, sc)
+    made = []
+
+    def knob(v):
+        def make(*p):
+            g = gvom_mod.Gvom(*p, voxel_statistics=False)
+            g.set_tuning("fastdiv", v)
+            made.append(g)
+            return g
+        return make
+    recs = [scenarios.run_and_record(knob(v), sc) for v in (-1, 0)]
+    with np.errstate(invalid="ignore"):
+        for got in recs:
+            assert compare_records(got, want, float_tol=1e-5) > 10
+    for key in recs[0]:
+        a, b = np.asarray(recs[0][key]), np.asarray(recs[1][key])
+        assert a.shape == b.shape and (np.array_equal(a, b, equal_nan=True) if a.dtype.kind in "fiub" else True), key
+    # every resolution of this list passes the host's check (it is a property of the divisor; 1.0 trivially so)
+    assert made[0].get_tuning("fastdiv") == 3 and made[1].get_tuning("fastdiv") == 0
+
+
 def test_trace_tuning_knobs_leave_results_unchanged(gvom_mod):
     """k_trace splits every ray into step segments handled by different waves (set-up + replay of the
     earlier steps + the segment's own steps); the segment count, the flush period of a wave's LDS line

@@ -15,7 +15,7 @@ params, scans = synth.config_inputs(name, n_scans=4)
 dev = [(hip.to_device(pc), pc.shape[0], pc.dtype, ego, tf) for (pc, ego, tf) in scans]
 gs = []
 for setting in settings:
-    g = gvom.Gvom(*params)
+    g = gvom.Gvom(*params, voxel_statistics=False)
     if setting != "-":
         for kv in setting.split(","):
             k, v = kv.split("="); g.set_tuning(k, int(v))
@@ -28,5 +28,12 @@ acc = [[] for _ in gs]
 for b in range(blocks):
     for i, g in enumerate(gs):
         t0 = time.perf_counter(); run(g, steps); acc[i].append((time.perf_counter() - t0) / steps * 1e6)
-for s, a in zip(settings, acc):
-    print("%-32s median %7.2f us  min %7.2f  (blocks %d x %d steps)" % (s, float(np.median(a)), min(a), blocks, steps), flush=True)
+stage = []
+for g in gs:                                             # HIP-event time of the kernels (sampled steps: ~80 us longer each)
+    g.set_profiling(True); st = []
+    for k in range(60):
+        d, npts, dt, ego, tf = dev[k % 4]; g.process_pointcloud_device(d.value, npts, dt, ego, tf); g.combine_maps(); st.append(g.last_stage_ms())
+    g.set_profiling(False)
+    stage.append({k_: round(float(np.median([a[k_] for a in st])) * 1e3, 2) for k_ in ("trace", "encode", "fuse", "map2d")})
+for s, a, st in zip(settings, acc, stage):
+    print("%-32s median %7.2f us  min %7.2f  (blocks %d x %d steps)  kernels us: %s" % (s, float(np.median(a)), min(a), blocks, steps, st), flush=True)

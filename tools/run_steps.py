@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Runs `steps` scan+combine steps of one config (device-resident cloud), for use under rocprofv3.
-Usage: tools/run_steps.py [config] [steps] [key=value tuning ...]"""
+Usage: tools/run_steps.py [config] [steps] [key=value tuning ...] [stats] [stage]
+(stats: voxel_statistics=True; default: voxel_statistics=False -- the north-star path, no statistics at any step)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "g-vom_amd")]
@@ -11,7 +12,7 @@ hip = bench.Hip(); hip.set_device(0)
 params, scans = synth.config_inputs(name, n_scans=4)
 scans = (scans * 4)[:4]
 dev = [(hip.to_device(pc), pc.shape[0], pc.dtype, ego, tf) for (pc, ego, tf) in scans]
-g = gvom.Gvom(*params)
+g = gvom.Gvom(*params, voxel_statistics=("stats" in sys.argv[3:]))
 stage = "stage" in sys.argv[3:]
 for kv in sys.argv[3:]:
     if "=" in kv:
