@@ -2531,40 +2531,52 @@ __global__ __launch_bounds__(256) void k_stats(const ScanParams P, const T *__re
     }
 }
 
-// k_stats_gather: half a wave per occupied voxel (= compact row; rowvox[row] is its voxel): a wave looks at GATHER_CPW
-// candidate rows at once (a row is the index of one of the voxel's returns: most candidates are not in use), then takes
-// the used ones two at a time (few candidates per wave: every used row is a chain of dependent round trips, and the
-// kernel's time is the longest chain -- 64 candidates per wave took 91 us, a wave per candidate 40); the lanes of a half fetch the neighbourhood's voxels in parallel (lane <-> neighbour offset), shift
-// their own-voxel moments by the offset (see k_stats) and a butterfly reduction sums them; the half's first lane adds the
-// directly accumulated part and turns the raw moments into the reference's per-scan metrics layout: mean xyz, population
-// covariance xx xy xz yy yz zz (gvom.py:1224-1230, 1289-1299), count.
+// k_stats_gather: a QUARTER wave (16 lanes) per occupied voxel (= compact row; rowvox[row] is its voxel).  A wave looks at
+// GATHER_CPW candidate rows at once (a row is the index of one of the voxel's returns: near the sensor most candidates are not in
+// use, far away -- one return per voxel -- all of them are) and takes the used ones FOUR at a time: every used row is a chain of
+// dependent round trips (neighbours' tags + states, their moments, the row's own sums), and the kernel's time is its longest
+// wave -- 16 used candidates at two per turn were 8 turns of ~4 us while a thousand SIMDs idled (round 6: SQ_WAVE_CYCLES says 0.9
+// resident waves per SIMD over its 46 us; 64 candidates per wave took 91 us, a wave per candidate 40).  The lanes of a quarter
+// take the neighbourhood's voxels two at a time (lane <-> neighbour offset; both neighbours' loads in flight together), shift
+// their own-voxel moments by the offset (see k_stats) and a butterfly reduction sums them; the quarter's first lane adds the
+// directly accumulated part (fetched BEFORE the neighbourhood, it does not depend on it) and turns the raw moments into the
+// reference's per-scan metrics layout: mean xyz, population covariance xx xy xz yy yz zz (gvom.py:1224-1230, 1289-1299), count.
 #define GATHER_CPW 16
-__global__ __launch_bounds__(256) void k_stats_gather(const ScanParams P, const int32_t *__restrict__ state,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_stats_gather(const ScanParams P, const int32_t *__restrict__ state,
                                                       const uint32_t *__restrict__ tags, int xy_e, int z_e,
                                                       const double *__restrict__ base, double *sums,
                                                       const uint32_t *__restrict__ rowvox,
                                                       uint32_t nrows, int direct_only)
 {
-    const int lane = threadIdx.x & (WAVE - 1), hl = lane & 31, half = lane >> 5;
+    const int lane = threadIdx.x & (WAVE - 1), ql = lane & 15, quarter = lane >> 4;
     const uint32_t wid = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const uint32_t nw = (gridDim.x * blockDim.x) >> 6;
     const int wx = 2 * xy_e + 1, wz = 2 * z_e + 1, nb = wx * wx * wz;
     // a compact row is the index of one of the voxel's returns (k_trace): row `row` is in use iff the
     // return claimed a voxel (rowvox != ~0, reset per scan) and that voxel's state still names it
-    for (uint32_t row0 = wid * GATHER_CPW; row0 < nrows; row0 += nw * GATHER_CPW) {
-        const uint32_t cand = row0 + (uint32_t)lane;
+    // candidates of a wave: rows wid + lane * waves of each pass (NOT 16 consecutive rows: consecutive returns of a beam far from the
+    // sensor are one voxel each -- 16 used candidates -- and near it all one voxel; strided, every wave gets its share of both)
+    for (uint32_t pass0 = 0; pass0 < nrows; pass0 += nw * GATHER_CPW) {
+        const uint32_t cand = pass0 + (uint32_t)lane * nw + wid;
         const uint32_t Lc = (lane < GATHER_CPW && cand < nrows) ? rowvox[cand] : 0xFFFFFFFFu;
         const bool used = Lc != 0xFFFFFFFFu && state[Lc] == (int32_t)cand;
         unsigned long long todo = lanes(used);
-        while (todo != 0ull) {                                         // wave-uniform: two used rows per turn
-            const int ka = __ffsll((long long)todo) - 1;
-            todo &= todo - 1ull;
-            int kb = -1;
-            if (todo != 0ull) { kb = __ffsll((long long)todo) - 1; todo &= todo - 1ull; }
-            const int k = half ? kb : ka;
+        while (todo != 0ull) {                                         // wave-uniform: four used rows per turn
+            int ks[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                ks[q] = -1;
+                if (todo != 0ull) { ks[q] = __ffsll((long long)todo) - 1; todo &= todo - 1ull; }
+            }
+            const int k = quarter == 0 ? ks[0] : (quarter == 1 ? ks[1] : (quarter == 2 ? ks[2] : ks[3]));
             const bool have = k >= 0;
-            const uint32_t row = row0 + (uint32_t)(have ? k : ka);
-            const uint32_t Lr = (uint32_t)__shfl((int)Lc, have ? k : ka);
+            const uint32_t row = pass0 + (uint32_t)(have ? k : ks[0]) * nw + wid;
+            const uint32_t Lr = (uint32_t)__shfl((int)Lc, have ? k : ks[0]);
+            double *o = sums + (size_t)row * 10;
+            double own[10];
+            const bool fin = ql == 0 && have;                           // the lane that finishes the row
+#pragma unroll
+            for (int q = 0; q < 10; ++q) own[q] = fin ? o[q] : 0.0;     // directly accumulated part: in flight beside the neighbourhood
             double m[10];
 #pragma unroll
             for (int q = 0; q < 10; ++q) m[q] = 0.0;
@@ -2572,41 +2584,57 @@ __global__ __launch_bounds__(256) void k_stats_gather(const ScanParams P, const 
                 const uint32_t L = Lr;
                 const int sx = (int)(L % P.xy), sz = (int)((L / P.xy) % P.zs), sy = (int)(L / ((uint32_t)P.xy * P.zs));
                 const int x = wrap_sub(sx, P.om[0], P.xy), y = wrap_sub(sy, P.om[1], P.xy), z = wrap_sub(sz, P.om[2], P.zs);
-                for (int j = hl; j < nb; j += 32) {
-                    const int dx = j / (wx * wz) - xy_e, dy = (j / wz) % wx - xy_e, dz = j % wz - z_e;
-                    const int xn = x + dx, yn = y + dy, zn = z + dz;
-                    if (xn < 0 || xn >= P.xy || yn < 0 || yn >= P.xy || zn < 0 || zn >= P.zs) continue;
-                    const int sxn = wrap_add(xn, P.om[0], P.xy), syn = wrap_add(yn, P.om[1], P.xy), szn = wrap_add(zn, P.om[2], P.zs);
-                    const uint32_t rzn = (uint32_t)syn * P.zs + szn;
-                    const uint32_t tgn = tags[rzn * P.nseg + (sxn >> 6)];
-                    const int32_t rn = state[rzn * P.xy + sxn];          // (issued beside the tag: stale where the tile is dead, and then unused)
-                    if (tgn != P.epoch || rn < 0) continue;
-                    const double *b = base + (size_t)rn * GVOM_BASE_PITCH;
-                    const double nn = b[9];
-                    if (!(nn > 0.0)) continue;
-                    // a point of voxel (x+dx, ...) with in-voxel position l sits at l + d relative to THIS voxel
-                    const double ddx = (double)dx, ddy = (double)dy, ddz = (double)dz;
-                    const double s0 = b[0], s1 = b[1], s2 = b[2];
-                    m[0] += s0 + nn * ddx; m[1] += s1 + nn * ddy; m[2] += s2 + nn * ddz;
-                    m[3] += b[3] + 2.0 * ddx * s0 + nn * ddx * ddx;
-                    m[4] += b[4] + ddx * s1 + ddy * s0 + nn * ddx * ddy;
-                    m[5] += b[5] + ddx * s2 + ddz * s0 + nn * ddx * ddz;
-                    m[6] += b[6] + 2.0 * ddy * s1 + nn * ddy * ddy;
-                    m[7] += b[7] + ddy * s2 + ddz * s1 + nn * ddy * ddz;
-                    m[8] += b[8] + 2.0 * ddz * s2 + nn * ddz * ddz;
-                    m[9] += nn;
+                for (int j0 = ql; j0 < nb; j0 += 32) {                  // two neighbours per pass: j0 and j0 + 16
+                    int dxa[2], dya[2], dza[2];
+                    bool in[2];
+                    uint32_t tix[2], six[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int j = j0 + 16 * u;
+                        const int dx = j / (wx * wz) - xy_e, dy = (j / wz) % wx - xy_e, dz = j % wz - z_e;
+                        const int xn = x + dx, yn = y + dy, zn = z + dz;
+                        in[u] = j < nb && xn >= 0 && xn < P.xy && yn >= 0 && yn < P.xy && zn >= 0 && zn < P.zs;
+                        const int sxn = wrap_add(in[u] ? xn : x, P.om[0], P.xy), syn = wrap_add(in[u] ? yn : y, P.om[1], P.xy),
+                                  szn = wrap_add(in[u] ? zn : z, P.om[2], P.zs);
+                        const uint32_t rzn = (uint32_t)syn * P.zs + szn;
+                        tix[u] = rzn * P.nseg + ((uint32_t)sxn >> 6); six[u] = rzn * P.xy + (uint32_t)sxn;
+                        dxa[u] = dx; dya[u] = dy; dza[u] = dz;
+                    }
+                    // (all four loads issued together; a state is stale where its tile is dead, and then unused)
+                    const uint32_t tg0 = tags[tix[0]], tg1 = tags[tix[1]];
+                    const int32_t rn0 = state[six[0]], rn1 = state[six[1]];
+                    const bool ok0 = in[0] && tg0 == P.epoch && rn0 >= 0, ok1 = in[1] && tg1 == P.epoch && rn1 >= 0;
+                    const double *b0 = base + (size_t)(ok0 ? rn0 : 0) * GVOM_BASE_PITCH, *b1 = base + (size_t)(ok1 ? rn1 : 0) * GVOM_BASE_PITCH;
+                    double v[2][10];
+#pragma unroll
+                    for (int q = 0; q < 10; ++q) { v[0][q] = ok0 ? b0[q] : 0.0; v[1][q] = ok1 ? b1[q] : 0.0; }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const double nn = v[u][9];
+                        if (!(u == 0 ? ok0 : ok1) || !(nn > 0.0)) continue;
+                        // a point of voxel (x+dx, ...) with in-voxel position l sits at l + d relative to THIS voxel
+                        const double ddx = (double)dxa[u], ddy = (double)dya[u], ddz = (double)dza[u];
+                        const double s0 = v[u][0], s1 = v[u][1], s2 = v[u][2];
+                        m[0] += s0 + nn * ddx; m[1] += s1 + nn * ddy; m[2] += s2 + nn * ddz;
+                        m[3] += v[u][3] + 2.0 * ddx * s0 + nn * ddx * ddx;
+                        m[4] += v[u][4] + ddx * s1 + ddy * s0 + nn * ddx * ddy;
+                        m[5] += v[u][5] + ddx * s2 + ddz * s0 + nn * ddx * ddz;
+                        m[6] += v[u][6] + 2.0 * ddy * s1 + nn * ddy * ddy;
+                        m[7] += v[u][7] + ddy * s2 + ddz * s1 + nn * ddy * ddz;
+                        m[8] += v[u][8] + 2.0 * ddz * s2 + nn * ddz * ddz;
+                        m[9] += nn;
+                    }
                 }
             }
             if (!direct_only) {
 #pragma unroll
                 for (int q = 0; q < 10; ++q)
 #pragma unroll
-                    for (int o = 16; o > 0; o >>= 1) m[q] += __shfl_xor(m[q], o);      // within the half (xor < 32)
+                    for (int sh = 8; sh > 0; sh >>= 1) m[q] += __shfl_xor(m[q], sh);      // within the quarter (xor < 16)
             }
-            if (hl != 0 || !have) continue;
-            double *o = sums + (size_t)row * 10;
+            if (!fin) continue;
 #pragma unroll
-            for (int q = 0; q < 10; ++q) m[q] += o[q];                       // directly accumulated part
+            for (int q = 0; q < 10; ++q) m[q] += own[q];                     // directly accumulated part
             const double nn = m[9];
             if (!(nn > 0.0)) { for (int q = 0; q < 9; ++q) o[q] = 0.0; o[9] = nn; continue; }
             const double mx = m[0] / nn, my = m[1] / nn, mz = m[2] / nn;
@@ -2650,46 +2678,35 @@ __device__ __forceinline__ void merge_metrics(float (&c)[10], const TO *o)
 
 // k_fuse_stats: the covariance half of gvom.py:821-912 for every occupied voxel of the fused map
 // written by k_fuse: sources in the reference's order (ring slots, then the previous fused map).
-// Occupied voxels are a few per 64-voxel tile (a surface), and the merge is ~300 instructions per source: with a wave
-// per tile 95 % of the lanes idled through it.  A (one-wave) workgroup therefore takes FS_TPW tiles at a time -- their
-// tags in one round trip, their states in a second -- lists their occupied voxels in LDS and merges them with one lane
-// per occupied voxel.  (A 16-wave workgroup with two barriers per 16 tiles took 148 us against 55: the merges of a
-// group waited for its slowest tile, and two such workgroups fill a CU.)
-#define FS_TPW 16
+// Occupied voxels are a few per 64-voxel tile (a surface) -- and a few HUNDRED in the tiles of a piece of ground plane -- and the
+// merge is ~300 instructions and two round trips per source.  A WAVE owns 64 tiles, SCATTERED through the slab (below: the
+// dense tiles of the ground plane, neighbours in tile order and all at one z level, spread over all waves): their tags in ONE instruction,
+// the live ones' states four tiles per round trip, their occupied voxels {voxel, row} listed in wave-private LDS, merged one lane
+// per voxel whenever 256 are listed and at the end -- no workgroup barrier.  Per voxel the sources' tags and states are fetched
+// two sources at a time, then their metrics, then merged in order.  (Round 5: one-wave workgroups of 16 CONSECUTIVE tiles, 46 us
+// at less than one resident wave per SIMD -- SQ_WAVE_CYCLES, profiles/r6_experiments.txt; four-wave workgroups over the same 16
+// tiles behind a barrier: 83 us.)
+#define FS_LIST 512
 template <bool MEM>
-__global__ __launch_bounds__(64) void k_fuse_stats(const FuseParams P, const FuseDescs KD,
-                                                   const MapDesc *__restrict__ descs_mem,
-                                                   const int32_t *__restrict__ fstate,
-                                                   const uint32_t *__restrict__ ftags, float *fmetrics)
+__global__ __launch_bounds__(256) void k_fuse_stats(const FuseParams P, const FuseDescs KD,
+                                                    const MapDesc *__restrict__ descs_mem,
+                                                    const int32_t *__restrict__ fstate,
+                                                    const uint32_t *__restrict__ ftags, float *fmetrics)
 {
-    __shared__ uint32_t s_list[64 * FS_TPW];
+    __shared__ uint32_t s_list[4][FS_LIST];
+    __shared__ int32_t s_rowl[4][FS_LIST];
     const cptr_desc descs = MEM ? (cptr_desc)descs_mem : (cptr_desc)KD.d;
-    const int lane = threadIdx.x;
-    const uint32_t t0 = (uint32_t)P.sy_lo * P.zs * P.nseg, t1 = (uint32_t)P.sy_hi * P.zs * P.nseg;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid >> 6;
+    const uint32_t t0 = (uint32_t)P.sy_lo * P.zs * P.nseg, nt = (uint32_t)(P.sy_hi - P.sy_lo) * P.zs * P.nseg;
+    const uint32_t nwaves = gridDim.x * 4u, wid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (uint32_t)w));
     const int nsrc = P.nslots + P.has_prev;
-    for (uint32_t g0 = t0 + blockIdx.x * FS_TPW; g0 < t1; g0 += gridDim.x * FS_TPW) {
-        const uint32_t tg = (lane < FS_TPW && g0 + (uint32_t)lane < t1) ? ftags[g0 + (uint32_t)lane] : ~P.epoch;
-        const uint32_t live = (uint32_t)lanes(tg == P.epoch);          // bit t: tile g0 + t is live
-        if (live == 0u) continue;                                        // wave-uniform
-        int32_t st[FS_TPW];
-#pragma unroll
-        for (int t = 0; t < FS_TPW; ++t) {                               // every live tile's states: independent loads, one round trip
-            const uint32_t tile = g0 + (uint32_t)t;
-            const int sx = (int)(tile % P.nseg) * 64 + lane;
-            st[t] = ((live >> t) & 1u) && sx < P.xy ? fstate[(tile / P.nseg) * P.xy + (uint32_t)sx] : -1;
-        }
-        uint32_t count = 0;
-#pragma unroll
-        for (int t = 0; t < FS_TPW; ++t) {
-            const unsigned long long m = lanes(st[t] >= 0);
-            const uint32_t tile = g0 + (uint32_t)t;
-            if (st[t] >= 0) s_list[count + (uint32_t)__popcll(m & lanemask_lt())] = (tile / P.nseg) * P.xy + (tile % P.nseg) * 64u + (uint32_t)lane;
-            count += (uint32_t)__popcll(m);
-        }
-        __syncthreads();
-        for (uint32_t e = (uint32_t)lane; e < count; e += 64u) {
-            const uint32_t L = s_list[e];
-            const int32_t row = fstate[L];
+    uint32_t n = 0;                                                          // voxels listed and not yet merged (wave-uniform)
+    auto merge_listed = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");               // (the list was written by other lanes of this wave)
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t e = (uint32_t)lane; e < n; e += 64u) {
+            const uint32_t L = s_list[w][e];
+            const int32_t row = s_rowl[w][e];
             const uint32_t rz = L / (uint32_t)P.xy;
             const int sx = (int)(L - rz * (uint32_t)P.xy), sy = (int)(rz / P.zs), sz = (int)(rz % P.zs);
             const uint32_t tl = rz * P.nseg + ((uint32_t)sx >> 6);
@@ -2697,20 +2714,87 @@ __global__ __launch_bounds__(64) void k_fuse_stats(const FuseParams P, const Fus
             float c[10];
 #pragma unroll
             for (int k = 0; k < 10; ++k) c[k] = 0.0f;                        // gvom.py:234-236
-            for (int s = 0; s < nsrc; ++s) {
-                const int xs = x + descs[s].d[0], ys = y + descs[s].d[1], zs_ = z + descs[s].d[2];
-                if (xs < 0 || xs >= P.xy || ys < 0 || ys >= P.xy || zs_ < 0 || zs_ >= P.zs) continue;
-                if (descs[s].tags[tl] != descs[s].epoch) continue;
-                const int st_s = descs[s].state[L];
-                if (st_s < 0 || !descs[s].metrics) continue;
-                if (s < P.nslots) merge_metrics<double>(c, (const double *)descs[s].metrics + (size_t)st_s * 10);
-                else merge_metrics<float>(c, (const float *)descs[s].metrics + (size_t)st_s * 10);
+            for (int s0 = 0; s0 < nsrc; s0 += 2) {                           // two sources per pass: their loads in flight together
+                bool in[2];
+                uint32_t tgv[2];
+                int stv[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int sI = s0 + u < nsrc ? s0 + u : s0;
+                    const int xs = x + descs[sI].d[0], ys = y + descs[sI].d[1], zs_ = z + descs[sI].d[2];
+                    in[u] = s0 + u < nsrc && descs[sI].metrics && !(xs < 0 || xs >= P.xy || ys < 0 || ys >= P.xy || zs_ < 0 || zs_ >= P.zs);
+                    tgv[u] = descs[sI].tags[tl];
+                    stv[u] = descs[sI].state[L];
+                }
+                float pm[10];                                                // the previous fused map's metrics (float32), if in this pass
+                double sm[2][10];                                            // ring slots' (float64)
+                bool ok[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int sI = s0 + u < nsrc ? s0 + u : s0;
+                    ok[u] = in[u] && tgv[u] == descs[sI].epoch && stv[u] >= 0;
+                    if (!ok[u]) continue;
+                    if (sI < P.nslots) {
+                        const double *q = (const double *)descs[sI].metrics + (size_t)stv[u] * 10;
+#pragma unroll
+                        for (int k = 0; k < 10; ++k) sm[u][k] = q[k];
+                    } else {
+                        const float *q = (const float *)descs[sI].metrics + (size_t)stv[u] * 10;
+#pragma unroll
+                        for (int k = 0; k < 10; ++k) pm[k] = q[k];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (!ok[u]) continue;
+                    if (s0 + u < P.nslots) merge_metrics<double>(c, sm[u]);
+                    else merge_metrics<float>(c, pm);
+                }
             }
 #pragma unroll
             for (int k = 0; k < 10; ++k) fmetrics[(size_t)row * 10 + k] = c[k];
         }
-        __syncthreads();
+        n = 0;
+        __builtin_amdgcn_wave_barrier();                                     // (nobody refills the list before every lane has read its entries)
+    };
+    // owned tile k of wave wid = k * waves + (wid + 149 k) mod waves: a plain stride of `waves` tiles is a whole number of storage rows
+    // on power-of-two grids and would hand a wave 64 tiles of ONE z level -- the ground plane's to a few waves, nothing to the rest
+    for (uint32_t kb = 0; kb * nwaves < nt; kb += 64u) {                      // 64 owned tiles per pass
+        const uint32_t kk = kb + (uint32_t)lane;
+        const uint32_t ti = kk * nwaves + (wid + 149u * kk) % nwaves;        // (index inside the slab)
+        const uint32_t tg = ti < nt ? ftags[t0 + ti] : ~P.epoch;
+        unsigned long long live = lanes(tg == P.epoch);
+        while (live != 0ull) {                                               // wave-uniform: four live tiles per round trip
+            int tq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                tq[q] = -1;
+                if (live != 0ull) { tq[q] = __ffsll((long long)live) - 1; live &= live - 1ull; }
+            }
+            int32_t st[4];
+            uint32_t Lb[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t kq = kb + (uint32_t)(tq[q] >= 0 ? tq[q] : 0);
+                const uint32_t tile = t0 + kq * nwaves + (wid + 149u * kq) % nwaves;
+                const int sx = (int)(tile % P.nseg) * 64 + lane;
+                Lb[q] = (tile / P.nseg) * P.xy + (uint32_t)sx;
+                st[q] = (tq[q] >= 0 && sx < P.xy) ? fstate[Lb[q]] : -1;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned long long m = lanes(st[q] >= 0);
+                if (st[q] >= 0) {
+                    const uint32_t pos = n + (uint32_t)__popcll(m & lanemask_lt());
+                    s_list[w][pos] = Lb[q];
+                    s_rowl[w][pos] = st[q];
+                }
+                n += (uint32_t)__popcll(m);
+            }
+            if (n > FS_LIST - 256u) merge_listed();                          // the next batch (<= 256 voxels) might not fit
+        }
     }
+    if (n) merge_listed();
 }
 
 // gvom.py:1333-1378 (eigenvalues) + :454-473 (debug voxel cloud): one output row of 8 floats per
@@ -2813,10 +2897,10 @@ hipError_t gvom_launch_fuse_stats(hipStream_t s, const FuseParams &P, const Fuse
 {
     const uint32_t ntiles = (uint32_t)(P.sy_hi - P.sy_lo) * P.zs * P.nseg;
     if (ntiles == 0) return hipSuccess;
-    unsigned blocks = (ntiles + FS_TPW - 1) / FS_TPW;
-    if (blocks > 32768) blocks = 32768;
-    if (descs_dev) hipLaunchKernelGGL(k_fuse_stats<true>, dim3(blocks), dim3(64), 0, s, P, KD, descs_dev, fstate, ftags, fmetrics);
-    else hipLaunchKernelGGL(k_fuse_stats<false>, dim3(blocks), dim3(64), 0, s, P, KD, descs_dev, fstate, ftags, fmetrics);
+    unsigned blocks = (ntiles + 255u) / 256u;               // a wave per 64 tiles, four waves per workgroup
+    if (blocks > 8192) blocks = 8192;                       // (beyond 2 M tiles a wave takes further passes of 64)
+    if (descs_dev) hipLaunchKernelGGL(k_fuse_stats<true>, dim3(blocks), dim3(256), 0, s, P, KD, descs_dev, fstate, ftags, fmetrics);
+    else hipLaunchKernelGGL(k_fuse_stats<false>, dim3(blocks), dim3(256), 0, s, P, KD, descs_dev, fstate, ftags, fmetrics);
     return hipGetLastError();
 }
 

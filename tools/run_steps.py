@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Runs `steps` scan+combine steps of one config (device-resident cloud), for use under rocprofv3.
-Usage: tools/run_steps.py [config] [steps] [key=value tuning ...] [stats] [stage]
+Usage: tools/run_steps.py [config] [steps] [key=value tuning ...] [stats] [stage] [sync]
 (stats: voxel_statistics=True; default: voxel_statistics=False -- the north-star path, no statistics at any step)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -19,9 +19,13 @@ for kv in sys.argv[3:]:
         k, v = kv.split("="); g.set_tuning(k, int(v))
 for k in range(60):                                      # first-use allocations (fused compact rows grow to 16 B x V)
     d, n, dt, ego, tf = dev[k % 4]; g.process_pointcloud_device(d.value, n, dt, ego, tf); g.combine_maps()
+sync = "sync" in sys.argv[3:]                            # every call followed by a wait for ALL the handle's streams: kernels run alone (intrinsic durations under rocprofv3)
 t0 = time.perf_counter()
 for k in range(steps):
-    d, n, dt, ego, tf = dev[k % 4]; g.process_pointcloud_device(d.value, n, dt, ego, tf); g.combine_maps()
+    d, n, dt, ego, tf = dev[k % 4]; g.process_pointcloud_device(d.value, n, dt, ego, tf)
+    if sync: g._lib.gvom_sync(g._h)
+    g.combine_maps()
+    if sync: g._lib.gvom_sync(g._h)
 print("%.1f us/step" % ((time.perf_counter() - t0) / steps * 1e6), end=" ")
 if stage:
     import numpy as np
