@@ -445,7 +445,7 @@ void fill_scan_params(const gvom_handle *h, const int64_t origin[3], const doubl
     P.epoch = 0;
 }
 
-// div_by_res() (gvom_kernels.hip) replaces (double)x / d, x a float32, by two fused multiply-adds around r = RN(1 / d).  It is
+// div_by_res() (gvom_trace.hip) replaces (double)x / d, x a float32, by two fused multiply-adds around r = RN(1 / d).  It is
 // used for a divisor only after this check: every float32 significand (2^23 of them: the rounding of the quotient depends on
 // nothing else, see there) through the same three operations, against the divide.  ~30 ms per divisor, once per process.
 __attribute__((target("fma"))) static bool verify_fastdiv_all(double d, double r)

@@ -1,4 +1,4 @@
-// gvom_internal.h -- shared between the kernels (gvom_kernels.hip) and the C-ABI host
+// gvom_internal.h -- shared between the kernels (gvom_trace / gvom_fuse / gvom_map2d / gvom_stats .hip) and the C-ABI host
 // layer (gvom_capi.hip).  Not part of the public interface (include/gvom_hip.h is).
 //
 // STORAGE LAYOUT (DESIGN.md "Data layout in HBM")
@@ -175,7 +175,7 @@ struct Map2dParams {
     uint32_t done_seq;
 };
 
-// ---- launchers (gvom_kernels.hip) --------------------------------------------------------
+// ---- launchers (gvom_trace / _fuse / _map2d / _stats .hip) --------------------------------------------------------
 hipError_t gvom_launch_trace(hipStream_t s, const ScanParams &P, const ShardExchange &X, int dtype, bool big_origin, const void *pts,
                              int64_t stride_elems, int64_t n, void *world, uint32_t *hit,
                              uint32_t *total, uint32_t *mh, int32_t *state, uint32_t *tags,

@@ -164,7 +164,7 @@ SUMMARY = """
 #  every other expression has the same type on both sides (d2 in the cloud's dtype, compares in float64, pt / end / slope float32
 #  locals, float32 accumulation of pt, int32 atomics).
 #
-# g-vom_amd's numba_cuda_typing=True (GVOM_FLAG_NUMBA_CUDA_TYPING) switches exactly the three DIFFER rows: csrc/gvom_kernels.hip
+# g-vom_amd's numba_cuda_typing=True (GVOM_FLAG_NUMBA_CUDA_TYPING) switches exactly the three DIFFER rows: csrc/gvom_trace.hip
 # ray_setup (`P.f32_sqrt ? (double)sqrtf(ss) : sqrt((double)ss)`; the quotient and the bound follow from it), oracle/gvom_oracle.c
 # likewise.  NOT covered by any switch, because it is code generation and not typing: NVVM contracts a*b + c into FMAs by
 # default on a real device (SURVEY App. A.3); without a CUDA device that cannot be pinned.

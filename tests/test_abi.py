@@ -73,7 +73,7 @@ def test_test_hooks_live_in_the_test_library_only():
     the production library contains none of the three strings, exports exactly the same symbols, and its public header does
     not mention them."""
     pkg = os.path.join(ROOT, "g-vom_amd")
-    build = subprocess.run(["make", "-C", pkg, "lib/libgvom_hip.so", "lib/libgvom_hip_test.so"], capture_output=True, text=True, timeout=900)
+    build = subprocess.run(["make", "-j6", "-C", pkg, "lib/libgvom_hip.so", "lib/libgvom_hip_test.so"], capture_output=True, text=True, timeout=900)
     assert build.returncode == 0, build.stderr[-2000:]
     prod, test = os.path.join(pkg, "lib", "libgvom_hip.so"), os.path.join(pkg, "lib", "libgvom_hip_test.so")
     blob_p, blob_t = open(prod, "rb").read(), open(test, "rb").read()

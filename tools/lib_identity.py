@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Identity of the library a measurement was taken on: sha256 of g-vom_amd/lib/libgvom_hip.so, sha256 of the sources it is
-built from (csrc/*.hip, csrc/*.h, include/gvom_hip.h, the Makefile -- in that order, so that anyone can recompute it from a
+built from (SOURCES below, in that order, so that anyone can recompute it from a
 commit), and the git commit.  hipcc's output is reproducible: the same sources give the same library bytes.
 The GPU box has no .git: `make -C g-vom_amd stamp` (run here, before gpurun) leaves the commit in g-vom_amd/lib/GIT_HEAD.
 
@@ -15,7 +15,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "g-vom_amd")
-SOURCES = ["csrc/gvom_kernels.hip", "csrc/gvom_capi.hip", "csrc/gvom_comm.hip", "csrc/gvom_internal.h", "../include/gvom_hip.h", "Makefile"]
+SOURCES = ["csrc/gvom_trace.hip", "csrc/gvom_fuse.hip", "csrc/gvom_map2d.hip", "csrc/gvom_stats.hip", "csrc/gvom_capi.hip", "csrc/gvom_comm.hip",
+           "csrc/gvom_device.h", "csrc/gvom_internal.h", "../include/gvom_hip.h", "../include/gvom_hip_test.h", "Makefile"]
 
 
 def sha256_file(path):
