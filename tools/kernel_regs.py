@@ -8,12 +8,23 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 
 
 def kernels(lib):
+    """{mangled kernel name: {"vgpr", "sgpr", "scratch", "lds"}} over EVERY code object of the library (one offload bundle per
+    translation unit, behind one another in .hip_fatbin)."""
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    notes = ""
     with tempfile.TemporaryDirectory() as t:
-        fat, co = os.path.join(t, "fat.bin"), os.path.join(t, "dev.co")
+        fat = os.path.join(t, "fat.bin")
         subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, lib, os.path.join(t, "discard.so")])
-        subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
-                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
-        notes = subprocess.check_output([os.path.join(LLVM, "llvm-readelf"), "--notes", co]).decode()
+        blob = open(fat, "rb").read()
+        starts = [i for i in range(len(blob)) if blob.startswith(magic, i)]
+        for n, a in enumerate(starts):
+            part, co = os.path.join(t, "part%d.bin" % n), os.path.join(t, "dev%d.co" % n)
+            with open(part, "wb") as f:
+                f.write(blob[a:starts[n + 1] if n + 1 < len(starts) else len(blob)])
+            subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + part,
+                                   "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
+            if os.path.getsize(co):
+                notes += subprocess.check_output([os.path.join(LLVM, "llvm-readelf"), "--notes", co]).decode() + "\n"
     out, cur = {}, None
     keys = {".private_segment_fixed_size": "scratch", ".vgpr_count": "vgpr", ".sgpr_count": "sgpr", ".group_segment_fixed_size": "lds"}
     block = {}
