@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Runs tests/test_hip_parity.py::_fuzz_case for a range of seeds on the GPU box and reports the
-seeds whose HIP records differ from the oracle.  Usage: tests/fuzz/fuzz_many.py <first> <count> [stats] [ilv=K] [p2] [eager] [dirsort]
+seeds whose HIP records differ from the oracle.  Usage: tests/fuzz/fuzz_many.py <first> <count> [stats|ondemand] [ilv=K] [p2] [eager] [dirsort]
 (ilv=K: the HIP mapper traces with the sub-cloud interleave forced to K -- a permutation of who traces which return; it applies
 to the scans whose length K divides; p2: grid sizes snapped to powers of two, z_size <= xy_size -- the grids on which k_trace takes
 its mask-wrap and no-window-test step bodies)"""
@@ -20,7 +20,9 @@ ilv = [int(a[4:]) for a in sys.argv[3:] if a.startswith("ilv=")]
 
 
 def hip_mapper(*p):
-    g = gvom.Gvom(*p, voxel_statistics=True) if stats else gvom.Gvom(*p)
+    # (default: no statistics at any step -- the north-star path, eager fusion included; "ondemand": the class default, statistics for as
+    # long as the recorded debug reads ask for them)
+    g = gvom.Gvom(*p, voxel_statistics=True) if stats else (gvom.Gvom(*p) if "ondemand" in sys.argv[3:] else gvom.Gvom(*p, voxel_statistics=False))
     if ilv:
         g.set_tuning("interleave", ilv[0])
     for a_ in sys.argv[3:]:

@@ -41,7 +41,8 @@ for seed in range(first, first + count):
     try:
         with contextlib.redirect_stdout(io.StringIO()):
             want = scenarios.run_and_record(oracle.OracleGvom, sc, record_debug=(seed % 4 == 0))
-            got = scenarios.run_and_record(gvom.Gvom, sc, record_debug=(seed % 4 == 0))
+            # (every third case through the class default -- statistics on demand --, the others without statistics at any step)
+            got = scenarios.run_and_record(gvom.Gvom if seed % 3 == 0 else (lambda *p: gvom.Gvom(*p, voxel_statistics=False)), sc, record_debug=(seed % 4 == 0))
         compare_records(got, want, float_tol=1e-5)
     except AssertionError as e:
         bad.append((seed, str(e)[:100]))

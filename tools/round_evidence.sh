@@ -2,11 +2,11 @@
 # The evidence set of a round, in parts that each fit one gpurun call (<= 20 min).  Outputs under gpurun_out/; copy what is to be
 # judged into profiles/.  Usage: tools/round_evidence.sh <round tag, e.g. r5> <part>
 #   suite     pytest -m gpu, tools/bench_round.sh (every bench line), tools/sim_shard_cost.py 1,2,4,8
-#   profiles  tools/profile_round.sh for m256 c3 c4 (rocprofv3 kernel stats + PMC traffic passes) + SQ passes for m256 and c4
+#   profiles  tools/profile_round.sh for m256 c1 c3 c4 (rocprofv3 kernel stats + PMC traffic passes, each with the library's identity) + SQ passes for m256 and c4
 #   c5        the same profile set for c5 (minutes of rocprofv3 passes of its own)
 #   soak      tools/soak.py on m256 / c2 / c4 and the whole GPU suite twice more
 #   campaigns tools/campaigns.sh eager many p2 mid
-TAG=${1:-r5}; PART=${2:-suite}
+TAG=${1:-r6}; PART=${2:-suite}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 O=gpurun_out/${TAG}_final; mkdir -p $O gpurun_out/${TAG}_profiles
@@ -24,7 +24,7 @@ case $PART in
     timeout -k 10 900 python3 -m pytest tests -x -q -m gpu > $O/gpu_suite.txt 2>&1; echo "suite rc=$?"; tail -3 $O/gpu_suite.txt
     bash tools/bench_round.sh $TAG > $O/bench_round.log 2>&1; tail -12 $O/bench_round.log
     python3 tools/sim_shard_cost.py 1,2,4,8 > $O/shard_cost.txt 2>&1; grep "^world .:" $O/shard_cost.txt ;;
-  profiles) bash tools/profile_round.sh $TAG m256 c3 c4 2>&1 | tail -40; sq m256 c4; ls -la gpurun_out/${TAG}_profiles ;;
+  profiles) bash tools/profile_round.sh $TAG m256 c1 c3 c4 2>&1 | tail -50; sq m256 c4; ls -la gpurun_out/${TAG}_profiles ;;
   c5) bash tools/profile_round.sh $TAG c5 2>&1 | tail -12; ls -la gpurun_out/${TAG}_profiles ;;
   soak)
     : > gpurun_out/${TAG}_soak.txt
