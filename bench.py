@@ -768,8 +768,9 @@ def run_single(args):
         st = run_with_statistics(hip, name, min(steps, 200), min(args.warmup, 40), poses)
         out["value_with_statistics"] = st["value"]
         out["statistics"] = dict(st, extra_ms_per_step=st["ms_per_step"] - res["ms_per_step"],
-                                 note="voxel_statistics=True (GVOM_VOXEL_STATISTICS=1): the per-voxel mean / covariance path "
-                                      "of the reference, off by default here because it is not on the north-star path")
+                                 note="voxel_statistics=True: the per-voxel mean / covariance path of the reference at EVERY step (the class "
+                                      "default computes it on demand: for as long as make_debug_voxel_map is being called, as the "
+                                      "unchanged node does every tick; the headline steps are those of a caller that does not ask)")
     if not args.no_extra and name == "m256":
         out["configs"] = {}
         # (c4 / c5: BASELINE's multi-GPU configs on this ONE GPU, short device-resident runs -- their paced 20 Hz streams and

@@ -315,6 +315,9 @@ def run(args):
             "cpu_baseline": {"see": "the N = 1 line of the same bench.py (cpu_baseline: the CPU oracle on this box's host cores, timed on "
                                     "rank 0 at N = 1 only, as the contract asks); BENCH_rNN.json / profiles/r4_bench_m256.json"},
             "peer_transport_rank0": rccl.peer_stats() if rccl.transport == "peer" else None,
+            # what RCCL was actually asked to move by rank 0 since the communicator was made (ncclSend + ncclRecv calls, their bytes,
+            # groups closed, ncclAllGather calls): non-zero on every N > 1 run over RCCL -- the data path has executed
+            "rccl_calls_rank0": rccl.wire_stats(),
             "map_hz": steps / med, "blocks": len(blocks),
             "ms_per_step_min": min(blocks) / steps * 1e3, "ms_per_step_max": max(blocks) / steps * 1e3,
             "stage_ms_rank0": stage_ms, "stream": stream,
