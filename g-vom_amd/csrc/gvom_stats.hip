@@ -468,7 +468,11 @@ hipError_t gvom_launch_fuse_stats(hipStream_t s, const FuseParams &P, const Fuse
 {
     const uint32_t ntiles = (uint32_t)(P.sy_hi - P.sy_lo) * P.zs * P.nseg;
     if (ntiles == 0) return hipSuccess;
-    unsigned blocks = (ntiles + 255u) / 256u;               // a wave per 64 tiles, four waves per workgroup
+    // a wave per 64 tiles on big grids, fewer tiles per wave on small ones (at least ~4096 waves wherever there are that many
+    // tiles: c1's 2,048 tiles in 32 waves left the chip empty), four waves per workgroup
+    unsigned per_wave = ntiles / 4096u;
+    per_wave = per_wave < 1u ? 1u : (per_wave > 64u ? 64u : per_wave);
+    unsigned blocks = ((ntiles + per_wave - 1u) / per_wave + 3u) / 4u;
     if (blocks > 8192) blocks = 8192;                       // (beyond 2 M tiles a wave takes further passes of 64)
     if (descs_dev) hipLaunchKernelGGL(k_fuse_stats<true>, dim3(blocks), dim3(256), 0, s, P, KD, descs_dev, fstate, ftags, fmetrics);
     else hipLaunchKernelGGL(k_fuse_stats<false>, dim3(blocks), dim3(256), 0, s, P, KD, descs_dev, fstate, ftags, fmetrics);
