@@ -131,6 +131,39 @@ def test_sharded_map_at_full_size(cfg, worlds, scans, buffer, transport):
     assert "shard_big: 0 mismatches" in out.stdout
 
 
+def test_a_rank_that_gives_up_ends_the_other_ranks_waits_at_once(monkeypatch):
+    """gvom_comm_abort (RcclComm.abort): a rank whose CALLER fails outside the library -- here rank 1's body raises between two
+    steps -- marks the communicator broken; rank 0, already waiting for it inside the next scan's count exchange, gets an error
+    naming the rank within milliseconds instead of after GVOM_COMM_TIMEOUT_S.  Thread-ranks over the RCCL loopback transport
+    (tests/shard_threads.run_ranks aborts for a failed body)."""
+    import time
+    import synth
+    from shard_threads import run_ranks
+    monkeypatch.setenv("GVOM_COMM_TIMEOUT_S", "120")
+    params = (0.2, 0.2, 64, 32, 2, 1.0, 0.5, 0.5, 0.3, 2.0, 4.0, 1.0, 1, 1)
+    scene = synth.make_scene(2, extent=5.5)
+    share = synth.lidar_scan(scene, beams=16, azimuths=512, sensor=(0.0, 0.0, 0.0))
+    seen = {}
+
+    def body(r, sh):
+        sh.process_pointcloud(share, (0.0, 0.0, 0.0))
+        assert sh.combine_maps() is not None
+        if r == 1:
+            raise RuntimeError("rank 1 gives up")
+        t0 = time.perf_counter()
+        try:
+            sh.process_pointcloud(share, (0.1, 0.0, 0.0))        # collective: rank 1 never comes
+        finally:
+            seen["waited_s"] = time.perf_counter() - t0
+        return True
+
+    with pytest.raises(Exception) as err:
+        with contextlib.redirect_stdout(io.StringIO()):
+            run_ranks(2, params, body, transport="loopback")
+    assert "rank 1 gives up" in str(err.value)                   # the first failure is the one reported
+    assert seen["waited_s"] < 10.0, seen
+
+
 def test_sharded_product_path_over_rccl_with_one_rank():
     """The product path end to end -- ShardedGvom + RcclComm (ncclCommInitRank, the shared-memory count
     exchange, grouped send/recv with no peers, in-place ncclAllGather) -- with the one rank a one-GPU box
