@@ -147,6 +147,11 @@ struct gvom_handle {
     int spec_nxt = 0, spec_slot = 0, spec_blocks = 0;
     uint32_t spec_epoch = 0;
     int64_t spec_origin[3] = {0, 0, 0};
+    // ... with per-voxel statistics: the speculative fusion's statistics half (k_fuse_stats on the statistics stream, behind the
+    // scan's own k_stats / k_stats_gather) is enqueued with the scan too; what it needs of eager_launch's frame is kept here
+    bool spec_has_metrics = false;                      // the speculative fused map will carry merged statistics
+    FuseParams spec_FP;
+    FuseDescs spec_KD;
     // DIRECTIONAL ORDER of unordered clouds (k_dirbin_*, ScanParams::perm): "dirsort" 1 always, -1 never, 0 automatic -- when the
     // layout probe found no spatial order in the previous cloud of this length (BASELINE c1's 50,000 random points: k_trace 65 -> 16 us)
     int tune_dirsort = 0;
@@ -588,7 +593,7 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, b
     CK(hipMalloc((void **)&h->blockcounts, (size_t)(h->fuse_blocks > 0 ? h->fuse_blocks : 1) * 4));
     CK(hipMemsetAsync(h->blockcounts, 0, (size_t)(h->fuse_blocks > 0 ? h->fuse_blocks : 1) * 4, h->stream));
     h->cnt_blocks = h->fuse_blocks;
-    if (!sharded && params->buffer_size == 1 && (!h->stats || h->stats_auto) && xy % 16 == 0 && zs >= 4) {       // eager fusion possible
+    if (!sharded && params->buffer_size == 1 && xy % 16 == 0 && zs >= 4) {       // eager fusion possible (with or without statistics)
         CK(hipMalloc((void **)&h->blockcounts2, (size_t)(h->fuse_blocks > 0 ? h->fuse_blocks : 1) * 4));
         CK(hipMemsetAsync(h->blockcounts2, 0, (size_t)(h->fuse_blocks > 0 ? h->fuse_blocks : 1) * 4, h->stream));
         CK(hipMalloc((void **)&h->hmaps2, h->cells2d * 24));
@@ -811,6 +816,21 @@ int eager_launch(gvom_handle *h, const ScanParams &P, Slot &st, const int64_t or
     if ((rc = ensure(h, F.rows, row_cap * 16))) return rc;
     F.valid = false;                                       // (the spare buffer: nobody reads it as a map)
     FP.epoch = ++h->epoch;
+    // the previous k_fuse_stats reads -- as its "previous map", or as a dropped speculation's target -- the fused buffer this kernel
+    // writes (the wait sits between k_trace and this kernel: the trace runs beside that merge)
+    if (h->fs_pending) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_fsdone, 0));
+    h->spec_has_metrics = false;
+    if (h->stats) {
+        // the statistics half of this speculative fusion (enqueued by scan_launch behind the scan's own statistics): sources = the
+        // staging slot (same frame: no shift) and the previous map if it carries statistics of its own
+        if ((rc = ensure(h, F.metrics, row_cap * 40))) return rc;
+        h->spec_FP = FP;
+        memset(&h->spec_KD, 0, sizeof h->spec_KD);
+        MapDesc &sd = h->spec_KD.d[0];
+        sd.state = st.state; sd.rows = (const uint4 *)st.crows.p; sd.epoch = st.epoch; sd.tags = st.tags; sd.metrics = st.metrics.p;
+        if (prev) { h->spec_KD.d[1] = pd; h->spec_KD.d[1].metrics = prev->has_metrics ? prev->metrics.p : nullptr; }
+        h->spec_has_metrics = true;
+    }
     HIPCHK(h, gvom_launch_encfuse(h->stream, P, FP, pd, h->hit, h->total, h->mh, st.state, (uint4 *)st.crows.p, st.tags,
                                   F.state, (uint4 *)F.rows.p, F.tags, h->blockcounts2, h->hmaps2, h->hmaps2 + p.xy_size,
                                   h->counters, (unsigned long long *)h->counters_host_dev, seq));
@@ -868,7 +888,11 @@ int scan_launch(gvom_handle *h, std::unique_lock<std::mutex> &lk, const void *de
         // previous scan's own statistics are NOT among them and keep running beside this scan's trace
         const uint32_t prev_par = (h->stats_scan + 1u) & 1u;
         if (!h->stats_prev_committed && h->s_pending) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_sdone, 0));
-        else if (h->before_valid[prev_par]) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_before[prev_par], 0));
+        else if (h->before_valid[prev_par]) {
+            // (normally long complete: then no wait packet goes in front of the trace)
+            if (hipEventQuery(h->ev_before[prev_par]) == hipSuccess) h->before_valid[prev_par] = false;
+            else { (void)hipGetLastError(); HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_before[prev_par], 0)); }
+        }
         HIPCHK(h, hipMemsetAsync(st.rowvox.p, 0xFF, st.rowvox.bytes, h->stream));   // no row claimed yet
     }
     ShardExchange X;
@@ -985,7 +1009,7 @@ int scan_launch(gvom_handle *h, std::unique_lock<std::mutex> &lk, const void *de
         return GVOM_OK;
     }
     // one-slot rings: encode + fuse in one pass, speculating that combine_maps comes next (see gvom_handle::hmaps2)
-    const bool eager = h->hmaps2 && !h->stats && h->tune_eager != 0 && (h->tune_eager == 1 || h->eager_waste < 3) && !gvom_diag_env("GVOM_TRACE_DEBUG");
+    const bool eager = h->hmaps2 && h->tune_eager != 0 && (h->tune_eager == 1 || h->eager_waste < 3) && !gvom_diag_env("GVOM_TRACE_DEBUG");
     h->last_scan_spec = false;
     if (eager) {
         if ((rc = eager_launch(h, P, st, origin, seq))) { scan_abort(h); return rc; }
@@ -1001,6 +1025,14 @@ int scan_launch(gvom_handle *h, std::unique_lock<std::mutex> &lk, const void *de
     }
     if (h->profiling) { HIPCHK(h, hipEventRecord(h->ev[2], h->stream)); h->ev_scan = true; }
     if (h->stats && (rc = enqueue_scan_stats(h, P, dtype, st, n, n, nullptr, 0))) return rc;
+    if (eager && h->spec_has_metrics) {
+        // behind k_stats / k_stats_gather on the statistics stream (which waited for k_encfuse): the merge of the speculative fusion
+        Fused &F = h->fused[h->spec_nxt];
+        HIPCHK(h, gvom_launch_fuse_stats(h->stream_s, h->spec_FP, h->spec_KD, nullptr, F.state, F.tags, (float *)F.metrics.p));
+        HIPCHK(h, hipEventRecord(h->ev_fsdone, h->stream_s));
+        HIPCHK(h, hipEventRecord(h->ev_sdone, h->stream_s));
+        h->s_pending = h->fs_pending = true;
+    }
     HT(h, 0, t0);                                        // scan: launches
     // Wait only for k_trace: k_encode's first thread publishes {seq, any-in-grid} to host-mapped
     // memory.  The caller gets control back while k_encode still runs; everything it can do next
@@ -1170,6 +1202,8 @@ int fuse_impl(gvom_handle *h, hipStream_t on = nullptr)
     if (!last.filled) return GVOM_EMPTY_BUFFER;                        // gvom.py:179-181
     // before any map descriptor below copies an epoch
     if (h->epoch >= 0xFFFFFF00u) { int rc0 = renumber_epochs(h); if (rc0) return rc0; }
+    // statistics on demand: three combines in a row that nobody read the statistics of -> the scans stop computing them
+    if (h->stats_auto && h->stats && ++h->stats_idle > 3) h->stats = false;
     if (h->spec_valid && !on && h->spec_slot == h->ring[h->last_buffer_index] && h->spec_nxt == (h->has_combined ? 1 - h->cur : 0)) {
         // eager fusion: k_encfuse has (or will have, in stream order) written exactly what this call would compute -- the one
         // slot, the previous map and the ego are what they were when the scan launched it.  Adopt: swap the spares in.
@@ -1177,7 +1211,7 @@ int fuse_impl(gvom_handle *h, hipStream_t on = nullptr)
         S.origin[0] = h->spec_origin[0]; S.origin[1] = h->spec_origin[1]; S.origin[2] = h->spec_origin[2];
         S.epoch = h->spec_epoch;
         S.valid = true;
-        S.has_metrics = false;
+        S.has_metrics = h->spec_has_metrics;               // (its k_fuse_stats runs, or has run, on the statistics stream: readers join it)
         std::swap(h->hmaps, h->hmaps2);
         h->height = h->hmaps; h->inferred = h->hmaps + h->prm.xy_size;
         std::swap(h->blockcounts, h->blockcounts2);
@@ -1206,8 +1240,6 @@ int fuse_impl(gvom_handle *h, hipStream_t on = nullptr)
     fill_fuse_frame(h, F.origin, P);
     int ns = 0;
     bool all_codes = true;
-    // statistics on demand: three combines in a row that nobody read the statistics of -> the scans stop computing them
-    if (h->stats_auto && h->stats && ++h->stats_idle > 3) h->stats = false;
     // this fusion merges the statistics iff every slot of the ring carries its own; a previous map WITHOUT them (the
     // statistics were switched on again after a pause) contributes none (k_fuse_stats skips a source without metrics): the
     // statistics restart from the ring

@@ -110,10 +110,12 @@ def test_voxel_statistics_run_on_demand(gvom_mod):
         a, w, n = step(k, True)
         assert n is None and a is not None and w is not None
         same_cloud(a, w, True)
-    assert auto.get_tuning("eager_adopted") == 0                # (statistics scans are encoded, fused and merged the long way)
+    # (one-slot ring: with or without statistics the scan's second kernel is the eager encode-and-fuse, and the statistics' own
+    # merge -- k_fuse_stats -- is enqueued with the scan as well; the combines adopt both)
+    assert auto.get_tuning("eager_adopted") == 3 and always.get_tuning("eager_adopted") == 3
     for k in range(3, 9):                                       # nobody asks: off after three unread combines
         step(k, False)
-    assert auto.get_tuning("eager_adopted") >= 2 and always.get_tuning("eager_adopted") == 0 and never.get_tuning("eager_adopted") == 9
+    assert auto.get_tuning("eager_adopted") == 9 and always.get_tuning("eager_adopted") == 9 and never.get_tuning("eager_adopted") == 9
     a, w, n = step(9, True)
     assert a is None and w is not None and n is None            # the read that switches them on again finds nothing
     a, w, n = step(10, True)                                    # one-slot ring: replaced by the next scan
