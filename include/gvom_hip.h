@@ -399,7 +399,8 @@ int gvom_host_timing(gvom_t *h, double us[8]);
  * one-wave probe kernel in front of the trace looks for that structure (64 sampled returns per candidate K <= 4) on the second
  * cloud of a length and every 32nd after it, and the following clouds of that length are traced accordingly; clouds whose
  * length changes from scan to scan are not looked at for sub-clouds (they are probed every 8th scan for the "dirsort" verdict only); 1: off.  Only WHO traces which return changes, never a result.
- * "eager": the EAGER FUSION of one-slot rings (buffer_size 1, unsharded, no statistics, xy_size % 16 == 0).  The scan launches
+ * "eager": the EAGER FUSION of one-slot rings (buffer_size 1, unsharded, xy_size % 16 == 0; with per-voxel statistics their merge is
+ * enqueued with the scan as well).  The scan launches
  * ONE kernel behind the trace that encodes the ring slot AND fuses it with the previous fused map (the work of the scan's
  * encode pass and of the next combine's fusion, in one pass over the scan's accumulators), into spare buffers -- speculating
  * that the next call is gvom_combine_maps*, the reference node's pattern (gvom_ros.py:82-115: one combine per scan).  That
