@@ -233,6 +233,7 @@ struct gvom_handle {
     // finds no data and switches them ON again for the scans that follow
     bool stats_auto = false;
     int stats_idle = 0;                                 // combines since the statistics were last read
+    bool stats_release = false;                         // they have just been switched off: their buffers go at the end of this combine
     int acc_pad = 7, sxq = 0;                           // accumulator row pitch (lines) = ceil(xy/4) + acc_pad
     bool profiling = false;
     hipEvent_t ev[8] = {nullptr};
@@ -641,7 +642,24 @@ int create_impl(const gvom_params *params, int device_id, int rank, int world, b
 static void stats_demand(gvom_handle *h)
 {
     h->stats_idle = 0;
-    if (h->stats_auto && !h->stats) h->stats = true;
+    if (h->stats_auto && !h->stats) { h->stats = true; h->stats_release = false; }
+}
+
+// Statistics on demand, switched off: their buffers (the slots' metrics / own-voxel moments / row tables, the fused maps' metrics,
+// the kept clouds -- 40 bytes per voxel and fused map alone: 2.7 GB on the 512^2 x 128 grid) go back to the allocator; a later
+// demand allocates them again.  Everything that can still read or write them runs on the statistics stream: waited for first
+// (a scan of another thread whose trace is still in flight writes its slot's tables: the release then waits for a later combine).
+static void release_statistics_buffers(gvom_handle *h)
+{
+    h->stats_release = false;
+    (void)hipStreamSynchronize(h->stream_s);
+    h->s_pending = h->fs_pending = false;
+    h->before_valid[0] = h->before_valid[1] = false;
+    auto fb = [](Buf &b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; };
+    for (auto &sl : h->slots) { fb(sl.metrics); fb(sl.base); fb(sl.rowvox); sl.has_metrics = false; }
+    for (int k = 0; k < 2; ++k) { fb(h->fused[k].metrics); h->fused[k].has_metrics = false; }
+    fb(h->world_pts[0]); fb(h->world_pts[1]);
+    h->spec_has_metrics = false;
 }
 
 // A failed scan must not leak into the next one: k_trace may already have added to the dense
@@ -1203,7 +1221,7 @@ int fuse_impl(gvom_handle *h, hipStream_t on = nullptr)
     // before any map descriptor below copies an epoch
     if (h->epoch >= 0xFFFFFF00u) { int rc0 = renumber_epochs(h); if (rc0) return rc0; }
     // statistics on demand: three combines in a row that nobody read the statistics of -> the scans stop computing them
-    if (h->stats_auto && h->stats && ++h->stats_idle > 3) h->stats = false;
+    if (h->stats_auto && h->stats && ++h->stats_idle > 3) { h->stats = false; h->stats_release = true; }
     if (h->spec_valid && !on && h->spec_slot == h->ring[h->last_buffer_index] && h->spec_nxt == (h->has_combined ? 1 - h->cur : 0)) {
         // eager fusion: k_encfuse has (or will have, in stream order) written exactly what this call would compute -- the one
         // slot, the previous map and the ego are what they were when the scan launched it.  Adopt: swap the spares in.
@@ -1224,6 +1242,7 @@ int fuse_impl(gvom_handle *h, hipStream_t on = nullptr)
         ++h->eager_stat[0];
         h->last_scan_spec = false; h->fresh_scan = false;
         h->stage_ms[3] = 0.0f;                             // (the fusion's time is inside the scan's second kernel)
+        if (h->stats_release && !h->scan_inflight) release_statistics_buffers(h);
         return GVOM_OK;
     }
     if (h->spec_valid) { h->spec_valid = false; ++h->eager_stat[1]; }
@@ -1317,6 +1336,7 @@ int fuse_impl(gvom_handle *h, hipStream_t on = nullptr)
     h->cur = nxt;
     h->has_combined = true;
     h->maps_valid = false;
+    if (h->stats_release && !h->scan_inflight) release_statistics_buffers(h);   // (this fusion merged no statistics: fstats was false)
     return GVOM_OK;
 }
 
