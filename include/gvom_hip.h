@@ -81,7 +81,8 @@ typedef struct gvom_params {
                                         * WHILE SOMEBODY READS IT: it starts on -- the reference computes it in every scan and
                                         * combine and its node reads it every tick (gvom_ros.py:171) -- goes off when three
                                         * combines in a row passed without a call of gvom_debug_voxel_map / _eigen /
-                                        * gvom_gather_metrics, and comes back with the next such call: that call returns
+                                        * gvom_gather_metrics (its buffers go back to the allocator then: 40 bytes per voxel and
+                                        * fused map alone), and comes back with the next such call: that call returns
                                         * GVOM_NO_DATA, the scans that follow carry statistics again, and the fused map has them
                                         * once every ring slot does (they then restart from the ring: what the map had merged
                                         * before the pause is not in them).  g-vom_amd/gvom.py's default. */
