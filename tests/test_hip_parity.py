@@ -209,6 +209,32 @@ def test_tile_epoch_renumbering_before_the_counter_wraps(gvom_mod, site):
             assert np.array_equal(np.asarray(wd[j]), gd[j]), (k, j)
 
 
+def test_returned_arrays_in_c_order_and_the_reference_objects_attributes(gvom_mod):
+    """combine_maps returns Fortran-ordered VIEWS of the pinned memory the GPU wrote (the node flattens them with order='F',
+    gvom_ros.py:141-162: a no-copy reshape); the reference returns C-contiguous copies (gvom.py:352-354).  Gvom(..., c_order=True)
+    returns those: same values, dtypes and [x, y] indexing, C-contiguous, their own memory.  And the reference object's remaining
+    attributes (gvom.py:54, 65-67, 94, 96) exist on a live mapper."""
+    import threading
+    params = (0.4, 0.2, 48, 16, 2, 0.5, 0.5, 0.5, 0.3, 2.0, 4.0, 1.0, 1, 1)
+    rng = np.random.default_rng(3)
+    f, c = gvom_mod.Gvom(*params), gvom_mod.Gvom(*params, c_order=True)
+    for k in range(3):
+        ego = (0.5 * k, -0.3 * k, 0.02 * k)
+        pc = np.stack([rng.uniform(-8, 8, 5000) + ego[0], rng.uniform(-8, 8, 5000) + ego[1], rng.normal(-0.8, 0.3, 5000)], 1)
+        f.process_pointcloud(pc, ego); c.process_pointcloud(pc, ego)
+        a, b = f.combine_maps(), c.combine_maps()
+        for x, y in zip(a, b):
+            assert x.dtype == y.dtype and x.shape == y.shape and np.array_equal(x, y)
+        for m in b[1:]:
+            assert m.flags["C_CONTIGUOUS"] and m.flags["OWNDATA"]
+        for m in a[1:]:
+            assert m.flags["F_CONTIGUOUS"] and np.shares_memory(np.reshape(m, -1, order="F"), m)     # the node's flatten: a view
+        assert np.array_equal(np.reshape(a[1], -1, order="F"), np.reshape(b[1], -1, order="F"))
+    assert len(f.semaphores) == params[4] and all(isinstance(sm, type(threading.Semaphore())) for sm in f.semaphores)
+    assert isinstance(f.ego_semaphore, type(threading.Semaphore())) and f.blocks == -(-f.voxel_count // f.threads_per_block)
+    assert np.array_equal(f.metrics.copy_to_host(), np.array([[3, 2]]))
+
+
 def test_asynchronous_combine_overlapped_with_the_next_scan(gvom_mod):
     """combine_maps_async(): the next scan is processed while the maps of the pending combine are still
     being computed / stored (k_map2d on the second stream).  Every result equals the synchronous
