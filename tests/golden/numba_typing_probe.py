@@ -73,7 +73,7 @@ def py_func_of(disp):
     raise AttributeError("no python function on %r" % (disp,))
 
 
-def report(numba, name, disp, argtypes, label, src_lines, first_line):
+def report(numba, name, disp, argtypes, label, first_line):
     from numba.core import ir
     func_ir, typemap, calltypes = infer(numba, py_func_of(disp), argtypes)
     print("## %s, %s" % (name, label))
@@ -108,8 +108,8 @@ def report(numba, name, disp, argtypes, label, src_lines, first_line):
                 if key in seen:
                     continue
                 seen.add(key)
-                text = src_lines[ln - first_line].strip() if 0 <= ln - first_line < len(src_lines) else ""
-                print("  :%d  %-62s -> %-10s | %s" % (ln, what[:62], ty, text[:70]))
+                # (the reference's source text is NOT reproduced: the line number cites it)
+                print("  :%d  %-62s -> %s" % (ln, what[:62], ty))
     print()
 
 
@@ -146,7 +146,7 @@ def main():
                 else:
                     args.append(types.float64)
             print("#   argument types: %s" % ", ".join("%s: %s" % (a, b) for a, b in zip(sig, args)))
-            report(numba, name, disp, tuple(args), label, src, first)
+            report(numba, name, disp, tuple(args), label, first)
 
 
 SUMMARY = """
