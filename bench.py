@@ -655,6 +655,9 @@ def roofline_of(alg, stages, profiled="m256", xy=None, lib_sha=None):
         valu = {"insts_per_launch": sq["SQ_INSTS_VALU"], "issue_rate_per_s": VALU_ISSUE_RATE,
                 "bound_us": bound_us, "frac": bound_us / (ms[dom] * 1e3),
                 "measured_quad_cycles_per_inst": (sq.get("SQ_ACTIVE_INST_VALU") or 0) / sq["SQ_INSTS_VALU"],
+                # the same ceiling at the rate this kernel's instruction mix is MEASURED to issue at (SQ_ACTIVE_INST_VALU quad-cycles per
+                # instruction; 1.0 = 4 cycles, twice the nominal 2): what the kernel is actually up against
+                "frac_at_measured_issue_rate": (bound_us / (ms[dom] * 1e3)) * 2.0 * ((sq.get("SQ_ACTIVE_INST_VALU") or 0) / sq["SQ_INSTS_VALU"]),
                 "note": "frac = the kernel's VALU wave-instructions / 1.2288e12 per s / its measured time; the SQ "
                         "counters of this kernel show one quad-cycle (4 cycles) of SQ_ACTIVE_INST_VALU per "
                         "instruction, i.e. half that rate is what the integer / compare mix sustains", "source": sq_src}
