@@ -138,7 +138,9 @@ def test_hip_voxel_statistics_match_oracle_c2(gvom_mod):
     sc = {"params": params, "steps": steps}
     want = scenarios.run_and_record(lambda *p: oracle.OracleGvom(*p, voxel_statistics=True), sc)
     got = scenarios.run_and_record(lambda *p: gvom_mod.Gvom(*p, voxel_statistics=True), sc)
-    assert compare_records(got, want, float_tol=1e-5, stats_rtol=1e-4, stats_atol=2e-5) > 20
+    # (measured, tools/stats_deviation.py c2: max |d| 3.7e-8 over 175,000 eigenvalue entries, 99.9 % of them below 1e-16 -- held to the
+    # north star's 1e-5 relative, 1e-7 absolute)
+    assert compare_records(got, want, float_tol=1e-5, stats_rtol=1e-5, stats_atol=1e-7) > 20
 
 
 def test_reference_statistics_attributes(gvom_mod):
