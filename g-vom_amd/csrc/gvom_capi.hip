@@ -150,6 +150,8 @@ struct gvom_handle {
     // ... with per-voxel statistics: the speculative fusion's statistics half (k_fuse_stats on the statistics stream, behind the
     // scan's own k_stats / k_stats_gather) is enqueued with the scan too; what it needs of eager_launch's frame is kept here
     bool spec_has_metrics = false;                      // the speculative fused map will carry merged statistics
+    Buf flink[2];                                       // per fused buffer: link[fused row] = row in the previous map (k_encfuse -> k_fuse_stats)
+    bool fs_reads[2] = {false, false};                  // the pending k_fuse_stats reads fused[i]'s states / tile tags
     FuseParams spec_FP;
     FuseDescs spec_KD;
     // DIRECTIONAL ORDER of unordered clouds (k_dirbin_*, ScanParams::perm): "dirsort" 1 always, -1 never, 0 automatic -- when the
@@ -658,7 +660,7 @@ static void release_statistics_buffers(gvom_handle *h)
     auto fb = [](Buf &b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; };
     for (auto &sl : h->slots) { fb(sl.metrics); fb(sl.base); fb(sl.rowvox); sl.has_metrics = false; }
     for (int k = 0; k < 2; ++k) { fb(h->fused[k].metrics); h->fused[k].has_metrics = false; }
-    fb(h->world_pts[0]); fb(h->world_pts[1]);
+    fb(h->world_pts[0]); fb(h->world_pts[1]); fb(h->flink[0]); fb(h->flink[1]);
     h->spec_has_metrics = false;
 }
 
@@ -834,11 +836,15 @@ int eager_launch(gvom_handle *h, const ScanParams &P, Slot &st, const int64_t or
     if ((rc = ensure(h, F.rows, row_cap * 16))) return rc;
     F.valid = false;                                       // (the spare buffer: nobody reads it as a map)
     FP.epoch = ++h->epoch;
-    // the previous k_fuse_stats reads -- as its "previous map", or as a dropped speculation's target -- the fused buffer this kernel
-    // writes (the wait sits between k_trace and this kernel: the trace runs beside that merge)
-    if (h->fs_pending) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_fsdone, 0));
+    // a pending k_fuse_stats that reads THIS buffer's states / tile tags -- the merge of a fusion through k_fuse1 / k_fuse4 (its
+    // "previous map"), or of a dropped speculation (its target) -- must be done before this kernel rewrites them (the wait sits
+    // between k_trace and this kernel).  The merge of an ADOPTED speculation does not: it reads its previous map through a link table.
+    if (h->fs_pending && h->fs_reads[nxt]) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_fsdone, 0));
     h->spec_has_metrics = false;
+    int32_t *flink = nullptr;
     if (h->stats) {
+        if ((rc = ensure(h, h->flink[nxt], row_cap * 4))) return rc;
+        flink = (int32_t *)h->flink[nxt].p;
         // the statistics half of this speculative fusion (enqueued by scan_launch behind the scan's own statistics): sources = the
         // staging slot (same frame: no shift) and the previous map if it carries statistics of its own
         if ((rc = ensure(h, F.metrics, row_cap * 40))) return rc;
@@ -846,10 +852,10 @@ int eager_launch(gvom_handle *h, const ScanParams &P, Slot &st, const int64_t or
         memset(&h->spec_KD, 0, sizeof h->spec_KD);
         MapDesc &sd = h->spec_KD.d[0];
         sd.state = st.state; sd.rows = (const uint4 *)st.crows.p; sd.epoch = st.epoch; sd.tags = st.tags; sd.metrics = st.metrics.p;
-        if (prev) { h->spec_KD.d[1] = pd; h->spec_KD.d[1].metrics = prev->has_metrics ? prev->metrics.p : nullptr; }
+        if (prev) { h->spec_KD.d[1] = pd; h->spec_KD.d[1].metrics = prev->has_metrics ? prev->metrics.p : nullptr; h->spec_KD.d[1].link = flink; }
         h->spec_has_metrics = true;
     }
-    HIPCHK(h, gvom_launch_encfuse(h->stream, P, FP, pd, h->hit, h->total, h->mh, st.state, (uint4 *)st.crows.p, st.tags,
+    HIPCHK(h, gvom_launch_encfuse(h->stream, P, FP, pd, flink, h->hit, h->total, h->mh, st.state, (uint4 *)st.crows.p, st.tags,
                                   F.state, (uint4 *)F.rows.p, F.tags, h->blockcounts2, h->hmaps2, h->hmaps2 + p.xy_size,
                                   h->counters, (unsigned long long *)h->counters_host_dev, seq));
     h->spec_valid = true; h->spec_nxt = nxt; h->spec_slot = h->staging; h->spec_blocks = nblocks; h->spec_epoch = FP.epoch;
@@ -1050,6 +1056,7 @@ int scan_launch(gvom_handle *h, std::unique_lock<std::mutex> &lk, const void *de
         HIPCHK(h, hipEventRecord(h->ev_fsdone, h->stream_s));
         HIPCHK(h, hipEventRecord(h->ev_sdone, h->stream_s));
         h->s_pending = h->fs_pending = true;
+        h->fs_reads[h->spec_nxt] = true; h->fs_reads[1 - h->spec_nxt] = false;      // (its previous map through the link table)
     }
     HT(h, 0, t0);                                        // scan: launches
     // Wait only for k_trace: k_encode's first thread publishes {seq, any-in-grid} to host-mapped
@@ -1328,6 +1335,7 @@ int fuse_impl(gvom_handle *h, hipStream_t on = nullptr)
         HIPCHK(h, hipEventRecord(h->ev_fz_s, fs));
         HIPCHK(h, hipStreamWaitEvent(h->stream_s, h->ev_fz_s, 0));
         HIPCHK(h, gvom_launch_fuse_stats(h->stream_s, P, KD, descs_mem, F.state, F.tags, (float *)F.metrics.p));
+        h->fs_reads[0] = h->fs_reads[1] = true;          // (its target's states and, as "previous map", the other buffer's)
         HIPCHK(h, hipEventRecord(h->ev_fsdone, h->stream_s));
         HIPCHK(h, hipEventRecord(h->ev_sdone, h->stream_s));
         h->s_pending = h->fs_pending = true;
@@ -1508,7 +1516,7 @@ VIS void gvom_destroy(gvom_t *h)
     if (h->x_host) hipHostFree(h->x_host);
     for (auto &s : h->slots) { hipFree(s.state); hipFree(s.code16); hipFree(s.tags); fb(s.crows); fb(s.metrics); fb(s.base); fb(s.rowvox); }
     for (auto &f : h->fused) { hipFree(f.state); hipFree(f.tags); fb(f.rows); fb(f.metrics); }
-    fb(h->in_pts); fb(h->world_pts[0]); fb(h->world_pts[1]); fb(h->tl); fb(h->dir_keys); fb(h->dir_perm); hipFree(h->dir_hist);
+    fb(h->in_pts); fb(h->world_pts[0]); fb(h->world_pts[1]); fb(h->flink[0]); fb(h->flink[1]); fb(h->tl); fb(h->dir_keys); fb(h->dir_perm); hipFree(h->dir_hist);
     hipFree(h->counters); if (h->counters_host) hipHostFree(h->counters_host);
     hipFree(h->descs_dev); if (h->descs_host) hipHostFree(h->descs_host);
     hipFree(h->blockcounts); hipFree(h->blockcounts2); hipFree(h->hmaps2);

@@ -972,7 +972,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 #define ENCFUSE_MAXIT 8                                    // wave iterations whose tile tags are fetched together
 #define ENCFUSE_LIST 128                                   // per wave: occupied voxels listed before they are settled
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_encfuse(
-    const ScanParams P, const FuseParams F, const MapDesc prev, uint32_t *hit, uint32_t *total, uint32_t *mh,
+    const ScanParams P, const FuseParams F, const MapDesc prev, int32_t *flink, uint32_t *hit, uint32_t *total, uint32_t *mh,
     int32_t *state, uint4 *crows, const uint32_t *__restrict__ stags, int32_t *fstate, uint4 *frows, uint32_t *ftags,
     uint32_t *blockcounts, double *height, double *inferred, uint32_t *counters, unsigned long long *host_flag, uint32_t seq)
 {
@@ -1055,6 +1055,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
                 const uint32_t row = rbase + running + (uint32_t)__popcll(ob & lanemask_lt());
                 frows[row] = make_uint4(hh, tt, mn, 0u);
                 fstate[L] = (int32_t)row;
+                if (flink) flink[row] = stp;                   // (statistics: which row of the previous map merges into this one, if any)
                 atomicMin(&s_zh[w][(meta >> 10) & 63u], ((unsigned long long)(meta & 1023u) << 32) | mn);   // lowest occupied level wins
             }
             running += (uint32_t)__popcll(ob);
@@ -1287,14 +1288,14 @@ void gvom_encfuse_shape(int xy, int zs, int nw_override, int *nw, int *nblocks, 
     *nw = w; *nblocks = (xy / 16) * (xy / 4);
     *row_cap = (size_t)*nblocks * (size_t)w * (size_t)niter * 256;
 }
-hipError_t gvom_launch_encfuse(hipStream_t s, const ScanParams &P, const FuseParams &F, const MapDesc &prev, uint32_t *hit,
+hipError_t gvom_launch_encfuse(hipStream_t s, const ScanParams &P, const FuseParams &F, const MapDesc &prev, int32_t *flink, uint32_t *hit,
                                uint32_t *total, uint32_t *mh, int32_t *state, uint4 *crows, const uint32_t *stags,
                                int32_t *fstate, uint4 *frows, uint32_t *ftags, uint32_t *blockcounts, double *height,
                                double *inferred, uint32_t *counters, unsigned long long *host_flag, uint32_t seq)
 {
     int nw, nblocks; size_t cap;
     gvom_encfuse_shape(P.xy, P.zs, F.nz, &nw, &nblocks, &cap);   // (F.nz: A/B knob "encfuse"; the caller sized the fused rows with the same call)
-    hipLaunchKernelGGL(k_encfuse, dim3((unsigned)nblocks), dim3(64u * (unsigned)nw), 0, s, P, F, prev, hit, total, mh, state, crows,
+    hipLaunchKernelGGL(k_encfuse, dim3((unsigned)nblocks), dim3(64u * (unsigned)nw), 0, s, P, F, prev, flink, hit, total, mh, state, crows,
                        stags, fstate, frows, ftags, blockcounts, height, inferred, counters, host_flag, seq);
     return hipGetLastError();
 }

@@ -125,7 +125,12 @@ struct MapDesc {          // one source map of the fusion (ring slot or previous
     uint32_t epoch;         // tile (T) of this map is live iff tags[T] == epoch
     const uint32_t *tags;
     const void *metrics;    // optional per-row statistics: double[rows][10] (ring slot) or float[rows][10] (fused)
-    const uint16_t *code16; // ring slots of xy % 4 == 0 grids: 16-bit codes (see k_encode); nullptr for the previous map
+    union {
+        const uint16_t *code16; // ring slots of xy % 4 == 0 grids: 16-bit codes (see k_encode); nullptr for the previous map
+        const int32_t *link;    // k_fuse_stats, the PREVIOUS map of an eager fusion: link[fused row] = that voxel's row in the previous
+                                //   map (< 0: it contributes nothing), written by k_encfuse -- the merge then reads neither the
+                                //   previous map's states nor its tile tags (which the NEXT scan's k_encfuse overwrites)
+    };
 };
 
 #define GVOM_KARG_DESCS 17   // ring slots + previous map passed by kernel argument when they fit
@@ -203,7 +208,8 @@ hipError_t gvom_launch_fuse(hipStream_t s, const FuseParams &P, const FuseDescs 
                             const MapDesc *descs_dev, int32_t *fstate, uint4 *frows,
                             uint32_t *ftags, uint32_t *blockcounts, double *height, double *inferred);
 void gvom_encfuse_shape(int xy, int zs, int nw_override, int *nw, int *nblocks, size_t *row_cap);
-hipError_t gvom_launch_encfuse(hipStream_t s, const ScanParams &P, const FuseParams &F, const MapDesc &prev, uint32_t *hit,
+// flink (or nullptr): per fused row, the voxel's row in the previous map -- what the statistics merge of this speculative fusion needs
+hipError_t gvom_launch_encfuse(hipStream_t s, const ScanParams &P, const FuseParams &F, const MapDesc &prev, int32_t *flink, uint32_t *hit,
                                uint32_t *total, uint32_t *mh, int32_t *state, uint4 *crows, const uint32_t *stags,
                                int32_t *fstate, uint4 *frows, uint32_t *ftags, uint32_t *blockcounts, double *height,
                                double *inferred, uint32_t *counters, unsigned long long *host_flag, uint32_t seq);

@@ -294,8 +294,11 @@ __global__ __launch_bounds__(256) void k_fuse_stats(const FuseParams P, const Fu
                     const int sI = s0 + u < nsrc ? s0 + u : s0;
                     const int xs = x + descs[sI].d[0], ys = y + descs[sI].d[1], zs_ = z + descs[sI].d[2];
                     in[u] = s0 + u < nsrc && descs[sI].metrics && !(xs < 0 || xs >= P.xy || ys < 0 || ys >= P.xy || zs_ < 0 || zs_ >= P.zs);
-                    tgv[u] = descs[sI].tags[tl];
-                    stv[u] = descs[sI].state[L];
+                    // the previous map of an eager fusion comes with a link table (k_encfuse: this fused row <- that row of the previous
+                    // map): neither its states nor its tile tags are read -- the next scan's k_encfuse may be rewriting them by now
+                    const int32_t *lk = sI >= P.nslots ? descs[sI].link : nullptr;
+                    tgv[u] = lk ? descs[sI].epoch : descs[sI].tags[tl];
+                    stv[u] = lk ? lk[row] : descs[sI].state[L];
                 }
                 float pm[10];                                                // the previous fused map's metrics (float32), if in this pass
                 double sm[2][10];                                            // ring slots' (float64)
